@@ -1,0 +1,68 @@
+// BatchNorm bookkeeping kernels (tiny, one thread per channel).
+// The heavy part of BatchNorm -- the reductions and the normalisation -- lives in the
+// producing / consuming convolution kernels; these turn the reduced sums into the
+// per-channel affine the consumers apply on load.
+#include "common.h"
+
+namespace {
+
+__global__ void bn_finalize_kernel(const double* __restrict__ stats, int C, double count,
+                                   const float* __restrict__ gamma, const float* __restrict__ beta,
+                                   float* running_mean, float* running_var, int64_t* nbt, float momentum,
+                                   float eps, float* scale, float* shift, float* mean_out, float* invstd_out) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c == 0 && nbt) *nbt += 1;
+  if (c >= C) return;
+  const double mean = stats[c] / count;
+  double var = stats[C + c] / count - mean * mean;  // biased
+  if (var < 0.0) var = 0.0;
+  const float invstd = (float)(1.0 / sqrt(var + (double)eps));
+  const float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
+  const float s = g * invstd;
+  scale[c] = s;
+  shift[c] = b - (float)mean * s;
+  if (mean_out) mean_out[c] = (float)mean;
+  if (invstd_out) invstd_out[c] = invstd;
+  if (running_mean) running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mean;
+  if (running_var) {
+    const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
+    running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
+  }
+}
+
+__global__ void bn_eval_affine_kernel(int C, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                      const float* __restrict__ rm, const float* __restrict__ rv, float eps,
+                                      float* scale, float* shift) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const float invstd = 1.f / sqrtf(rv[c] + eps);
+  const float s = (gamma ? gamma[c] : 1.f) * invstd;
+  scale[c] = s;
+  shift[c] = (beta ? beta[c] : 0.f) - rm[c] * s;
+}
+
+}  // namespace
+
+extern "C" int t3d_bn_finalize(const double* stats, int C, double count, const float* gamma, const float* beta,
+                               float* running_mean, float* running_var, int64_t* num_batches_tracked,
+                               float momentum, float eps, float* scale, float* shift, float* mean, float* invstd,
+                               void* stream) {
+  if (!stats || !scale || !shift || C <= 0 || count <= 0) return T3D_ERR_ARG;
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, 256)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                     stats, C, count, gamma, beta, running_mean, running_var, num_batches_tracked, momentum, eps,
+                     scale, shift, mean, invstd);
+  T3D_CHECK_LAUNCH();
+  return T3D_OK;
+}
+
+extern "C" int t3d_bn_eval_affine(int C, const float* gamma, const float* beta, const float* running_mean,
+                                  const float* running_var, float eps, float* scale, float* shift, void* stream) {
+  if (!running_mean || !running_var || !scale || !shift || C <= 0) return T3D_ERR_ARG;
+  hipLaunchKernelGGL(bn_eval_affine_kernel, dim3(cdiv(C, 256)), dim3(256), 0,
+                     reinterpret_cast<hipStream_t>(stream), C, gamma, beta, running_mean, running_var, eps, scale,
+                     shift);
+  T3D_CHECK_LAUNCH();
+  return T3D_OK;
+}
+
+extern "C" int t3d_version(void) { return 1; }

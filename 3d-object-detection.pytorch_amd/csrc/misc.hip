@@ -1,0 +1,35 @@
+// Small utility kernels: weight packing (fp32 master -> storage dtype, optional transpose).
+#include "common.h"
+
+namespace {
+
+template <typename T>
+__global__ void pack_kernel(const float* __restrict__ w, T* __restrict__ out, int rows, int cols, int transpose) {
+  const size_t n = (size_t)rows * cols;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    if (!transpose) {
+      out[i] = (T)w[i];
+    } else {  // out [cols][rows]
+      const size_t r = i / cols, c = i % cols;
+      out[c * rows + r] = (T)w[i];
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" int t3d_pack_weight(int dtype, const float* w, void* out, int rows, int cols, int transpose,
+                               void* stream) {
+  if (!w || !out || rows <= 0 || cols <= 0) return T3D_ERR_ARG;
+  const size_t n = (size_t)rows * cols;
+  const int grid = (int)((n + 255) / 256 < 1024 ? (n + 255) / 256 : 1024);
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (dtype == T3D_F32)
+    hipLaunchKernelGGL(pack_kernel<float>, dim3(grid), dim3(256), 0, st, w, (float*)out, rows, cols, transpose);
+  else if (dtype == T3D_BF16)
+    hipLaunchKernelGGL(pack_kernel<bf16_t>, dim3(grid), dim3(256), 0, st, w, (bf16_t*)out, rows, cols, transpose);
+  else
+    return T3D_ERR_ARG;
+  T3D_CHECK_LAUNCH();
+  return T3D_OK;
+}

@@ -1,0 +1,362 @@
+// Pointwise (1x1) convolution forward and data-gradient as one MFMA GEMM family (gfx950).
+//
+//   out[m][n] = epilogue( sum_k  pro(A)[m][k] * W[n][k] ),   m = pixel (B*H*W), NHWC rows
+//
+// The contraction runs on the matrix cores (bf16: v_mfma_f32_16x16x32_bf16, fp32 parity
+// mode: v_mfma_f32_16x16x4_f32 = exact fp32 fma chain), but the kernel is HBM-bound
+// (<= 39 FLOP/B), so the design goal is ONE pass over the activations:
+//   * the A operand is staged global -> registers -> LDS in full 128-B row segments; the
+//     producer's BatchNorm affine + activation (+SE), or -- for the data gradient -- the
+//     BatchNorm-backward affine  dy = alpha*dz + beta*y + gamma, is applied in that
+//     register stage, so neither ever costs a pass over HBM;
+//   * the product is computed transposed (D = W * A^T) with the weight rows permuted so
+//     that every lane ends up with 4*NT CONSECUTIVE output channels of one pixel:
+//     16-B vector stores, no LDS transpose of the accumulators;
+//   * forward epilogue: raw output + per-channel sum / sum-of-squares for the following
+//     BatchNorm; dgrad epilogue: multiply by act'(BN(y_in)), emit sum(dz), sum(dz*y_in)
+//     for the BatchNorm backward of the producer (or per-sample sums when an SE gate
+//     sits in between).  Sums are reduced over the 16 pixels of a DPP row, parked in
+//     LDS across the block's persistent tile loop and leave as one fp64 atomic per
+//     channel per block.
+#include <type_traits>
+#include "common.h"
+
+namespace {
+
+template <typename T> struct MM;
+template <> struct MM<bf16_t> { static constexpr int BK = 64, EPV = 8, LDK = 72; };
+template <> struct MM<float> { static constexpr int BK = 32, EPV = 4, LDK = 36; };
+
+constexpr int BM = 128;  // pixels per tile (4 waves x 2 x 16)
+
+struct GemmArgs {
+  const void* a0;   // FWD: x (raw or finished); DGRAD: dz
+  const void* a1;   // DGRAD: y (raw output of the differentiated conv), else null
+  const float *p0, *p1, *p2;  // FWD: scale, shift, se[B][K]; DGRAD: alpha, beta, gamma
+  int act, se_after, per_sample, dgrad;
+  const void* w;     // [Nout][Kin] storage dtype
+  const float* bias; // [Nout] or null
+  const void* e_y;   // DGRAD epilogue: raw input tensor of the forward conv [M][Nout]
+  const float *e_scale, *e_shift, *e_se;
+  int e_act, e_se_after;
+  const void* e_res;  // residual gradient to add [M][Nout]
+  void* out;
+  double* stats;      // [2][Nout]
+  float* ps_stats;    // [B][Nout][2] per-sample sums (SE case)
+  int M, HW, Kin, Nout, mtiles;
+};
+
+template <typename T> __device__ __forceinline__ void ldvec(const T* p, float* v);
+template <> __device__ __forceinline__ void ldvec<float>(const float* p, float* v) {
+  const float4 a = *reinterpret_cast<const float4*>(p);
+  v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w;
+}
+template <> __device__ __forceinline__ void ldvec<bf16_t>(const bf16_t* p, float* v) { Vec8<bf16_t>::load(p, v); }
+template <typename T> __device__ __forceinline__ void stvec(T* p, const float* v);
+template <> __device__ __forceinline__ void stvec<float>(float* p, const float* v) {
+  *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
+}
+template <> __device__ __forceinline__ void stvec<bf16_t>(bf16_t* p, const float* v) { Vec8<bf16_t>::store(p, v); }
+
+template <typename T, int NT>
+__global__ __launch_bounds__(256, 2) void pw_gemm_kernel(const GemmArgs a) {
+  constexpr int BK = MM<T>::BK, EPV = MM<T>::EPV, LDK = MM<T>::LDK;
+  constexpr int BN = NT * 16;
+  constexpr int WV = NT / 2;  // 16-B weight vectors per thread per chunk
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  T* As = reinterpret_cast<T*>(smem);                         // [BM][LDK]
+  T* Ws = As + BM * LDK;                                      // [BN][LDK]
+  float* lstat = reinterpret_cast<float*>(Ws + BN * LDK);     // [BN][2]
+  float* coef = lstat + BN * 2;                               // [3][kpad]
+  const int kpad = (a.Kin + BK - 1) / BK * BK;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lg = lane >> 4, lc = lane & 15;
+  const int n0 = blockIdx.y * BN;
+  const T* __restrict__ A0 = reinterpret_cast<const T*>(a.a0);
+  const T* __restrict__ A1 = reinterpret_cast<const T*>(a.a1);
+  const T* __restrict__ Wg = reinterpret_cast<const T*>(a.w);
+  T* __restrict__ out = reinterpret_cast<T*>(a.out);
+
+  for (int i = tid; i < BN * 2; i += 256) lstat[i] = 0.f;
+  for (int i = tid; i < kpad; i += 256) {
+    const bool v = i < a.Kin;
+    if (!a.dgrad) {
+      coef[i] = (v && a.p0) ? a.p0[i] : 1.f;
+      coef[kpad + i] = (v && a.p0) ? a.p1[i] : 0.f;
+    } else {
+      coef[i] = (v && !a.per_sample) ? a.p0[i] : 0.f;
+      coef[kpad + i] = v ? a.p1[i] : 0.f;
+      coef[2 * kpad + i] = (v && !a.per_sample) ? a.p2[i] : 0.f;
+    }
+  }
+  const bool plainA = (!a.dgrad && !a.p0 && !a.p2 && a.act == T3D_ACT_NONE);
+  const int arow = tid >> 3, aseg = tid & 7;  // A staging: rows arow + 32*i, 16-B segment aseg
+  const int nk = kpad / BK;
+
+  for (int mt = blockIdx.x; mt < a.mtiles; mt += gridDim.x) {
+    const int m0 = mt * BM;
+    f32x4 acc[2][NT];
+#pragma unroll
+    for (int r = 0; r < 2; ++r)
+#pragma unroll
+      for (int t = 0; t < NT; ++t) acc[r][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    uint4 ra[4], rb[4], rw[WV];
+    auto gload = [&](int kc) {
+      const int k = kc * BK + aseg * EPV;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int m = m0 + arow + 32 * i;
+        const bool ok = (m < a.M) && (k < a.Kin);
+        ra[i] = ok ? *reinterpret_cast<const uint4*>(A0 + (size_t)m * a.Kin + k) : uint4{0, 0, 0, 0};
+        if (a.dgrad) rb[i] = ok ? *reinterpret_cast<const uint4*>(A1 + (size_t)m * a.Kin + k) : uint4{0, 0, 0, 0};
+      }
+#pragma unroll
+      for (int i = 0; i < WV; ++i) {
+        const int idx = tid + 256 * i;
+        const int n = n0 + (idx >> 3), kk = kc * BK + (idx & 7) * EPV;
+        rw[i] = (n < a.Nout && kk < a.Kin) ? *reinterpret_cast<const uint4*>(Wg + (size_t)n * a.Kin + kk)
+                                           : uint4{0, 0, 0, 0};
+      }
+    };
+    auto lstore = [&](int kc) {
+      const int kl = aseg * EPV, k = kc * BK + kl;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int row = arow + 32 * i;
+        T* dst = As + row * LDK + kl;
+        if (plainA) {
+          *reinterpret_cast<uint4*>(dst) = ra[i];
+          continue;
+        }
+        const int m = m0 + row;
+        float v[EPV], y[EPV];
+        ldvec<T>(reinterpret_cast<const T*>(&ra[i]), v);
+        const bool ok = (m < a.M) && (k < a.Kin);
+        if (!a.dgrad) {
+          const float* se = (a.p2 && ok) ? a.p2 + (size_t)(m / a.HW) * a.Kin + k : nullptr;
+#pragma unroll
+          for (int j = 0; j < EPV; ++j) {
+            float u = v[j] * coef[k + j] + coef[kpad + k + j];
+            const float sv = se ? se[j] : 1.f;
+            if (!a.se_after) u *= sv;
+            u = act_apply(u, a.act);
+            if (a.se_after) u *= sv;
+            v[j] = ok ? u : 0.f;
+          }
+        } else {
+          ldvec<T>(reinterpret_cast<const T*>(&rb[i]), y);
+          const size_t pb = (a.per_sample && ok) ? (size_t)(m / a.HW) * a.Kin + k : 0;
+#pragma unroll
+          for (int j = 0; j < EPV; ++j) {
+            const float al = a.per_sample ? (ok ? a.p0[pb + j] : 0.f) : coef[k + j];
+            const float ga = a.per_sample ? (ok ? a.p2[pb + j] : 0.f) : coef[2 * kpad + k + j];
+            v[j] = ok ? (al * v[j] + coef[kpad + k + j] * y[j] + ga) : 0.f;
+          }
+        }
+        stvec<T>(dst, v);
+      }
+#pragma unroll
+      for (int i = 0; i < WV; ++i) {
+        const int idx = tid + 256 * i;
+        *reinterpret_cast<uint4*>(Ws + (idx >> 3) * LDK + (idx & 7) * EPV) = rw[i];
+      }
+    };
+
+    gload(0);
+    for (int kc = 0; kc < nk; ++kc) {
+      __syncthreads();  // previous chunk consumed (and coef/lstat init visible)
+      lstore(kc);
+      __syncthreads();
+      if (kc + 1 < nk) gload(kc + 1);
+      const T* ap = As + (wave * 32 + lc) * LDK;
+      // weight row owned by MFMA row lc of tile t:  n_local = (lc>>2)*4*NT + 4*t + (lc&3)
+      const T* wp = Ws + ((lc >> 2) * 4 * NT + (lc & 3)) * LDK;
+      if constexpr (std::is_same<T, bf16_t>::value) {
+#pragma unroll
+        for (int ks = 0; ks < BK / 32; ++ks) {
+          const int ko = ks * 32 + lg * 8;
+          const bf16x8 b0 = *reinterpret_cast<const bf16x8*>(ap + ko);
+          const bf16x8 b1 = *reinterpret_cast<const bf16x8*>(ap + 16 * LDK + ko);
+#pragma unroll
+          for (int t = 0; t < NT; ++t) {
+            const bf16x8 wf = *reinterpret_cast<const bf16x8*>(wp + 4 * t * LDK + ko);
+            acc[0][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, b0, acc[0][t], 0, 0, 0);
+            acc[1][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, b1, acc[1][t], 0, 0, 0);
+          }
+        }
+      } else {
+#pragma unroll
+        for (int kg = 0; kg < BK / 16; ++kg) {
+          const int ko = kg * 16 + lg * 4;
+          const float4 b0 = *reinterpret_cast<const float4*>(ap + ko);
+          const float4 b1 = *reinterpret_cast<const float4*>(ap + 16 * LDK + ko);
+          const float b0v[4] = {b0.x, b0.y, b0.z, b0.w}, b1v[4] = {b1.x, b1.y, b1.z, b1.w};
+#pragma unroll
+          for (int t = 0; t < NT; ++t) {
+            const float4 wq = *reinterpret_cast<const float4*>(wp + 4 * t * LDK + ko);
+            const float wv[4] = {wq.x, wq.y, wq.z, wq.w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              acc[0][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[j], b0v[j], acc[0][t], 0, 0, 0);
+              acc[1][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[j], b1v[j], acc[1][t], 0, 0, 0);
+            }
+          }
+        }
+      }
+    }
+
+    // ---------------- epilogue: lane holds channels nb .. nb+4*NT-1 of pixel m ----------
+    const int nb = n0 + lg * 4 * NT;
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      const int mrow0 = m0 + wave * 32 + r * 16;
+      const int m = mrow0 + lc;
+      const bool mok = m < a.M;
+      // all 16 pixels of the DPP row in one sample and in range -> reduce in-row, one lane adds
+      const int mlast = mrow0 + 15;
+      const bool uni = (mlast < a.M) && (mrow0 / a.HW == mlast / a.HW);
+      const int bidx = mok ? m / a.HW : 0;
+#pragma unroll
+      for (int q = 0; q < NT / 2; ++q) {
+        const int n = nb + 8 * q;
+        if (n >= a.Nout) continue;  // whole 8-channel groups are in or out (Nout % 8 == 0)
+        float v[8], yv[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = acc[r][2 * q + (j >> 2)][j & 3];
+        if (a.bias) {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) v[j] += a.bias[n + j];
+        }
+        if (a.e_y) {
+          if (mok) Vec8<T>::load(reinterpret_cast<const T*>(a.e_y) + (size_t)m * a.Nout + n, yv);
+          else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) yv[j] = 0.f;
+          }
+          const float* se = (a.e_se && mok) ? a.e_se + (size_t)bidx * a.Nout + n : nullptr;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            float u = yv[j] * (a.e_scale ? a.e_scale[n + j] : 1.f) + (a.e_scale ? a.e_shift[n + j] : 0.f);
+            const float sv = se ? se[j] : 1.f;
+            if (!a.e_se_after) {
+              v[j] *= act_grad(u * sv, a.e_act);          // d/d(se*u) of act(se*u)
+            } else {
+              v[j] *= sv * act_grad(u, a.e_act);          // d/du of se*act(u)  (gate treated as constant here)
+            }
+          }
+        }
+        if (a.e_res && mok) {
+          float rr[8];
+          Vec8<T>::load(reinterpret_cast<const T*>(a.e_res) + (size_t)m * a.Nout + n, rr);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) v[j] += rr[j];
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = mok ? Vec8<T>::round(v[j]) : 0.f;
+        if (mok) Vec8<T>::store(out + (size_t)m * a.Nout + n, v);
+        if (a.stats || a.ps_stats) {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            float s1 = v[j];
+            float s2 = a.e_y ? v[j] * yv[j] : v[j] * v[j];
+            if (a.ps_stats) {
+              if (uni) {
+                s1 = row16_sum(s1);
+                s2 = row16_sum(s2);
+                if (lc == 0) {
+                  unsafeAtomicAdd(a.ps_stats + ((size_t)bidx * a.Nout + n + j) * 2, s1);
+                  unsafeAtomicAdd(a.ps_stats + ((size_t)bidx * a.Nout + n + j) * 2 + 1, s2);
+                }
+              } else if (mok) {
+                unsafeAtomicAdd(a.ps_stats + ((size_t)bidx * a.Nout + n + j) * 2, s1);
+                unsafeAtomicAdd(a.ps_stats + ((size_t)bidx * a.Nout + n + j) * 2 + 1, s2);
+              }
+            } else {
+              s1 = row16_sum(s1);
+              s2 = row16_sum(s2);
+              if (lc == 0) {
+                atomicAdd(lstat + (n - n0 + j) * 2, s1);
+                atomicAdd(lstat + (n - n0 + j) * 2 + 1, s2);
+              }
+            }
+          }
+        }
+      }
+    }
+  }
+
+  if (a.stats) {
+    __syncthreads();
+    for (int i = tid; i < BN * 2; i += 256) {
+      const int n = n0 + (i >> 1);
+      if (n < a.Nout) atomicAdd(a.stats + (size_t)(i & 1) * a.Nout + n, (double)lstat[i]);
+    }
+  }
+}
+
+template <typename T, int NT>
+int launch_nt(GemmArgs& a, hipStream_t st) {
+  constexpr int BN = NT * 16;
+  const int kpad = (a.Kin + MM<T>::BK - 1) / MM<T>::BK * MM<T>::BK;
+  const size_t lds = (size_t)(BM + BN) * MM<T>::LDK * sizeof(T) + BN * 2 * 4 + (size_t)3 * kpad * 4;
+  a.mtiles = cdiv(a.M, BM);
+  const int ny = cdiv(a.Nout, BN);
+  int gx = a.mtiles < 2048 / ny ? a.mtiles : 2048 / ny;
+  if (gx < 1) gx = 1;
+  if (lds > 64 * 1024)
+    (void)hipFuncSetAttribute((const void*)pw_gemm_kernel<T, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipLaunchKernelGGL((pw_gemm_kernel<T, NT>), dim3(gx, ny), dim3(256), lds, st, a);
+  T3D_CHECK_LAUNCH();
+  return T3D_OK;
+}
+
+template <typename T>
+int launch(GemmArgs& a, hipStream_t st) {
+  if (a.Nout <= 32) return launch_nt<T, 2>(a, st);
+  if (a.Nout <= 64) return launch_nt<T, 4>(a, st);
+  return launch_nt<T, 8>(a, st);  // wider outputs tile over grid.y (A re-read comes from L2)
+}
+
+int dispatch(int dtype, GemmArgs& a, void* stream) {
+  if (a.M <= 0 || a.Kin <= 0 || a.Nout <= 0 || (a.Kin % 8) || (a.Nout % 8) || a.HW <= 0) return T3D_ERR_ARG;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (dtype == T3D_F32) return launch<float>(a, st);
+  if (dtype == T3D_BF16) return launch<bf16_t>(a, st);
+  return T3D_ERR_ARG;
+}
+
+}  // namespace
+
+extern "C" int t3d_pwconv_fwd(int dtype, const void* x, const t3d_prologue* pro, const void* w, const float* bias,
+                              void* y, double* stats, int M, int HW, int K, int N, void* stream) {
+  if (!x || !w || !y) return T3D_ERR_ARG;
+  GemmArgs a{};
+  a.a0 = x;
+  if (pro) { a.p0 = pro->scale; a.p1 = pro->shift; a.p2 = pro->se; a.act = pro->act; a.se_after = pro->se_after_act; }
+  a.w = w; a.bias = bias; a.out = y; a.stats = stats;
+  a.M = M; a.HW = HW; a.Kin = K; a.Nout = N;
+  return dispatch(dtype, a, stream);
+}
+
+extern "C" int t3d_pwconv_dgrad(int dtype, const void* dz, const void* y, const t3d_bnbwd* bb, const void* wt,
+                                const void* x_raw, const t3d_prologue* pro_in, const void* residual, void* dx,
+                                double* stats, float* ps_stats, int M, int HW, int K, int N, void* stream) {
+  if (!dz || !y || !bb || !wt || !dx || !bb->beta) return T3D_ERR_ARG;
+  GemmArgs a{};
+  a.dgrad = 1;
+  a.a0 = dz; a.a1 = y;
+  a.p0 = bb->alpha; a.p1 = bb->beta; a.p2 = bb->gamma; a.per_sample = bb->per_sample;
+  a.w = wt;
+  if (x_raw) {
+    a.e_y = x_raw;
+    if (pro_in) {
+      a.e_scale = pro_in->scale; a.e_shift = pro_in->shift; a.e_se = pro_in->se;
+      a.e_act = pro_in->act; a.e_se_after = pro_in->se_after_act;
+    }
+  }
+  a.e_res = residual; a.out = dx; a.stats = stats; a.ps_stats = ps_stats;
+  a.M = M; a.HW = HW; a.Kin = N; a.Nout = K;  // contraction runs over the forward OUTPUT channels
+  return dispatch(dtype, a, stream);
+}

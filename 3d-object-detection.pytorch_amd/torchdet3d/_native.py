@@ -1,0 +1,94 @@
+"""ctypes binding of libt3d_hip.so (the C ABI declared in include/t3d.h).
+
+The product path has NO fallback: if the library is missing or a call fails, a
+RuntimeError is raised.  Tensors cross the boundary as raw device pointers.
+"""
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(os.path.dirname(_HERE), 'libt3d_hip.so')
+
+F32, BF16 = 0, 1
+ACT = {'none': 0, 'relu': 1, 'relu6': 2, 'hswish': 3}
+_P, _I, _F, _D, _L = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_double, ctypes.c_longlong
+
+
+class BnBwd(ctypes.Structure):
+    _fields_ = [('alpha', _P), ('beta', _P), ('gamma', _P), ('per_sample', _I)]
+
+
+class Prologue(ctypes.Structure):
+    _fields_ = [('scale', _P), ('shift', _P), ('se', _P), ('act', _I), ('se_after_act', _I)]
+
+
+_PP = ctypes.POINTER(Prologue)
+_BP = ctypes.POINTER(BnBwd)
+
+# name -> argtypes (restype is always int); mirrors include/t3d.h one to one
+SIGNATURES = {
+    't3d_version': [],
+    't3d_dwconv_fwd': [_I, _P, _PP, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
+    't3d_bn_finalize': [_P, _I, _D, _P, _P, _P, _P, _P, _F, _F, _P, _P, _P, _P, _P],
+    't3d_bn_eval_affine': [_I, _P, _P, _P, _P, _F, _P, _P, _P],
+    't3d_pwconv_fwd': [_I, _P, _PP, _P, _P, _P, _P, _I, _I, _I, _I, _P],
+    't3d_pwconv_dgrad': [_I, _P, _P, _BP, _P, _P, _PP, _P, _P, _P, _P, _I, _I, _I, _I, _P],
+    't3d_pack_weight': [_I, _P, _P, _I, _I, _I, _P],
+}
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(f'{LIB_PATH} not found: build it with `python __graft_entry__.py` '
+                               '(there is no CPU fallback for the HIP path)')
+        _lib = ctypes.CDLL(LIB_PATH)
+        for name, args in SIGNATURES.items():
+            fn = getattr(_lib, name)
+            fn.argtypes = args
+            fn.restype = _I
+    return _lib
+
+
+def ptr(t):
+    """Device pointer of a tensor (None -> NULL)."""
+    if t is None:
+        return None
+    assert t.is_cuda and t.is_contiguous(), 'native ops need contiguous device tensors'
+    return t.data_ptr()
+
+
+def dtype_code(t):
+    if t.dtype == torch.float32:
+        return F32
+    if t.dtype == torch.bfloat16:
+        return BF16
+    raise RuntimeError(f'unsupported storage dtype {t.dtype}')
+
+
+def stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def call(name, *args):
+    rc = getattr(lib(), name)(*args)
+    if rc != 0:
+        raise RuntimeError(f'{name} failed with code {rc}')
+
+
+def prologue(scale=None, shift=None, se=None, act='none', se_after_act=False):
+    """Keeps the referenced tensors alive on the returned object."""
+    p = Prologue(ptr(scale), ptr(shift), ptr(se), ACT[act] if isinstance(act, str) else act, int(se_after_act))
+    p._keep = (scale, shift, se)
+    return p
+
+
+def bnbwd(alpha, beta, gamma, per_sample=False):
+    b = BnBwd(ptr(alpha), ptr(beta), ptr(gamma), int(per_sample))
+    b._keep = (alpha, beta, gamma)
+    return b

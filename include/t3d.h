@@ -1,0 +1,110 @@
+/* t3d.h -- C ABI of the MI355X-native 3D-box keypoint-regression hot path.
+ *
+ * The reference (sovrasov/3d-object-detection.pytorch) is 100 % Python and has no
+ * FFI of its own: every device op on its hot path is an ATen call issued from
+ *   torchdet3d/models/mobilenetv3.py:110-166   (conv / BN / activation / SE)
+ *   torchdet3d/builders/model_builder.py:96-146 (pool, per-class heads, cls head)
+ *   torchdet3d/losses/regression_losses.py, builders/loss_builder.py (losses)
+ *   torchdet3d/evaluation/metrics.py:10-37     (ADD / SADD / accuracy)
+ * Each entry point below names the reference call site it replaces.  The
+ * library (libt3d_hip.so, hand-written HIP for gfx950) is what the reference's
+ * Python would bind with ctypes.
+ *
+ * Conventions
+ *   - plain pointers + sizes; all buffers are caller-allocated DEVICE memory,
+ *     no ownership transfer, no hidden allocation or synchronisation;
+ *   - every call only ENQUEUES on `stream` (a hipStream_t passed as void*);
+ *   - activations are NHWC ("channels last"), storage dtype T3D_F32 or T3D_BF16,
+ *     arithmetic always accumulates in fp32 (statistics in fp64);
+ *   - channel counts are multiples of 8;
+ *   - return 0 on success, a negative T3D_ERR_* otherwise.
+ */
+#ifndef T3D_H_
+#define T3D_H_
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum { T3D_F32 = 0, T3D_BF16 = 1 };
+enum { T3D_ACT_NONE = 0, T3D_ACT_RELU = 1, T3D_ACT_RELU6 = 2, T3D_ACT_HSWISH = 3 };
+enum { T3D_OK = 0, T3D_ERR_ARG = -1, T3D_ERR_LAUNCH = -2, T3D_ERR_UNSUPPORTED = -3 };
+
+/* How a consumer turns a stored RAW (pre-BatchNorm) tensor into its activated
+ * input on load, so BN/activation/SE never cost a pass over HBM:
+ *   u = scale[c]*x + shift[c]            (scale == NULL: u = x)
+ *   se_after_act == 0:  a = act(u * se[b][c])      (expand layout, mobilenetv3.py:153-156)
+ *   se_after_act == 1:  a = act(u) * se[b][c]      (no-expand layout, mobilenetv3.py:137-140)
+ * se == NULL: no squeeze-excite factor. */
+typedef struct {
+  const float* scale;
+  const float* shift;
+  const float* se;
+  int act;
+  int se_after_act;
+} t3d_prologue;
+
+int t3d_version(void);
+
+/* Depthwise k x k conv forward, k in {3,5}, stride in {1,2}, pad (k-1)/2.
+ * Replaces nn.Conv2d(C,C,k,s,(k-1)//2,groups=C) + the following BatchNorm2d's
+ * statistics pass (mobilenetv3.py:136-137,152-153).
+ *   x [B,H,W,C] (dtype), w [C,k*k] fp32 (= the reference's [C,1,k,k]),
+ *   y [B,Ho,Wo,C] raw output (dtype),
+ *   stats  [2*C] fp64 or NULL: += sum(y), sum(y^2) per channel (must be zeroed by caller),
+ *   gap_sum [B*C] fp32 or NULL: += sum over (Ho,Wo) of y per sample/channel (for SE). */
+int t3d_dwconv_fwd(int dtype, const void* x, const t3d_prologue* pro, const float* w, void* y,
+                   double* stats, float* gap_sum, int B, int H, int W, int C, int k, int stride,
+                   void* stream);
+
+/* BatchNorm training-mode statistics -> per-channel affine (mobilenetv3.py:113 etc.;
+ * PyTorch defaults eps=1e-5, momentum=0.1, biased var to normalise, unbiased running var).
+ *   stats [2*C] fp64 sums over `count` elements; scale = gamma*invstd, shift = beta - mean*scale.
+ *   running_mean/var, num_batches_tracked may be NULL (not updated). */
+int t3d_bn_finalize(const double* stats, int C, double count, const float* gamma, const float* beta,
+                    float* running_mean, float* running_var, int64_t* num_batches_tracked,
+                    float momentum, float eps, float* scale, float* shift, float* mean, float* invstd,
+                    void* stream);
+
+/* Eval-mode BatchNorm folded to the same per-channel affine from the running estimates. */
+int t3d_bn_eval_affine(int C, const float* gamma, const float* beta, const float* running_mean,
+                       const float* running_var, float eps, float* scale, float* shift, void* stream);
+
+/* BatchNorm backward as a per-channel affine of two tensors, applied by the consumer on load:
+ *   dy = alpha*dz + beta*y + gamma      (dz: gradient at the BN output, y: raw BN input)
+ * alpha/gamma are [C], or [B*C] when per_sample != 0 (a squeeze-excite gate sits between). */
+typedef struct {
+  const float* alpha;
+  const float* beta;
+  const float* gamma;
+  int per_sample;
+} t3d_bnbwd;
+
+/* Pointwise (1x1) conv forward as an MFMA GEMM.  Replaces nn.Conv2d(K,N,1) / nn.Linear(K,N)
+ * + the statistics pass of the BatchNorm that follows (mobilenetv3.py:120-121,142-143,148-149,
+ * 158-159,192-193).
+ *   x [M,K] rows = NHWC pixels (M = B*H*W, HW = H*W for per-sample SE indexing),
+ *   w [N,K] in the storage dtype, bias [N] fp32 or NULL, y [M,N] raw output,
+ *   stats [2*N] fp64 or NULL: += sum(y), sum(y^2) per output channel (caller zeroes). */
+int t3d_pwconv_fwd(int dtype, const void* x, const t3d_prologue* pro, const void* w, const float* bias,
+                   void* y, double* stats, int M, int HW, int K, int N, void* stream);
+
+/* Pointwise conv data gradient (autograd of the conv above + the surrounding BN/activation).
+ *   dz [M,N], y [M,N]: gradient at / raw input of the BatchNorm after the conv, bb its backward affine;
+ *   wt [K,N]: TRANSPOSED weight in the storage dtype;
+ *   x_raw [M,K] + pro_in: raw tensor the forward conv read and how it was activated; if given the
+ *     result is multiplied by act'(.) and sum(dx), sum(dx*x_raw) are accumulated into
+ *     stats [2*K] fp64 (per channel) or ps_stats [B*K*2] fp32 (per sample, SE case);
+ *   residual [M,K] or NULL is added (skip connection); dx [M,K]. */
+int t3d_pwconv_dgrad(int dtype, const void* dz, const void* y, const t3d_bnbwd* bb, const void* wt,
+                     const void* x_raw, const t3d_prologue* pro_in, const void* residual, void* dx,
+                     double* stats, float* ps_stats, int M, int HW, int K, int N, void* stream);
+
+/* Weight packing: fp32 master weight [rows,cols] -> storage dtype, optionally transposed to
+ * [cols,rows] (the dgrad GEMM reads the transposed copy). */
+int t3d_pack_weight(int dtype, const float* w, void* out, int rows, int cols, int transpose, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* T3D_H_ */

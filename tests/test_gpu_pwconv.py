@@ -1,0 +1,146 @@
+"""GPU parity: pointwise-conv GEMM (forward + data gradient) through the C ABI vs torch-CPU math."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _dt(dt):
+    return torch.float32 if dt == 'f32' else torch.bfloat16
+
+
+def _q(x, dtype):
+    return x.to(dtype).float()
+
+
+def _act(x, kind):
+    from oracle.model import act_fn
+    return act_fn(x, kind)
+
+
+def _act_grad(u, kind):
+    u = u.clone().requires_grad_(True)
+    _act(u, kind).sum().backward()
+    return u.grad
+
+
+def _pack(w, dtype, transpose=False):
+    from torchdet3d import _native as N
+    wd = w.contiguous().cuda()
+    r, c = w.shape
+    out = torch.empty((c, r) if transpose else (r, c), device='cuda', dtype=dtype)
+    N.call('t3d_pack_weight', N.dtype_code(out), N.ptr(wd), N.ptr(out), r, c, int(transpose), N.stream())
+    return out
+
+
+SHAPES = [  # B, HW, K, N
+    (2, 36, 16, 96), (3, 49, 96, 24), (2, 100, 24, 144), (5, 9, 160, 960), (2, 144, 672, 112),
+    (7, 1, 960, 1280), (2, 333, 72, 40), (1, 130, 200, 80), (2, 64, 320, 1280), (2, 200, 8, 8)]
+
+
+@pytest.mark.parametrize('B,HW,K,N', SHAPES)
+@pytest.mark.parametrize('dt', ['f32', 'bf16'])
+@pytest.mark.parametrize('mode', ['plain', 'bnact', 'se_pre', 'se_post'])
+def test_pwconv_fwd(B, HW, K, N, dt, mode):
+    from torchdet3d import _native as Nt
+    dtype = _dt(dt)
+    g = torch.Generator().manual_seed(B + HW + K + N)
+    M = B * HW
+    x = torch.randn(M, K, generator=g)
+    w = torch.randn(N, K, generator=g) / K ** 0.5
+    bias = torch.randn(N, generator=g) if mode == 'plain' else None
+    scale, shift = torch.rand(K, generator=g) + 0.5, torch.randn(K, generator=g) * 0.3
+    se = torch.rand(B, K, generator=g)
+    act = {'plain': 'none', 'bnact': 'relu6', 'se_pre': 'hswish', 'se_post': 'relu'}[mode]
+    xq = _q(x, dtype)
+    sev = se.repeat_interleave(HW, 0)
+    if mode == 'plain':
+        a = xq
+    else:
+        u = xq * scale + shift
+        a = _act(u * sev, act) if mode == 'se_pre' else (_act(u, act) * sev if mode == 'se_post' else _act(u, act))
+    a = _q(a, dtype)
+    ref = a.double() @ _q(w, dtype).double().t()
+    if bias is not None:
+        ref = ref + bias.double()
+    xd = x.to('cuda', dtype)
+    wd = _pack(w, dtype)
+    y = torch.empty(M, N, device='cuda', dtype=dtype)
+    stats = torch.zeros(2 * N, device='cuda', dtype=torch.float64)
+    keep = [t.cuda() for t in (scale, shift, se)]
+    bd = bias.cuda() if bias is not None else None
+    p = None if mode == 'plain' else Nt.prologue(keep[0], keep[1], keep[2] if mode.startswith('se') else None, act,
+                                                 mode == 'se_post')
+    Nt.call('t3d_pwconv_fwd', Nt.dtype_code(xd), Nt.ptr(xd), p, Nt.ptr(wd), Nt.ptr(bd), Nt.ptr(y), Nt.ptr(stats),
+            M, HW, K, N, Nt.stream())
+    torch.cuda.synchronize()
+    got = y.float().cpu()
+    tol = 1e-5 if dt == 'f32' else 1e-2
+    np.testing.assert_allclose(got.numpy(), ref.float().numpy(), atol=tol * max(1., ref.abs().max().item()), rtol=tol)
+    st = stats.cpu().view(2, N)
+    np.testing.assert_allclose(st[0].numpy(), got.double().sum(0).numpy(), rtol=1e-5, atol=1e-4 * M ** .5)
+    np.testing.assert_allclose(st[1].numpy(), (got.double() ** 2).sum(0).numpy(), rtol=1e-5, atol=1e-4)
+
+
+@pytest.mark.parametrize('B,HW,K,N', SHAPES)
+@pytest.mark.parametrize('dt', ['f32', 'bf16'])
+@pytest.mark.parametrize('mode', ['input', 'input_res', 'bnact', 'se_pre', 'persample'])
+def test_pwconv_dgrad(B, HW, K, N, dt, mode):
+    """dx = (alpha*dz + beta*y + gamma) @ W, then the producer's activation derivative / residual."""
+    from torchdet3d import _native as Nt
+    dtype = _dt(dt)
+    g = torch.Generator().manual_seed(B + HW + K + N + 7)
+    M = B * HW
+    dz, y = torch.randn(M, N, generator=g), torch.randn(M, N, generator=g)
+    w = torch.randn(N, K, generator=g) / N ** 0.5
+    xraw = torch.randn(M, K, generator=g)
+    res = torch.randn(M, K, generator=g)
+    scale, shift = torch.rand(K, generator=g) + 0.5, torch.randn(K, generator=g) * 0.3
+    se = torch.rand(B, K, generator=g)
+    ps = mode == 'persample'
+    shp = (B, N) if ps else (N,)
+    alpha, gamma = torch.rand(shp, generator=g) + 0.5, torch.randn(shp, generator=g) * 0.1
+    beta = torch.randn(N, generator=g) * 0.2
+    rep = (lambda t: t.repeat_interleave(HW, 0)) if ps else (lambda t: t)
+    dy = rep(alpha) * _q(dz, dtype) + beta * _q(y, dtype) + rep(gamma)
+    dy = _q(dy, dtype)
+    gref = dy.double() @ _q(w, dtype).double()
+    xq = _q(xraw, dtype)
+    act = {'bnact': 'hswish', 'se_pre': 'relu6', 'persample': 'relu'}.get(mode, 'none')
+    if mode in ('bnact', 'persample'):
+        gref = gref * _act_grad(xq * scale + shift, act).double()
+    elif mode == 'se_pre':
+        sev = se.repeat_interleave(HW, 0)
+        gref = gref * _act_grad((xq * scale + shift) * sev, act).double()
+    if mode == 'input_res':
+        gref = gref + _q(res, dtype).double()
+    d = lambda t: t.to('cuda', dtype)
+    dzd, yd, xd, rd = d(dz), d(y), d(xraw), d(res)
+    wt = _pack(w, dtype, transpose=True)
+    dx = torch.empty(M, K, device='cuda', dtype=dtype)
+    stats = torch.zeros(2 * K, device='cuda', dtype=torch.float64)
+    psst = torch.zeros(B, K, 2, device='cuda')
+    keep = [t.cuda().contiguous() for t in (alpha, beta, gamma, scale, shift, se)]
+    bb = Nt.bnbwd(keep[0], keep[1], keep[2], ps)
+    has_act = mode in ('bnact', 'se_pre', 'persample')
+    pin = Nt.prologue(keep[3], keep[4], keep[5] if mode == 'se_pre' else None, act, False) if has_act else None
+    use_ps = mode == 'se_pre'
+    Nt.call('t3d_pwconv_dgrad', Nt.dtype_code(dzd), Nt.ptr(dzd), Nt.ptr(yd), bb, Nt.ptr(wt),
+            Nt.ptr(xd) if has_act else None, pin, Nt.ptr(rd) if mode == 'input_res' else None, Nt.ptr(dx),
+            Nt.ptr(stats) if (has_act and not use_ps) else None, Nt.ptr(psst) if use_ps else None,
+            M, HW, K, N, Nt.stream())
+    torch.cuda.synchronize()
+    got = dx.float().cpu()
+    tol = 2e-5 if dt == 'f32' else 1.5e-2
+    np.testing.assert_allclose(got.numpy(), gref.float().numpy(), atol=tol * max(1., gref.abs().max().item()), rtol=tol)
+    if has_act and not use_ps:
+        st = stats.cpu().view(2, K)
+        np.testing.assert_allclose(st[0].numpy(), got.double().sum(0).numpy(), rtol=1e-5, atol=1e-4 * M ** .5)
+        np.testing.assert_allclose(st[1].numpy(), (got.double() * xq.double()).sum(0).numpy(), rtol=1e-5,
+                                   atol=1e-4 * M ** .5)
+    if use_ps:
+        p1 = got.double().view(B, HW, K).sum(1)
+        p2 = (got.double() * xq.double()).view(B, HW, K).sum(1)
+        np.testing.assert_allclose(psst.cpu()[..., 0].numpy(), p1.numpy(), rtol=1e-4, atol=1e-3)
+        np.testing.assert_allclose(psst.cpu()[..., 1].numpy(), p2.numpy(), rtol=1e-4, atol=1e-3)
