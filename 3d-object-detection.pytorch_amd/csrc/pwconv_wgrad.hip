@@ -1,0 +1,208 @@
+// Pointwise (1x1) convolution weight gradient for gfx950:
+//
+//   dW[n][k] += sum_m  dy[m][n] * a[m][k],      dy = alpha*dz + beta*y + gamma   (BatchNorm backward)
+//                                               a  = act(scale*x + shift [, se])  (recomputed, never stored)
+//
+// A "TN" GEMM whose contraction runs over pixels, so both operands arrive pixel-major.
+// bf16: both tiles are transposed on their way into LDS (two pixels packed per ds_write_b32,
+// 16-B blocks XOR-swizzled by (row>>3) so the transposing writes are bank-conflict free) and
+// feed v_mfma_f32_16x16x32_bf16; fp32 parity mode keeps the natural layout and uses
+// v_mfma_f32_16x16x4_f32 (one element per lane, exact fp32).
+// Grid = (N tiles, K tiles, pixel splits); each block owns a 64x64 tile of dW over its pixel
+// range and leaves with fp32 atomics into the fp32 gradient buffer (the reference's [N,K,1,1]).
+#include <type_traits>
+#include "common.h"
+
+namespace {
+
+constexpr int TN = 64, TK = 64, BMK = 64;
+
+struct WgArgs {
+  const void *dz, *y, *x;
+  const float *alpha, *beta, *gamma;  // dy affine ([N] or [B*N] for alpha/gamma)
+  int per_sample;
+  const float *scale, *shift, *se;    // x prologue
+  int act, se_after;
+  float* dw;  // [N][K]
+  int M, HW, K, N, rows_per_split;
+};
+
+// LDS element offset of (row, m) in a transposed bf16 tile: [row][8 blocks of 8][pad]
+__device__ __forceinline__ int tr_off(int row, int m) {
+  return row * 72 + ((((m >> 3) ^ (row >> 3)) & 7) << 3) + (m & 7);
+}
+
+template <typename T>
+__global__ __launch_bounds__(256, 2) void pw_wgrad_kernel(const WgArgs a) {
+  constexpr bool BF = std::is_same<T, bf16_t>::value;
+  constexpr int EPV = BF ? 8 : 4;
+  constexpr int LDF = 68;  // fp32 tile row stride (floats)
+  __shared__ __attribute__((aligned(16))) unsigned char smem[BF ? 2 * 64 * 72 * 2 : 2 * BMK * LDF * 4];
+  T* Dy = reinterpret_cast<T*>(smem);                              // bf16: [TN][72]; f32: [BMK][LDF]
+  T* Ax = Dy + (BF ? 64 * 72 : BMK * LDF);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lg = lane >> 4, lc = lane & 15;
+  const int n0 = blockIdx.x * TN, k0 = blockIdx.y * TK;
+  const int mbeg = blockIdx.z * a.rows_per_split;
+  const int mend = min(a.M, mbeg + a.rows_per_split);
+  const T* __restrict__ dz = reinterpret_cast<const T*>(a.dz);
+  const T* __restrict__ yy = reinterpret_cast<const T*>(a.y);
+  const T* __restrict__ xx = reinterpret_cast<const T*>(a.x);
+
+  f32x4 acc[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // staging map.  bf16: thread = (pixel pair pp, 8-channel segment seg), rows 2pp, 2pp+1.
+  //               f32 : thread = (row r = tid>>4 (+16 i), 4-channel segment seg = tid&15), 4 rows each.
+  constexpr int NV = BF ? 2 : 4;
+  const int seg = BF ? (tid & 7) : (tid & 15);
+  const int prow = BF ? (tid >> 3) * 2 : (tid >> 4);
+  const int nch = n0 + seg * EPV, kch = k0 + seg * EPV;
+  const bool nok = nch < a.N, kok = kch < a.K;
+  float be[EPV], al[EPV], ga[EPV], sc[EPV], sh[EPV];
+#pragma unroll
+  for (int j = 0; j < EPV; ++j) {
+    be[j] = nok ? a.beta[nch + j] : 0.f;
+    al[j] = (nok && !a.per_sample) ? a.alpha[nch + j] : 0.f;
+    ga[j] = (nok && !a.per_sample) ? a.gamma[nch + j] : 0.f;
+    sc[j] = (kok && a.scale) ? a.scale[kch + j] : 1.f;
+    sh[j] = (kok && a.scale) ? a.shift[kch + j] : 0.f;
+  }
+  uint4 rz[NV], ry[NV], rx[NV];
+  auto gload = [&](int m0) {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int m = m0 + prow + (BF ? i : 16 * i);
+      const bool mok = m < mend;
+      rz[i] = (mok && nok) ? *reinterpret_cast<const uint4*>(dz + (size_t)m * a.N + nch) : uint4{0, 0, 0, 0};
+      ry[i] = (mok && nok) ? *reinterpret_cast<const uint4*>(yy + (size_t)m * a.N + nch) : uint4{0, 0, 0, 0};
+      rx[i] = (mok && kok) ? *reinterpret_cast<const uint4*>(xx + (size_t)m * a.K + kch) : uint4{0, 0, 0, 0};
+    }
+  };
+  auto xform = [&](int m0, int i, float* dyv, float* av) {
+    const int m = m0 + prow + (BF ? i : 16 * i);
+    const bool mok = m < mend;
+    const int b = mok ? m / a.HW : 0;
+    float zv[EPV], yv[EPV], xv[EPV];
+    if constexpr (BF) {
+      Vec8<bf16_t>::load(reinterpret_cast<const bf16_t*>(&rz[i]), zv);
+      Vec8<bf16_t>::load(reinterpret_cast<const bf16_t*>(&ry[i]), yv);
+      Vec8<bf16_t>::load(reinterpret_cast<const bf16_t*>(&rx[i]), xv);
+    } else {
+      zv[0] = __builtin_bit_cast(float, rz[i].x); zv[1] = __builtin_bit_cast(float, rz[i].y);
+      zv[2] = __builtin_bit_cast(float, rz[i].z); zv[3] = __builtin_bit_cast(float, rz[i].w);
+      yv[0] = __builtin_bit_cast(float, ry[i].x); yv[1] = __builtin_bit_cast(float, ry[i].y);
+      yv[2] = __builtin_bit_cast(float, ry[i].z); yv[3] = __builtin_bit_cast(float, ry[i].w);
+      xv[0] = __builtin_bit_cast(float, rx[i].x); xv[1] = __builtin_bit_cast(float, rx[i].y);
+      xv[2] = __builtin_bit_cast(float, rx[i].z); xv[3] = __builtin_bit_cast(float, rx[i].w);
+    }
+    const bool dok = mok && nok, aok = mok && kok;
+#pragma unroll
+    for (int j = 0; j < EPV; ++j) {
+      const float alj = a.per_sample ? (dok ? a.alpha[(size_t)b * a.N + nch + j] : 0.f) : al[j];
+      const float gaj = a.per_sample ? (dok ? a.gamma[(size_t)b * a.N + nch + j] : 0.f) : ga[j];
+      dyv[j] = dok ? (alj * zv[j] + be[j] * yv[j] + gaj) : 0.f;
+      float u = xv[j] * sc[j] + sh[j];
+      const float sv = (a.se && aok) ? a.se[(size_t)b * a.K + kch + j] : 1.f;
+      if (!a.se_after) u *= sv;
+      u = act_apply(u, a.act);
+      if (a.se_after) u *= sv;
+      av[j] = aok ? u : 0.f;
+    }
+  };
+  auto lstore = [&](int m0) {
+    if constexpr (BF) {
+      float d0[8], d1[8], a0[8], a1[8];
+      xform(m0, 0, d0, a0);
+      xform(m0, 1, d1, a1);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int row = seg * 8 + j;
+        bf16_t pd[2] = {(bf16_t)d0[j], (bf16_t)d1[j]};
+        bf16_t pa[2] = {(bf16_t)a0[j], (bf16_t)a1[j]};
+        *reinterpret_cast<uint32_t*>(Dy + tr_off(row, prow)) = __builtin_bit_cast(uint32_t, pd);
+        *reinterpret_cast<uint32_t*>(Ax + tr_off(row, prow)) = __builtin_bit_cast(uint32_t, pa);
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        float d[4], av[4];
+        xform(m0, i, d, av);
+        const int r = prow + 16 * i;
+        *reinterpret_cast<float4*>(Dy + r * LDF + seg * 4) = make_float4(d[0], d[1], d[2], d[3]);
+        *reinterpret_cast<float4*>(Ax + r * LDF + seg * 4) = make_float4(av[0], av[1], av[2], av[3]);
+      }
+    }
+  };
+
+  if (mbeg < mend) gload(mbeg);
+  for (int m0 = mbeg; m0 < mend; m0 += BMK) {
+    __syncthreads();
+    lstore(m0);
+    __syncthreads();
+    if (m0 + BMK < mend) gload(m0 + BMK);
+    if constexpr (BF) {
+      const int arow = wave * 16 + lc;  // dy^T row (n) owned by this lane as MFMA A operand
+#pragma unroll
+      for (int ks = 0; ks < BMK / 32; ++ks) {
+        const int mo = ks * 32 + lg * 8;
+        const bf16x8 af = *reinterpret_cast<const bf16x8*>(Dy + tr_off(arow, mo));
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          const bf16x8 bfr = *reinterpret_cast<const bf16x8*>(Ax + tr_off(t * 16 + lc, mo));
+          acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bfr, acc[t], 0, 0, 0);
+        }
+      }
+    } else {
+#pragma unroll 4
+      for (int ms = 0; ms < BMK / 4; ++ms) {
+        const int mr = ms * 4 + lg;
+        const float av = reinterpret_cast<const float*>(Dy)[mr * LDF + wave * 16 + lc];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          const float bv = reinterpret_cast<const float*>(Ax)[mr * LDF + t * 16 + lc];
+          acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc[t], 0, 0, 0);
+        }
+      }
+    }
+  }
+  // D[row = 4*lg + reg -> n][col = lc -> k]
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    const int k = k0 + t * 16 + lc;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int n = n0 + wave * 16 + lg * 4 + r;
+      if (n < a.N && k < a.K) unsafeAtomicAdd(a.dw + (size_t)n * a.K + k, acc[t][r]);
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" int t3d_pwconv_wgrad(int dtype, const void* dz, const void* y, const t3d_bnbwd* bb, const void* x,
+                                const t3d_prologue* pro, float* dw, int M, int HW, int K, int N, void* stream) {
+  if (!dz || !y || !bb || !x || !dw || M <= 0 || K <= 0 || N <= 0 || (K % 8) || (N % 8) || HW <= 0) return T3D_ERR_ARG;
+  WgArgs a{};
+  a.dz = dz; a.y = y; a.x = x;
+  a.alpha = bb->alpha; a.beta = bb->beta; a.gamma = bb->gamma; a.per_sample = bb->per_sample;
+  if (pro) { a.scale = pro->scale; a.shift = pro->shift; a.se = pro->se; a.act = pro->act; a.se_after = pro->se_after_act; }
+  a.dw = dw; a.M = M; a.HW = HW; a.K = K; a.N = N;
+  const int tn = cdiv(N, TN), tk = cdiv(K, TK);
+  int S = 1024 / (tn * tk);
+  const int maxs = cdiv(M, BMK * 2);
+  if (S > maxs) S = maxs;
+  if (S < 1) S = 1;
+  a.rows_per_split = cdiv(cdiv(M, S), BMK) * BMK;
+  S = cdiv(M, a.rows_per_split);
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (dtype == T3D_F32)
+    hipLaunchKernelGGL(pw_wgrad_kernel<float>, dim3(tn, tk, S), dim3(256), 0, st, a);
+  else if (dtype == T3D_BF16)
+    hipLaunchKernelGGL(pw_wgrad_kernel<bf16_t>, dim3(tn, tk, S), dim3(256), 0, st, a);
+  else
+    return T3D_ERR_ARG;
+  T3D_CHECK_LAUNCH();
+  return T3D_OK;
+}

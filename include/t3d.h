@@ -104,6 +104,20 @@ int t3d_pwconv_dgrad(int dtype, const void* dz, const void* y, const t3d_bnbwd* 
  * [cols,rows] (the dgrad GEMM reads the transposed copy). */
 int t3d_pack_weight(int dtype, const float* w, void* out, int rows, int cols, int transpose, void* stream);
 
+/* Pointwise conv weight gradient: dw[N,K] (fp32, the reference's [N,K,1,1]) += dy^T * a, with
+ * dy = bb(dz, y) and a = pro(x) recomputed on load; the caller zeroes dw once per step. */
+int t3d_pwconv_wgrad(int dtype, const void* dz, const void* y, const t3d_bnbwd* bb, const void* x,
+                     const t3d_prologue* pro, float* dw, int M, int HW, int K, int N, void* stream);
+
+/* Depthwise conv backward: data gradient and weight gradient in one pass.
+ *   dz, y [B,Ho,Wo,C]: gradient at / raw input of the BatchNorm after the conv; bb its backward affine;
+ *   w [C,k*k] fp32; x [B,H,W,C] + pro: tensor the forward conv read and how it was activated (no SE);
+ *   residual [B,H,W,C] or NULL is added; dx [B,H,W,C];
+ *   stats [2*C] fp64 or NULL: += sum(dx), sum(dx*x); dw [C,k*k] fp32 or NULL: += weight gradient. */
+int t3d_dwconv_bwd(int dtype, const void* dz, const void* y, const t3d_bnbwd* bb, const float* w,
+                   const void* x, const t3d_prologue* pro, const void* residual, void* dx, double* stats,
+                   float* dw, int B, int H, int W, int C, int k, int stride, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -101,3 +101,60 @@ def test_bn_finalize_matches_batchnorm():
     ref_e = F.batch_norm(y, rm0, rv0, gamma, beta, False, 0.1, 1e-5)
     got_e = y * out[0].cpu().view(1, C, 1, 1) + out[1].cpu().view(1, C, 1, 1)
     np.testing.assert_allclose(got_e.numpy(), ref_e.numpy(), atol=2e-5)
+
+
+@pytest.mark.parametrize('B,C,H,W,k,s', SHAPES)
+@pytest.mark.parametrize('dt', ['f32', 'bf16'])
+@pytest.mark.parametrize('mode', ['plain_res', 'bnact', 'bnact_ps'])
+def test_dwconv_bwd(B, C, H, W, k, s, dt, mode):
+    """dx, dw and the BN-backward sums vs torch autograd of the same (pre-rounded) operands."""
+    from torchdet3d import _native as N
+    dtype = torch.float32 if dt == 'f32' else torch.bfloat16
+    q = lambda t: t.to(dtype).float()
+    g = torch.Generator().manual_seed(B * 100 + C + k * 7 + s)
+    x = torch.randn(B, C, H, W, generator=g)
+    w = torch.randn(C, 1, k, k, generator=g) * 0.3
+    scale, shift = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g) * 0.3
+    act = 'hswish' if mode != 'plain_res' else 'none'
+    xq = q(x)
+    u = (xq * scale.view(1, C, 1, 1) + shift.view(1, C, 1, 1)) if mode != 'plain_res' else xq
+    u = u.clone().requires_grad_(True)
+    a1 = _act(u, act)
+    a1q = a1 + (q(a1) - a1).detach()              # LDS tile holds the storage-dtype rounding
+    wr = w.clone().requires_grad_(True)
+    yref = F.conv2d(a1q, wr, None, s, (k - 1) // 2, 1, C)
+    Ho, Wo = yref.shape[2:]
+    dz, y2 = torch.randn(B, C, Ho, Wo, generator=g), torch.randn(B, C, Ho, Wo, generator=g)
+    ps = mode == 'bnact_ps'
+    shp = (B, C, 1, 1) if ps else (1, C, 1, 1)
+    alpha, gamma = torch.rand(shp, generator=g) + 0.5, torch.randn(shp, generator=g) * 0.1
+    beta = torch.randn(1, C, 1, 1, generator=g) * 0.2
+    dy = q(alpha * q(dz) + beta * q(y2) + gamma)
+    yref.backward(dy)
+    res = torch.randn(B, C, H, W, generator=g)
+    dx_ref = u.grad + (q(res) if mode == 'plain_res' else 0)
+    d = lambda t: _nhwc(t, dtype)
+    dzd, yd, xd, rd = d(dz), d(y2), d(x), d(res)
+    keep = [t.reshape(-1, C).squeeze(0).contiguous().cuda() for t in (alpha, beta, gamma)] + [scale.cuda(), shift.cuda()]
+    bb = N.bnbwd(keep[0], keep[1], keep[2], ps)
+    pro = None if mode == 'plain_res' else N.prologue(keep[3], keep[4], None, act, False)
+    wd = w.view(C, k * k).contiguous().cuda()
+    dx = torch.empty(B, H, W, C, device='cuda', dtype=dtype)
+    stats = torch.zeros(2 * C, device='cuda', dtype=torch.float64)
+    dw = torch.zeros(C, k * k, device='cuda')
+    N.call('t3d_dwconv_bwd', N.dtype_code(xd), N.ptr(dzd), N.ptr(yd), bb, N.ptr(wd), N.ptr(xd), pro,
+           N.ptr(rd) if mode == 'plain_res' else None, N.ptr(dx), N.ptr(stats) if pro is not None else None,
+           N.ptr(dw), B, H, W, C, k, s, N.stream())
+    torch.cuda.synchronize()
+    got = dx.float().cpu().permute(0, 3, 1, 2)
+    tol = 3e-5 if dt == 'f32' else 2e-2
+    np.testing.assert_allclose(got.numpy(), dx_ref.numpy(), atol=tol * max(1., dx_ref.abs().max().item()), rtol=tol)
+    tolw = 3e-5 if dt == 'f32' else 3e-3
+    np.testing.assert_allclose(dw.cpu().view(C, 1, k, k).numpy(), wr.grad.numpy(),
+                               atol=tolw * max(1., wr.grad.abs().max().item()), rtol=tolw)
+    if pro is not None:
+        st = stats.cpu().view(2, C)
+        n = B * H * W
+        np.testing.assert_allclose(st[0].numpy(), got.double().sum(dim=(0, 2, 3)).numpy(), rtol=1e-5, atol=1e-4 * n ** .5)
+        np.testing.assert_allclose(st[1].numpy(), (got.double() * xq.double()).sum(dim=(0, 2, 3)).numpy(), rtol=1e-5,
+                                   atol=1e-4 * n ** .5)

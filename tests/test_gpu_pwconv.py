@@ -144,3 +144,44 @@ def test_pwconv_dgrad(B, HW, K, N, dt, mode):
         p2 = (got.double() * xq.double()).view(B, HW, K).sum(1)
         np.testing.assert_allclose(psst.cpu()[..., 0].numpy(), p1.numpy(), rtol=1e-4, atol=1e-3)
         np.testing.assert_allclose(psst.cpu()[..., 1].numpy(), p2.numpy(), rtol=1e-4, atol=1e-3)
+
+
+@pytest.mark.parametrize('B,HW,K,N', SHAPES + [(16, 196, 96, 576), (64, 49, 160, 960)])
+@pytest.mark.parametrize('dt', ['f32', 'bf16'])
+@pytest.mark.parametrize('mode', ['plain', 'bnact', 'se_pre_ps'])
+def test_pwconv_wgrad(B, HW, K, N, dt, mode):
+    from torchdet3d import _native as Nt
+    dtype = _dt(dt)
+    g = torch.Generator().manual_seed(B + HW + K + N + 11)
+    M = B * HW
+    dz, y = torch.randn(M, N, generator=g), torch.randn(M, N, generator=g)
+    x = torch.randn(M, K, generator=g)
+    scale, shift = torch.rand(K, generator=g) + 0.5, torch.randn(K, generator=g) * 0.3
+    se = torch.rand(B, K, generator=g)
+    ps = mode == 'se_pre_ps'
+    shp = (B, N) if ps else (N,)
+    alpha, gamma = torch.rand(shp, generator=g) + 0.5, torch.randn(shp, generator=g) * 0.1
+    beta = torch.randn(N, generator=g) * 0.2
+    rep = (lambda t: t.repeat_interleave(HW, 0)) if ps else (lambda t: t)
+    dy = _q(rep(alpha) * _q(dz, dtype) + beta * _q(y, dtype) + rep(gamma), dtype)
+    xq = _q(x, dtype)
+    if mode == 'plain':
+        a = xq
+    elif mode == 'bnact':
+        a = _act(xq * scale + shift, 'relu6')
+    else:
+        a = _act((xq * scale + shift) * se.repeat_interleave(HW, 0), 'hswish')
+    a = _q(a, dtype)
+    ref = dy.double().t() @ a.double()
+    d = lambda t: t.to('cuda', dtype)
+    dzd, yd, xd = d(dz), d(y), d(x)
+    keep = [t.cuda().contiguous() for t in (alpha, beta, gamma, scale, shift, se)]
+    bb = Nt.bnbwd(keep[0], keep[1], keep[2], ps)
+    pro = None if mode == 'plain' else Nt.prologue(keep[3], keep[4], keep[5] if ps else None,
+                                                   'relu6' if mode == 'bnact' else 'hswish', False)
+    dw = torch.zeros(N, K, device='cuda')
+    Nt.call('t3d_pwconv_wgrad', Nt.dtype_code(dzd), Nt.ptr(dzd), Nt.ptr(yd), bb, Nt.ptr(xd), pro, Nt.ptr(dw),
+            M, HW, K, N, Nt.stream())
+    torch.cuda.synchronize()
+    tol = 2e-5 if dt == 'f32' else 2e-3   # operands are pre-rounded to bf16 in the reference, accumulation is fp32
+    np.testing.assert_allclose(dw.cpu().numpy(), ref.float().numpy(), atol=tol * max(1., ref.abs().max().item()), rtol=tol)
