@@ -41,6 +41,24 @@ __global__ void bn_eval_affine_kernel(int C, const float* __restrict__ gamma, co
   shift[c] = (beta ? beta[c] : 0.f) - rm[c] * s;
 }
 
+__global__ void bn_bwd_finalize_kernel(const double* __restrict__ stats, int C, double count,
+                                       const float* __restrict__ gamma, const float* __restrict__ mean,
+                                       const float* __restrict__ invstd, float* alpha, float* beta, float* gammac,
+                                       float* dgamma, float* dbeta) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const double s1 = stats[c], s2 = stats[C + c];
+  const double mu = (double)mean[c], is = (double)invstd[c];
+  const double dg = is * (s2 - mu * s1);
+  const double a = (double)(gamma ? gamma[c] : 1.f) * is;
+  const double b = -a * is * dg / count;
+  alpha[c] = (float)a;
+  beta[c] = (float)b;
+  gammac[c] = (float)(-a * s1 / count - b * mu);
+  if (dgamma) dgamma[c] = (float)dg;
+  if (dbeta) dbeta[c] = (float)s1;
+}
+
 }  // namespace
 
 extern "C" int t3d_bn_finalize(const double* stats, int C, double count, const float* gamma, const float* beta,
@@ -66,3 +84,14 @@ extern "C" int t3d_bn_eval_affine(int C, const float* gamma, const float* beta, 
 }
 
 extern "C" int t3d_version(void) { return 1; }
+
+extern "C" int t3d_bn_bwd_finalize(const double* stats, int C, double count, const float* gamma, const float* mean,
+                                   const float* invstd, float* alpha, float* beta, float* gammac, float* dgamma,
+                                   float* dbeta, void* stream) {
+  if (!stats || !mean || !invstd || !alpha || !beta || !gammac || C <= 0 || count <= 0) return T3D_ERR_ARG;
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(C, 256)), dim3(256), 0,
+                     reinterpret_cast<hipStream_t>(stream), stats, C, count, gamma, mean, invstd, alpha, beta,
+                     gammac, dgamma, dbeta);
+  T3D_CHECK_LAUNCH();
+  return T3D_OK;
+}

@@ -1,0 +1,325 @@
+// Streaming (one-pass, HBM-bound) kernels around the convolutions, NHWC, 8 channels (16 B bf16 /
+// 32 B fp32) per lane:
+//   * stem patch gather (NCHW fp32 crops -> [pixels, 32] patch rows for the stem GEMM),
+//   * block-output materialisation  z = act(scale*y + shift) + residual  and its activation backward,
+//   * global average pool forward / backward.
+// Per-channel reductions: every thread keeps ONE fixed 8-channel group across its grid-stride
+// loop, so the sums stay in registers, meet in LDS once per block and leave as one fp64 atomic
+// per channel per block.
+#include "common.h"
+
+namespace {
+
+// ------------------------------------------------------------------ stem im2col
+// One thread per output pixel: 27 scalar gathers (coalesced along x within a row: stride-2 reads,
+// each input byte is used by ~2.25 patches and served from L1/L2), 4 x 16-B stores.
+template <typename T>
+__global__ __launch_bounds__(256) void im2col_kernel(const float* __restrict__ x, T* __restrict__ col, int B,
+                                                     int H, int W, int Ho, int Wo) {
+  const size_t npix = (size_t)B * Ho * Wo;
+  for (size_t p = blockIdx.x * (size_t)256 + threadIdx.x; p < npix; p += (size_t)gridDim.x * 256) {
+    const int ox = (int)(p % Wo), oy = (int)((p / Wo) % Ho), b = (int)(p / ((size_t)Wo * Ho));
+    float v[32];
+#pragma unroll
+    for (int i = 27; i < 32; ++i) v[i] = 0.f;
+#pragma unroll
+    for (int ci = 0; ci < 3; ++ci)
+#pragma unroll
+      for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+          const int iy = oy * 2 - 1 + ky, ix = ox * 2 - 1 + kx;
+          const bool ok = iy >= 0 && iy < H && ix >= 0 && ix < W;
+          v[(ci * 3 + ky) * 3 + kx] = ok ? x[(((size_t)b * 3 + ci) * H + iy) * W + ix] : 0.f;
+        }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) Vec8<T>::store(col + p * 32 + q * 8, v + q * 8);
+  }
+}
+
+// ------------------------------------------------------------------ channel-group bookkeeping
+struct EwArgs {
+  const void *a, *b;   // primary / secondary input
+  const void* res;
+  void* out;
+  const float *scale, *shift;
+  const float* vec;    // per-sample fp32 vector (gap bwd: dpooled)
+  float* pooled;
+  double* stats;
+  int act;
+  int M, C, HW;
+  float inv_hw;
+};
+
+__device__ __forceinline__ void load_affine(const EwArgs& a, int c0, float sc[8], float sh[8]) {
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    sc[i] = a.scale ? a.scale[c0 + i] : 1.f;
+    sh[i] = a.scale ? a.shift[c0 + i] : 0.f;
+  }
+}
+
+// block-level merge of per-thread (sum, sumsq-like) pairs for a fixed channel group per thread
+__device__ __forceinline__ void flush_stats(float* lstat, int C, int c0, bool on, const float s1[8],
+                                            const float s2[8], double* stats) {
+  for (int i = threadIdx.x; i < 2 * C; i += blockDim.x) lstat[i] = 0.f;
+  __syncthreads();
+  if (on) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      atomicAdd(lstat + c0 + i, s1[i]);
+      atomicAdd(lstat + C + c0 + i, s2[i]);
+    }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 2 * C; i += blockDim.x) atomicAdd(stats + i, (double)lstat[i]);
+}
+
+// z = act(scale*y + shift) + res
+template <typename T>
+__global__ __launch_bounds__(256) void bn_apply_kernel(const EwArgs a) {
+  const int CG = a.C / 8;
+  const size_t nvec = (size_t)a.M * CG;
+  const T* __restrict__ y = reinterpret_cast<const T*>(a.a);
+  const T* __restrict__ r = reinterpret_cast<const T*>(a.res);
+  T* __restrict__ z = reinterpret_cast<T*>(a.out);
+  // stride is a multiple of CG -> each thread keeps one channel group
+  const size_t nthr = ((size_t)gridDim.x * 256 / CG) * CG;
+  const size_t g = blockIdx.x * (size_t)256 + threadIdx.x;
+  if (g >= nthr) return;
+  const int c0 = (int)(g % CG) * 8;
+  float sc[8], sh[8];
+  load_affine(a, c0, sc, sh);
+  for (size_t i = g; i < nvec; i += nthr) {
+    float v[8];
+    Vec8<T>::load(y + i * 8, v);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = act_apply(v[j] * sc[j] + sh[j], a.act);
+    if (r) {
+      float rr[8];
+      Vec8<T>::load(r + i * 8, rr);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] += rr[j];
+    }
+    Vec8<T>::store(z + i * 8, v);
+  }
+}
+
+// dzp = dz * act'(scale*y + shift), stats += sum(dzp), sum(dzp*y)
+template <typename T>
+__global__ __launch_bounds__(256) void bn_act_bwd_kernel(const EwArgs a) {
+  extern __shared__ float lstat[];
+  const int CG = a.C / 8;
+  const size_t nvec = (size_t)a.M * CG;
+  const T* __restrict__ dz = reinterpret_cast<const T*>(a.a);
+  const T* __restrict__ y = reinterpret_cast<const T*>(a.b);
+  T* __restrict__ o = reinterpret_cast<T*>(a.out);
+  const size_t nthr = ((size_t)gridDim.x * 256 / CG) * CG;
+  const size_t g = blockIdx.x * (size_t)256 + threadIdx.x;
+  const bool on = g < nthr;
+  const int c0 = (int)(g % CG) * 8;
+  float sc[8], sh[8], s1[8], s2[8];
+  load_affine(a, c0, sc, sh);
+#pragma unroll
+  for (int j = 0; j < 8; ++j) s1[j] = s2[j] = 0.f;
+  if (on) {
+    for (size_t i = g; i < nvec; i += nthr) {
+      float d[8], yv[8];
+      Vec8<T>::load(dz + i * 8, d);
+      Vec8<T>::load(y + i * 8, yv);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float v = Vec8<T>::round(d[j] * act_grad(yv[j] * sc[j] + sh[j], a.act));
+        d[j] = v;
+        s1[j] += v;
+        s2[j] = fmaf(v, yv[j], s2[j]);
+      }
+      Vec8<T>::store(o + i * 8, d);
+    }
+  }
+  if (a.stats) flush_stats(lstat, a.C, c0, on, s1, s2, a.stats);
+}
+
+// pooled[b][c] = mean_hw act(scale*y + shift);   grid (B, ceil(CG/32)), block 256 = 32 groups x 8 hw slots
+template <typename T>
+__global__ __launch_bounds__(256) void gap_fwd_kernel(const EwArgs a) {
+  __shared__ float red[8][32 * 8];
+  const int CG = a.C / 8, b = blockIdx.x;
+  const int cgl = threadIdx.x & 31, slot = threadIdx.x >> 5;
+  const int cg = blockIdx.y * 32 + cgl;
+  const bool on = cg < CG;
+  const int c0 = on ? cg * 8 : 0;
+  const T* __restrict__ y = reinterpret_cast<const T*>(a.a);
+  float sc[8], sh[8], acc[8];
+  load_affine(a, c0, sc, sh);
+#pragma unroll
+  for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+  if (on) {
+    for (int hw = slot; hw < a.HW; hw += 8) {
+      float v[8];
+      Vec8<T>::load(y + ((size_t)b * a.HW + hw) * a.C + c0, v);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc[j] += act_apply(v[j] * sc[j] + sh[j], a.act);
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 8; ++j) red[slot][cgl * 8 + j] = acc[j];
+  __syncthreads();
+  const int t = threadIdx.x;  // 256 = 32 groups x 8 channels
+  const int c = blockIdx.y * 256 + t;
+  if (c < a.C) {
+    float s = 0.f;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) s += red[q][t];
+    a.pooled[(size_t)b * a.C + c] = s * a.inv_hw;
+  }
+}
+
+// dz[b][hw][c] = dpooled[b][c]/HW * act'(scale*y+shift); stats.  grid (nb, ceil(CG/32)): block loops over samples
+template <typename T>
+__global__ __launch_bounds__(256) void gap_bwd_kernel(const EwArgs a, int B) {
+  __shared__ float red[2][8][32 * 8];
+  const int CG = a.C / 8;
+  const int cgl = threadIdx.x & 31, slot = threadIdx.x >> 5;
+  const int cg = blockIdx.y * 32 + cgl;
+  const bool on = cg < CG;
+  const int c0 = on ? cg * 8 : 0;
+  const T* __restrict__ y = reinterpret_cast<const T*>(a.a);
+  T* __restrict__ dz = reinterpret_cast<T*>(a.out);
+  float sc[8], sh[8], s1[8], s2[8];
+  load_affine(a, c0, sc, sh);
+#pragma unroll
+  for (int j = 0; j < 8; ++j) s1[j] = s2[j] = 0.f;
+  if (on) {
+    for (int b = blockIdx.x; b < B; b += gridDim.x) {
+      float dp[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) dp[j] = a.vec[(size_t)b * a.C + c0 + j] * a.inv_hw;
+      for (int hw = slot; hw < a.HW; hw += 8) {
+        const size_t off = ((size_t)b * a.HW + hw) * a.C + c0;
+        float v[8], d[8];
+        Vec8<T>::load(y + off, v);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          d[j] = Vec8<T>::round(dp[j] * act_grad(v[j] * sc[j] + sh[j], a.act));
+          s1[j] += d[j];
+          s2[j] = fmaf(d[j], v[j], s2[j]);
+        }
+        Vec8<T>::store(dz + off, d);
+      }
+    }
+  }
+  if (a.stats) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      red[0][slot][cgl * 8 + j] = s1[j];
+      red[1][slot][cgl * 8 + j] = s2[j];
+    }
+    __syncthreads();
+    const int t = threadIdx.x, c = blockIdx.y * 256 + t;
+    if (c < a.C) {
+      double u1 = 0.0, u2 = 0.0;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        u1 += (double)red[0][q][t];
+        u2 += (double)red[1][q][t];
+      }
+      atomicAdd(a.stats + c, u1);
+      atomicAdd(a.stats + a.C + c, u2);
+    }
+  }
+}
+
+inline void fill_pro(EwArgs& a, const t3d_prologue* pro) {
+  if (pro) { a.scale = pro->scale; a.shift = pro->shift; a.act = pro->act; }
+}
+inline int ew_grid(size_t nvec) {
+  size_t g = (nvec + 255) / 256;
+  return (int)(g < 1 ? 1 : (g > 2048 ? 2048 : g));
+}
+
+}  // namespace
+
+extern "C" int t3d_stem_im2col(int dtype, const float* x, void* col, int B, int H, int W, void* stream) {
+  if (!x || !col || B <= 0 || H <= 0 || W <= 0) return T3D_ERR_ARG;
+  const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
+  const size_t npix = (size_t)B * Ho * Wo;
+  const int grid = (int)((npix + 255) / 256 > 8192 ? 8192 : (npix + 255) / 256);
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (dtype == T3D_F32)
+    hipLaunchKernelGGL(im2col_kernel<float>, dim3(grid), dim3(256), 0, st, x, (float*)col, B, H, W, Ho, Wo);
+  else if (dtype == T3D_BF16)
+    hipLaunchKernelGGL(im2col_kernel<bf16_t>, dim3(grid), dim3(256), 0, st, x, (bf16_t*)col, B, H, W, Ho, Wo);
+  else
+    return T3D_ERR_ARG;
+  T3D_CHECK_LAUNCH();
+  return T3D_OK;
+}
+
+extern "C" int t3d_bn_apply(int dtype, const void* y, const t3d_prologue* pro, const void* residual, void* z,
+                            int M, int C, void* stream) {
+  if (!y || !z || M <= 0 || C <= 0 || (C % 8)) return T3D_ERR_ARG;
+  if (pro && pro->se) return T3D_ERR_UNSUPPORTED;
+  EwArgs a{};
+  a.a = y; a.res = residual; a.out = z; a.M = M; a.C = C;
+  fill_pro(a, pro);
+  const int grid = ew_grid((size_t)M * (C / 8));
+  if ((size_t)grid * 256 < (size_t)(C / 8)) return T3D_ERR_UNSUPPORTED;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (dtype == T3D_F32) hipLaunchKernelGGL(bn_apply_kernel<float>, dim3(grid), dim3(256), 0, st, a);
+  else if (dtype == T3D_BF16) hipLaunchKernelGGL(bn_apply_kernel<bf16_t>, dim3(grid), dim3(256), 0, st, a);
+  else return T3D_ERR_ARG;
+  T3D_CHECK_LAUNCH();
+  return T3D_OK;
+}
+
+extern "C" int t3d_bn_act_bwd(int dtype, const void* dz, const void* y, const t3d_prologue* pro, void* dzp,
+                              double* stats, int M, int C, void* stream) {
+  if (!dz || !y || !dzp || M <= 0 || C <= 0 || (C % 8)) return T3D_ERR_ARG;
+  if (pro && pro->se) return T3D_ERR_UNSUPPORTED;
+  EwArgs a{};
+  a.a = dz; a.b = y; a.out = dzp; a.stats = stats; a.M = M; a.C = C;
+  fill_pro(a, pro);
+  int grid = ew_grid((size_t)M * (C / 8));
+  if (grid > 1024) grid = 1024;
+  if ((size_t)grid * 256 < (size_t)(C / 8)) return T3D_ERR_UNSUPPORTED;
+  const size_t lds = (size_t)2 * C * sizeof(float);
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (dtype == T3D_F32) hipLaunchKernelGGL(bn_act_bwd_kernel<float>, dim3(grid), dim3(256), lds, st, a);
+  else if (dtype == T3D_BF16) hipLaunchKernelGGL(bn_act_bwd_kernel<bf16_t>, dim3(grid), dim3(256), lds, st, a);
+  else return T3D_ERR_ARG;
+  T3D_CHECK_LAUNCH();
+  return T3D_OK;
+}
+
+extern "C" int t3d_gap_fwd(int dtype, const void* y, const t3d_prologue* pro, float* pooled, int B, int HW, int C,
+                           void* stream) {
+  if (!y || !pooled || B <= 0 || HW <= 0 || C <= 0 || (C % 8)) return T3D_ERR_ARG;
+  if (pro && pro->se) return T3D_ERR_UNSUPPORTED;
+  EwArgs a{};
+  a.a = y; a.pooled = pooled; a.C = C; a.HW = HW; a.inv_hw = 1.f / (float)HW;
+  fill_pro(a, pro);
+  dim3 grid(B, cdiv(C / 8, 32));
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (dtype == T3D_F32) hipLaunchKernelGGL(gap_fwd_kernel<float>, grid, dim3(256), 0, st, a);
+  else if (dtype == T3D_BF16) hipLaunchKernelGGL(gap_fwd_kernel<bf16_t>, grid, dim3(256), 0, st, a);
+  else return T3D_ERR_ARG;
+  T3D_CHECK_LAUNCH();
+  return T3D_OK;
+}
+
+extern "C" int t3d_gap_bwd(int dtype, const float* dpooled, const void* y, const t3d_prologue* pro, void* dz,
+                           double* stats, int B, int HW, int C, void* stream) {
+  if (!dpooled || !y || !dz || B <= 0 || HW <= 0 || C <= 0 || (C % 8)) return T3D_ERR_ARG;
+  if (pro && pro->se) return T3D_ERR_UNSUPPORTED;
+  EwArgs a{};
+  a.a = y; a.vec = dpooled; a.out = dz; a.stats = stats; a.C = C; a.HW = HW; a.inv_hw = 1.f / (float)HW;
+  fill_pro(a, pro);
+  dim3 grid(B < 256 ? B : 256, cdiv(C / 8, 32));
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (dtype == T3D_F32) hipLaunchKernelGGL(gap_bwd_kernel<float>, grid, dim3(256), 0, st, a, B);
+  else if (dtype == T3D_BF16) hipLaunchKernelGGL(gap_bwd_kernel<bf16_t>, grid, dim3(256), 0, st, a, B);
+  else return T3D_ERR_ARG;
+  T3D_CHECK_LAUNCH();
+  return T3D_OK;
+}

@@ -1,0 +1,193 @@
+// Per-class 9-keypoint regression heads + class head (fp32; ModelWrapper.forward,
+// torchdet3d/builders/model_builder.py:126-146) as wavefront reductions.
+//
+// The reference runs a Python loop of B GEMVs (`regressors[c](sample)`, :137).  Here one
+// workgroup per sample stages the (activated) feature vector in LDS once, and each wave
+// produces rows of the class-selected 18 x F matrix (and of the class head) as a 64-lane dot
+// product + wave reduction.  The head weights (9*18*F + ncls*F floats, <1 MB) stay L2-resident.
+// Backward: data gradient per sample (thread = feature column, coalesced weight reads);
+// weight gradient as a deterministic segmented reduction over the batch (thread = feature
+// column, block = (class, column chunk)), no atomics.
+#include "common.h"
+
+namespace {
+
+constexpr int NKP = 18;  // 9 keypoints x (x, y)
+
+struct HeadArgs {
+  const float* f;
+  const float *scale, *shift;
+  int act;
+  const int64_t* cats;
+  const float *wreg, *breg, *wcls, *bcls, *mask;
+  float *kp, *logits;
+  const float *kpin, *dkp, *dlogits;
+  float *dpre, *df;
+  double* stats;
+  float *dwreg, *dbreg, *dwcls, *dbcls;
+  int B, F, ncls;
+};
+
+__device__ __forceinline__ float feat(const HeadArgs& a, int b, int j) {
+  const float v = a.f[(size_t)b * a.F + j];
+  return a.scale ? act_apply(v * a.scale[j] + a.shift[j], a.act) : v;
+}
+
+__global__ __launch_bounds__(256) void head_fwd_kernel(const HeadArgs a) {
+  extern __shared__ float fs[];  // [F] activated features, [F] masked features
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  float* fm = fs + a.F;
+  for (int j = tid; j < a.F; j += 256) {
+    const float v = feat(a, b, j);
+    fs[j] = v;
+    fm[j] = a.mask ? v * a.mask[(size_t)b * a.F + j] : v;
+  }
+  __syncthreads();
+  int c = (int)a.cats[b];
+  c = c < 0 ? 0 : (c > 8 ? 8 : c);
+  const int nrows = NKP + (a.logits ? a.ncls : 0);
+  for (int r = wave; r < nrows; r += 4) {
+    const bool reg = r < NKP;
+    const float* w = reg ? a.wreg + ((size_t)c * NKP + r) * a.F : a.wcls + (size_t)(r - NKP) * a.F;
+    const float* x = reg ? fs : fm;
+    float s = 0.f;
+    for (int j = lane; j < a.F; j += 64) s = fmaf(w[j], x[j], s);
+    s = wave_sum(s);
+    if (lane == 0) {
+      if (reg) {
+        s += a.breg[c * NKP + r];
+        a.kp[(size_t)b * NKP + r] = 1.f / (1.f + expf(-s));
+      } else {
+        a.logits[(size_t)b * a.ncls + (r - NKP)] = s + a.bcls[r - NKP];
+      }
+    }
+  }
+}
+
+// data gradient: one block per sample
+__global__ __launch_bounds__(256) void head_bwd_data_kernel(const HeadArgs a) {
+  __shared__ float dp[NKP];
+  __shared__ float dl[64];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  if (tid < NKP) {
+    const float k = a.kpin[(size_t)b * NKP + tid];
+    const float v = a.dkp[(size_t)b * NKP + tid] * k * (1.f - k);  // sigmoid'
+    dp[tid] = v;
+    a.dpre[(size_t)b * NKP + tid] = v;
+  }
+  if (tid >= 64 && tid < 64 + a.ncls && a.dlogits) dl[tid - 64] = a.dlogits[(size_t)b * a.ncls + tid - 64];
+  __syncthreads();
+  int c = (int)a.cats[b];
+  c = c < 0 ? 0 : (c > 8 ? 8 : c);
+  const float* wr = a.wreg + (size_t)c * NKP * a.F;
+  for (int j = tid; j < a.F; j += 256) {
+    float g = 0.f;
+#pragma unroll
+    for (int r = 0; r < NKP; ++r) g = fmaf(dp[r], wr[(size_t)r * a.F + j], g);
+    if (a.dlogits) {
+      float gc = 0.f;
+      for (int q = 0; q < a.ncls; ++q) gc = fmaf(dl[q], a.wcls[(size_t)q * a.F + j], gc);
+      g += a.mask ? gc * a.mask[(size_t)b * a.F + j] : gc;
+    }
+    if (a.scale) {
+      const float raw = a.f[(size_t)b * a.F + j];
+      g *= act_grad(raw * a.scale[j] + a.shift[j], a.act);  // gradient at the BatchNorm1d output
+      if (a.stats) {
+        atomicAdd(a.stats + j, (double)g);
+        atomicAdd(a.stats + a.F + j, (double)g * (double)raw);
+      }
+    }
+    a.df[(size_t)b * a.F + j] = g;
+  }
+}
+
+// weight gradient: grid (10, ceil(F/256)); blockIdx.x < 9: regressor of that class, == 9: class head
+__global__ __launch_bounds__(256) void head_bwd_weight_kernel(const HeadArgs a) {
+  const int cls = blockIdx.x, j = blockIdx.y * 256 + threadIdx.x;
+  const bool jon = j < a.F;
+  if (cls < 9) {
+    float acc[NKP], bacc = 0.f;
+#pragma unroll
+    for (int r = 0; r < NKP; ++r) acc[r] = 0.f;
+    const bool bias_thread = (blockIdx.y == 0 && threadIdx.x < NKP);
+    for (int b = 0; b < a.B; ++b) {
+      int c = (int)a.cats[b];
+      c = c < 0 ? 0 : (c > 8 ? 8 : c);
+      if (c != cls) continue;  // block-uniform
+      const float x = jon ? feat(a, b, j) : 0.f;
+#pragma unroll
+      for (int r = 0; r < NKP; ++r) acc[r] = fmaf(a.dpre[(size_t)b * NKP + r], x, acc[r]);
+      if (bias_thread) bacc += a.dpre[(size_t)b * NKP + threadIdx.x];
+    }
+    if (jon) {
+#pragma unroll
+      for (int r = 0; r < NKP; ++r) a.dwreg[((size_t)cls * NKP + r) * a.F + j] = acc[r];
+    }
+    if (bias_thread) a.dbreg[cls * NKP + threadIdx.x] = bacc;
+  } else if (a.dlogits && a.dwcls) {
+    for (int q0 = 0; q0 < a.ncls; q0 += 16) {
+      float acc[16];
+#pragma unroll
+      for (int q = 0; q < 16; ++q) acc[q] = 0.f;
+      for (int b = 0; b < a.B; ++b) {
+        float x = jon ? feat(a, b, j) : 0.f;
+        if (a.mask && jon) x *= a.mask[(size_t)b * a.F + j];
+#pragma unroll
+        for (int q = 0; q < 16; ++q)
+          if (q0 + q < a.ncls) acc[q] = fmaf(a.dlogits[(size_t)b * a.ncls + q0 + q], x, acc[q]);
+      }
+      if (jon) {
+#pragma unroll
+        for (int q = 0; q < 16; ++q)
+          if (q0 + q < a.ncls) a.dwcls[(size_t)(q0 + q) * a.F + j] = acc[q];
+      }
+    }
+    if (blockIdx.y == 0 && threadIdx.x < a.ncls) {
+      float s = 0.f;
+      for (int b = 0; b < a.B; ++b) s += a.dlogits[(size_t)b * a.ncls + threadIdx.x];
+      a.dbcls[threadIdx.x] = s;
+    }
+  }
+}
+
+inline void fill(HeadArgs& a, const t3d_prologue* pro) {
+  if (pro) { a.scale = pro->scale; a.shift = pro->shift; a.act = pro->act; }
+}
+
+}  // namespace
+
+extern "C" int t3d_head_fwd(const float* f, const t3d_prologue* pro, const int64_t* cats, const float* wreg,
+                            const float* breg, const float* wcls, const float* bcls, const float* mask, float* kp,
+                            float* logits, int B, int F, int ncls, void* stream) {
+  if (!f || !cats || !wreg || !breg || !kp || B <= 0 || F <= 0) return T3D_ERR_ARG;
+  if (logits && (!wcls || !bcls || ncls <= 0 || ncls > 64)) return T3D_ERR_ARG;
+  if (pro && pro->se) return T3D_ERR_UNSUPPORTED;
+  HeadArgs a{};
+  a.f = f; a.cats = cats; a.wreg = wreg; a.breg = breg; a.wcls = wcls; a.bcls = bcls; a.mask = mask;
+  a.kp = kp; a.logits = logits; a.B = B; a.F = F; a.ncls = ncls;
+  fill(a, pro);
+  hipLaunchKernelGGL(head_fwd_kernel, dim3(B), dim3(256), (size_t)2 * F * sizeof(float),
+                     reinterpret_cast<hipStream_t>(stream), a);
+  T3D_CHECK_LAUNCH();
+  return T3D_OK;
+}
+
+extern "C" int t3d_head_bwd(const float* f, const t3d_prologue* pro, const int64_t* cats, const float* wreg,
+                            const float* wcls, const float* mask, const float* kp, const float* dkp,
+                            const float* dlogits, float* dpre, float* df, double* stats, float* dwreg,
+                            float* dbreg, float* dwcls, float* dbcls, int B, int F, int ncls, void* stream) {
+  if (!f || !cats || !wreg || !kp || !dkp || !dpre || !df || !dwreg || !dbreg || B <= 0 || F <= 0)
+    return T3D_ERR_ARG;
+  if (dlogits && (!wcls || !dwcls || !dbcls || ncls <= 0 || ncls > 64)) return T3D_ERR_ARG;
+  if (pro && pro->se) return T3D_ERR_UNSUPPORTED;
+  HeadArgs a{};
+  a.f = f; a.cats = cats; a.wreg = wreg; a.wcls = wcls; a.mask = mask; a.kpin = kp; a.dkp = dkp;
+  a.dlogits = dlogits; a.dpre = dpre; a.df = df; a.stats = stats; a.dwreg = dwreg; a.dbreg = dbreg;
+  a.dwcls = dwcls; a.dbcls = dbcls; a.B = B; a.F = F; a.ncls = ncls;
+  fill(a, pro);
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  hipLaunchKernelGGL(head_bwd_data_kernel, dim3(B), dim3(256), 0, st, a);
+  hipLaunchKernelGGL(head_bwd_weight_kernel, dim3(10, cdiv(F, 256)), dim3(256), 0, st, a);
+  T3D_CHECK_LAUNCH();
+  return T3D_OK;
+}

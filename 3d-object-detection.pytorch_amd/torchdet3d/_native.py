@@ -24,8 +24,14 @@ class Prologue(ctypes.Structure):
     _fields_ = [('scale', _P), ('shift', _P), ('se', _P), ('act', _I), ('se_after_act', _I)]
 
 
+class LossCfg(ctypes.Structure):
+    _fields_ = [(n, _F) for n in ('c_l1', 'c_mse', 'c_smoothl1', 'smoothl1_beta', 'c_add', 'c_diag', 'c_wing',
+                                  'wing_w', 'wing_eps', 'c_ce', 'lam_reg', 'lam_cls')]
+
+
 _PP = ctypes.POINTER(Prologue)
 _BP = ctypes.POINTER(BnBwd)
+_LP = ctypes.POINTER(LossCfg)
 
 # name -> argtypes (restype is always int); mirrors include/t3d.h one to one
 SIGNATURES = {
@@ -38,6 +44,15 @@ SIGNATURES = {
     't3d_pack_weight': [_I, _P, _P, _I, _I, _I, _P],
     't3d_dwconv_bwd': [_I, _P, _P, _BP, _P, _P, _PP, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
     't3d_pwconv_wgrad': [_I, _P, _P, _BP, _P, _PP, _P, _I, _I, _I, _I, _P],
+    't3d_bn_bwd_finalize': [_P, _I, _D, _P, _P, _P, _P, _P, _P, _P, _P, _P],
+    't3d_stem_im2col': [_I, _P, _P, _I, _I, _I, _P],
+    't3d_bn_apply': [_I, _P, _PP, _P, _P, _I, _I, _P],
+    't3d_bn_act_bwd': [_I, _P, _P, _PP, _P, _P, _I, _I, _P],
+    't3d_gap_fwd': [_I, _P, _PP, _P, _I, _I, _I, _P],
+    't3d_gap_bwd': [_I, _P, _P, _PP, _P, _P, _I, _I, _I, _P],
+    't3d_head_fwd': [_P, _PP, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P],
+    't3d_head_bwd': [_P, _PP, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P],
+    't3d_loss_fwd_bwd': [_LP, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P],
 }
 
 _lib = None

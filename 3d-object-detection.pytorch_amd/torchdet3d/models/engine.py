@@ -1,0 +1,495 @@
+"""Execution engine of the regression network on MI355X: chains the C-ABI HIP kernels
+(include/t3d.h) into the forward and the hand-derived backward of
+
+    crops -> stem -> InvertedResidual x N -> 1x1 conv -> global pool [-> classifier] -> heads
+
+i.e. `MobileNetV3.extract_features` (torchdet3d/models/mobilenetv3.py:199-203) +
+`ModelWrapper.forward` (torchdet3d/builders/model_builder.py:126-146) and their autograd.
+
+Data layout in HBM
+  * activations are NHWC, stored as 2-D [B*H*W, C] in the storage dtype (fp32 parity mode or
+    bf16 throughput mode); every convolution stores its RAW (pre-BatchNorm) output once and
+    emits the BatchNorm batch sums from its epilogue; the consumer applies
+    `act(scale*y + shift)` (and the squeeze-excite gate) on load, so BatchNorm, activation and
+    SE never cost a pass over HBM.  Only the narrow block outputs are materialised
+    (`t3d_bn_apply`: BatchNorm + skip connection).
+  * backward mirrors this: a gradient-producing kernel stores the gradient at the producer's
+    BatchNorm OUTPUT together with sum(dz), sum(dz*y); `t3d_bn_bwd_finalize` turns those into
+    the affine  dy = alpha*dz + beta*y + gamma  that the wgrad / dgrad kernels apply on load.
+  * all learnable parameters live in ONE flat fp32 buffer (`flat`), their gradients in a second
+    (`gflat`): one fused optimizer update, one RCCL all-reduce bucket list; the state-dict
+    tensors are views into it.
+There is no fallback: every op goes through libt3d_hip.so or raises.
+"""
+import math
+
+import torch
+
+from .. import _native as N
+from .arch import Arch
+
+BN_EPS, BN_MOM = 1e-5, 0.1      # PyTorch defaults the reference relies on
+
+
+class _BN:
+    """Per-BatchNorm bookkeeping: parameter views + per-step scratch slices."""
+    __slots__ = ('name', 'C', 'gamma', 'beta', 'dgamma', 'dbeta', 'rm', 'rv', 'nbt', 'stats', 'bstats', 'scale',
+                 'shift', 'mean', 'invstd', 'alpha', 'bbeta', 'gammac', 'count', 'pro_cache')
+
+
+class _Src:
+    """A tensor as a consumer sees it: `t` [M,C] + how to read it (`pro`), and, for the backward,
+    the raw producer tensor / BatchNorm its gradient must be reported against."""
+    __slots__ = ('t', 'pro', 'B', 'H', 'W', 'C', 'raw', 'bn', 'gpro', 'finished_act', 'dz')
+
+    def __init__(self, t, pro, B, H, W, C, raw=None, bn=None, gpro=None, finished_act=False):
+        self.t, self.pro, self.B, self.H, self.W, self.C = t, pro, B, H, W, C
+        self.raw, self.bn, self.gpro, self.finished_act = raw, bn, gpro, finished_act
+        self.dz = None
+
+
+class Net:
+    def __init__(self, name, num_classes=9, device='cuda', dtype=torch.float32):
+        self.arch = Arch(name)
+        self.name, self.num_classes = name, num_classes
+        self.device = torch.device(device)
+        assert dtype in (torch.float32, torch.bfloat16)
+        self.dtype = dtype
+        self.dt = N.F32 if dtype == torch.float32 else N.BF16
+        self._layout()
+        self._bufs = {}
+        self._packed_dirty = True
+        self.saved = None
+
+    # ------------------------------------------------------------------ parameters
+    def _layout(self):
+        a = self.arch
+        shapes = a.param_shapes(self.num_classes)
+        self.shapes = shapes
+        # flat order: everything in state-dict order, except the 9 regressors which are packed as
+        # [9,18,F] weights + [9,18] biases so the head kernel indexes them by class
+        order = [k for k, (s, kind) in shapes.items() if kind == 'param' and not k.startswith('regressors.')]
+        off, self.offsets = 0, {}
+        for k in order:
+            n = int(math.prod(shapes[k][0]))
+            self.offsets[k] = (off, n)
+            off += (n + 3) // 4 * 4          # keep every tensor 16-B aligned
+        F = a.feat_c
+        self.offsets['__wreg'] = (off, 9 * 18 * F)
+        off += 9 * 18 * F
+        self.offsets['__breg'] = (off, 9 * 18 + 2)
+        off += 164
+        for k in range(9):
+            self.offsets[f'regressors.{k}.0.weight'] = (self.offsets['__wreg'][0] + k * 18 * F, 18 * F)
+            self.offsets[f'regressors.{k}.0.bias'] = (self.offsets['__breg'][0] + k * 18, 18)
+        self.nparams = off
+        dev = self.device
+        self.flat = torch.zeros(off, device=dev)
+        self.gflat = torch.zeros(off, device=dev)
+        self.p, self.g = {}, {}
+        for k, (s, kind) in shapes.items():
+            if kind == 'param':
+                o, n = self.offsets[k]
+                self.p[k] = self.flat[o:o + n].view(s)
+                self.g[k] = self.gflat[o:o + n].view(s)
+        self.wreg, self.breg = self._view('__wreg', (9, 18, F)), self._view('__breg', (9, 18), 162)
+        self.dwreg = self._view('__wreg', (9, 18, F), g=True)
+        self.dbreg = self._view('__breg', (9, 18), 162, g=True)
+        # buffers
+        self.buffers = {}
+        self.bns = {}
+        for k, (s, kind) in shapes.items():
+            if kind == 'buffer':
+                self.buffers[k] = (torch.zeros(s, device=dev, dtype=torch.int64) if k.endswith('tracked')
+                                   else (torch.ones(s, device=dev) if k.endswith('var') else torch.zeros(s, device=dev)))
+        nbn = [k[:-len('.running_mean')] for k in shapes if k.endswith('.running_mean')]
+        tot = sum(shapes[k + '.weight'][0][0] for k in nbn)
+        self._statbuf = torch.zeros(4 * tot, device=dev, dtype=torch.float64)     # fwd sums | bwd sums
+        self._aff = torch.zeros(7 * tot, device=dev)                            # scale shift mean invstd alpha beta gammac
+        o = 0
+        for k in nbn:
+            C = shapes[k + '.weight'][0][0]
+            b = _BN()
+            b.name, b.C = k, C
+            b.gamma, b.beta = self.p[k + '.weight'], self.p[k + '.bias']
+            b.dgamma, b.dbeta = self.g[k + '.weight'], self.g[k + '.bias']
+            b.rm, b.rv, b.nbt = self.buffers[k + '.running_mean'], self.buffers[k + '.running_var'], \
+                self.buffers[k + '.num_batches_tracked']
+            b.stats = self._statbuf[2 * o:2 * o + 2 * C]
+            b.bstats = self._statbuf[2 * tot + 2 * o:2 * tot + 2 * o + 2 * C]
+            sl = [self._aff[i * tot + o:i * tot + o + C] for i in range(7)]
+            b.scale, b.shift, b.mean, b.invstd, b.alpha, b.bbeta, b.gammac = sl
+            b.pro_cache = {}
+            self.bns[k] = b
+            o += C
+        self._bn_total = tot
+        self.reset_parameters()
+
+    def _view(self, key, shape, n=None, g=False):
+        o, m = self.offsets[key]
+        return (self.gflat if g else self.flat)[o:o + (n or m)].view(shape)
+
+    @torch.no_grad()
+    def reset_parameters(self, seed=None):
+        """Initialisation of the reference: mobilenetv3.py:205-218 for the backbone (conv N(0, sqrt(2/(k*k*Cout))),
+        BN 1/0, Linear N(0, .01)/0), PyTorch's default Linear init for the heads added afterwards by
+        ModelWrapper (model_builder.py:79-85)."""
+        gen = torch.Generator(device='cpu')
+        if seed is not None:
+            gen.manual_seed(seed)
+        for k, (s, kind) in self.shapes.items():
+            if kind != 'param':
+                continue
+            if k.startswith('regressors') or k.startswith('cls_fc'):
+                bound = 1.0 / math.sqrt(self.arch.feat_c)
+                v = (torch.rand(s, generator=gen) * 2 - 1) * bound
+            elif len(s) == 4:
+                v = torch.randn(s, generator=gen) * math.sqrt(2.0 / (s[2] * s[3] * s[0]))
+            elif len(s) == 2:
+                v = torch.randn(s, generator=gen) * 0.01
+            elif k.endswith('.bias'):
+                v = torch.zeros(s)
+            else:
+                v = torch.ones(s)
+            self.p[k].copy_(v)
+        self._packed_dirty = True
+
+    def state_dict(self):
+        out = {}
+        for k, (s, kind) in self.shapes.items():
+            out[k] = (self.p[k] if kind == 'param' else self.buffers[k]).detach().clone()
+        return out
+
+    @torch.no_grad()
+    def load_state_dict(self, sd, strict=True):
+        missing = [k for k in self.shapes if k not in sd]
+        if strict and missing:
+            raise RuntimeError(f'missing keys: {missing[:5]}...')
+        for k, v in sd.items():
+            if k not in self.shapes:
+                if strict:
+                    raise RuntimeError(f'unexpected key {k}')
+                continue
+            dst = self.p[k] if self.shapes[k][1] == 'param' else self.buffers[k]
+            dst.copy_(torch.as_tensor(v).to(dst.device, dst.dtype).view(dst.shape))
+        self._packed_dirty = True
+
+    # ------------------------------------------------------------------ scratch
+    def _buf(self, tag, shape, dtype=None, zero=False):
+        dtype = dtype or self.dtype
+        key = (tag, tuple(shape), dtype)
+        t = self._bufs.get(key)
+        if t is None:
+            t = torch.empty(shape, device=self.device, dtype=dtype)
+            self._bufs[key] = t
+            if zero:
+                t.zero_()
+        elif zero:
+            t.zero_()
+        return t
+
+    def _pack(self):
+        """fp32 master weights -> storage dtype (+ transposed copies for the data-gradient GEMMs)."""
+        if not self._packed_dirty:
+            return
+        st = N.stream()
+        self.w, self.wt = {}, {}
+        for k, (s, kind) in self.shapes.items():
+            if kind != 'param' or len(s) != 4 or s[2] != 1:
+                continue
+            n, kk = s[0], s[1]
+            src = self.p[k]
+            if self.dt == N.F32:
+                self.w[k] = src
+            else:
+                self.w[k] = self._buf('w:' + k, (n, kk))
+                N.call('t3d_pack_weight', self.dt, N.ptr(src), N.ptr(self.w[k]), n, kk, 0, st)
+            self.wt[k] = self._buf('wt:' + k, (kk, n))
+            N.call('t3d_pack_weight', self.dt, N.ptr(src), N.ptr(self.wt[k]), n, kk, 1, st)
+        # stem: [C,3,3,3] -> [C,32] patch-row weights (columns 27..31 zero)
+        c0 = self.arch.stem_c
+        w32 = self._buf('stem32', (c0, 32), torch.float32, zero=True)
+        w32[:, :27] = self.p['features.0.0.weight'].view(c0, 27)
+        if self.dt == N.F32:
+            self.w['stem'] = w32
+        else:
+            self.w['stem'] = self._buf('w:stem', (c0, 32))
+            N.call('t3d_pack_weight', self.dt, N.ptr(w32), N.ptr(self.w['stem']), c0, 32, 0, st)
+        if self.arch.classifier:
+            wc = self.p['classifier.0.weight']
+            self.wt['classifier'] = self._buf('wt:cls', (wc.shape[1], wc.shape[0]), torch.float32)
+            N.call('t3d_pack_weight', N.F32, N.ptr(wc), N.ptr(self.wt['classifier']), wc.shape[0], wc.shape[1], 1, st)
+        self._packed_dirty = False
+
+    # ------------------------------------------------------------------ BatchNorm helpers
+    def _bn_fwd(self, bn, count, act):
+        """Batch sums -> consumer affine (train) or running estimates -> affine (eval)."""
+        st = N.stream()
+        if self.training:
+            bn.count = float(count)
+            N.call('t3d_bn_finalize', N.ptr(bn.stats), bn.C, float(count), N.ptr(bn.gamma), N.ptr(bn.beta),
+                   N.ptr(bn.rm), N.ptr(bn.rv), N.ptr(bn.nbt), BN_MOM, BN_EPS, N.ptr(bn.scale), N.ptr(bn.shift),
+                   N.ptr(bn.mean), N.ptr(bn.invstd), st)
+        else:
+            N.call('t3d_bn_eval_affine', bn.C, N.ptr(bn.gamma), N.ptr(bn.beta), N.ptr(bn.rm), N.ptr(bn.rv), BN_EPS,
+                   N.ptr(bn.scale), N.ptr(bn.shift), st)
+        return self._pro(bn, act)
+
+    def _pro(self, bn, act, se=None, se_after=False):
+        if se is None:
+            p = bn.pro_cache.get(act)
+            if p is None:
+                p = bn.pro_cache[act] = N.prologue(bn.scale, bn.shift, None, act, False)
+            return p
+        return N.prologue(bn.scale, bn.shift, se, act, se_after)
+
+    def _bn_bwd(self, bn):
+        N.call('t3d_bn_bwd_finalize', N.ptr(bn.bstats), bn.C, bn.count, N.ptr(bn.gamma), N.ptr(bn.mean),
+               N.ptr(bn.invstd), N.ptr(bn.alpha), N.ptr(bn.bbeta), N.ptr(bn.gammac), N.ptr(bn.dgamma),
+               N.ptr(bn.dbeta), N.stream())
+        return N.bnbwd(bn.alpha, bn.bbeta, bn.gammac, False)
+
+    def _st(self, bn):
+        return N.ptr(bn.stats) if self.training else None
+
+    # ------------------------------------------------------------------ forward
+    def forward(self, imgs, cats, train=False, dropout_mask=None):
+        """imgs [B,3,H,W] fp32 NCHW (the reference's input contract), cats int64 [B] ->
+        kp [B,9,2] fp32 in (0,1), logits [B,num_classes] fp32 (None when num_classes == 1)."""
+        a, st, dt = self.arch, N.stream(), self.dt
+        assert imgs.is_cuda and imgs.dtype == torch.float32 and imgs.dim() == 4 and imgs.shape[1] == 3
+        imgs = imgs.contiguous()
+        cats = cats.to(self.device, torch.int64).contiguous()
+        self.training = bool(train)
+        if train:
+            self._packed_dirty = True     # the optimizer has (possibly) moved the master weights
+        self._pack()
+        B, _, H, W = imgs.shape
+        if train:
+            self._statbuf.zero_()
+        sv = dict(B=B, imgs=imgs, cats=cats, blocks=[])
+
+        # ---- stem: patch gather + GEMM (mobilenetv3.py:110-115,178)
+        Ho, Wo = (H + 2 - 3) // 2 + 1, (W + 2 - 3) // 2 + 1
+        M = B * Ho * Wo
+        col = self._buf('col', (M, 32))
+        N.call('t3d_stem_im2col', dt, N.ptr(imgs), N.ptr(col), B, H, W, st)
+        bn0 = self.bns['features.0.1']
+        y0 = self._buf('y:stem', (M, a.stem_c))
+        N.call('t3d_pwconv_fwd', dt, N.ptr(col), None, N.ptr(self.w['stem']), None, N.ptr(y0), self._st(bn0),
+               M, Ho * Wo, 32, a.stem_c, st)
+        pro0 = self._bn_fwd(bn0, M, a.stem_act)
+        cur = _Src(y0, pro0, B, Ho, Wo, a.stem_c, raw=y0, bn=bn0, gpro=pro0)
+        sv['col'], sv['stem'] = col, cur
+
+        for i, blk in enumerate(a.blocks):
+            cur = self._block_fwd(i, blk, cur, sv)
+
+        # ---- last 1x1 conv (mobilenetv3.py:118-123,188) + global average pool (model_builder.py:96-110)
+        ln = a.last_name
+        bnl = self.bns[ln + '.1']
+        M = cur.B * cur.H * cur.W
+        yl = self._buf('y:last', (M, a.last_c))
+        N.call('t3d_pwconv_fwd', dt, N.ptr(cur.t), cur.pro, N.ptr(self.w[ln + '.0.weight']), None, N.ptr(yl),
+               self._st(bnl), M, cur.H * cur.W, cur.C, a.last_c, st)
+        prol = self._bn_fwd(bnl, M, a.last_act)
+        pooled = self._buf('pooled', (B, a.last_c), torch.float32)
+        N.call('t3d_gap_fwd', dt, N.ptr(yl), prol, N.ptr(pooled), B, cur.H * cur.W, a.last_c, st)
+        sv.update(last_in=cur, yl=yl, prol=prol, pooled=pooled, HWl=cur.H * cur.W)
+
+        # ---- classifier Linear + BatchNorm1d + h_swish, MobileNetV3 only (mobilenetv3.py:191-195)
+        f, fpro = pooled, None
+        if a.classifier:
+            bnc = self.bns['classifier.1']
+            yc = self._buf('y:cls', (B, a.classifier), torch.float32)
+            N.call('t3d_pwconv_fwd', N.F32, N.ptr(pooled), None, N.ptr(self.p['classifier.0.weight']),
+                   N.ptr(self.p['classifier.0.bias']), N.ptr(yc), self._st(bnc), B, 1, a.last_c, a.classifier, st)
+            fpro = self._bn_fwd(bnc, B, 'hswish')
+            f = yc
+        # ---- heads (model_builder.py:137-144)
+        ncls = self.num_classes
+        mask = None
+        if train and ncls > 1:
+            mask = dropout_mask
+            if mask is None:        # nn.Dropout(0.5): keep with p = .5, scale by 2 (model_builder.py:83)
+                mask = (torch.rand(B, a.feat_c, device=self.device) >= 0.5).float() * 2.0
+            mask = mask.to(self.device, torch.float32).contiguous()
+        kp = torch.empty(B, 18, device=self.device)
+        logits = torch.empty(B, ncls, device=self.device) if ncls > 1 else None
+        N.call('t3d_head_fwd', N.ptr(f), fpro, N.ptr(cats), N.ptr(self.wreg), N.ptr(self.breg),
+               N.ptr(self.p['cls_fc.1.weight']), N.ptr(self.p['cls_fc.1.bias']), N.ptr(mask), N.ptr(kp),
+               N.ptr(logits), B, a.feat_c, ncls, st)
+        sv.update(f=f, fpro=fpro, mask=mask, kp=kp)
+        self.saved = sv if train else None
+        return kp.view(B, 9, 2), logits
+
+    def _finish(self, src, tag):
+        """Materialise act(BN(y)) (needed when a deferred tensor also feeds a skip connection)."""
+        M = src.B * src.H * src.W
+        z = self._buf(tag, (M, src.C))
+        N.call('t3d_bn_apply', self.dt, N.ptr(src.t), src.pro, None, N.ptr(z), M, src.C, N.stream())
+        return _Src(z, None, src.B, src.H, src.W, src.C, raw=src.raw, bn=src.bn, gpro=src.gpro, finished_act=True)
+
+    def _block_fwd(self, i, blk, x, sv):
+        st, dt = N.stream(), self.dt
+        p = f'features.{i + 1}.conv'
+        B, H, W = x.B, x.H, x.W
+        if blk.res and x.pro is not None:
+            x = self._finish(x, f'z:in{i}')
+        rec = dict(x=x)
+        src = x
+        if blk.expand:                                                    # mobilenetv3.py:146-150
+            bn1 = self.bns[p + '.1']
+            M = B * H * W
+            y1 = self._buf(f'y1:{i}', (M, blk.cexp))
+            N.call('t3d_pwconv_fwd', dt, N.ptr(x.t), x.pro, N.ptr(self.w[p + '.0.weight']), None, N.ptr(y1),
+                   self._st(bn1), M, H * W, blk.cin, blk.cexp, st)
+            pro1 = self._bn_fwd(bn1, M, blk.act)
+            src = _Src(y1, pro1, B, H, W, blk.cexp, raw=y1, bn=bn1, gpro=pro1)
+            rec['s1'] = src
+            dwn, bnn, pwn, bn3n = p + '.3.weight', p + '.4', p + '.7.weight', p + '.8'
+        else:                                                             # mobilenetv3.py:133-144
+            dwn, bnn, pwn, bn3n = p + '.0.weight', p + '.1', p + '.4.weight', p + '.5'
+        if blk.se:
+            raise NotImplementedError('squeeze-excite blocks')
+        # depthwise k x k (mobilenetv3.py:136,152)
+        pad = (blk.k - 1) // 2
+        Ho, Wo = (H + 2 * pad - blk.k) // blk.s + 1, (W + 2 * pad - blk.k) // blk.s + 1
+        M2 = B * Ho * Wo
+        bn2 = self.bns[bnn]
+        y2 = self._buf(f'y2:{i}', (M2, blk.cexp))
+        N.call('t3d_dwconv_fwd', dt, N.ptr(src.t), src.pro, N.ptr(self.p[dwn]), N.ptr(y2), self._st(bn2), None,
+               B, H, W, blk.cexp, blk.k, blk.s, st)
+        pro2 = self._bn_fwd(bn2, M2, blk.act)
+        s2 = _Src(y2, pro2, B, Ho, Wo, blk.cexp, raw=y2, bn=bn2, gpro=pro2)
+        # linear 1x1 projection (mobilenetv3.py:142-143,158-159)
+        bn3 = self.bns[bn3n]
+        y3 = self._buf(f'y3:{i}', (M2, blk.cout))
+        N.call('t3d_pwconv_fwd', dt, N.ptr(y2), pro2, N.ptr(self.w[pwn]), None, N.ptr(y3), self._st(bn3),
+               M2, Ho * Wo, blk.cexp, blk.cout, st)
+        pro3 = self._bn_fwd(bn3, M2, 'none')
+        z = self._buf(f'z:{i}', (M2, blk.cout))
+        N.call('t3d_bn_apply', dt, N.ptr(y3), pro3, N.ptr(x.t) if blk.res else None, N.ptr(z), M2, blk.cout, st)
+        out = _Src(z, None, B, Ho, Wo, blk.cout, raw=y3, bn=bn3, gpro=None)
+        rec.update(src=src, s2=s2, y3=y3, bn3=bn3, out=out, names=(dwn, pwn), blk=blk, idx=i)
+        sv['blocks'].append(rec)
+        return out
+
+    # ------------------------------------------------------------------ backward
+    def backward(self, dkp, dlogits=None):
+        """Gradient of the last train-mode forward w.r.t. every parameter -> `gflat` (overwritten).
+        dkp [B,9,2] / dlogits [B,num_classes]: d loss / d outputs (fp32)."""
+        sv = self.saved
+        assert sv is not None, 'backward() needs a preceding forward(train=True)'
+        a, st, dt, B = self.arch, N.stream(), self.dt, sv['B']
+        self.gflat.zero_()
+        dkp = dkp.reshape(B, 18).to(torch.float32).contiguous()
+        ncls = self.num_classes
+        if ncls > 1:
+            assert dlogits is not None
+            dlogits = dlogits.to(torch.float32).contiguous()
+        else:
+            dlogits = None
+        F = a.feat_c
+        dpre = self._buf('dpre', (B, 18), torch.float32)
+        df = self._buf('df', (B, F), torch.float32)
+        bnc = self.bns['classifier.1'] if a.classifier else None
+        N.call('t3d_head_bwd', N.ptr(sv['f']), sv['fpro'], N.ptr(sv['cats']), N.ptr(self.wreg),
+               N.ptr(self.p['cls_fc.1.weight']), N.ptr(sv['mask']), N.ptr(sv['kp']), N.ptr(dkp), N.ptr(dlogits),
+               N.ptr(dpre), N.ptr(df), N.ptr(bnc.bstats) if bnc else None, N.ptr(self.dwreg), N.ptr(self.dbreg),
+               N.ptr(self.g['cls_fc.1.weight']), N.ptr(self.g['cls_fc.1.bias']), B, F, ncls, st)
+        dpooled = df
+        if a.classifier:
+            bb = self._bn_bwd(bnc)
+            yc, pooled = sv['f'], sv['pooled']
+            N.call('t3d_pwconv_wgrad', N.F32, N.ptr(df), N.ptr(yc), bb, N.ptr(pooled), None,
+                   N.ptr(self.g['classifier.0.weight']), B, 1, a.last_c, a.classifier, st)
+            # bias gradient = sum_b dy = alpha*sum(dz) + beta*sum(y) + B*gamma (exactly 0 in exact arithmetic)
+            C = a.classifier
+            self.g['classifier.0.bias'].copy_((bnc.alpha.double() * bnc.bstats[:C] + bnc.bbeta.double() * bnc.stats[:C]
+                                               + B * bnc.gammac.double()).float())
+            dpooled = self._buf('dpooled', (B, a.last_c), torch.float32)
+            N.call('t3d_pwconv_dgrad', N.F32, N.ptr(df), N.ptr(yc), bb, N.ptr(self.wt['classifier']), None, None,
+                   None, N.ptr(dpooled), None, None, B, 1, a.last_c, a.classifier, st)
+        # ---- pool + last conv
+        ln = a.last_name
+        bnl = self.bns[ln + '.1']
+        x = sv['last_in']
+        M, HW = B * sv['HWl'], sv['HWl']
+        dzl = self._buf('dz:last', (M, a.last_c))
+        N.call('t3d_gap_bwd', dt, N.ptr(dpooled), N.ptr(sv['yl']), sv['prol'], N.ptr(dzl), N.ptr(bnl.bstats),
+               B, HW, a.last_c, st)
+        bb = self._bn_bwd(bnl)
+        N.call('t3d_pwconv_wgrad', dt, N.ptr(dzl), N.ptr(sv['yl']), bb, N.ptr(x.t), x.pro,
+               N.ptr(self.g[ln + '.0.weight']), M, HW, x.C, a.last_c, st)
+        dz = self._pw_dgrad(dzl, sv['yl'], bb, self.wt[ln + '.0.weight'], x, None, M, HW, x.C, a.last_c, 'dz:lastin')
+
+        for rec in reversed(sv['blocks']):
+            dz = self._block_bwd(rec, dz)
+
+        # ---- stem weight gradient
+        s0 = sv['stem']
+        bn0 = s0.bn
+        bb = self._bn_bwd(bn0)
+        M = s0.B * s0.H * s0.W
+        dw32 = self._buf('dstem32', (a.stem_c, 32), torch.float32, zero=True)
+        N.call('t3d_pwconv_wgrad', dt, N.ptr(dz), N.ptr(s0.raw), bb, N.ptr(sv['col']), None, N.ptr(dw32),
+               M, s0.H * s0.W, 32, a.stem_c, st)
+        self.g['features.0.0.weight'].view(a.stem_c, 27).copy_(dw32[:, :27])
+        self.saved = None
+
+    def _pw_dgrad(self, dz, y, bb, wt, x, residual, M, HW, K, Nn, tag):
+        """Data gradient of a 1x1 conv into its input `x` (a _Src): returns the gradient at the BatchNorm output
+        of x's producer, with that BatchNorm's backward sums accumulated."""
+        dx = self._buf(tag, (M, K))
+        with_stats = x.bn is not None and not x.finished_act
+        N.call('t3d_pwconv_dgrad', self.dt, N.ptr(dz), N.ptr(y), bb, N.ptr(wt),
+               N.ptr(x.raw) if with_stats else None, x.gpro if with_stats else None,
+               N.ptr(residual) if residual is not None else None, N.ptr(dx),
+               N.ptr(x.bn.bstats) if with_stats else None, None, M, HW, K, Nn, N.stream())
+        if x.finished_act:
+            dx = self._act_bwd(dx, x, tag + ':a')
+        return dx
+
+    def _act_bwd(self, dz, x, tag):
+        M = x.B * x.H * x.W
+        out = self._buf(tag, (M, x.C))
+        N.call('t3d_bn_act_bwd', self.dt, N.ptr(dz), N.ptr(x.raw), x.gpro, N.ptr(out), N.ptr(x.bn.bstats), M, x.C,
+               N.stream())
+        return out
+
+    def _block_bwd(self, rec, dz):
+        """dz: gradient w.r.t. the block output z (= at the output of the projection BatchNorm)."""
+        st, dt = N.stream(), self.dt
+        blk, i, x, src, s2 = rec['blk'], rec['idx'], rec['x'], rec['src'], rec['s2']
+        dwn, pwn = rec['names']
+        B = x.B
+        M2, HW2 = s2.B * s2.H * s2.W, s2.H * s2.W
+        bb3 = self._bn_bwd(rec['bn3'])
+        N.call('t3d_pwconv_wgrad', dt, N.ptr(dz), N.ptr(rec['y3']), bb3, N.ptr(s2.t), s2.pro, N.ptr(self.g[pwn]),
+               M2, HW2, blk.cexp, blk.cout, st)
+        dv2 = self._pw_dgrad(dz, rec['y3'], bb3, self.wt[pwn], s2, None, M2, HW2, blk.cexp, blk.cout, f'dv2:{i}')
+        bb2 = self._bn_bwd(s2.bn)
+        M1 = B * x.H * x.W
+        res = dz if blk.res else None
+        if blk.expand:
+            s1 = rec['s1']
+            d1 = self._buf(f'dz1:{i}', (M1, blk.cexp))
+            N.call('t3d_dwconv_bwd', dt, N.ptr(dv2), N.ptr(s2.raw), bb2, N.ptr(self.p[dwn]), N.ptr(s1.t), s1.pro, None,
+                   N.ptr(d1), N.ptr(s1.bn.bstats), N.ptr(self.g[dwn]), B, x.H, x.W, blk.cexp, blk.k, blk.s, st)
+            bb1 = self._bn_bwd(s1.bn)
+            p = f'features.{i + 1}.conv'
+            N.call('t3d_pwconv_wgrad', dt, N.ptr(d1), N.ptr(s1.raw), bb1, N.ptr(x.t), x.pro,
+                   N.ptr(self.g[p + '.0.weight']), M1, x.H * x.W, blk.cin, blk.cexp, st)
+            return self._pw_dgrad(d1, s1.raw, bb1, self.wt[p + '.0.weight'], x, res, M1, x.H * x.W, blk.cin,
+                                  blk.cexp, f'dzin:{i}')
+        # no-expand layout: the depthwise conv reads the block input directly
+        dx = self._buf(f'dzin:{i}', (M1, blk.cexp))
+        deferred = x.pro is not None           # raw producer tensor read through its prologue
+        N.call('t3d_dwconv_bwd', dt, N.ptr(dv2), N.ptr(s2.raw), bb2, N.ptr(self.p[dwn]), N.ptr(x.t), x.pro,
+               N.ptr(res) if res is not None else None, N.ptr(dx),
+               N.ptr(x.bn.bstats) if deferred else None, N.ptr(self.g[dwn]), B, x.H, x.W, blk.cexp, blk.k, blk.s, st)
+        if not deferred:
+            # finished input: the producer's BatchNorm sums have to be taken against its RAW tensor
+            dx = self._act_bwd(dx, x, f'dzin:{i}:a')
+        return dx

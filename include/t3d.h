@@ -118,6 +118,77 @@ int t3d_dwconv_bwd(int dtype, const void* dz, const void* y, const t3d_bnbwd* bb
                    const void* x, const t3d_prologue* pro, const void* residual, void* dx, double* stats,
                    float* dw, int B, int H, int W, int C, int k, int stride, void* stream);
 
+/* BatchNorm backward bookkeeping: from the reductions the gradient-producing kernel emitted,
+ *   stats [2*C] fp64 = sum(dz), sum(dz*y)  over `count` elements (dz: gradient at the BN output,
+ *   y: raw BN input), and the forward's mean / invstd, build the backward affine
+ *   dy = alpha*dz + beta*y + gammac  and the parameter gradients (autograd of nn.BatchNorm2d in
+ *   training mode, mobilenetv3.py:113 etc.):
+ *     dbeta = sum(dz), dgamma = invstd*(sum(dz*y) - mean*sum(dz)),
+ *     alpha = gamma*invstd, beta = -alpha*invstd*dgamma/count, gammac = -alpha*sum(dz)/count - beta*mean.
+ *   dgamma / dbeta (may be NULL) are OVERWRITTEN. */
+int t3d_bn_bwd_finalize(const double* stats, int C, double count, const float* gamma, const float* mean,
+                        const float* invstd, float* alpha, float* beta, float* gammac, float* dgamma,
+                        float* dbeta, void* stream);
+
+/* Stem patch gather: crops x [B,3,H,W] fp32 NCHW (the reference's input contract,
+ * dataloaders/objectron_main.py:51-96) -> col [B*Ho*Wo, 32] (dtype), the 3x3 / stride-2 / pad-1
+ * patches of nn.Conv2d(3,C,3,2,1) (mobilenetv3.py:110-115) in (ci,ky,kx) order, columns 27..31 zero.
+ * The stem conv itself then runs as t3d_pwconv_{fwd,wgrad} with K = 32. */
+int t3d_stem_im2col(int dtype, const float* x, void* col, int B, int H, int W, void* stream);
+
+/* Materialise a block output:  z = act(scale*y + shift) + residual   (residual may be NULL; scale NULL = identity).
+ * Replaces the BatchNorm normalise pass + `x + self.conv(x)` (mobilenetv3.py:159,162-164). y,z,residual [M,C]. */
+int t3d_bn_apply(int dtype, const void* y, const t3d_prologue* pro, const void* residual, void* z, int M, int C,
+                 void* stream);
+
+/* Backward of t3d_bn_apply's activation:  dzp = dz * act'(scale*y + shift);
+ * stats [2*C] fp64 += sum(dzp), sum(dzp*y) (caller zeroes). */
+int t3d_bn_act_bwd(int dtype, const void* dz, const void* y, const t3d_prologue* pro, void* dzp, double* stats,
+                   int M, int C, void* stream);
+
+/* Global average pool of the activated last feature map (model_builder.py:96-110, mode 'avg'):
+ *   pooled[b][c] = mean_hw act(scale*y + shift),  y [B,HW,C] raw (dtype), pooled [B,C] fp32. */
+int t3d_gap_fwd(int dtype, const void* y, const t3d_prologue* pro, float* pooled, int B, int HW, int C,
+                void* stream);
+
+/* ... and its backward: dz[b][hw][c] = dpooled[b][c]/HW * act'(scale*y + shift) (dtype),
+ * stats [2*C] fp64 += sum(dz), sum(dz*y). */
+int t3d_gap_bwd(int dtype, const float* dpooled, const void* y, const t3d_prologue* pro, void* dz, double* stats,
+                int B, int HW, int C, void* stream);
+
+/* Regression + class heads (ModelWrapper.forward, model_builder.py:126-146):
+ *   f' = act(scale*f + shift)                       (classifier BatchNorm1d + h_swish, or identity: pro NULL)
+ *   kp[b]     = sigmoid(Wreg[cats[b]] f'[b] + breg[cats[b]])      [B,18]   (:137-139, class-gathered GEMV)
+ *   logits[b] = Wcls (f'[b] * mask[b]) + bcls                     [B,ncls] (:142; mask = Dropout(0.5) keep/scale
+ *               factors {0,2}, NULL in eval mode); logits may be NULL (num_classes == 1, :144).
+ * f [B,F] fp32, Wreg [9,18,F], breg [9,18], Wcls [ncls,F], cats int64 [B]. */
+int t3d_head_fwd(const float* f, const t3d_prologue* pro, const int64_t* cats, const float* wreg,
+                 const float* breg, const float* wcls, const float* bcls, const float* mask, float* kp,
+                 float* logits, int B, int F, int ncls, void* stream);
+
+/* Head backward.  dkp [B,18], dlogits [B,ncls] (may be NULL) -> df [B,F] (when pro is given: the gradient
+ * at the BatchNorm1d OUTPUT, i.e. already multiplied by act'; then stats [2*F] fp64 += sum(df), sum(df*f)),
+ * dwreg [9,18,F], dbreg [9,18], dwcls [ncls,F], dbcls [ncls] (all OVERWRITTEN, deterministic order).
+ * dpre [B,18] fp32 scratch. */
+int t3d_head_bwd(const float* f, const t3d_prologue* pro, const int64_t* cats, const float* wreg,
+                 const float* wcls, const float* mask, const float* kp, const float* dkp, const float* dlogits,
+                 float* dpre, float* df, double* stats, float* dwreg, float* dbreg, float* dwcls, float* dbcls,
+                 int B, int F, int ncls, void* stream);
+
+/* Keypoint / class losses of torchdet3d/losses/regression_losses.py + builders/loss_builder.py:7-28,
+ * combined as LossManager.parse_losses does (:79-95), value AND gradient in one launch, plus the
+ * training metrics of evaluation/metrics.py:10-37.  A coefficient of 0 disables a term.
+ *   total = lam_reg * sum_i c_i * L_i(kp, gt)  +  lam_cls * c_ce * CE(logits, cats)
+ * out[0] total, out[1] sum_i c_i L_i, out[2] c_ce*CE, out[3] ADD (mean), out[4] SADD (mean), out[5] accuracy,
+ * out[6] sum ADD / 9 ... (metrics with reduce_mean=False: out[6] ADD, out[7] SADD, out[8] correct count).
+ * dkp [B,18] / dlogits [B,ncls] (may be NULL: values only) receive d total / d input. */
+typedef struct {
+  float c_l1, c_mse, c_smoothl1, smoothl1_beta, c_add, c_diag, c_wing, wing_w, wing_eps, c_ce;
+  float lam_reg, lam_cls;
+} t3d_loss_cfg;
+int t3d_loss_fwd_bwd(const t3d_loss_cfg* cfg, const float* kp, const float* gt_kp, const float* logits,
+                     const int64_t* cats, float* out, float* dkp, float* dlogits, int B, int ncls, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
