@@ -92,8 +92,40 @@ def stream():
     return torch.cuda.current_stream().cuda_stream
 
 
-def call(name, *args):
-    rc = getattr(lib(), name)(*args)
+class KernelTimer:
+    """Optional per-launch device timing (HIP events on the launch stream), used by bench.py.
+    `only`: set of entry-point names to time (None = all).  Events are resolved after a sync."""
+
+    def __init__(self, only=None):
+        self.only, self.rec = only, []
+
+    def summary(self):
+        torch.cuda.synchronize()
+        out = {}
+        for name, nbytes, e0, e1 in self.rec:
+            d = out.setdefault(name, dict(launches=0, ms=0.0, bytes=0))
+            d['launches'] += 1
+            d['ms'] += e0.elapsed_time(e1)
+            d['bytes'] += nbytes or 0
+        return out
+
+
+timer = None    # set to a KernelTimer to time launches
+
+
+def call(name, *args, nbytes=None):
+    """Enqueue one C-ABI entry point on the current stream; `nbytes` = algorithmic HBM bytes of the launch
+    (bookkeeping for the roofline report only)."""
+    fn = getattr(lib(), name)
+    t = timer
+    if t is not None and (t.only is None or name in t.only):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        rc = fn(*args)
+        e1.record()
+        t.rec.append((name, nbytes, e0, e1))
+    else:
+        rc = fn(*args)
     if rc != 0:
         raise RuntimeError(f'{name} failed with code {rc}')
 

@@ -56,10 +56,15 @@ class Net:
         assert dtype in (torch.float32, torch.bfloat16)
         self.dtype = dtype
         self.dt = N.F32 if dtype == torch.float32 else N.BF16
+        self.esz = 4 if dtype == torch.float32 else 2      # bytes per stored activation element
         self._layout()
         self._bufs = {}
         self._packed_dirty = True
         self.saved = None
+        # called as grad_hook(lo) once every gradient at flat offsets >= lo is final (backward runs from the
+        # end of `gflat` towards its start): lets a data-parallel wrapper start the RCCL all-reduce of that
+        # tail while the rest of the backward is still being computed
+        self.grad_hook = None
 
     # ------------------------------------------------------------------ parameters
     def _layout(self):
@@ -277,7 +282,7 @@ class Net:
         bn0 = self.bns['features.0.1']
         y0 = self._buf('y:stem', (M, a.stem_c))
         N.call('t3d_pwconv_fwd', dt, N.ptr(col), None, N.ptr(self.w['stem']), None, N.ptr(y0), self._st(bn0),
-               M, Ho * Wo, 32, a.stem_c, st)
+               M, Ho * Wo, 32, a.stem_c, st, nbytes=M * (32 + a.stem_c) * self.esz)
         pro0 = self._bn_fwd(bn0, M, a.stem_act)
         cur = _Src(y0, pro0, B, Ho, Wo, a.stem_c, raw=y0, bn=bn0, gpro=pro0)
         sv['col'], sv['stem'] = col, cur
@@ -291,7 +296,7 @@ class Net:
         M = cur.B * cur.H * cur.W
         yl = self._buf('y:last', (M, a.last_c))
         N.call('t3d_pwconv_fwd', dt, N.ptr(cur.t), cur.pro, N.ptr(self.w[ln + '.0.weight']), None, N.ptr(yl),
-               self._st(bnl), M, cur.H * cur.W, cur.C, a.last_c, st)
+               self._st(bnl), M, cur.H * cur.W, cur.C, a.last_c, st, nbytes=M * (cur.C + a.last_c) * self.esz)
         prol = self._bn_fwd(bnl, M, a.last_act)
         pooled = self._buf('pooled', (B, a.last_c), torch.float32)
         N.call('t3d_gap_fwd', dt, N.ptr(yl), prol, N.ptr(pooled), B, cur.H * cur.W, a.last_c, st)
@@ -343,7 +348,7 @@ class Net:
             M = B * H * W
             y1 = self._buf(f'y1:{i}', (M, blk.cexp))
             N.call('t3d_pwconv_fwd', dt, N.ptr(x.t), x.pro, N.ptr(self.w[p + '.0.weight']), None, N.ptr(y1),
-                   self._st(bn1), M, H * W, blk.cin, blk.cexp, st)
+                   self._st(bn1), M, H * W, blk.cin, blk.cexp, st, nbytes=M * (blk.cin + blk.cexp) * self.esz)
             pro1 = self._bn_fwd(bn1, M, blk.act)
             src = _Src(y1, pro1, B, H, W, blk.cexp, raw=y1, bn=bn1, gpro=pro1)
             rec['s1'] = src
@@ -359,14 +364,14 @@ class Net:
         bn2 = self.bns[bnn]
         y2 = self._buf(f'y2:{i}', (M2, blk.cexp))
         N.call('t3d_dwconv_fwd', dt, N.ptr(src.t), src.pro, N.ptr(self.p[dwn]), N.ptr(y2), self._st(bn2), None,
-               B, H, W, blk.cexp, blk.k, blk.s, st)
+               B, H, W, blk.cexp, blk.k, blk.s, st, nbytes=(B * H * W + M2) * blk.cexp * self.esz)
         pro2 = self._bn_fwd(bn2, M2, blk.act)
         s2 = _Src(y2, pro2, B, Ho, Wo, blk.cexp, raw=y2, bn=bn2, gpro=pro2)
         # linear 1x1 projection (mobilenetv3.py:142-143,158-159)
         bn3 = self.bns[bn3n]
         y3 = self._buf(f'y3:{i}', (M2, blk.cout))
         N.call('t3d_pwconv_fwd', dt, N.ptr(y2), pro2, N.ptr(self.w[pwn]), None, N.ptr(y3), self._st(bn3),
-               M2, Ho * Wo, blk.cexp, blk.cout, st)
+               M2, Ho * Wo, blk.cexp, blk.cout, st, nbytes=M2 * (blk.cexp + blk.cout) * self.esz)
         pro3 = self._bn_fwd(bn3, M2, 'none')
         z = self._buf(f'z:{i}', (M2, blk.cout))
         N.call('t3d_bn_apply', dt, N.ptr(y3), pro3, N.ptr(x.t) if blk.res else None, N.ptr(z), M2, blk.cout, st)
@@ -421,11 +426,15 @@ class Net:
                B, HW, a.last_c, st)
         bb = self._bn_bwd(bnl)
         N.call('t3d_pwconv_wgrad', dt, N.ptr(dzl), N.ptr(sv['yl']), bb, N.ptr(x.t), x.pro,
-               N.ptr(self.g[ln + '.0.weight']), M, HW, x.C, a.last_c, st)
+               N.ptr(self.g[ln + '.0.weight']), M, HW, x.C, a.last_c, st, nbytes=M * (x.C + a.last_c) * self.esz)
         dz = self._pw_dgrad(dzl, sv['yl'], bb, self.wt[ln + '.0.weight'], x, None, M, HW, x.C, a.last_c, 'dz:lastin')
 
+        if self.grad_hook:
+            self.grad_hook(self.offsets[ln + '.0.weight'][0])
         for rec in reversed(sv['blocks']):
             dz = self._block_bwd(rec, dz)
+            if self.grad_hook:
+                self.grad_hook(self.offsets[f"features.{rec['idx'] + 1}.conv.0.weight"][0])
 
         # ---- stem weight gradient
         s0 = sv['stem']
@@ -434,8 +443,10 @@ class Net:
         M = s0.B * s0.H * s0.W
         dw32 = self._buf('dstem32', (a.stem_c, 32), torch.float32, zero=True)
         N.call('t3d_pwconv_wgrad', dt, N.ptr(dz), N.ptr(s0.raw), bb, N.ptr(sv['col']), None, N.ptr(dw32),
-               M, s0.H * s0.W, 32, a.stem_c, st)
+               M, s0.H * s0.W, 32, a.stem_c, st, nbytes=M * (32 + a.stem_c) * self.esz)
         self.g['features.0.0.weight'].view(a.stem_c, 27).copy_(dw32[:, :27])
+        if self.grad_hook:
+            self.grad_hook(0)
         self.saved = None
 
     def _pw_dgrad(self, dz, y, bb, wt, x, residual, M, HW, K, Nn, tag):
@@ -446,7 +457,8 @@ class Net:
         N.call('t3d_pwconv_dgrad', self.dt, N.ptr(dz), N.ptr(y), bb, N.ptr(wt),
                N.ptr(x.raw) if with_stats else None, x.gpro if with_stats else None,
                N.ptr(residual) if residual is not None else None, N.ptr(dx),
-               N.ptr(x.bn.bstats) if with_stats else None, None, M, HW, K, Nn, N.stream())
+               N.ptr(x.bn.bstats) if with_stats else None, None, M, HW, K, Nn, N.stream(),
+               nbytes=M * (K + Nn) * self.esz)
         if x.finished_act:
             dx = self._act_bwd(dx, x, tag + ':a')
         return dx
@@ -467,7 +479,7 @@ class Net:
         M2, HW2 = s2.B * s2.H * s2.W, s2.H * s2.W
         bb3 = self._bn_bwd(rec['bn3'])
         N.call('t3d_pwconv_wgrad', dt, N.ptr(dz), N.ptr(rec['y3']), bb3, N.ptr(s2.t), s2.pro, N.ptr(self.g[pwn]),
-               M2, HW2, blk.cexp, blk.cout, st)
+               M2, HW2, blk.cexp, blk.cout, st, nbytes=M2 * (blk.cexp + blk.cout) * self.esz)
         dv2 = self._pw_dgrad(dz, rec['y3'], bb3, self.wt[pwn], s2, None, M2, HW2, blk.cexp, blk.cout, f'dv2:{i}')
         bb2 = self._bn_bwd(s2.bn)
         M1 = B * x.H * x.W
@@ -476,11 +488,13 @@ class Net:
             s1 = rec['s1']
             d1 = self._buf(f'dz1:{i}', (M1, blk.cexp))
             N.call('t3d_dwconv_bwd', dt, N.ptr(dv2), N.ptr(s2.raw), bb2, N.ptr(self.p[dwn]), N.ptr(s1.t), s1.pro, None,
-                   N.ptr(d1), N.ptr(s1.bn.bstats), N.ptr(self.g[dwn]), B, x.H, x.W, blk.cexp, blk.k, blk.s, st)
+                   N.ptr(d1), N.ptr(s1.bn.bstats), N.ptr(self.g[dwn]), B, x.H, x.W, blk.cexp, blk.k, blk.s, st,
+                   nbytes=2 * (M1 + M2) * blk.cexp * self.esz)
             bb1 = self._bn_bwd(s1.bn)
             p = f'features.{i + 1}.conv'
             N.call('t3d_pwconv_wgrad', dt, N.ptr(d1), N.ptr(s1.raw), bb1, N.ptr(x.t), x.pro,
-                   N.ptr(self.g[p + '.0.weight']), M1, x.H * x.W, blk.cin, blk.cexp, st)
+                   N.ptr(self.g[p + '.0.weight']), M1, x.H * x.W, blk.cin, blk.cexp, st,
+                   nbytes=M1 * (blk.cin + blk.cexp) * self.esz)
             return self._pw_dgrad(d1, s1.raw, bb1, self.wt[p + '.0.weight'], x, res, M1, x.H * x.W, blk.cin,
                                   blk.cexp, f'dzin:{i}')
         # no-expand layout: the depthwise conv reads the block input directly
@@ -488,7 +502,8 @@ class Net:
         deferred = x.pro is not None           # raw producer tensor read through its prologue
         N.call('t3d_dwconv_bwd', dt, N.ptr(dv2), N.ptr(s2.raw), bb2, N.ptr(self.p[dwn]), N.ptr(x.t), x.pro,
                N.ptr(res) if res is not None else None, N.ptr(dx),
-               N.ptr(x.bn.bstats) if deferred else None, N.ptr(self.g[dwn]), B, x.H, x.W, blk.cexp, blk.k, blk.s, st)
+               N.ptr(x.bn.bstats) if deferred else None, N.ptr(self.g[dwn]), B, x.H, x.W, blk.cexp, blk.k, blk.s, st,
+               nbytes=2 * (M1 + M2) * blk.cexp * self.esz)
         if not deferred:
             # finished input: the producer's BatchNorm sums have to be taken against its RAW tensor
             dx = self._act_bwd(dx, x, f'dzin:{i}:a')
