@@ -52,6 +52,8 @@ SIGNATURES = {
     't3d_gap_bwd': [_I, _P, _P, _PP, _P, _P, _I, _I, _I, _P],
     't3d_head_fwd': [_P, _PP, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P],
     't3d_head_bwd': [_P, _PP, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P],
+    't3d_se_fwd': [_P] * 11 + [_I, _I, _I, _I, _P],
+    't3d_se_bwd': [_P] * 18 + [_I, _I, _I, _I, _P],
     't3d_loss_fwd_bwd': [_LP, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P],
 }
 
@@ -97,7 +99,12 @@ class KernelTimer:
     `only`: set of entry-point names to time (None = all).  Events are resolved after a sync."""
 
     def __init__(self, only=None):
-        self.only, self.rec = only, []
+        self.only, self.rec, self.sig = only, [], []
+
+    def per_launch(self):
+        """[(name, int-args signature, ms, algorithmic bytes)] in launch order."""
+        torch.cuda.synchronize()
+        return [(n, sg, e0.elapsed_time(e1), nb) for (n, nb, e0, e1), sg in zip(self.rec, self.sig)]
 
     def summary(self):
         torch.cuda.synchronize()
@@ -124,6 +131,7 @@ def call(name, *args, nbytes=None):
         rc = fn(*args)
         e1.record()
         t.rec.append((name, nbytes, e0, e1))
+        t.sig.append(tuple(a for a in args[:-1] if isinstance(a, int) and not isinstance(a, bool) and 0 <= a < (1 << 31)))
     else:
         rc = fn(*args)
     if rc != 0:

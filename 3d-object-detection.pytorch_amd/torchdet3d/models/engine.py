@@ -355,17 +355,31 @@ class Net:
             dwn, bnn, pwn, bn3n = p + '.3.weight', p + '.4', p + '.7.weight', p + '.8'
         else:                                                             # mobilenetv3.py:133-144
             dwn, bnn, pwn, bn3n = p + '.0.weight', p + '.1', p + '.4.weight', p + '.5'
-        if blk.se:
-            raise NotImplementedError('squeeze-excite blocks')
+        if blk.se and not blk.expand:
+            raise NotImplementedError('squeeze-excite AFTER the activation (no-expand layout, mobilenetv3_small '
+                                      'features.1) is not built yet')
+        sen = (p + '.5') if blk.se else None
         # depthwise k x k (mobilenetv3.py:136,152)
         pad = (blk.k - 1) // 2
         Ho, Wo = (H + 2 * pad - blk.k) // blk.s + 1, (W + 2 * pad - blk.k) // blk.s + 1
         M2 = B * Ho * Wo
         bn2 = self.bns[bnn]
         y2 = self._buf(f'y2:{i}', (M2, blk.cexp))
-        N.call('t3d_dwconv_fwd', dt, N.ptr(src.t), src.pro, N.ptr(self.p[dwn]), N.ptr(y2), self._st(bn2), None,
+        gap = self._buf(f'gap:{i}', (B, blk.cexp), torch.float32, zero=True) if blk.se else None
+        N.call('t3d_dwconv_fwd', dt, N.ptr(src.t), src.pro, N.ptr(self.p[dwn]), N.ptr(y2), self._st(bn2), N.ptr(gap),
                B, H, W, blk.cexp, blk.k, blk.s, st, nbytes=(B * H * W + M2) * blk.cexp * self.esz)
         pro2 = self._bn_fwd(bn2, M2, blk.act)
+        if blk.se:                                                        # mobilenetv3.py:92-107,155
+            C, R = blk.cexp, blk.se
+            se = dict(gap=gap, m=self._buf(f'se_m:{i}', (B, C), torch.float32),
+                      h=self._buf(f'se_h:{i}', (B, R), torch.float32), q=self._buf(f'se_q:{i}', (B, C), torch.float32),
+                      s=self._buf(f'se_s:{i}', (B, C), torch.float32), name=sen, HW=Ho * Wo)
+            N.call('t3d_se_fwd', N.ptr(gap), N.ptr(bn2.scale), N.ptr(bn2.shift), N.ptr(self.p[sen + '.fc.0.weight']),
+                   N.ptr(self.p[sen + '.fc.0.bias']), N.ptr(self.p[sen + '.fc.2.weight']),
+                   N.ptr(self.p[sen + '.fc.2.bias']), N.ptr(se['m']), N.ptr(se['h']), N.ptr(se['q']), N.ptr(se['s']),
+                   B, C, R, Ho * Wo, st)
+            pro2 = self._pro(bn2, blk.act, se['s'], False)                # SE before the activation (:155-156)
+            rec['se'] = se
         s2 = _Src(y2, pro2, B, Ho, Wo, blk.cexp, raw=y2, bn=bn2, gpro=pro2)
         # linear 1x1 projection (mobilenetv3.py:142-143,158-159)
         bn3 = self.bns[bn3n]
@@ -480,8 +494,33 @@ class Net:
         bb3 = self._bn_bwd(rec['bn3'])
         N.call('t3d_pwconv_wgrad', dt, N.ptr(dz), N.ptr(rec['y3']), bb3, N.ptr(s2.t), s2.pro, N.ptr(self.g[pwn]),
                M2, HW2, blk.cexp, blk.cout, st, nbytes=M2 * (blk.cexp + blk.cout) * self.esz)
-        dv2 = self._pw_dgrad(dz, rec['y3'], bb3, self.wt[pwn], s2, None, M2, HW2, blk.cexp, blk.cout, f'dv2:{i}')
-        bb2 = self._bn_bwd(s2.bn)
+        se = rec.get('se')
+        if se is None:
+            dv2 = self._pw_dgrad(dz, rec['y3'], bb3, self.wt[pwn], s2, None, M2, HW2, blk.cexp, blk.cout, f'dv2:{i}')
+            bb2 = self._bn_bwd(s2.bn)
+        else:
+            # gated tensor: the data gradient reports per-SAMPLE sums; the gate's backward turns them into the
+            # BatchNorm sums and the per-sample affine  dy = (alpha*s) dv + beta y + (gamma + alpha*g)
+            C, R, sen = blk.cexp, blk.se, se['name']
+            ps = self._buf(f'se_ps:{i}', (B, C, 2), torch.float32, zero=True)
+            dv2 = self._buf(f'dv2:{i}', (M2, C))
+            N.call('t3d_pwconv_dgrad', dt, N.ptr(dz), N.ptr(rec['y3']), bb3, N.ptr(self.wt[pwn]), N.ptr(s2.raw), s2.gpro,
+                   None, N.ptr(dv2), None, N.ptr(ps), M2, HW2, C, blk.cout, st, nbytes=M2 * (C + blk.cout) * self.esz)
+            g = self._buf(f'se_g:{i}', (B, C), torch.float32)
+            dq = self._buf(f'se_dq:{i}', (B, C), torch.float32)
+            dp = self._buf(f'se_dp:{i}', (B, R), torch.float32)
+            bn2 = s2.bn
+            N.call('t3d_se_bwd', N.ptr(ps), N.ptr(se['gap']), N.ptr(bn2.scale), N.ptr(bn2.shift),
+                   N.ptr(self.p[sen + '.fc.0.weight']), N.ptr(self.p[sen + '.fc.2.weight']), N.ptr(se['m']),
+                   N.ptr(se['h']), N.ptr(se['q']), N.ptr(se['s']), N.ptr(g), N.ptr(dq), N.ptr(dp), N.ptr(bn2.bstats),
+                   N.ptr(self.g[sen + '.fc.0.weight']), N.ptr(self.g[sen + '.fc.0.bias']),
+                   N.ptr(self.g[sen + '.fc.2.weight']), N.ptr(self.g[sen + '.fc.2.bias']), B, C, R, se['HW'], st)
+            self._bn_bwd(bn2)
+            aps = self._buf(f'se_aps:{i}', (B, C), torch.float32)
+            gps = self._buf(f'se_gps:{i}', (B, C), torch.float32)
+            torch.mul(se['s'], bn2.alpha, out=aps)
+            torch.addcmul(bn2.gammac.expand(B, C), g, bn2.alpha.expand(B, C), out=gps)
+            bb2 = N.bnbwd(aps, bn2.bbeta, gps, True)
         M1 = B * x.H * x.W
         res = dz if blk.res else None
         if blk.expand:

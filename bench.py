@@ -42,6 +42,7 @@ def parse():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-batch', type=int, default=32)
     ap.add_argument('--cpu-steps', type=int, default=4)
+    ap.add_argument('--per-launch', action='store_true', help='print every conv launch of one step (stderr)')
     ap.add_argument('--profile-all', action='store_true', help='time every kernel family, print a table to stderr')
     return ap.parse_args()
 
@@ -153,6 +154,14 @@ def main():
             bw = v['bytes'] / (v['ms'] * 1e-3) / 1e12 if v['ms'] > 0 and v['bytes'] else 0
             print(f'  {k:22s} {v["launches"]:5d} launches {v["ms"]:9.3f} ms {100 * v["ms"] / tot:5.1f}%  '
                   f'{bw:6.2f} TB/s algorithmic', file=sys.stderr)
+
+    if args.per_launch and rank == 0:
+        N.timer = N.KernelTimer(set(CONV_KERNELS))
+        step(0)
+        for n, sg, ms, nb in N.timer.per_launch():
+            print(f'  {n:20s} {str(sg):44s} {ms * 1e3:8.1f} us  {(nb or 0) / 1e6:8.1f} MB  {(nb or 0) / ms / 1e9:6.2f} TB/s',
+                  file=sys.stderr)
+        N.timer = None
 
     # ---- timed region: exactly K steps, only the dominant family carries event pairs
     N.timer = N.KernelTimer({dominant}) if dominant else None

@@ -189,6 +189,23 @@ typedef struct {
 int t3d_loss_fwd_bwd(const t3d_loss_cfg* cfg, const float* kp, const float* gt_kp, const float* logits,
                      const int64_t* cats, float* out, float* dkp, float* dlogits, int B, int ncls, void* stream);
 
+/* Squeeze-excite gate (SELayer, mobilenetv3.py:92-107) from the depthwise kernel's per-sample sums:
+ *   m = scale*gap_sum/HW + shift (= mean_hw of the BatchNorm output), h = relu(W1 m + b1), q = W2 h + b2,
+ *   s = h_sigmoid(q).  gap_sum, m, q, s [B,C]; h [B,R]; W1 [R,C]; W2 [C,R]; all fp32. */
+int t3d_se_fwd(const float* gap_sum, const float* scale, const float* shift, const float* w1, const float* b1,
+               const float* w2, const float* b2, float* m, float* h, float* q, float* s, int B, int C, int R, int HW,
+               void* stream);
+
+/* Backward of the gate.  ps_stats [B,C,2] = per-sample sum_hw(dv), sum_hw(dv*y) from t3d_pwconv_dgrad
+ * (dv: gradient at the gated tensor, y: raw depthwise output).  Produces g [B,C] (the pooled path's
+ * per-pixel gradient, so that du = s*dv + g), accumulates the depthwise BatchNorm's backward sums
+ * stats [2*C] fp64 += sum(du), sum(du*y), and OVERWRITES the FC gradients dw1 [R,C], db1 [R], dw2 [C,R], db2 [C].
+ * dq [B,C], dp [B,R]: scratch. */
+int t3d_se_bwd(const float* ps_stats, const float* gap_sum, const float* scale, const float* shift, const float* w1,
+               const float* w2, const float* m, const float* h, const float* q, const float* s, float* g, float* dq,
+               float* dp, double* stats, float* dw1, float* db1, float* dw2, float* db2, int B, int C, int R, int HW,
+               void* stream);
+
 #ifdef __cplusplus
 }
 #endif

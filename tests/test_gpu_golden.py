@@ -1,0 +1,79 @@
+"""GPU parity of the HIP path against the REFERENCE's own outputs: the golden vectors in tests/golden/*.npz were
+produced by importing sovrasov/3d-object-detection.pytorch (oracle/gen_golden.py) and running its
+`build_model('mobilenetv3_large')`, `LossManager.parse_losses` and autograd on the deterministic
+weights / crops of oracle/weights.py.  fp32 storage.
+
+Tolerances: keypoints / logits / loss 1e-4 (north-star), class arg-max bit-exact, BatchNorm running statistics
+1e-5.  Gradients: within 5e-2 of each tensor's largest entry (typically ~1e-4; the bound covers a ReLU / h-swish
+kink flipping under train-mode BatchNorm over 36-98 samples per channel, see tests/test_gpu_engine.py)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+CASES = [('mnv3_large_b4_96', 'mobilenetv3_large', 4, 96, 9, ['l1', 'add_loss', 'cross_entropy'], ([1., .1], [.2])),
+         ('mnv3_large_c1_b8_96', 'mobilenetv3_large', 8, 96, 1, ['mse', 'diag_loss', 'add_loss'], ([1., .5, .1], [])),
+         ('mnv3_large_b2_224', 'mobilenetv3_large', 2, 224, 9, ['smoothl1', 'wing', 'cross_entropy'], ([1., .3], [.5]))]
+
+
+@pytest.mark.parametrize('tag,name,B,HW,nc,lnames,coeffs', CASES)
+def test_hip_path_matches_reference_golden(golden_dir, tag, name, B, HW, nc, lnames, coeffs):
+    from oracle.weights import make_inputs, make_state_dict
+    from test_gpu_engine import _loss_cfg
+    from torchdet3d import _native as N
+    from torchdet3d.models.engine import Net
+    g = np.load(os.path.join(golden_dir, tag + '.npz'))
+    sd = make_state_dict(name, nc)
+    imgs, gt_kp, cats = make_inputs(B, HW, HW, nc)
+    net = Net(name, nc, 'cuda', torch.float32)
+    net.load_state_dict(sd)
+    im, ca = imgs.cuda(), cats.cuda()
+    kp, lg = net.forward(im, ca, train=False)
+    np.testing.assert_allclose(kp.cpu().numpy(), g['eval_kp'], atol=1e-4)
+    if nc > 1:
+        np.testing.assert_allclose(lg.cpu().numpy(), g['eval_targets'], atol=1e-4)
+        assert (lg.argmax(1).cpu().numpy() == g['eval_argmax']).all()
+    # export-mode forward: all 9 heads (model_builder.py:112-124)
+    for k in range(9):
+        kpk, _ = net.forward(im, torch.full_like(ca, k), train=False)
+        np.testing.assert_allclose(kpk.cpu().numpy(), g['onnx_kp'][k], atol=1e-4)
+    mask = torch.from_numpy(g['dropout_mask'].astype(np.float32)).cuda() if 'dropout_mask' in g.files else None
+    kp, lg = net.forward(im, ca, train=True, dropout_mask=mask)
+    np.testing.assert_allclose(kp.cpu().numpy(), g['train_kp'], atol=1e-4)
+    if nc > 1:
+        np.testing.assert_allclose(lg.cpu().numpy(), g['train_targets'], atol=1e-4)
+    out = torch.zeros(16, device='cuda')
+    dkp = torch.empty(B, 18, device='cuda')
+    dlg = torch.empty(B, nc, device='cuda') if nc > 1 else None
+    gtd = gt_kp.cuda().view(B, 18).contiguous()
+    N.call('t3d_loss_fwd_bwd', _loss_cfg(lnames, coeffs), N.ptr(kp), N.ptr(gtd), N.ptr(lg), N.ptr(ca), N.ptr(out),
+           N.ptr(dkp), N.ptr(dlg), B, nc, N.stream())
+    np.testing.assert_allclose(out[0].item(), g['loss'][0], rtol=1e-4)
+    np.testing.assert_allclose(dkp.cpu().numpy().reshape(B, 9, 2), g['dkp'], atol=1e-6, rtol=1e-3)
+    net.backward(dkp, dlg)
+    torch.cuda.synchronize()
+    bad = []
+    for k in [f for f in g.files if f.startswith('grad:') or f.startswith('gradrows:')]:
+        name_ = k.split(':', 1)[1]
+        ref = g[k]
+        got = net.g[name_].cpu().numpy()
+        if k.startswith('gradrows:'):
+            got = got[:6]
+        scale = max(np.abs(ref).max(), 1e-3)
+        err = np.abs(got - ref).max() / scale
+        if not err < 5e-2:
+            bad.append((name_, err))
+    for k in [f for f in g.files if f.startswith('gsum:')]:
+        ref = g[k][1]
+        got = net.g[k[5:]].double().abs().sum().item()
+        if abs(got - ref) > 5e-2 * max(ref, 1e-2):
+            bad.append((k, got, ref))
+    assert not bad, bad[:10]
+    for k in [f for f in g.files if f.startswith('rm:')]:
+        bn = k[3:]
+        np.testing.assert_allclose(net.buffers[bn + '.running_mean'].cpu().numpy(), g[k], atol=1e-5)
+        np.testing.assert_allclose(net.buffers[bn + '.running_var'].cpu().numpy(), g['rv:' + bn], rtol=1e-4, atol=1e-6)
+        assert int(net.buffers[bn + '.num_batches_tracked']) == int(g['nbt:' + bn])
