@@ -1,0 +1,34 @@
+"""Loader boundary.  The reference's Objectron dataset + albumentations pipeline
+(torchdet3d/builders/loader_builder.py:14-36, dataloaders/objectron_main.py) is CPU data preparation and out of
+scope for this build; what the hot path needs is its OUTPUT CONTRACT
+(objectron_main.py:51-96 + utils/transforms.py:103-114): batches `(imgs f32 [B,3,H,W] normalised, gt_kp f32
+[B,9,2] in [0,1], gt_cats int64 [B])`.  `SyntheticCrops` produces exactly that; `build_loader` serves it when
+`cfg.data.root == 'synthetic'`."""
+import torch
+
+
+class SyntheticCrops(torch.utils.data.Dataset):
+    def __init__(self, n, size=(224, 224), num_classes=9, seed=0):
+        g = torch.Generator().manual_seed(seed)
+        self.imgs = torch.randn(n, 3, size[1], size[0], generator=g)
+        self.kp = torch.rand(n, 9, 2, generator=g)
+        self.cats = torch.randint(0, max(num_classes, 1), (n,), generator=g)
+
+    def __len__(self):
+        return self.imgs.shape[0]
+
+    def __getitem__(self, i):
+        return self.imgs[i], self.kp[i], self.cats[i]
+
+
+def build_loader(config, mode='train'):
+    if config.data.root != 'synthetic':
+        raise NotImplementedError('only the synthetic crop source is built (cfg.data.root = "synthetic"); the '
+                                  'Objectron JSON/albumentations loader is out of scope')
+    n = config.data.synthetic_len or 64
+    size = tuple(config.data.resize) if config.data.resize else (224, 224)
+    mk = lambda seed: SyntheticCrops(n, size, config.model.num_classes or 9, seed)
+    train = torch.utils.data.DataLoader(mk(1), batch_size=config.data.train_batch_size or 8, shuffle=True, drop_last=True)
+    val = torch.utils.data.DataLoader(mk(2), batch_size=config.data.val_batch_size or 8, shuffle=False)
+    test = torch.utils.data.DataLoader(mk(3), batch_size=1, shuffle=False)
+    return train, val, test

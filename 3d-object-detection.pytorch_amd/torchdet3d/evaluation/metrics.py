@@ -1,0 +1,92 @@
+"""Training / validation metrics (torchdet3d/evaluation/metrics.py): ADD and symmetric ADD (:10-29), arg-max
+accuracy (:31-37), per-class aggregation (:39-68) and the 2-D based 3-D IoU (:70-89).
+
+ADD / SADD / accuracy come out of the single-launch wavefront-reduction kernel `t3d_loss_fwd_bwd`
+(csrc/loss.hip) instead of the reference's 9x9 Python loop of tiny kernels; the 3-D IoU stays on the host in
+numpy fp64 exactly like the reference (lift_2d + box IoU per sample)."""
+import numpy as np
+import scipy.spatial
+import torch
+
+from .. import _native as N
+from ..utils.geometry import lift_2d
+from .box_iou import Box, IoU
+
+_METRIC_CFG = None
+
+
+def _reduce(pred_kp, gt_kp, pred_cats, gt_cats):
+    """One launch -> out[3:9] = ADD, SADD, acc (means), then the reduce_mean=False forms."""
+    global _METRIC_CFG
+    if _METRIC_CFG is None:
+        _METRIC_CFG = N.LossCfg()
+        _METRIC_CFG.smoothl1_beta, _METRIC_CFG.wing_w, _METRIC_CFG.wing_eps = 0.2, 1.0, 1.0
+    B = pred_kp.shape[0]
+    dev = pred_kp.device
+    if not pred_kp.is_cuda:
+        raise RuntimeError('metrics run on the HIP path only (no CPU fallback)')
+    p = pred_kp.detach().reshape(B, 18).float().contiguous()
+    t = gt_kp.detach().reshape(B, 18).to(dev).float().contiguous()
+    cats = (gt_cats if gt_cats is not None else torch.zeros(B, dtype=torch.int64, device=dev)).to(dev).long().contiguous()
+    logits, ncls = None, 1
+    if pred_cats is not None and pred_cats.dtype.is_floating_point and pred_cats.dim() == 2:
+        logits = pred_cats.detach().float().contiguous()
+        ncls = logits.shape[1]
+    out = torch.zeros(16, device=dev)
+    N.call('t3d_loss_fwd_bwd', _METRIC_CFG, N.ptr(p), N.ptr(t), N.ptr(logits), N.ptr(cats), N.ptr(out), None, None,
+           B, ncls, N.stream())
+    return out
+
+
+@torch.no_grad()
+def compute_average_distance(pred_kp, gt_kp, num_keypoint=9, reduce_mean=True):
+    assert num_keypoint == 9
+    if pred_kp.shape[0] == 0:
+        return 0., 0.
+    o = _reduce(pred_kp, gt_kp, None, None).tolist()
+    return (o[3], o[4]) if reduce_mean else (o[6], o[7])
+
+
+@torch.no_grad()
+def compute_accuracy(pred_cats, gt_cats, reduce_mean=True):
+    if pred_cats.dtype.is_floating_point and pred_cats.dim() == 2 and pred_cats.shape[1] <= 64 and pred_cats.is_cuda:
+        B = pred_cats.shape[0]
+        dummy = torch.zeros(B, 18, device=pred_cats.device)
+        o = _reduce(dummy, dummy, pred_cats, gt_cats).tolist()
+        return o[5] if reduce_mean else o[8]
+    # width-1 integer "targets" (num_classes == 1, model_builder.py:144): arg-max is always 0
+    hit = (torch.argmax(pred_cats, dim=1) == gt_cats).float()
+    return hit.mean().item() if reduce_mean else hit.sum().item()
+
+
+def compute_2d_based_iou(pred_kp, gt_kp, reduce_mean=True):
+    """metrics.py:70-89: degenerate hulls / singular fits contribute 0."""
+    p = pred_kp.detach().cpu().numpy().astype(np.float64)
+    g = gt_kp.detach().cpu().numpy().astype(np.float64)
+    total = 0.
+    for i in range(p.shape[0]):
+        k3 = lift_2d([p[i], g[i]], portrait=True)
+        try:
+            total += IoU(Box(k3[0]), Box(k3[1])).iou()
+        except (scipy.spatial.QhullError, np.linalg.LinAlgError):
+            pass
+    if reduce_mean:
+        return total / p.shape[0] if p.shape[0] else 0
+    return total
+
+
+@torch.no_grad()
+def compute_metrics_per_cls(pred_kp, gt_kp, pred_cats, gt_cats, compute_iou=True):
+    """metrics.py:39-68: per class present in the batch, sums / class count; totals / batch size."""
+    out = []
+    tA = tS = tI = tC = 0.
+    bs = pred_kp.shape[0]
+    for cl in torch.unique(gt_cats):
+        m = gt_cats == cl
+        A, S = compute_average_distance(pred_kp[m], gt_kp[m], reduce_mean=False)
+        I = compute_2d_based_iou(pred_kp[m], gt_kp[m], reduce_mean=False) if compute_iou else 0.
+        C = compute_accuracy(pred_cats[m], gt_cats[m], reduce_mean=False)
+        n = int(m.sum())
+        out.append((int(cl), A / n, S / n, I / n, C / n))
+        tA, tS, tI, tC = tA + A, tS + S, tI + I, tC + C
+    return out, tA / bs, tS / bs, tI / bs, tC / bs

@@ -146,7 +146,7 @@ def test_pwconv_dgrad(B, HW, K, N, dt, mode):
         np.testing.assert_allclose(psst.cpu()[..., 1].numpy(), p2.numpy(), rtol=1e-4, atol=1e-3)
 
 
-@pytest.mark.parametrize('B,HW,K,N', SHAPES + [(16, 196, 96, 576), (64, 49, 160, 960)])
+@pytest.mark.parametrize('B,HW,K,N', SHAPES + [(16, 196, 96, 576), (64, 49, 160, 960), (2, 49, 320, 1280), (3, 49, 960, 160)])
 @pytest.mark.parametrize('dt', ['f32', 'bf16'])
 @pytest.mark.parametrize('mode', ['plain', 'bnact', 'se_pre_ps'])
 def test_pwconv_wgrad(B, HW, K, N, dt, mode):

@@ -12,6 +12,8 @@ name, B, HW, nc = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[
 dtype = torch.bfloat16 if len(sys.argv) > 5 and sys.argv[5] == 'bf16' else torch.float32
 lnames, coeffs = (['l1', 'add_loss', 'cross_entropy'], ([1., .1], [.2])) if nc > 1 else (['mse', 'diag_loss', 'add_loss'], ([1., .5, .1], []))
 sd = make_state_dict(name, nc)
+if os.environ.get('INIT') == 'ref':
+    _n = Net(name, nc, 'cuda', torch.float32); _n.reset_parameters(seed=11); sd = {k: v.cpu() for k, v in _n.state_dict().items()}
 imgs, gt_kp, cats = make_inputs(B, HW, HW, nc)
 F = 1280 if 'small' not in name else 1024
 mode = os.environ.get('DBG', '')
@@ -40,4 +42,6 @@ for k in reversed(list(g64.keys())):
     e = (net.g[k].cpu().double() - ref).abs().max().item() / sc
     er = (r32[3][k].double() - ref).abs().max().item() / sc
     flag = ' <<<' if e > max(2e-3, 3 * er) else ''
-    if flag or os.environ.get('ALL'): print(f'{k:34s} ours {e:9.2e}  f32-oracle {er:9.2e}  scale {sc:9.2e}{flag}')
+    a_, b_ = net.g[k].cpu().double().flatten(), ref.flatten()
+    cos = ((a_ @ b_) / (a_.norm() * b_.norm() + 1e-300)).item()
+    if flag or os.environ.get('ALL'): print(f'{k:34s} ours {e:9.2e}  f32-oracle {er:9.2e}  scale {sc:9.2e} cos {cos:.4f}{flag}')
