@@ -19,7 +19,9 @@
 //     LDS across the block's persistent tile loop and leave as one fp64 atomic per
 //     channel per block.
 #include <type_traits>
-#include "common.h"
+#include "pwconv_common.h"
+
+using namespace t3d_pw;
 
 namespace {
 
@@ -28,35 +30,6 @@ template <> struct MM<bf16_t> { static constexpr int BK = 64, EPV = 8, LDK = 72;
 template <> struct MM<float> { static constexpr int BK = 32, EPV = 4, LDK = 36; };
 
 constexpr int BM = 128;  // pixels per tile (4 waves x 2 x 16)
-
-struct GemmArgs {
-  const void* a0;   // FWD: x (raw or finished); DGRAD: dz
-  const void* a1;   // DGRAD: y (raw output of the differentiated conv), else null
-  const float *p0, *p1, *p2;  // FWD: scale, shift, se[B][K]; DGRAD: alpha, beta, gamma
-  int act, se_after, per_sample, dgrad;
-  const void* w;     // [Nout][Kin] storage dtype
-  const float* bias; // [Nout] or null
-  const void* e_y;   // DGRAD epilogue: raw input tensor of the forward conv [M][Nout]
-  const float *e_scale, *e_shift, *e_se;
-  int e_act, e_se_after;
-  const void* e_res;  // residual gradient to add [M][Nout]
-  void* out;
-  double* stats;      // [2][Nout]
-  float* ps_stats;    // [B][Nout][2] per-sample sums (SE case)
-  int M, HW, Kin, Nout, mtiles;
-};
-
-template <typename T> __device__ __forceinline__ void ldvec(const T* p, float* v);
-template <> __device__ __forceinline__ void ldvec<float>(const float* p, float* v) {
-  const float4 a = *reinterpret_cast<const float4*>(p);
-  v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w;
-}
-template <> __device__ __forceinline__ void ldvec<bf16_t>(const bf16_t* p, float* v) { Vec8<bf16_t>::load(p, v); }
-template <typename T> __device__ __forceinline__ void stvec(T* p, const float* v);
-template <> __device__ __forceinline__ void stvec<float>(float* p, const float* v) {
-  *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
-}
-template <> __device__ __forceinline__ void stvec<bf16_t>(bf16_t* p, const float* v) { Vec8<bf16_t>::store(p, v); }
 
 template <typename T, int NT>
 __global__ __launch_bounds__(256, 2) void pw_gemm_kernel(const GemmArgs a) {
@@ -323,7 +296,11 @@ int dispatch(int dtype, GemmArgs& a, void* stream) {
   if (a.M <= 0 || a.Kin <= 0 || a.Nout <= 0 || (a.Kin % 8) || (a.Nout % 8) || a.HW <= 0) return T3D_ERR_ARG;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   if (dtype == T3D_F32) return launch<float>(a, st);
-  if (dtype == T3D_BF16) return launch<bf16_t>(a, st);
+  if (dtype == T3D_BF16) {
+    const int rc = stream_launch(a, st);
+    if (rc != T3D_ERR_UNSUPPORTED) return rc;
+    return launch<bf16_t>(a, st);
+  }
   return T3D_ERR_ARG;
 }
 

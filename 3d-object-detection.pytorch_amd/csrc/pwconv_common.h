@@ -1,0 +1,41 @@
+// Shared between the two pointwise-conv GEMM kernels (pwconv.hip: LDS-staged, fp32 + bf16;
+// pwconv_stream.hip: barrier-free streaming kernel, bf16).
+#pragma once
+#include "common.h"
+
+namespace t3d_pw {
+
+struct GemmArgs {
+  const void* a0;   // FWD: x (raw or finished); DGRAD: dz
+  const void* a1;   // DGRAD: y (raw output of the differentiated conv), else null
+  const float *p0, *p1, *p2;  // FWD: scale, shift, se[B][K]; DGRAD: alpha, beta, gamma
+  int act, se_after, per_sample, dgrad;
+  const void* w;     // [Nout][Kin] storage dtype
+  const float* bias; // [Nout] or null
+  const void* e_y;   // DGRAD epilogue: raw input tensor of the forward conv [M][Nout]
+  const float *e_scale, *e_shift, *e_se;
+  int e_act, e_se_after;
+  const void* e_res;  // residual gradient to add [M][Nout]
+  void* out;
+  double* stats;      // [2][Nout]
+  float* ps_stats;    // [B][Nout][2] per-sample sums (SE case)
+  int M, HW, Kin, Nout, mtiles;
+};
+
+template <typename T> __device__ __forceinline__ void ldvec(const T* p, float* v);
+template <> __device__ __forceinline__ void ldvec<float>(const float* p, float* v) {
+  const float4 a = *reinterpret_cast<const float4*>(p);
+  v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w;
+}
+template <> __device__ __forceinline__ void ldvec<bf16_t>(const bf16_t* p, float* v) { Vec8<bf16_t>::load(p, v); }
+template <typename T> __device__ __forceinline__ void stvec(T* p, const float* v);
+template <> __device__ __forceinline__ void stvec<float>(float* p, const float* v) {
+  *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
+}
+template <> __device__ __forceinline__ void stvec<bf16_t>(bf16_t* p, const float* v) { Vec8<bf16_t>::store(p, v); }
+
+
+// bf16 streaming kernel (pwconv_stream.hip); returns T3D_ERR_UNSUPPORTED when the shape does not fit it
+int stream_launch(GemmArgs& a, hipStream_t st);
+
+}  // namespace t3d_pw

@@ -1,0 +1,310 @@
+// Pointwise (1x1) convolution forward / data-gradient, bf16 storage: barrier-free streaming GEMM for gfx950.
+//
+//   out[m][n] = epilogue( sum_k  pro(A)[m][k] * W[n][k] )        m = NHWC pixel (B*H*W rows), HBM-bound
+//
+// The layers are HBM-bound with tiny weight matrices (<= 110 KB except at 7x7), so the kernel is built
+// around ONE pass over the activations with no LDS round trip and no barrier in the main loop:
+//   * the block's weight chunk W[n0 : n0+16*NT][:] is staged ONCE into LDS, already in MFMA-fragment
+//     order ([tile][k-step][lane] x 16 B), so every A-operand read is one conflict-free ds_read_b128;
+//   * each wave streams its own 16*R-pixel groups: the activation fragment of v_mfma_f32_16x16x32_bf16's
+//     B operand (pixel = lane&15, k = 8*(lane>>4)..+8) is exactly a 16-B global load per lane, so the
+//     producer's BatchNorm affine + activation (forward) or the BatchNorm-backward affine
+//     dy = alpha*dz + beta*y + gamma (data gradient) is applied in registers on the way to the MFMA;
+//   * the product is computed transposed (D = W * A^T) with permuted weight rows, so every lane ends up
+//     with 4*NT CONSECUTIVE output channels of one pixel: 16-B stores, no accumulator transpose;
+//   * BatchNorm sums (sum y, sum y^2 | sum dx, sum dx*x) live in per-lane registers across the wave's
+//     whole persistent loop (2 VALU ops per output element) and are reduced across lanes / waves once
+//     per block: one fp64 atomic per channel per block.
+// Latency is hidden by wave-level parallelism (8-16 resident waves per CU, each with its own loads in
+// flight), not by a block-wide pipeline.
+#include "pwconv_common.h"
+
+namespace t3d_pw {
+namespace {
+
+constexpr int WAVES = 8;  // 512 threads
+
+template <int NT, int R>
+__global__ __launch_bounds__(512, 2) void pw_stream_kernel(const GemmArgs a, const int nchunks, const int KS) {
+  constexpr int BN = NT * 16;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  bf16x8* Wf = reinterpret_cast<bf16x8*>(smem);                                   // [NT][KS][64]
+  const int kpad = KS * 32;
+  float* coef = reinterpret_cast<float*>(smem + (size_t)NT * KS * 1024);          // [3][kpad]
+  float* lstat = coef + 3 * kpad;                                                 // [BN][2]
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lg = lane >> 4, lc = lane & 15;
+  const int chunk = blockIdx.x % nchunks, xb = blockIdx.x / nchunks, nxb = gridDim.x / nchunks;
+  const int n0 = chunk * BN;
+  const bf16_t* __restrict__ A0 = reinterpret_cast<const bf16_t*>(a.a0);
+  const bf16_t* __restrict__ A1 = reinterpret_cast<const bf16_t*>(a.a1);
+  const bf16_t* __restrict__ Wg = reinterpret_cast<const bf16_t*>(a.w);
+  bf16_t* __restrict__ out = reinterpret_cast<bf16_t*>(a.out);
+
+  // ---- stage the weight chunk in fragment order: MFMA row lc of tile t <-> n_local = (lc>>2)*4*NT + 4*t + (lc&3)
+  for (int i = tid; i < NT * KS * 64; i += 512) {
+    const int l = i & 63, ks = (i >> 6) % KS, t = (i >> 6) / KS;
+    const int n = n0 + ((l & 15) >> 2) * 4 * NT + 4 * t + (l & 3), k = ks * 32 + (l >> 4) * 8;
+    bf16x8 v;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = (bf16_t)0.f;
+    if (n < a.Nout && k < a.Kin) v = *reinterpret_cast<const bf16x8*>(Wg + (size_t)n * a.Kin + k);
+    Wf[i] = v;
+  }
+  for (int i = tid; i < BN * 2; i += 512) lstat[i] = 0.f;
+  for (int i = tid; i < kpad; i += 512) {
+    const bool v = i < a.Kin;
+    if (!a.dgrad) {
+      coef[i] = (v && a.p0) ? a.p0[i] : 1.f;
+      coef[kpad + i] = (v && a.p0) ? a.p1[i] : 0.f;
+    } else {
+      coef[i] = (v && !a.per_sample) ? a.p0[i] : 0.f;
+      coef[kpad + i] = v ? a.p1[i] : 0.f;
+      coef[2 * kpad + i] = (v && !a.per_sample) ? a.p2[i] : 0.f;
+    }
+  }
+  __syncthreads();
+
+  const bool plainA = (!a.dgrad && !a.p0 && !a.p2 && a.act == T3D_ACT_NONE);
+  const bool keep_stats = a.stats != nullptr;
+  float st1[NT / 2][8], st2[NT / 2][8];
+#pragma unroll
+  for (int q = 0; q < NT / 2; ++q)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) st1[q][j] = st2[q][j] = 0.f;
+
+  const int ngroups = (a.M + 16 * R - 1) / (16 * R);
+  const int nb = n0 + lg * 4 * NT;
+  constexpr int KU = 2;  // k-steps whose loads are issued together
+
+  for (int g = xb * WAVES + wave; g < ngroups; g += nxb * WAVES) {
+    const int m0 = g * 16 * R;
+    f32x4 acc[R][NT];
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+#pragma unroll
+      for (int t = 0; t < NT; ++t) acc[r][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    int mrow[R];
+    bool mok[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      mrow[r] = m0 + r * 16 + lc;
+      mok[r] = mrow[r] < a.M;
+    }
+
+    for (int ks0 = 0; ks0 < KS; ks0 += KU) {
+      bf16x8 fa[KU][R], fb[KU][R];
+#pragma unroll
+      for (int u = 0; u < KU; ++u) {
+        const int k = (ks0 + u) * 32 + lg * 8;
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+          const bool ok = mok[r] && (k < a.Kin);
+          bf16x8 z;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) z[j] = (bf16_t)0.f;
+          fa[u][r] = ok ? *reinterpret_cast<const bf16x8*>(A0 + (size_t)mrow[r] * a.Kin + k) : z;
+          if (a.dgrad) fb[u][r] = ok ? *reinterpret_cast<const bf16x8*>(A1 + (size_t)mrow[r] * a.Kin + k) : z;
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < KU; ++u) {
+        const int ks = ks0 + u;
+        if (ks < KS) {
+          const int k = ks * 32 + lg * 8;
+          bf16x8 b[R];
+          if (plainA) {
+#pragma unroll
+            for (int r = 0; r < R; ++r) b[r] = fa[u][r];
+          } else {
+            const float4 c0a = *reinterpret_cast<const float4*>(coef + k), c0b = *reinterpret_cast<const float4*>(coef + k + 4);
+            const float4 c1a = *reinterpret_cast<const float4*>(coef + kpad + k),
+                         c1b = *reinterpret_cast<const float4*>(coef + kpad + k + 4);
+            const float c0[8] = {c0a.x, c0a.y, c0a.z, c0a.w, c0b.x, c0b.y, c0b.z, c0b.w};
+            const float c1[8] = {c1a.x, c1a.y, c1a.z, c1a.w, c1b.x, c1b.y, c1b.z, c1b.w};
+            if (!a.dgrad) {
+#pragma unroll
+              for (int r = 0; r < R; ++r) {
+                const bool ok = mok[r] && (k < a.Kin);
+                const float* se = (a.p2 && ok) ? a.p2 + (size_t)(mrow[r] / a.HW) * a.Kin + k : nullptr;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                  float x = (float)fa[u][r][j] * c0[j] + c1[j];
+                  const float sv = se ? se[j] : 1.f;
+                  if (!a.se_after) x *= sv;
+                  x = act_apply(x, a.act);
+                  if (a.se_after) x *= sv;
+                  b[r][j] = (bf16_t)(ok ? x : 0.f);
+                }
+              }
+            } else {
+              const float4 c2a = *reinterpret_cast<const float4*>(coef + 2 * kpad + k),
+                           c2b = *reinterpret_cast<const float4*>(coef + 2 * kpad + k + 4);
+              const float c2[8] = {c2a.x, c2a.y, c2a.z, c2a.w, c2b.x, c2b.y, c2b.z, c2b.w};
+#pragma unroll
+              for (int r = 0; r < R; ++r) {
+                const bool ok = mok[r] && (k < a.Kin);
+                const size_t pb = (a.per_sample && ok) ? (size_t)(mrow[r] / a.HW) * a.Kin + k : 0;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                  const float al = a.per_sample ? (ok ? a.p0[pb + j] : 0.f) : c0[j];
+                  const float ga = a.per_sample ? (ok ? a.p2[pb + j] : 0.f) : c2[j];
+                  b[r][j] = (bf16_t)(ok ? (al * (float)fa[u][r][j] + c1[j] * (float)fb[u][r][j] + ga) : 0.f);
+                }
+              }
+            }
+          }
+#pragma unroll
+          for (int t = 0; t < NT; ++t) {
+            const bf16x8 wf = Wf[(t * KS + ks) * 64 + lane];
+#pragma unroll
+            for (int r = 0; r < R; ++r) acc[r][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, b[r], acc[r][t], 0, 0, 0);
+          }
+        }
+      }
+    }
+
+    // ---------------- epilogue: lane holds channels nb .. nb+4*NT-1 of pixel mrow[r] ----------
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const int m = mrow[r];
+      const bool ok = mok[r];
+      const int mrow0 = m0 + r * 16, mlast = mrow0 + 15;
+      const bool uni = (mlast < a.M) && (mrow0 / a.HW == mlast / a.HW);
+      const int bidx = ok ? m / a.HW : 0;
+#pragma unroll
+      for (int q = 0; q < NT / 2; ++q) {
+        const int n = nb + 8 * q;
+        if (n >= a.Nout) continue;  // whole 8-channel groups are in or out (Nout % 8 == 0)
+        float v[8], yv[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = acc[r][2 * q + (j >> 2)][j & 3];
+        if (a.bias) {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) v[j] += a.bias[n + j];
+        }
+        if (a.e_y) {
+          if (ok) Vec8<bf16_t>::load(reinterpret_cast<const bf16_t*>(a.e_y) + (size_t)m * a.Nout + n, yv);
+          else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) yv[j] = 0.f;
+          }
+          const float* se = (a.e_se && ok) ? a.e_se + (size_t)bidx * a.Nout + n : nullptr;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            const float u = yv[j] * (a.e_scale ? a.e_scale[n + j] : 1.f) + (a.e_scale ? a.e_shift[n + j] : 0.f);
+            const float sv = se ? se[j] : 1.f;
+            if (!a.e_se_after) v[j] *= act_grad(u * sv, a.e_act);
+            else v[j] *= sv * act_grad(u, a.e_act);
+          }
+        }
+        if (a.e_res && ok) {
+          float rr[8];
+          Vec8<bf16_t>::load(reinterpret_cast<const bf16_t*>(a.e_res) + (size_t)m * a.Nout + n, rr);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) v[j] += rr[j];
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = ok ? Vec8<bf16_t>::round(v[j]) : 0.f;
+        if (ok) Vec8<bf16_t>::store(out + (size_t)m * a.Nout + n, v);
+        if (keep_stats) {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            st1[q][j] += v[j];
+            st2[q][j] = fmaf(v[j], a.e_y ? yv[j] : v[j], st2[q][j]);
+          }
+        } else if (a.ps_stats) {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            float s1 = v[j], s2 = v[j] * yv[j];
+            if (uni) {
+              s1 = row16_sum(s1);
+              s2 = row16_sum(s2);
+              if (lc == 0) {
+                unsafeAtomicAdd(a.ps_stats + ((size_t)bidx * a.Nout + n + j) * 2, s1);
+                unsafeAtomicAdd(a.ps_stats + ((size_t)bidx * a.Nout + n + j) * 2 + 1, s2);
+              }
+            } else if (ok) {
+              unsafeAtomicAdd(a.ps_stats + ((size_t)bidx * a.Nout + n + j) * 2, s1);
+              unsafeAtomicAdd(a.ps_stats + ((size_t)bidx * a.Nout + n + j) * 2 + 1, s2);
+            }
+          }
+        }
+      }
+    }
+  }
+
+  if (keep_stats) {
+#pragma unroll
+    for (int q = 0; q < NT / 2; ++q) {
+      const int n = nb + 8 * q;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float s1 = row16_sum(st1[q][j]), s2 = row16_sum(st2[q][j]);
+        if (lc == 0 && n < a.Nout) {
+          atomicAdd(lstat + (n - n0 + j) * 2, s1);
+          atomicAdd(lstat + (n - n0 + j) * 2 + 1, s2);
+        }
+      }
+    }
+    __syncthreads();
+    for (int i = tid; i < BN * 2; i += 512) {
+      const int n = n0 + (i >> 1);
+      if (n < a.Nout) atomicAdd(a.stats + (size_t)(i & 1) * a.Nout + n, (double)lstat[i]);
+    }
+  }
+}
+
+template <int NT, int R>
+int launch_nt(GemmArgs& a, int KS, hipStream_t st) {
+  constexpr int BN = NT * 16;
+  const int kpad = KS * 32;
+  const size_t lds = (size_t)NT * KS * 1024 + (size_t)3 * kpad * 4 + BN * 2 * 4;
+  if (lds > 150 * 1024) return T3D_ERR_UNSUPPORTED;
+  const int nchunks = cdiv(a.Nout, BN);
+  const int ngroups = cdiv(a.M, 16 * R);
+  // resident blocks: LDS allows floor(160K/lds) per CU, the register file ~2 (512-thread blocks); a few
+  // waves' worth of groups per wave keeps the weight staging amortised
+  int per_cu = (int)(160 * 1024 / lds);
+  if (per_cu > 2) per_cu = 2;
+  if (per_cu < 1) per_cu = 1;
+  int nxb = (256 * per_cu) / nchunks;
+  const int need = cdiv(ngroups, WAVES);
+  if (nxb > need) nxb = need;
+  if (nxb < 1) nxb = 1;
+  if (lds > 64 * 1024)
+    (void)hipFuncSetAttribute((const void*)pw_stream_kernel<NT, R>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipLaunchKernelGGL((pw_stream_kernel<NT, R>), dim3(nxb * nchunks), dim3(512), lds, st, a, nchunks, KS);
+  T3D_CHECK_LAUNCH();
+  return T3D_OK;
+}
+
+}  // namespace
+
+int stream_launch(GemmArgs& a, hipStream_t st) {
+  const int KS = cdiv(a.Kin, 32);
+  // widest chunk whose weights fit ~120 KB of LDS, at most 10 tiles (register budget: 8*NT stat + 4*NT*R acc)
+  int nt_cap = (120 * 1024 / 1024) / KS;
+  if (nt_cap > 10) nt_cap = 10;
+  nt_cap &= ~1;
+  if (nt_cap < 2) return T3D_ERR_UNSUPPORTED;
+  int NT = 2;
+  {
+    // fewest chunks first, then least padding
+    int best_chunks = 1 << 30, best_pad = 1 << 30;
+    for (int nt = 2; nt <= nt_cap; nt += 2) {
+      const int ch = cdiv(a.Nout, nt * 16), pad = ch * nt * 16 - a.Nout;
+      if (ch < best_chunks || (ch == best_chunks && pad < best_pad)) { best_chunks = ch; best_pad = pad; NT = nt; }
+    }
+  }
+  switch (NT) {
+    case 2: return launch_nt<2, 2>(a, KS, st);
+    case 4: return launch_nt<4, 2>(a, KS, st);
+    case 6: return launch_nt<6, 1>(a, KS, st);
+    case 8: return launch_nt<8, 1>(a, KS, st);
+    default: return launch_nt<10, 1>(a, KS, st);
+  }
+}
+
+}  // namespace t3d_pw
