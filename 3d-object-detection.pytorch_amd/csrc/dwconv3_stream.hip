@@ -1,0 +1,284 @@
+// Depthwise 3x3 convolution forward (stride 1 / 2), barrier-free streaming kernel for gfx950 (NHWC).
+//
+// HBM-bound (3.4 FLOP/B): the whole job is to touch every input and output byte once with wide
+// coalesced accesses and enough loads in flight.  No LDS, no barriers:
+//   * a thread owns 8 channels (one 16-B bf16 vector) of ONE output column and walks down a chunk of
+//     rows; lanes are laid out (channel-group fastest, then column), so a wave's load of one input row
+//     is a contiguous 1 KiB segment, and the three column taps (x-1, x, x+1) are three such loads
+//     shifted by one pixel (the overlap is served by L1 / L2, HBM sees each byte once);
+//   * stride 1: every input row is loaded ONCE and scattered into three rotating accumulators (the
+//     output rows it contributes to); stride 2: two new rows per output row, the shared odd row is
+//     kept in registers;
+//   * the producer's BatchNorm affine + activation is applied on load (zero padding AFTER the
+//     activation, as the reference pads the activated tensor);
+//   * per-channel sum / sum-of-squares for the following BatchNorm stay in the thread's registers
+//     for its whole chunk, meet in LDS once per block and leave as one fp64 atomic per channel.
+// The 9 x 8 weights of the thread's channels live in registers for the whole walk.
+#include <cstdlib>
+#include "common.h"
+
+namespace {
+
+struct Dw3Args {
+  const void* x;
+  void* y;
+  const float* w;  // [C][9]
+  const float *scale, *shift;
+  int act;
+  double* stats;
+  int B, H, W, C, Ho, Wo;
+  int rows_per_chunk, nchunks;
+  int slab;        // 0: flattened (column, channel-group) mapping; 1: 64-group channel slabs (wide layers)
+  int nitems;      // work items a thread walks: flattened: B*nchunks; slab: Wo*B*nchunks
+};
+
+template <typename T, int CH> using rawvec = T __attribute__((ext_vector_type(CH)));
+
+// raw vector -> activated fp32.  Zero padding applies to the ACTIVATED tensor: taps outside the image are removed by
+// zeroing the WEIGHTS of an out-of-image column (per item) and by skipping out-of-image rows (wave-uniform).
+template <typename T, int CH>
+__device__ __forceinline__ void activate(const rawvec<T, CH>& r, const float* sc, const float* sh, int act, bool affine,
+                                         float* v) {
+#pragma unroll
+  for (int i = 0; i < CH; ++i) v[i] = (float)r[i];
+  if (affine) act_affine_vec<CH>(v, sc, sh, act);
+}
+
+template <typename T, int CH>
+__device__ __forceinline__ void store_round(T* p, const float* acc, float* psum, float* psq) {
+  rawvec<T, CH> o;
+#pragma unroll
+  for (int i = 0; i < CH; ++i) {
+    o[i] = (T)acc[i];
+    const float r = (float)o[i];
+    psum[i] += r;
+    psq[i] = fmaf(r, r, psq[i]);
+  }
+  *reinterpret_cast<rawvec<T, CH>*>(p) = o;
+}
+
+// CH channels per thread (8 -> 16-B bf16 vectors, 4 -> 8-B: more resident waves), PF input rows in flight
+template <typename T, int S, int CH, int PF>
+__global__ __launch_bounds__(256) void dw3_fwd_kernel(const Dw3Args a) {
+  extern __shared__ float lstat[];  // [2][C]
+  using RV = rawvec<T, CH>;
+  const int CG = a.C / CH;
+  // A thread keeps ONE channel group for its whole life (weights + BatchNorm partial sums stay in registers)
+  // and walks a list of (column, row-chunk, sample) items.
+  //   flattened (CG < 64): thread = (column, group) of the row strip, items = (sample, chunk)
+  //   slab      (CG >= 64): lane = group inside a 64-group slab (blockIdx.y), items = (column, sample, chunk);
+  //                         a block then touches <= 64*CH channels when it flushes its sums
+  int cg, ox_fixed = 0, q0, qstride;
+  bool on;
+  if (!a.slab) {
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    on = j < a.Wo * CG;
+    cg = on ? j % CG : 0;
+    ox_fixed = on ? j / CG : 0;
+    q0 = blockIdx.y;
+    qstride = gridDim.y;
+  } else {
+    cg = blockIdx.y * 64 + (threadIdx.x & 63);
+    on = cg < CG;
+    if (!on) cg = 0;
+    q0 = blockIdx.x * 4 + (threadIdx.x >> 6);
+    qstride = gridDim.x * 4;
+  }
+  const int c0 = cg * CH;
+  const bool affine = a.scale != nullptr || a.act != T3D_ACT_NONE;
+
+  float wt[9][CH], sc[CH], sh[CH], psum[CH], psq[CH];
+  {
+    // the CH*9 weights of this thread's channels are contiguous: 16-B loads, transposed in registers
+    float wb[CH * 9];
+    const float4* wp = reinterpret_cast<const float4*>(a.w + (size_t)c0 * 9);   // c0*9*4 B is 16-B aligned (CH % 4 == 0)
+#pragma unroll
+    for (int i = 0; i < CH * 9 / 4; ++i) {
+      const float4 q = wp[i];
+      wb[4 * i] = q.x; wb[4 * i + 1] = q.y; wb[4 * i + 2] = q.z; wb[4 * i + 3] = q.w;
+    }
+#pragma unroll
+    for (int i = 0; i < CH; ++i) {
+      sc[i] = a.scale ? a.scale[c0 + i] : 1.f;
+      sh[i] = a.scale ? a.shift[c0 + i] : 0.f;
+      psum[i] = psq[i] = 0.f;
+#pragma unroll
+      for (int t = 0; t < 9; ++t) wt[t][i] = wb[i * 9 + t];
+    }
+  }
+  for (int q = q0; q < a.nitems && on; q += qstride) {
+  int ox, rest;
+  if (!a.slab) { ox = ox_fixed; rest = q; } else { ox = q % a.Wo; rest = q / a.Wo; }
+  const int chunk = rest % a.nchunks, b = rest / a.nchunks;
+  const T* __restrict__ x = reinterpret_cast<const T*>(a.x) + (size_t)b * a.H * a.W * a.C + c0;
+  T* __restrict__ y = reinterpret_cast<T*>(a.y) + (size_t)b * a.Ho * a.Wo * a.C + c0;
+  const int oy0 = chunk * a.rows_per_chunk;
+  const int oy1 = min(a.Ho, oy0 + a.rows_per_chunk);
+  const int ix0 = ox * S - 1;
+  const bool cok[3] = {ix0 >= 0, true, ix0 + 2 < a.W};  // ix0+1 = ox*S < W always
+  float wk[9][CH];   // this item's weights: columns outside the image contribute nothing
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int i = 0; i < CH; ++i) wk[t][i] = cok[t % 3] ? wt[t][i] : 0.f;
+  // input rows this thread walks: iy_first .. iy_last (inclusive)
+  const int iy_first = oy0 * S - 1, iy_last = (oy1 - 1) * S + 1;
+
+  RV ring[PF][3];
+  auto fetch = [&](int iy, RV* dst) {
+    const bool rok = iy >= 0 && iy < a.H && iy <= iy_last;
+    const T* rp = x + ((size_t)(rok ? iy : 0) * a.W + ix0) * a.C;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      RV z;
+#pragma unroll
+      for (int i = 0; i < CH; ++i) z[i] = (T)0.f;
+      dst[c] = (rok && cok[c]) ? *reinterpret_cast<const RV*>(rp + (size_t)c * a.C) : z;
+    }
+  };
+
+  {
+#pragma unroll
+    for (int u = 0; u < PF; ++u) fetch(iy_first + u, ring[u]);
+    float accA[CH], accB[CH], accC[CH];  // S=1: output rows iy-1, iy, iy+1.  S=2: accA = current output row
+#pragma unroll
+    for (int i = 0; i < CH; ++i) accA[i] = accB[i] = accC[i] = 0.f;
+    for (int base = iy_first; base <= iy_last; base += PF) {
+#pragma unroll
+      for (int u = 0; u < PF; ++u) {
+        const int iy = base + u;
+        if (iy <= iy_last) {
+          const bool rok = iy >= 0 && iy < a.H;
+          float v[3][CH];
+#pragma unroll
+          for (int c = 0; c < 3; ++c) {
+            activate<T, CH>(ring[u][c], sc, sh, a.act, affine, v[c]);
+#pragma unroll
+            for (int i = 0; i < CH; ++i) v[c][i] = rok ? v[c][i] : 0.f;   // out-of-image row (scalar condition)
+          }
+          fetch(iy + PF, ring[u]);   // refill this slot: PF rows ahead
+          if constexpr (S == 1) {
+            // row iy feeds output rows iy+1 (ky=0), iy (ky=1), iy-1 (ky=2)
+#pragma unroll
+            for (int c = 0; c < 3; ++c)
+#pragma unroll
+              for (int i = 0; i < CH; ++i) {
+                accA[i] = fmaf(v[c][i], wk[6 + c][i], accA[i]);
+                accB[i] = fmaf(v[c][i], wk[3 + c][i], accB[i]);
+                accC[i] = fmaf(v[c][i], wk[c][i], accC[i]);
+              }
+            const int oy = iy - 1;
+            if (oy >= oy0 && oy < oy1) store_round<T, CH>(y + ((size_t)oy * a.Wo + ox) * a.C, accA, psum, psq);
+#pragma unroll
+            for (int i = 0; i < CH; ++i) {
+              accA[i] = accB[i];
+              accB[i] = accC[i];
+              accC[i] = 0.f;
+            }
+          } else {
+            // rows 2oy-1 (ky=0), 2oy (ky=1), 2oy+1 (ky=2, and ky=0 of the next output row)
+            const int rel = iy - iy_first;      // 0: ky=0 of oy0; odd: ky=1; even>0: ky=2 of oy and ky=0 of oy+1
+            if (rel & 1) {
+#pragma unroll
+              for (int c = 0; c < 3; ++c)
+#pragma unroll
+                for (int i = 0; i < CH; ++i) accA[i] = fmaf(v[c][i], wk[3 + c][i], accA[i]);
+            } else {
+              if (rel > 0) {
+#pragma unroll
+                for (int c = 0; c < 3; ++c)
+#pragma unroll
+                  for (int i = 0; i < CH; ++i) accA[i] = fmaf(v[c][i], wk[6 + c][i], accA[i]);
+                const int oy = oy0 + (rel >> 1) - 1;
+                store_round<T, CH>(y + ((size_t)oy * a.Wo + ox) * a.C, accA, psum, psq);
+              }
+#pragma unroll
+              for (int c = 0; c < 3; ++c)
+#pragma unroll
+                for (int i = 0; i < CH; ++i) accA[i] = (c == 0 ? 0.f : accA[i]) + v[c][i] * wk[c][i];
+            }
+          }
+        }
+      }
+    }
+  }
+
+  }  // item loop
+
+  if (a.stats) {
+    for (int i = threadIdx.x; i < 2 * a.C; i += 256) lstat[i] = 0.f;
+    __syncthreads();
+    if (on) {
+#pragma unroll
+      for (int i = 0; i < CH; ++i) {
+        atomicAdd(lstat + c0 + i, psum[i]);
+        atomicAdd(lstat + a.C + c0 + i, psq[i]);
+      }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 2 * a.C; i += 256)
+      if (lstat[i] != 0.f) atomicAdd(a.stats + i, (double)lstat[i]);
+  }
+}
+
+template <typename T, int CH>
+int launch_ch(Dw3Args& a, int s, hipStream_t st) {
+  constexpr int PF = 3;
+  const int CG = a.C / CH;
+  // row chunks: enough work items to fill the chip (several resident waves per SIMD), but long enough that
+  // the 1-2 halo rows re-read per chunk stay a small fraction
+  const long long per_row_chunk = (long long)a.B * a.Wo * CG;
+  int nchunks = (int)((256LL * 64 * 40 + per_row_chunk - 1) / per_row_chunk);
+  int max_chunks = a.Ho / 8;
+  if (max_chunks < 1) max_chunks = 1;
+  if (nchunks > max_chunks) nchunks = max_chunks;
+  if (nchunks < 1) nchunks = 1;
+  a.rows_per_chunk = cdiv(a.Ho, nchunks);
+  a.nchunks = cdiv(a.Ho, a.rows_per_chunk);
+  dim3 grid;
+  const int target_blocks = 256 * 8;   // ~8 resident 4-wave blocks per CU's worth of persistent blocks
+  if (CG < 64) {
+    a.slab = 0;
+    a.nitems = a.B * a.nchunks;
+    const int jb = cdiv(a.Wo * CG, 256);
+    int gy = target_blocks / jb;
+    if (gy > a.nitems) gy = a.nitems;
+    if (gy < 1) gy = 1;
+    grid = dim3(jb, gy);
+  } else {
+    a.slab = 1;
+    a.nitems = a.Wo * a.B * a.nchunks;
+    const int ns = cdiv(CG, 64);
+    int gx = target_blocks / ns;
+    if (gx > cdiv(a.nitems, 4)) gx = cdiv(a.nitems, 4);
+    if (gx < 1) gx = 1;
+    grid = dim3(gx, ns);
+  }
+  const size_t lds = (size_t)2 * a.C * sizeof(float);
+  if (s == 1) hipLaunchKernelGGL((dw3_fwd_kernel<T, 1, CH, PF>), grid, dim3(256), lds, st, a);
+  else hipLaunchKernelGGL((dw3_fwd_kernel<T, 2, CH, PF>), grid, dim3(256), lds, st, a);
+  T3D_CHECK_LAUNCH();
+  return T3D_OK;
+}
+
+template <typename T>
+int launch(Dw3Args& a, int s, hipStream_t st) {
+  static const int ch = getenv("T3D_DW_CH") ? atoi(getenv("T3D_DW_CH")) : 4;
+  return ch == 8 ? launch_ch<T, 8>(a, s, st) : launch_ch<T, 4>(a, s, st);
+}
+
+}  // namespace
+
+// Called by t3d_dwconv_fwd for k == 3 without a squeeze-excite pooled output.
+int t3d_dw3_fwd_stream(int dtype, const void* x, const t3d_prologue* pro, const float* w, void* y, double* stats, int B,
+                       int H, int W, int C, int stride, hipStream_t st) {
+  Dw3Args a{};
+  a.x = x; a.y = y; a.w = w; a.stats = stats;
+  if (pro) { a.scale = pro->scale; a.shift = pro->shift; a.act = pro->act; }
+  a.B = B; a.H = H; a.W = W; a.C = C;
+  a.Ho = (H + 2 - 3) / stride + 1;
+  a.Wo = (W + 2 - 3) / stride + 1;
+  if (dtype == T3D_F32) return launch<float>(a, stride, st);
+  if (dtype == T3D_BF16) return launch<bf16_t>(a, stride, st);
+  return T3D_ERR_ARG;
+}

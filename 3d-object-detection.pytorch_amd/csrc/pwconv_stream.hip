@@ -22,9 +22,10 @@
 namespace t3d_pw {
 namespace {
 
-constexpr int WAVES = 8;  // 512 threads
 
-template <int NT, int R>
+// DG: data-gradient variant (two input tensors, BN-backward affine, act' epilogue); GEN: squeeze-excite / per-sample
+// coefficients present (MobileNetV3 only) -- compiled out of the common variants to keep registers down.
+template <int NT, int R, bool DG, bool GEN>
 __global__ __launch_bounds__(512, 2) void pw_stream_kernel(const GemmArgs a, const int nchunks, const int KS) {
   constexpr int BN = NT * 16;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -43,7 +44,8 @@ __global__ __launch_bounds__(512, 2) void pw_stream_kernel(const GemmArgs a, con
   bf16_t* __restrict__ out = reinterpret_cast<bf16_t*>(a.out);
 
   // ---- stage the weight chunk in fragment order: MFMA row lc of tile t <-> n_local = (lc>>2)*4*NT + 4*t + (lc&3)
-  for (int i = tid; i < NT * KS * 64; i += 512) {
+  const int nthr = blockDim.x, WAVES = nthr >> 6;
+  for (int i = tid; i < NT * KS * 64; i += nthr) {
     const int l = i & 63, ks = (i >> 6) % KS, t = (i >> 6) / KS;
     const int n = n0 + ((l & 15) >> 2) * 4 * NT + 4 * t + (l & 3), k = ks * 32 + (l >> 4) * 8;
     bf16x8 v;
@@ -52,10 +54,10 @@ __global__ __launch_bounds__(512, 2) void pw_stream_kernel(const GemmArgs a, con
     if (n < a.Nout && k < a.Kin) v = *reinterpret_cast<const bf16x8*>(Wg + (size_t)n * a.Kin + k);
     Wf[i] = v;
   }
-  for (int i = tid; i < BN * 2; i += 512) lstat[i] = 0.f;
-  for (int i = tid; i < kpad; i += 512) {
+  for (int i = tid; i < BN * 2; i += nthr) lstat[i] = 0.f;
+  for (int i = tid; i < kpad; i += nthr) {
     const bool v = i < a.Kin;
-    if (!a.dgrad) {
+    if (!DG) {
       coef[i] = (v && a.p0) ? a.p0[i] : 1.f;
       coef[kpad + i] = (v && a.p0) ? a.p1[i] : 0.f;
     } else {
@@ -66,7 +68,7 @@ __global__ __launch_bounds__(512, 2) void pw_stream_kernel(const GemmArgs a, con
   }
   __syncthreads();
 
-  const bool plainA = (!a.dgrad && !a.p0 && !a.p2 && a.act == T3D_ACT_NONE);
+  const bool plainA = (!DG && !a.p0 && !a.p2 && a.act == T3D_ACT_NONE);
   const bool keep_stats = a.stats != nullptr;
   float st1[NT / 2][8], st2[NT / 2][8];
 #pragma unroll
@@ -105,7 +107,7 @@ __global__ __launch_bounds__(512, 2) void pw_stream_kernel(const GemmArgs a, con
 #pragma unroll
           for (int j = 0; j < 8; ++j) z[j] = (bf16_t)0.f;
           fa[u][r] = ok ? *reinterpret_cast<const bf16x8*>(A0 + (size_t)mrow[r] * a.Kin + k) : z;
-          if (a.dgrad) fb[u][r] = ok ? *reinterpret_cast<const bf16x8*>(A1 + (size_t)mrow[r] * a.Kin + k) : z;
+          if (DG) fb[u][r] = ok ? *reinterpret_cast<const bf16x8*>(A1 + (size_t)mrow[r] * a.Kin + k) : z;
         }
       }
 #pragma unroll
@@ -123,20 +125,29 @@ __global__ __launch_bounds__(512, 2) void pw_stream_kernel(const GemmArgs a, con
                          c1b = *reinterpret_cast<const float4*>(coef + kpad + k + 4);
             const float c0[8] = {c0a.x, c0a.y, c0a.z, c0a.w, c0b.x, c0b.y, c0b.z, c0b.w};
             const float c1[8] = {c1a.x, c1a.y, c1a.z, c1a.w, c1b.x, c1b.y, c1b.z, c1b.w};
-            if (!a.dgrad) {
+            if (!DG) {
 #pragma unroll
               for (int r = 0; r < R; ++r) {
                 const bool ok = mok[r] && (k < a.Kin);
-                const float* se = (a.p2 && ok) ? a.p2 + (size_t)(mrow[r] / a.HW) * a.Kin + k : nullptr;
+                float x[8];
 #pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                  float x = (float)fa[u][r][j] * c0[j] + c1[j];
-                  const float sv = se ? se[j] : 1.f;
-                  if (!a.se_after) x *= sv;
-                  x = act_apply(x, a.act);
-                  if (a.se_after) x *= sv;
-                  b[r][j] = (bf16_t)(ok ? x : 0.f);
+                for (int j = 0; j < 8; ++j) x[j] = (float)fa[u][r][j];
+                if (GEN && a.p2) {
+                  const float* se = ok ? a.p2 + (size_t)(mrow[r] / a.HW) * a.Kin + k : nullptr;
+#pragma unroll
+                  for (int j = 0; j < 8; ++j) {
+                    float t = x[j] * c0[j] + c1[j];
+                    const float sv = se ? se[j] : 1.f;
+                    if (!a.se_after) t *= sv;
+                    t = act_apply(t, a.act);
+                    if (a.se_after) t *= sv;
+                    x[j] = t;
+                  }
+                } else {
+                  act_affine_vec<8>(x, c0, c1, a.act);
                 }
+#pragma unroll
+                for (int j = 0; j < 8; ++j) b[r][j] = (bf16_t)(ok ? x[j] : 0.f);
               }
             } else {
               const float4 c2a = *reinterpret_cast<const float4*>(coef + 2 * kpad + k),
@@ -145,11 +156,11 @@ __global__ __launch_bounds__(512, 2) void pw_stream_kernel(const GemmArgs a, con
 #pragma unroll
               for (int r = 0; r < R; ++r) {
                 const bool ok = mok[r] && (k < a.Kin);
-                const size_t pb = (a.per_sample && ok) ? (size_t)(mrow[r] / a.HW) * a.Kin + k : 0;
+                const size_t pb = (GEN && a.per_sample && ok) ? (size_t)(mrow[r] / a.HW) * a.Kin + k : 0;
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
-                  const float al = a.per_sample ? (ok ? a.p0[pb + j] : 0.f) : c0[j];
-                  const float ga = a.per_sample ? (ok ? a.p2[pb + j] : 0.f) : c2[j];
+                  const float al = (GEN && a.per_sample) ? (ok ? a.p0[pb + j] : 0.f) : c0[j];
+                  const float ga = (GEN && a.per_sample) ? (ok ? a.p2[pb + j] : 0.f) : c2[j];
                   b[r][j] = (bf16_t)(ok ? (al * (float)fa[u][r][j] + c1[j] * (float)fb[u][r][j] + ga) : 0.f);
                 }
               }
@@ -180,26 +191,36 @@ __global__ __launch_bounds__(512, 2) void pw_stream_kernel(const GemmArgs a, con
         float v[8], yv[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) v[j] = acc[r][2 * q + (j >> 2)][j & 3];
-        if (a.bias) {
+        if (!DG && a.bias) {
 #pragma unroll
           for (int j = 0; j < 8; ++j) v[j] += a.bias[n + j];
         }
-        if (a.e_y) {
+        if (DG && a.e_y) {
           if (ok) Vec8<bf16_t>::load(reinterpret_cast<const bf16_t*>(a.e_y) + (size_t)m * a.Nout + n, yv);
           else {
 #pragma unroll
             for (int j = 0; j < 8; ++j) yv[j] = 0.f;
           }
-          const float* se = (a.e_se && ok) ? a.e_se + (size_t)bidx * a.Nout + n : nullptr;
+          if (GEN && a.e_se) {
+            const float* se = ok ? a.e_se + (size_t)bidx * a.Nout + n : nullptr;
 #pragma unroll
-          for (int j = 0; j < 8; ++j) {
-            const float u = yv[j] * (a.e_scale ? a.e_scale[n + j] : 1.f) + (a.e_scale ? a.e_shift[n + j] : 0.f);
-            const float sv = se ? se[j] : 1.f;
-            if (!a.e_se_after) v[j] *= act_grad(u * sv, a.e_act);
-            else v[j] *= sv * act_grad(u, a.e_act);
+            for (int j = 0; j < 8; ++j) {
+              const float u = yv[j] * (a.e_scale ? a.e_scale[n + j] : 1.f) + (a.e_scale ? a.e_shift[n + j] : 0.f);
+              const float sv = se ? se[j] : 1.f;
+              if (!a.e_se_after) v[j] *= act_grad(u * sv, a.e_act);
+              else v[j] *= sv * act_grad(u, a.e_act);
+            }
+          } else if (a.e_act != T3D_ACT_NONE) {
+            float es[8], eh[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+              es[j] = a.e_scale ? a.e_scale[n + j] : 1.f;
+              eh[j] = a.e_scale ? a.e_shift[n + j] : 0.f;
+            }
+            act_grad_affine_vec<8>(v, yv, es, eh, a.e_act);
           }
         }
-        if (a.e_res && ok) {
+        if (DG && a.e_res && ok) {
           float rr[8];
           Vec8<bf16_t>::load(reinterpret_cast<const bf16_t*>(a.e_res) + (size_t)m * a.Nout + n, rr);
 #pragma unroll
@@ -212,9 +233,9 @@ __global__ __launch_bounds__(512, 2) void pw_stream_kernel(const GemmArgs a, con
 #pragma unroll
           for (int j = 0; j < 8; ++j) {
             st1[q][j] += v[j];
-            st2[q][j] = fmaf(v[j], a.e_y ? yv[j] : v[j], st2[q][j]);
+            st2[q][j] = fmaf(v[j], (DG && a.e_y) ? yv[j] : v[j], st2[q][j]);
           }
-        } else if (a.ps_stats) {
+        } else if (GEN && a.ps_stats) {
 #pragma unroll
           for (int j = 0; j < 8; ++j) {
             float s1 = v[j], s2 = v[j] * yv[j];
@@ -249,35 +270,51 @@ __global__ __launch_bounds__(512, 2) void pw_stream_kernel(const GemmArgs a, con
       }
     }
     __syncthreads();
-    for (int i = tid; i < BN * 2; i += 512) {
+    for (int i = tid; i < BN * 2; i += nthr) {
       const int n = n0 + (i >> 1);
       if (n < a.Nout) atomicAdd(a.stats + (size_t)(i & 1) * a.Nout + n, (double)lstat[i]);
     }
   }
 }
 
-template <int NT, int R>
-int launch_nt(GemmArgs& a, int KS, hipStream_t st) {
+template <int NT, int R, bool DG, bool GEN>
+int launch_v(GemmArgs& a, int KS, hipStream_t st) {
   constexpr int BN = NT * 16;
   const int kpad = KS * 32;
   const size_t lds = (size_t)NT * KS * 1024 + (size_t)3 * kpad * 4 + BN * 2 * 4;
   if (lds > 150 * 1024) return T3D_ERR_UNSUPPORTED;
   const int nchunks = cdiv(a.Nout, BN);
   const int ngroups = cdiv(a.M, 16 * R);
-  // resident blocks: LDS allows floor(160K/lds) per CU, the register file ~2 (512-thread blocks); a few
-  // waves' worth of groups per wave keeps the weight staging amortised
-  int per_cu = (int)(160 * 1024 / lds);
-  if (per_cu > 2) per_cu = 2;
+  // small weight chunks: 4-wave blocks, as many per CU as registers / LDS admit (each wave hides its own
+  // load latency, so resident waves per CU are what matters); big chunks: one 8-wave block shares the copy
+  const int threads = lds <= 48 * 1024 ? 256 : 512;
+  const void* fn = (const void*)pw_stream_kernel<NT, R, DG, GEN>;
+  if (lds > 64 * 1024) (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  static int occ_cache[2] = {0, 0};   // per instantiation, per block size
+  int& occ = occ_cache[threads == 512];
+  if (occ == 0) {
+    int n = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, fn, threads, 0) != hipSuccess || n < 1) n = 1;
+    occ = n;
+  }
+  int per_cu = occ;
+  const int by_lds = (int)(160 * 1024 / (lds + 512));
+  if (per_cu > by_lds) per_cu = by_lds;
   if (per_cu < 1) per_cu = 1;
   int nxb = (256 * per_cu) / nchunks;
-  const int need = cdiv(ngroups, WAVES);
+  const int need = cdiv(ngroups, threads / 64);
   if (nxb > need) nxb = need;
   if (nxb < 1) nxb = 1;
-  if (lds > 64 * 1024)
-    (void)hipFuncSetAttribute((const void*)pw_stream_kernel<NT, R>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  hipLaunchKernelGGL((pw_stream_kernel<NT, R>), dim3(nxb * nchunks), dim3(512), lds, st, a, nchunks, KS);
+  hipLaunchKernelGGL((pw_stream_kernel<NT, R, DG, GEN>), dim3(nxb * nchunks), dim3(threads), lds, st, a, nchunks, KS);
   T3D_CHECK_LAUNCH();
   return T3D_OK;
+}
+
+template <int NT, int R>
+int launch_nt(GemmArgs& a, int KS, hipStream_t st) {
+  const bool gen = a.per_sample || a.ps_stats || a.e_se || (!a.dgrad && a.p2);
+  if (a.dgrad) return gen ? launch_v<NT, R, true, true>(a, KS, st) : launch_v<NT, R, true, false>(a, KS, st);
+  return gen ? launch_v<NT, R, false, true>(a, KS, st) : launch_v<NT, R, false, false>(a, KS, st);
 }
 
 }  // namespace

@@ -1,0 +1,69 @@
+"""Profiling aid: launch ONE conv entry point repeatedly on a given shape (for rocprofv3 --pmc / --kernel-trace).
+usage: run_kernel.py dwfwd|dwbwd|pwfwd|pwdgrad|pwwgrad  B H W C [k s] | M HW K N   [--reps R] [--f32]"""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, '3d-object-detection.pytorch_amd')]
+import torch
+from torchdet3d import _native as N
+
+args = [a for a in sys.argv[1:] if not a.startswith('--')]
+reps = int(sys.argv[sys.argv.index('--reps') + 1]) if '--reps' in sys.argv else 5
+dt = torch.float32 if '--f32' in sys.argv else torch.bfloat16
+kind, dims = args[0], [int(v) for v in args[1:]]
+dev = 'cuda'
+g = torch.Generator(device=dev).manual_seed(0)
+rnd = lambda *s: torch.randn(*s, device=dev, generator=g)
+keep = []
+if kind in ('dwfwd', 'dwbwd'):
+    B, H, W, C = dims[:4]
+    k, s = (dims[4], dims[5]) if len(dims) > 5 else (3, 1)
+    Ho, Wo = (H + 2 * (k // 2) - k) // s + 1, (W + 2 * (k // 2) - k) // s + 1
+    x = rnd(B * H * W, C).to(dt); w = rnd(C, k * k) * 0.3
+    sc, sh = torch.rand(C, device=dev) + 0.5, rnd(C) * 0.2
+    pro = N.prologue(sc, sh, None, 'relu6', False)
+    y = torch.empty(B * Ho * Wo, C, device=dev, dtype=dt)
+    stats = torch.zeros(2 * C, device=dev, dtype=torch.float64)
+    if kind == 'dwfwd':
+        fn = lambda: N.call('t3d_dwconv_fwd', N.dtype_code(x), N.ptr(x), pro, N.ptr(w), N.ptr(y), N.ptr(stats), None,
+                            B, H, W, C, k, s, N.stream())
+        nbytes = (x.numel() + y.numel()) * x.element_size()
+    else:
+        dz, yy = rnd(B * Ho * Wo, C).to(dt), rnd(B * Ho * Wo, C).to(dt)
+        al, be, ga = torch.rand(C, device=dev) + 0.5, rnd(C) * 0.1, rnd(C) * 0.1
+        bb = N.bnbwd(al, be, ga, False)
+        dx = torch.empty_like(x); dw = torch.zeros(C, k * k, device=dev)
+        fn = lambda: N.call('t3d_dwconv_bwd', N.dtype_code(x), N.ptr(dz), N.ptr(yy), bb, N.ptr(w), N.ptr(x), pro, None,
+                            N.ptr(dx), N.ptr(stats), N.ptr(dw), B, H, W, C, k, s, N.stream())
+        nbytes = 2 * (x.numel() + y.numel()) * x.element_size()
+else:
+    M, HW, K, Nn = dims[:4]
+    x = rnd(M, K).to(dt); wf = (rnd(Nn, K) / K ** .5)
+    wq = wf.to(dt).contiguous(); wt = wf.t().contiguous().to(dt)
+    sc, sh = torch.rand(K, device=dev) + 0.5, rnd(K) * 0.2
+    pro = N.prologue(sc, sh, None, 'relu6', False)
+    y = torch.empty(M, Nn, device=dev, dtype=dt)
+    dz, yy = rnd(M, Nn).to(dt), rnd(M, Nn).to(dt)
+    al, be, ga = torch.rand(Nn, device=dev) + 0.5, rnd(Nn) * 0.1, rnd(Nn) * 0.1
+    bb = N.bnbwd(al, be, ga, False)
+    dx = torch.empty(M, K, device=dev, dtype=dt)
+    nbytes = M * (K + Nn) * x.element_size()
+    if kind == 'pwfwd':
+        stats = torch.zeros(2 * Nn, device=dev, dtype=torch.float64)
+        fn = lambda: N.call('t3d_pwconv_fwd', N.dtype_code(x), N.ptr(x), pro, N.ptr(wq), None, N.ptr(y), N.ptr(stats),
+                            M, HW, K, Nn, N.stream())
+    elif kind == 'pwdgrad':
+        stats = torch.zeros(2 * K, device=dev, dtype=torch.float64)
+        fn = lambda: N.call('t3d_pwconv_dgrad', N.dtype_code(x), N.ptr(dz), N.ptr(yy), bb, N.ptr(wt), N.ptr(x), pro, None,
+                            N.ptr(dx), N.ptr(stats), None, M, HW, K, Nn, N.stream())
+    else:
+        dw = torch.zeros(Nn, K, device=dev)
+        fn = lambda: N.call('t3d_pwconv_wgrad', N.dtype_code(x), N.ptr(dz), N.ptr(yy), bb, N.ptr(x), pro, N.ptr(dw),
+                            M, HW, K, Nn, N.stream())
+fn(); torch.cuda.synchronize()
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+e0.record()
+for _ in range(reps):
+    fn()
+e1.record(); torch.cuda.synchronize()
+us = e0.elapsed_time(e1) * 1e3 / reps
+print(f'{kind} {dims}: {us:.1f} us  {nbytes / us / 1e6:.2f} TB/s algorithmic')
