@@ -6,15 +6,20 @@
 
 namespace {
 
-__global__ void bn_finalize_kernel(const double* __restrict__ stats, int C, double count,
+__global__ void bn_finalize_kernel(const double* __restrict__ stats, int nrep, long long rstride, int C, double count,
                                    const float* __restrict__ gamma, const float* __restrict__ beta,
                                    float* running_mean, float* running_var, int64_t* nbt, float momentum,
                                    float eps, float* scale, float* shift, float* mean_out, float* invstd_out) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c == 0 && nbt) *nbt += 1;
   if (c >= C) return;
-  const double mean = stats[c] / count;
-  double var = stats[C + c] / count - mean * mean;  // biased
+  double s1 = 0.0, s2 = 0.0;
+  for (int r = 0; r < nrep; ++r) {
+    s1 += stats[r * rstride + c];
+    s2 += stats[r * rstride + C + c];
+  }
+  const double mean = s1 / count;
+  double var = s2 / count - mean * mean;  // biased
   if (var < 0.0) var = 0.0;
   const float invstd = (float)(1.0 / sqrt(var + (double)eps));
   const float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
@@ -41,13 +46,17 @@ __global__ void bn_eval_affine_kernel(int C, const float* __restrict__ gamma, co
   shift[c] = (beta ? beta[c] : 0.f) - rm[c] * s;
 }
 
-__global__ void bn_bwd_finalize_kernel(const double* __restrict__ stats, int C, double count,
+__global__ void bn_bwd_finalize_kernel(const double* __restrict__ stats, int nrep, long long rstride, int C, double count,
                                        const float* __restrict__ gamma, const float* __restrict__ mean,
                                        const float* __restrict__ invstd, float* alpha, float* beta, float* gammac,
                                        float* dgamma, float* dbeta) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= C) return;
-  const double s1 = stats[c], s2 = stats[C + c];
+  double s1 = 0.0, s2 = 0.0;
+  for (int r = 0; r < nrep; ++r) {
+    s1 += stats[r * rstride + c];
+    s2 += stats[r * rstride + C + c];
+  }
   const double mu = (double)mean[c], is = (double)invstd[c];
   const double dg = is * (s2 - mu * s1);
   const double a = (double)(gamma ? gamma[c] : 1.f) * is;
@@ -67,7 +76,7 @@ extern "C" int t3d_bn_finalize(const double* stats, int C, double count, const f
                                void* stream) {
   if (!stats || !scale || !shift || C <= 0 || count <= 0) return T3D_ERR_ARG;
   hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, 256)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
-                     stats, C, count, gamma, beta, running_mean, running_var, num_batches_tracked, momentum, eps,
+                     stats, g_t3d_reduce.nrep, g_t3d_reduce.stats_stride, C, count, gamma, beta, running_mean, running_var, num_batches_tracked, momentum, eps,
                      scale, shift, mean, invstd);
   T3D_CHECK_LAUNCH();
   return T3D_OK;
@@ -90,7 +99,7 @@ extern "C" int t3d_bn_bwd_finalize(const double* stats, int C, double count, con
                                    float* dbeta, void* stream) {
   if (!stats || !mean || !invstd || !alpha || !beta || !gammac || C <= 0 || count <= 0) return T3D_ERR_ARG;
   hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(C, 256)), dim3(256), 0,
-                     reinterpret_cast<hipStream_t>(stream), stats, C, count, gamma, mean, invstd, alpha, beta,
+                     reinterpret_cast<hipStream_t>(stream), stats, g_t3d_reduce.nrep, g_t3d_reduce.stats_stride, C, count, gamma, mean, invstd, alpha, beta,
                      gammac, dgamma, dbeta);
   T3D_CHECK_LAUNCH();
   return T3D_OK;

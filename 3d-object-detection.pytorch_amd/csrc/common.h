@@ -17,6 +17,12 @@ typedef __attribute__((ext_vector_type(4))) float f32x4;
 
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 
+// Reduction replicas (t3d_set_reduction_replicas, misc.hip): contended atomics into one small array run an order of
+// magnitude below the chip's atomic rate, so block b adds its BatchNorm sums / depthwise weight gradient into
+// replica b % nrep; the finalize kernels (and the caller, for dw) sum the replicas.
+struct T3dReduceCfg { int nrep; long long stats_stride; };
+extern T3dReduceCfg g_t3d_reduce;
+
 // ---- 8-channel vector load/store, storage type T, math in fp32 ------------
 template <typename T> struct Vec8;
 template <> struct Vec8<float> {
@@ -80,22 +86,22 @@ __device__ __forceinline__ void act_affine_vec(float* v, const float* sc, const 
   switch (act) {
     case T3D_ACT_RELU:
 #pragma unroll
-      for (int i = 0; i < NV; ++i) v[i] = fmaxf(v[i] * sc[i] + sh[i], 0.f);
+      for (int i = 0; i < NV; ++i) v[i] = fmaxf(fmaf(v[i], sc[i], sh[i]), 0.f);
       break;
     case T3D_ACT_RELU6:
 #pragma unroll
-      for (int i = 0; i < NV; ++i) v[i] = __builtin_amdgcn_fmed3f(v[i] * sc[i] + sh[i], 0.f, 6.f);
+      for (int i = 0; i < NV; ++i) v[i] = __builtin_amdgcn_fmed3f(fmaf(v[i], sc[i], sh[i]), 0.f, 6.f);
       break;
     case T3D_ACT_HSWISH:
 #pragma unroll
       for (int i = 0; i < NV; ++i) {
-        const float u = v[i] * sc[i] + sh[i];
+        const float u = fmaf(v[i], sc[i], sh[i]);
         v[i] = u * (__builtin_amdgcn_fmed3f(u + 3.f, 0.f, 6.f) * T3D_SIXTH);
       }
       break;
     default:
 #pragma unroll
-      for (int i = 0; i < NV; ++i) v[i] = v[i] * sc[i] + sh[i];
+      for (int i = 0; i < NV; ++i) v[i] = fmaf(v[i], sc[i], sh[i]);
   }
 }
 //   g[i] *= act'(y[i]*sc[i] + sh[i])
@@ -104,18 +110,18 @@ __device__ __forceinline__ void act_grad_affine_vec(float* g, const float* y, co
   switch (act) {
     case T3D_ACT_RELU:
 #pragma unroll
-      for (int i = 0; i < NV; ++i) g[i] = (y[i] * sc[i] + sh[i] > 0.f) ? g[i] : 0.f;
+      for (int i = 0; i < NV; ++i) g[i] = (fmaf(y[i], sc[i], sh[i]) > 0.f) ? g[i] : 0.f;
       break;
     case T3D_ACT_RELU6:
 #pragma unroll
       for (int i = 0; i < NV; ++i) {
-        const float u = y[i] * sc[i] + sh[i];
+        const float u = fmaf(y[i], sc[i], sh[i]);
         g[i] = (u > 0.f && u < 6.f) ? g[i] : 0.f;
       }
       break;
     case T3D_ACT_HSWISH:
 #pragma unroll
-      for (int i = 0; i < NV; ++i) g[i] *= act_grad(y[i] * sc[i] + sh[i], T3D_ACT_HSWISH);
+      for (int i = 0; i < NV; ++i) g[i] *= act_grad(fmaf(y[i], sc[i], sh[i]), T3D_ACT_HSWISH);
       break;
     default:
       break;

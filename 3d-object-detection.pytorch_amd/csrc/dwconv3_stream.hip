@@ -30,6 +30,8 @@ struct Dw3Args {
   int rows_per_chunk, nchunks;
   int slab;        // 0: flattened (column, channel-group) mapping; 1: 64-group channel slabs (wide layers)
   int nitems;      // work items a thread walks: flattened: B*nchunks; slab: Wo*B*nchunks
+  int nrep;        // reduction replicas (common.h)
+  long long rstride;
 };
 
 template <typename T, int CH> using rawvec = T __attribute__((ext_vector_type(CH)));
@@ -124,60 +126,66 @@ __global__ __launch_bounds__(256) void dw3_fwd_kernel(const Dw3Args a) {
   // input rows this thread walks: iy_first .. iy_last (inclusive)
   const int iy_first = oy0 * S - 1, iy_last = (oy1 - 1) * S + 1;
 
+  // loads are unconditional from clamped (always valid) addresses: out-of-image columns are cancelled by the
+  // zeroed weights above, out-of-image rows are skipped below -- no divergent branches around the loads
+  int coff[3];
+#pragma unroll
+  for (int c = 0; c < 3; ++c) coff[c] = min(max(ix0 + c, 0), a.W - 1) * a.C;
   RV ring[PF][3];
   auto fetch = [&](int iy, RV* dst) {
-    const bool rok = iy >= 0 && iy < a.H && iy <= iy_last;
-    const T* rp = x + ((size_t)(rok ? iy : 0) * a.W + ix0) * a.C;
+    const T* rp = x + (size_t)min(max(iy, 0), a.H - 1) * a.W * a.C;
 #pragma unroll
-    for (int c = 0; c < 3; ++c) {
-      RV z;
-#pragma unroll
-      for (int i = 0; i < CH; ++i) z[i] = (T)0.f;
-      dst[c] = (rok && cok[c]) ? *reinterpret_cast<const RV*>(rp + (size_t)c * a.C) : z;
-    }
+    for (int c = 0; c < 3; ++c) dst[c] = *reinterpret_cast<const RV*>(rp + coff[c]);
   };
 
   {
 #pragma unroll
     for (int u = 0; u < PF; ++u) fetch(iy_first + u, ring[u]);
-    float accA[CH], accB[CH], accC[CH];  // S=1: output rows iy-1, iy, iy+1.  S=2: accA = current output row
+    static_assert(PF == 3, "the three rotating accumulators take their roles from the unroll index");
+    float acc[3][CH];   // S=1: roles (row iy-1, iy, iy+1) = acc[u%3], acc[(u+1)%3], acc[(u+2)%3].  S=2: acc[0] only
 #pragma unroll
-    for (int i = 0; i < CH; ++i) accA[i] = accB[i] = accC[i] = 0.f;
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+      for (int i = 0; i < CH; ++i) acc[r][i] = 0.f;
     for (int base = iy_first; base <= iy_last; base += PF) {
 #pragma unroll
       for (int u = 0; u < PF; ++u) {
         const int iy = base + u;
         if (iy <= iy_last) {
-          const bool rok = iy >= 0 && iy < a.H;
+          const bool rok = iy >= 0 && iy < a.H;   // wave-uniform in the slab mapping, near-uniform otherwise
           float v[3][CH];
 #pragma unroll
-          for (int c = 0; c < 3; ++c) {
-            activate<T, CH>(ring[u][c], sc, sh, a.act, affine, v[c]);
-#pragma unroll
-            for (int i = 0; i < CH; ++i) v[c][i] = rok ? v[c][i] : 0.f;   // out-of-image row (scalar condition)
-          }
+          for (int c = 0; c < 3; ++c) activate<T, CH>(ring[u][c], sc, sh, a.act, affine, v[c]);
           fetch(iy + PF, ring[u]);   // refill this slot: PF rows ahead
           if constexpr (S == 1) {
+            float* accA = acc[u % 3];
+            float* accB = acc[(u + 1) % 3];
+            float* accC = acc[(u + 2) % 3];
             // row iy feeds output rows iy+1 (ky=0), iy (ky=1), iy-1 (ky=2)
+            if (rok) {
 #pragma unroll
-            for (int c = 0; c < 3; ++c)
+              for (int c = 0; c < 3; ++c)
 #pragma unroll
-              for (int i = 0; i < CH; ++i) {
-                accA[i] = fmaf(v[c][i], wk[6 + c][i], accA[i]);
-                accB[i] = fmaf(v[c][i], wk[3 + c][i], accB[i]);
-                accC[i] = fmaf(v[c][i], wk[c][i], accC[i]);
-              }
+                for (int i = 0; i < CH; ++i) {
+                  accA[i] = fmaf(v[c][i], wk[6 + c][i], accA[i]);
+                  accB[i] = fmaf(v[c][i], wk[3 + c][i], accB[i]);
+                  accC[i] = fmaf(v[c][i], wk[c][i], accC[i]);
+                }
+            }
             const int oy = iy - 1;
             if (oy >= oy0 && oy < oy1) store_round<T, CH>(y + ((size_t)oy * a.Wo + ox) * a.C, accA, psum, psq);
 #pragma unroll
-            for (int i = 0; i < CH; ++i) {
-              accA[i] = accB[i];
-              accB[i] = accC[i];
-              accC[i] = 0.f;
-            }
+            for (int i = 0; i < CH; ++i) accA[i] = 0.f;   // becomes the "row iy+2" accumulator of the next row
           } else {
+            float* accA = acc[0];
             // rows 2oy-1 (ky=0), 2oy (ky=1), 2oy+1 (ky=2, and ky=0 of the next output row)
             const int rel = iy - iy_first;      // 0: ky=0 of oy0; odd: ky=1; even>0: ky=2 of oy and ky=0 of oy+1
+            if (!rok) {
+#pragma unroll
+              for (int c = 0; c < 3; ++c)
+#pragma unroll
+                for (int i = 0; i < CH; ++i) v[c][i] = 0.f;
+            }
             if (rel & 1) {
 #pragma unroll
               for (int c = 0; c < 3; ++c)
@@ -193,16 +201,17 @@ __global__ __launch_bounds__(256) void dw3_fwd_kernel(const Dw3Args a) {
                 store_round<T, CH>(y + ((size_t)oy * a.Wo + ox) * a.C, accA, psum, psq);
               }
 #pragma unroll
-              for (int c = 0; c < 3; ++c)
+              for (int i = 0; i < CH; ++i) accA[i] = v[0][i] * wk[0][i];
 #pragma unroll
-                for (int i = 0; i < CH; ++i) accA[i] = (c == 0 ? 0.f : accA[i]) + v[c][i] * wk[c][i];
+              for (int c = 1; c < 3; ++c)
+#pragma unroll
+                for (int i = 0; i < CH; ++i) accA[i] = fmaf(v[c][i], wk[c][i], accA[i]);
             }
           }
         }
       }
     }
   }
-
   }  // item loop
 
   if (a.stats) {
@@ -217,7 +226,8 @@ __global__ __launch_bounds__(256) void dw3_fwd_kernel(const Dw3Args a) {
     }
     __syncthreads();
     for (int i = threadIdx.x; i < 2 * a.C; i += 256)
-      if (lstat[i] != 0.f) atomicAdd(a.stats + i, (double)lstat[i]);
+      if (lstat[i] != 0.f)
+        atomicAdd(a.stats + (size_t)((blockIdx.x + blockIdx.y) % a.nrep) * a.rstride + i, (double)lstat[i]);
   }
 }
 
@@ -236,7 +246,9 @@ int launch_ch(Dw3Args& a, int s, hipStream_t st) {
   a.rows_per_chunk = cdiv(a.Ho, nchunks);
   a.nchunks = cdiv(a.Ho, a.rows_per_chunk);
   dim3 grid;
-  const int target_blocks = 256 * 8;   // ~8 resident 4-wave blocks per CU's worth of persistent blocks
+  const int target_blocks = 256 * 6;   // persistent blocks: enough to fill the chip, few enough that the per-block flush stays cheap
+  a.nrep = g_t3d_reduce.nrep;
+  a.rstride = g_t3d_reduce.stats_stride;
   if (CG < 64) {
     a.slab = 0;
     a.nitems = a.B * a.nchunks;

@@ -12,6 +12,7 @@
 //          OUTPUT pixels; k*8 accumulators live in registers across the block's whole
 //          (persistent) tile loop and leave as fp32 atomics once per block.
 // Algorithmic traffic: read x, dz, y once, write dx once = 2*(in + out) elements.
+#include <cstdlib>
 #include "common.h"
 
 namespace {
@@ -29,6 +30,8 @@ struct DwBwdArgs {
   int B, H, W, C, Ho, Wo;
   int TH, TW, tiles_x, tiles_y, cgb, pix_stride;
   int a_off, d_off;                    // byte offsets of the A and D tiles
+  int nrep;                            // reduction replicas (common.h)
+  long long rstride;
 };
 
 template <typename T, int K, int S>
@@ -234,7 +237,7 @@ __global__ __launch_bounds__(256) void dw_bwd_kernel(const DwBwdArgs a) {
           const int sl = q * K + ky;
           s += scratch[((sl * cgb + (cc >> 3)) * K + kx) * 8 + (cc & 7)];
         }
-        unsafeAtomicAdd(a.dw + (size_t)c * (K * K) + tap, s);
+        unsafeAtomicAdd(a.dw + (size_t)(blockIdx.x % a.nrep) * a.C * (K * K) + (size_t)c * (K * K) + tap, s);
       }
     }
   }
@@ -254,7 +257,7 @@ __global__ __launch_bounds__(256) void dw_bwd_kernel(const DwBwdArgs a) {
       if (c < a.C) {
         double s = 0.0;
         for (int q = 0; q < nslots; ++q) s += (double)scratch[(q * CB + cc) * 2 + which];
-        atomicAdd(a.stats + (size_t)which * a.C + c, s);
+        atomicAdd(a.stats + (size_t)(blockIdx.x % a.nrep) * a.rstride + (size_t)which * a.C + c, s);
       }
     }
   }
@@ -263,6 +266,8 @@ __global__ __launch_bounds__(256) void dw_bwd_kernel(const DwBwdArgs a) {
 template <typename T>
 int launch(const DwBwdArgs& a0, int k, int s, hipStream_t st) {
   DwBwdArgs a = a0;
+  a.nrep = g_t3d_reduce.nrep;
+  a.rstride = g_t3d_reduce.stats_stride;
   const int P = (k - 1) / 2, DLO = P / s, DHI = (s - 1 + P) / s;
   const int CG = a.C / 8;
   const int nchunks = cdiv(CG, 8);
@@ -313,11 +318,20 @@ int launch(const DwBwdArgs& a0, int k, int s, hipStream_t st) {
 
 }  // namespace
 
+int t3d_dw3_bwd_stream(int dtype, const void* dz, const void* y, const t3d_bnbwd* bb, const float* w, const void* x,
+                       const t3d_prologue* pro, const void* residual, void* dx, double* stats, float* dw, int B, int H,
+                       int W, int C, int stride, hipStream_t st);   // dwconv3_bwd_stream.hip
+
 extern "C" int t3d_dwconv_bwd(int dtype, const void* dz, const void* y, const t3d_bnbwd* bb, const float* w,
                               const void* x, const t3d_prologue* pro, const void* residual, void* dx, double* stats,
                               float* dw, int B, int H, int W, int C, int k, int stride, void* stream) {
   if (!dz || !y || !bb || !w || !x || !dx || B <= 0 || H <= 0 || W <= 0 || C <= 0 || (C % 8)) return T3D_ERR_ARG;
   if (pro && pro->se) return T3D_ERR_UNSUPPORTED;  // no SE gate ever precedes a depthwise conv
+  if (k == 3 && getenv("T3D_DW_BWD_STREAM")) {   // experimental streaming variant (dwconv3_bwd_stream.hip), off by default
+    const int rc = t3d_dw3_bwd_stream(dtype, dz, y, bb, w, x, pro, residual, dx, stats, dw, B, H, W, C, stride,
+                                      reinterpret_cast<hipStream_t>(stream));
+    if (rc != T3D_ERR_UNSUPPORTED) return rc;
+  }
   DwBwdArgs a{};
   a.dz = dz; a.y = y; a.x = x; a.res = residual; a.dx = dx; a.w = w;
   a.alpha = bb->alpha; a.beta = bb->beta; a.gamma = bb->gamma; a.per_sample = bb->per_sample;

@@ -30,6 +30,8 @@ struct DwFwdArgs {
   int cgb;                       // channel groups (of 8) per block
   int pix_stride;                // LDS elements per staged pixel
   int tile_off;                  // byte offset of the tile region in LDS
+  int nrep;                      // reduction replicas (common.h)
+  long long rstride;
 };
 
 template <typename T, int K, int S>
@@ -194,7 +196,7 @@ __global__ __launch_bounds__(256) void dw_fwd_kernel(const DwFwdArgs a) {
       if (c < a.C) {
         double s = 0.0;
         for (int q = 0; q < nslots; ++q) s += (double)scratch[(q * CB + cc) * 2 + which];
-        atomicAdd(a.stats + (size_t)which * a.C + c, s);
+        atomicAdd(a.stats + (size_t)(blockIdx.x % a.nrep) * a.rstride + (size_t)which * a.C + c, s);
       }
     }
   }
@@ -203,6 +205,8 @@ __global__ __launch_bounds__(256) void dw_fwd_kernel(const DwFwdArgs a) {
 template <typename T>
 int launch(const DwFwdArgs& a0, int k, int s, hipStream_t st) {
   DwFwdArgs a = a0;
+  a.nrep = g_t3d_reduce.nrep;
+  a.rstride = g_t3d_reduce.stats_stride;
   const int CG = a.C / 8;
   const int nchunks = cdiv(CG, 8);
   a.cgb = cdiv(CG, nchunks);

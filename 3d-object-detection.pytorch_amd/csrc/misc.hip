@@ -33,3 +33,12 @@ extern "C" int t3d_pack_weight(int dtype, const float* w, void* out, int rows, i
   T3D_CHECK_LAUNCH();
   return T3D_OK;
 }
+
+T3dReduceCfg g_t3d_reduce = {1, 0};
+
+extern "C" int t3d_set_reduction_replicas(int nrep, long long stats_stride) {
+  if (nrep < 1 || nrep > 64 || (nrep > 1 && stats_stride <= 0)) return T3D_ERR_ARG;
+  g_t3d_reduce.nrep = nrep;
+  g_t3d_reduce.stats_stride = nrep > 1 ? stats_stride : 0;
+  return T3D_OK;
+}

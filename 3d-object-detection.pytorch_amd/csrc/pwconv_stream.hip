@@ -26,7 +26,7 @@ namespace {
 // DG: data-gradient variant (two input tensors, BN-backward affine, act' epilogue); GEN: squeeze-excite / per-sample
 // coefficients present (MobileNetV3 only) -- compiled out of the common variants to keep registers down.
 template <int NT, int R, bool DG, bool GEN>
-__global__ __launch_bounds__(512, 2) void pw_stream_kernel(const GemmArgs a, const int nchunks, const int KS) {
+__global__ __launch_bounds__(512, 2) void pw_stream_kernel(const GemmArgs a, const int nchunks, const int KS, const int nrep, const long long rstride) {
   constexpr int BN = NT * 16;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   bf16x8* Wf = reinterpret_cast<bf16x8*>(smem);                                   // [NT][KS][64]
@@ -272,7 +272,7 @@ __global__ __launch_bounds__(512, 2) void pw_stream_kernel(const GemmArgs a, con
     __syncthreads();
     for (int i = tid; i < BN * 2; i += nthr) {
       const int n = n0 + (i >> 1);
-      if (n < a.Nout) atomicAdd(a.stats + (size_t)(i & 1) * a.Nout + n, (double)lstat[i]);
+      if (n < a.Nout) atomicAdd(a.stats + (size_t)(xb % nrep) * rstride + (size_t)(i & 1) * a.Nout + n, (double)lstat[i]);
     }
   }
 }
@@ -305,7 +305,8 @@ int launch_v(GemmArgs& a, int KS, hipStream_t st) {
   const int need = cdiv(ngroups, threads / 64);
   if (nxb > need) nxb = need;
   if (nxb < 1) nxb = 1;
-  hipLaunchKernelGGL((pw_stream_kernel<NT, R, DG, GEN>), dim3(nxb * nchunks), dim3(threads), lds, st, a, nchunks, KS);
+  hipLaunchKernelGGL((pw_stream_kernel<NT, R, DG, GEN>), dim3(nxb * nchunks), dim3(threads), lds, st, a, nchunks, KS,
+                     g_t3d_reduce.nrep, g_t3d_reduce.stats_stride);
   T3D_CHECK_LAUNCH();
   return T3D_OK;
 }

@@ -54,6 +54,7 @@ SIGNATURES = {
     't3d_head_bwd': [_P, _PP, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P],
     't3d_se_fwd': [_P] * 11 + [_I, _I, _I, _I, _P],
     't3d_se_bwd': [_P] * 18 + [_I, _I, _I, _I, _P],
+    't3d_set_reduction_replicas': [_I, _L],
     't3d_loss_fwd_bwd': [_LP, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P],
 }
 

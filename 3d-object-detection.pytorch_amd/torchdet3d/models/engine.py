@@ -29,6 +29,7 @@ from .. import _native as N
 from .arch import Arch
 
 BN_EPS, BN_MOM = 1e-5, 0.1      # PyTorch defaults the reference relies on
+NREP = 16                       # reduction replicas (include/t3d.h: t3d_set_reduction_replicas)
 
 
 class _BN:
@@ -109,7 +110,8 @@ class Net:
                                    else (torch.ones(s, device=dev) if k.endswith('var') else torch.zeros(s, device=dev)))
         nbn = [k[:-len('.running_mean')] for k in shapes if k.endswith('.running_mean')]
         tot = sum(shapes[k + '.weight'][0][0] for k in nbn)
-        self._statbuf = torch.zeros(4 * tot, device=dev, dtype=torch.float64)     # fwd sums | bwd sums
+        self._statbuf = torch.zeros(NREP, 4 * tot, device=dev, dtype=torch.float64)   # replicas x (fwd sums | bwd sums)
+        self._stat_stride = 4 * tot
         self._aff = torch.zeros(7 * tot, device=dev)                            # scale shift mean invstd alpha beta gammac
         o = 0
         for k in nbn:
@@ -120,8 +122,8 @@ class Net:
             b.dgamma, b.dbeta = self.g[k + '.weight'], self.g[k + '.bias']
             b.rm, b.rv, b.nbt = self.buffers[k + '.running_mean'], self.buffers[k + '.running_var'], \
                 self.buffers[k + '.num_batches_tracked']
-            b.stats = self._statbuf[2 * o:2 * o + 2 * C]
-            b.bstats = self._statbuf[2 * tot + 2 * o:2 * tot + 2 * o + 2 * C]
+            b.stats = self._statbuf[0, 2 * o:2 * o + 2 * C]          # replica 0; replica r is _stat_stride doubles further
+            b.bstats = self._statbuf[0, 2 * tot + 2 * o:2 * tot + 2 * o + 2 * C]
             sl = [self._aff[i * tot + o:i * tot + o + C] for i in range(7)]
             b.scale, b.shift, b.mean, b.invstd, b.alpha, b.bbeta, b.gammac = sl
             b.pro_cache = {}
@@ -259,6 +261,13 @@ class Net:
 
     # ------------------------------------------------------------------ forward
     def forward(self, imgs, cats, train=False, dropout_mask=None):
+        N.call('t3d_set_reduction_replicas', NREP, self._stat_stride)
+        try:
+            return self._forward(imgs, cats, train, dropout_mask)
+        finally:
+            N.call('t3d_set_reduction_replicas', 1, 0)
+
+    def _forward(self, imgs, cats, train=False, dropout_mask=None):
         """imgs [B,3,H,W] fp32 NCHW (the reference's input contract), cats int64 [B] ->
         kp [B,9,2] fp32 in (0,1), logits [B,num_classes] fp32 (None when num_classes == 1)."""
         a, st, dt = self.arch, N.stream(), self.dt
@@ -396,6 +405,13 @@ class Net:
 
     # ------------------------------------------------------------------ backward
     def backward(self, dkp, dlogits=None):
+        N.call('t3d_set_reduction_replicas', NREP, self._stat_stride)
+        try:
+            return self._backward(dkp, dlogits)
+        finally:
+            N.call('t3d_set_reduction_replicas', 1, 0)
+
+    def _backward(self, dkp, dlogits=None):
         """Gradient of the last train-mode forward w.r.t. every parameter -> `gflat` (overwritten).
         dkp [B,9,2] / dlogits [B,num_classes]: d loss / d outputs (fp32)."""
         sv = self.saved
@@ -425,7 +441,11 @@ class Net:
                    N.ptr(self.g['classifier.0.weight']), B, 1, a.last_c, a.classifier, st)
             # bias gradient = sum_b dy = alpha*sum(dz) + beta*sum(y) + B*gamma (exactly 0 in exact arithmetic)
             C = a.classifier
-            self.g['classifier.0.bias'].copy_((bnc.alpha.double() * bnc.bstats[:C] + bnc.bbeta.double() * bnc.stats[:C]
+            o = bnc.stats.storage_offset()
+            tot2 = self._stat_stride // 2
+            sy = self._statbuf[:, o:o + C].sum(0)
+            sdz = self._statbuf[:, o + tot2:o + tot2 + C].sum(0)
+            self.g['classifier.0.bias'].copy_((bnc.alpha.double() * sdz + bnc.bbeta.double() * sy
                                                + B * bnc.gammac.double()).float())
             dpooled = self._buf('dpooled', (B, a.last_c), torch.float32)
             N.call('t3d_pwconv_dgrad', N.F32, N.ptr(df), N.ptr(yc), bb, N.ptr(self.wt['classifier']), None, None,
@@ -526,9 +546,11 @@ class Net:
         if blk.expand:
             s1 = rec['s1']
             d1 = self._buf(f'dz1:{i}', (M1, blk.cexp))
+            dwrep = self._buf(f'dwrep:{i}', (NREP, blk.cexp * blk.k * blk.k), torch.float32, zero=True)
             N.call('t3d_dwconv_bwd', dt, N.ptr(dv2), N.ptr(s2.raw), bb2, N.ptr(self.p[dwn]), N.ptr(s1.t), s1.pro, None,
-                   N.ptr(d1), N.ptr(s1.bn.bstats), N.ptr(self.g[dwn]), B, x.H, x.W, blk.cexp, blk.k, blk.s, st,
+                   N.ptr(d1), N.ptr(s1.bn.bstats), N.ptr(dwrep), B, x.H, x.W, blk.cexp, blk.k, blk.s, st,
                    nbytes=2 * (M1 + M2) * blk.cexp * self.esz)
+            torch.sum(dwrep, 0, out=self.g[dwn].view(-1))
             bb1 = self._bn_bwd(s1.bn)
             p = f'features.{i + 1}.conv'
             N.call('t3d_pwconv_wgrad', dt, N.ptr(d1), N.ptr(s1.raw), bb1, N.ptr(x.t), x.pro,
@@ -538,11 +560,13 @@ class Net:
                                   blk.cexp, f'dzin:{i}')
         # no-expand layout: the depthwise conv reads the block input directly
         dx = self._buf(f'dzin:{i}', (M1, blk.cexp))
+        dwrep = self._buf(f'dwrep:{i}', (NREP, blk.cexp * blk.k * blk.k), torch.float32, zero=True)
         deferred = x.pro is not None           # raw producer tensor read through its prologue
         N.call('t3d_dwconv_bwd', dt, N.ptr(dv2), N.ptr(s2.raw), bb2, N.ptr(self.p[dwn]), N.ptr(x.t), x.pro,
                N.ptr(res) if res is not None else None, N.ptr(dx),
-               N.ptr(x.bn.bstats) if deferred else None, N.ptr(self.g[dwn]), B, x.H, x.W, blk.cexp, blk.k, blk.s, st,
+               N.ptr(x.bn.bstats) if deferred else None, N.ptr(dwrep), B, x.H, x.W, blk.cexp, blk.k, blk.s, st,
                nbytes=2 * (M1 + M2) * blk.cexp * self.esz)
+        torch.sum(dwrep, 0, out=self.g[dwn].view(-1))
         if not deferred:
             # finished input: the producer's BatchNorm sums have to be taken against its RAW tensor
             dx = self._act_bwd(dx, x, f'dzin:{i}:a')

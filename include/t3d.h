@@ -206,6 +206,14 @@ int t3d_se_bwd(const float* ps_stats, const float* gap_sum, const float* scale, 
                float* dp, double* stats, float* dw1, float* db1, float* dw2, float* db2, int B, int C, int R, int HW,
                void* stream);
 
+/* Reduction replicas.  Every `+=` reduction output of the kernels (the fp64 BatchNorm sums `stats`, the depthwise
+ * weight gradient `dw`) is hit by one atomic per channel per workgroup; with hundreds of workgroups on a few KB of
+ * addresses those atomics serialise.  With nrep > 1 the streaming kernels add into replica (workgroup % nrep):
+ *   stats replica r lives at  stats + r*stats_stride  (doubles);   dw replica r at  dw + r*C*k*k  (floats);
+ * t3d_bn_finalize / t3d_bn_bwd_finalize sum the nrep stats replicas, the caller sums the dw replicas.
+ * Process-wide setting (default 1 = plain behaviour); kernels that do not implement replicas use replica 0. */
+int t3d_set_reduction_replicas(int nrep, long long stats_stride);
+
 #ifdef __cplusplus
 }
 #endif

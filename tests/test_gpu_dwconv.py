@@ -19,7 +19,7 @@ def _act(x, kind):
 SHAPES = [  # B, C, H, W, k, s
     (2, 32, 24, 24, 3, 1), (2, 96, 24, 24, 3, 2), (3, 72, 13, 17, 5, 2), (2, 120, 12, 12, 5, 1),
     (2, 16, 48, 48, 3, 1), (4, 960, 3, 3, 5, 1), (2, 200, 6, 6, 3, 1), (1, 8, 7, 7, 3, 1), (2, 144, 56, 56, 3, 1),
-    (2, 672, 14, 14, 5, 2)]
+    (2, 672, 14, 14, 5, 2), (3, 576, 6, 6, 3, 1), (2, 960, 3, 3, 3, 1), (2, 384, 12, 12, 3, 2), (5, 264, 9, 7, 3, 1)]
 
 
 @pytest.mark.parametrize('B,C,H,W,k,s', SHAPES)
