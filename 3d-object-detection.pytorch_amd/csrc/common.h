@@ -23,6 +23,11 @@ static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 struct T3dReduceCfg { int nrep; long long stats_stride; };
 extern T3dReduceCfg g_t3d_reduce;
 
+// Scratch workspace in device memory (t3d_set_workspace, misc.hip): partial results of split reductions (the pointwise
+// weight gradient) are written there with plain stores and summed by a second small kernel instead of leaving as atomics.
+struct T3dWorkspace { void* ptr; long long bytes; };
+extern T3dWorkspace g_t3d_ws;
+
 // ---- 8-channel vector load/store, storage type T, math in fp32 ------------
 template <typename T> struct Vec8;
 template <> struct Vec8<float> {

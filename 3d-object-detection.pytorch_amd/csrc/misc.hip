@@ -42,3 +42,12 @@ extern "C" int t3d_set_reduction_replicas(int nrep, long long stats_stride) {
   g_t3d_reduce.stats_stride = nrep > 1 ? stats_stride : 0;
   return T3D_OK;
 }
+
+T3dWorkspace g_t3d_ws = {nullptr, 0};
+
+extern "C" int t3d_set_workspace(void* ptr, long long bytes) {
+  if ((ptr == nullptr) != (bytes <= 0)) return T3D_ERR_ARG;
+  g_t3d_ws.ptr = ptr;
+  g_t3d_ws.bytes = ptr ? bytes : 0;
+  return T3D_OK;
+}

@@ -10,6 +10,7 @@
 // v_mfma_f32_16x16x4_f32 (one element per lane, exact fp32).
 // Grid = (N tiles, K tiles, pixel splits); each block owns a 64x64 tile of dW over its pixel
 // range and leaves with fp32 atomics into the fp32 gradient buffer (the reference's [N,K,1,1]).
+#include <cstdlib>
 #include <type_traits>
 #include "common.h"
 
@@ -181,9 +182,14 @@ __global__ __launch_bounds__(256, 2) void pw_wgrad_kernel(const WgArgs a) {
 
 }  // namespace
 
+int t3d_pw_wgrad_tr_entry(const void* dz, const void* y, const t3d_bnbwd* bb, const void* x, const t3d_prologue* pro,
+                          float* dw, int M, int HW, int K, int N, hipStream_t st);   // pwconv_wgrad_tr.hip (bf16)
+
 extern "C" int t3d_pwconv_wgrad(int dtype, const void* dz, const void* y, const t3d_bnbwd* bb, const void* x,
                                 const t3d_prologue* pro, float* dw, int M, int HW, int K, int N, void* stream) {
   if (!dz || !y || !bb || !x || !dw || M <= 0 || K <= 0 || N <= 0 || (K % 8) || (N % 8) || HW <= 0) return T3D_ERR_ARG;
+  if (dtype == T3D_BF16 && !getenv("T3D_WGRAD_TILED"))
+    return t3d_pw_wgrad_tr_entry(dz, y, bb, x, pro, dw, M, HW, K, N, reinterpret_cast<hipStream_t>(stream));
   WgArgs a{};
   a.dz = dz; a.y = y; a.x = x;
   a.alpha = bb->alpha; a.beta = bb->beta; a.gamma = bb->gamma; a.per_sample = bb->per_sample;

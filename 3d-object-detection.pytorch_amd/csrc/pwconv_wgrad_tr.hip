@@ -1,0 +1,328 @@
+// Pointwise (1x1) convolution weight gradient, bf16 storage, gfx950:
+//
+//   dW[n][k] += sum_m dy[m][n] * a[m][k],     dy = alpha*dz + beta*y + gamma   (BatchNorm backward, on load)
+//                                             a  = act(scale*x + shift [, se])  (recomputed, never stored)
+//
+// The contraction runs over PIXELS, i.e. along the slow axis of both (pixel-major) operands, so both MFMA
+// fragments are transposes of what memory holds.  gfx950's ds_read_b64_tr_b16 delivers exactly that
+// transpose for free (16 lanes read a 4-row x 16-column block column-major), so staging stays trivial:
+//   * per 32-pixel step the block converts its slices of dz/y -> dy and x -> a in registers and stores them
+//     ROW-major into LDS with 16-B writes (double-buffered: one barrier per step, the next step's global
+//     loads are in flight during the MFMAs);
+//   * wave w owns rows {w, w+4, ...}*16 of the block's dW tile ("P" side, split over waves) and ALL its
+//     columns ("Q" side, shared): per step it reads the Q fragments once, then per own row tile one P
+//     fragment + NTQ MFMAs (v_mfma_f32_16x16x32_bf16).  Accumulators live in registers for the block's
+//     whole pixel range;
+//   * the block tile is as wide as the register file allows (up to 384 x 64 / 192 x 160), so for most
+//     layers every operand byte is read exactly once; wider dW are tiled over P (the tensor on the P side
+//     is then still read once, the Q side once per P tile);
+//   * the larger channel count always takes the P role (`swap` transposes the roles of dy and a).
+// Grid = (P tiles * Q tiles) x pixel splits; partial dW leave as fp32 atomics (few, large, spread over the
+// whole dW -- no contention problem here, unlike per-channel sums).
+#include <cstdlib>
+#include "common.h"
+
+namespace {
+
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+
+struct WgtArgs {
+  const void *dz, *y, *x;
+  const float *alpha, *beta, *gamma;
+  int per_sample;
+  const float *scale, *shift, *se;
+  int act, se_after;
+  float* dw;
+  int M, HW, K, N;
+  int swap;          // 0: P = N (dy side), Q = K (a side); 1: P = K, Q = N
+  int ptiles, qtiles, rows_per_split;
+  float* ws;         // partial tiles [split][tile][PB][QB] (plain stores) or null (atomics into dw)
+};
+
+// one 16x16 tile row (transposed) fragment: pixels 8*lg .. 8*lg+7 of the step, channels ch0..ch0+15
+__device__ __forceinline__ bf16x8 tr_frag(const bf16_t* tile, int rs, int ch0, int lane) {
+  const int g = lane >> 4, q = (lane & 15) >> 2, p = lane & 3;
+  const bf16_t* a0 = tile + (8 * g + q) * rs + ch0 + 4 * p;
+  const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(a0));
+  const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(a0 + 4 * rs));
+  typedef __attribute__((ext_vector_type(8))) short s16x8;
+  const s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+  return __builtin_bit_cast(bf16x8, v);
+}
+
+// NTPW: 16-row tiles per wave on the P side (block: 64*NTPW rows); NTQ: 16-column tiles on the Q side
+template <int NTPW, int NTQ, bool SWAP>
+__global__ __launch_bounds__(256) void pw_wgrad_tr_kernel(const WgtArgs a) {
+  constexpr int PB = 64 * NTPW, QB = 16 * NTQ;
+  constexpr int RSP = PB + 8, RSQ = QB + 8;            // LDS row strides (elements): +16 B against bank conflicts
+  constexpr int STEP = 32;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  constexpr int BUFE = STEP * (RSP + RSQ);              // elements per buffer: P tile then Q tile
+  bf16_t* const tiles = reinterpret_cast<bf16_t*>(smem);  // (computed, not an indexed pointer array: no scratch)
+  float* coef = reinterpret_cast<float*>(tiles + 2 * BUFE);   // dy side: [3][nd]  | a side: [2][na]
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int P = SWAP ? a.K : a.N, Q = SWAP ? a.N : a.K;
+  const int tile = blockIdx.x, pt = tile / a.qtiles, qt = tile % a.qtiles;
+  const int p0 = pt * PB, q0 = qt * QB;
+  const int mbeg = blockIdx.y * a.rows_per_split, mend = min(a.M, mbeg + a.rows_per_split);
+  // which side carries dy (N channels) / a (K channels)
+  constexpr int dyB = SWAP ? QB : PB, aB = SWAP ? PB : QB;
+  const int dy0 = SWAP ? q0 : p0, a0c = SWAP ? p0 : q0;
+  float* cdy = coef;                 // [3][dyB]
+  float* ca = coef + 3 * dyB;        // [2][aB]
+  for (int i = tid; i < dyB; i += 256) {
+    const int n = dy0 + i;
+    const bool v = n < a.N;
+    cdy[i] = (v && !a.per_sample) ? a.alpha[n] : 0.f;
+    cdy[dyB + i] = v ? a.beta[n] : 0.f;
+    cdy[2 * dyB + i] = (v && !a.per_sample) ? a.gamma[n] : 0.f;
+  }
+  for (int i = tid; i < aB; i += 256) {
+    const int k = a0c + i;
+    const bool v = k < a.K;
+    ca[i] = (v && a.scale) ? a.scale[k] : 1.f;
+    ca[aB + i] = (v && a.scale) ? a.shift[k] : 0.f;
+  }
+  const bf16_t* __restrict__ dz = reinterpret_cast<const bf16_t*>(a.dz);
+  const bf16_t* __restrict__ yy = reinterpret_cast<const bf16_t*>(a.y);
+  const bf16_t* __restrict__ xx = reinterpret_cast<const bf16_t*>(a.x);
+  const bool plain_a = !a.scale && !a.se && a.act == T3D_ACT_NONE;
+
+  // staging map: vector v (8 channels x 1 pixel) of the dy slice / the a slice, v = tid + 256*i
+  constexpr int dyV = dyB / 8, aV = aB / 8;                  // vectors per pixel row
+  constexpr int ndv = STEP * dyV, nav = STEP * aV;
+  constexpr int VDY = (ndv + 255) / 256, VA = (nav + 255) / 256;   // vectors per thread and step
+  bf16x8 rz[VDY], ry[VDY], rx[VA];
+
+  auto gload = [&](int m0) {
+#pragma unroll
+    for (int i = 0; i < VDY; ++i) {
+      const int v = tid + 256 * i;
+      bf16x8 z;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) z[j] = (bf16_t)0.f;
+      rz[i] = ry[i] = z;
+      if (v < ndv) {
+        const int row = v / dyV, n = dy0 + (v % dyV) * 8, m = m0 + row;
+        if (m < mend && n < a.N) {
+          rz[i] = *reinterpret_cast<const bf16x8*>(dz + (size_t)m * a.N + n);
+          ry[i] = *reinterpret_cast<const bf16x8*>(yy + (size_t)m * a.N + n);
+        }
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < VA; ++i) {
+      const int v = tid + 256 * i;
+      bf16x8 z;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) z[j] = (bf16_t)0.f;
+      rx[i] = z;
+      if (v < nav) {
+        const int row = v / aV, k = a0c + (v % aV) * 8, m = m0 + row;
+        if (m < mend && k < a.K) rx[i] = *reinterpret_cast<const bf16x8*>(xx + (size_t)m * a.K + k);
+      }
+    }
+  };
+  auto lstore = [&](int m0, int buf) {
+    bf16_t* const pb_ = tiles + buf * BUFE;
+    bf16_t* const qb_ = pb_ + STEP * RSP;
+    bf16_t* dyt = SWAP ? qb_ : pb_;
+    bf16_t* at = SWAP ? pb_ : qb_;
+    constexpr int rsd = SWAP ? RSQ : RSP, rsa = SWAP ? RSP : RSQ;
+#pragma unroll
+    for (int i = 0; i < VDY; ++i) {
+      const int v = tid + 256 * i;
+      if (v < ndv) {
+        const int row = v / dyV, cl = (v % dyV) * 8, m = m0 + row;
+        const bool ok = m < mend && dy0 + cl < a.N;
+        bf16x8 o;
+        float al[8], ga[8];
+        if (a.per_sample && ok) {
+          const size_t pb = (size_t)(m / a.HW) * a.N + dy0 + cl;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) { al[j] = a.alpha[pb + j]; ga[j] = a.gamma[pb + j]; }
+        } else {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) { al[j] = cdy[cl + j]; ga[j] = cdy[2 * dyB + cl + j]; }
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+          o[j] = (bf16_t)(ok ? fmaf(al[j], (float)rz[i][j], fmaf(cdy[dyB + cl + j], (float)ry[i][j], ga[j])) : 0.f);
+        *reinterpret_cast<bf16x8*>(dyt + row * rsd + cl) = o;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < VA; ++i) {
+      const int v = tid + 256 * i;
+      if (v < nav) {
+        const int row = v / aV, cl = (v % aV) * 8, m = m0 + row;
+        const bool ok = m < mend && a0c + cl < a.K;
+        bf16x8 o = rx[i];
+        if (!plain_a) {
+          float u[8];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) u[j] = (float)rx[i][j];
+          if (a.se) {
+            const float* se = ok ? a.se + (size_t)(m / a.HW) * a.K + a0c + cl : nullptr;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+              float t = fmaf(u[j], ca[cl + j], ca[aB + cl + j]);
+              const float sv = se ? se[j] : 1.f;
+              if (!a.se_after) t *= sv;
+              t = act_apply(t, a.act);
+              if (a.se_after) t *= sv;
+              u[j] = t;
+            }
+          } else {
+            act_affine_vec<8>(u, ca + cl, ca + aB + cl, a.act);
+          }
+#pragma unroll
+          for (int j = 0; j < 8; ++j) o[j] = (bf16_t)(ok ? u[j] : 0.f);
+        }
+        *reinterpret_cast<bf16x8*>(at + row * rsa + cl) = o;
+      }
+    }
+  };
+
+  f32x4 acc[NTPW][NTQ];
+#pragma unroll
+  for (int i = 0; i < NTPW; ++i)
+#pragma unroll
+    for (int j = 0; j < NTQ; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  __syncthreads();   // coefficients visible
+  if (mbeg < mend) {
+    gload(mbeg);
+    lstore(mbeg, 0);
+  }
+  __syncthreads();
+  int buf = 0;
+  for (int m0 = mbeg; m0 < mend; m0 += STEP) {
+    const bool more = m0 + STEP < mend;
+    if (more) gload(m0 + STEP);
+    const bf16_t* pcur = tiles + buf * BUFE;
+    const bf16_t* qcur = pcur + STEP * RSP;
+    bf16x8 qf[NTQ];
+#pragma unroll
+    for (int j = 0; j < NTQ; ++j) qf[j] = tr_frag(qcur, RSQ, j * 16, lane);
+#pragma unroll
+    for (int i = 0; i < NTPW; ++i) {
+      const bf16x8 pf = tr_frag(pcur, RSP, (wave + 4 * i) * 16, lane);
+#pragma unroll
+      for (int j = 0; j < NTQ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pf, qf[j], acc[i][j], 0, 0, 0);
+    }
+    if (more) lstore(m0 + STEP, buf ^ 1);
+    __syncthreads();
+    buf ^= 1;
+  }
+
+  // D[row = 4*(lane>>4) + reg -> p][col = lane&15 -> q]
+  const int lg = lane >> 4, lc = lane & 15;
+  if (a.ws) {
+    float* wsb = a.ws + ((size_t)blockIdx.y * gridDim.x + tile) * (PB * QB);
+#pragma unroll
+    for (int i = 0; i < NTPW; ++i)
+#pragma unroll
+      for (int j = 0; j < NTQ; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          wsb[((wave + 4 * i) * 16 + lg * 4 + r) * QB + j * 16 + lc] = acc[i][j][r];
+    return;
+  }
+#pragma unroll
+  for (int i = 0; i < NTPW; ++i)
+#pragma unroll
+    for (int j = 0; j < NTQ; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int p = p0 + (wave + 4 * i) * 16 + lg * 4 + r, q = q0 + j * 16 + lc;
+        if (p < P && q < Q) {
+          const int n = SWAP ? q : p, k = SWAP ? p : q;
+          unsafeAtomicAdd(a.dw + (size_t)n * a.K + k, acc[i][j][r]);
+        }
+      }
+}
+
+// dw[n][k] += sum over splits of the partial tiles.  grid.y chunks of the split range run in parallel (a small dW
+// with hundreds of splits would otherwise be summed by a handful of threads); each chunk adds its sum atomically
+// (<= 16 adds per element).
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw, int N, int K,
+                                                           int swap, int PB, int QB, int qtiles, int tiles, int S) {
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  if (e >= N * K) return;
+  const int n = e / K, k = e % K;
+  const int p = swap ? k : n, q = swap ? n : k;
+  const int tile = (p / PB) * qtiles + q / QB;
+  const float* src = ws + (size_t)tile * (PB * QB) + (size_t)(p % PB) * QB + q % QB;
+  const size_t stride = (size_t)tiles * PB * QB;
+  const int per = (S + gridDim.y - 1) / gridDim.y;
+  const int i0 = blockIdx.y * per, i1 = min(S, i0 + per);
+  float s = 0.f;
+#pragma unroll 8
+  for (int i = i0; i < i1; ++i) s += src[(size_t)i * stride];
+  if (i0 < i1) unsafeAtomicAdd(dw + e, s);
+}
+
+template <int NTPW, int NTQ, bool SWAP>
+int launch_sw(WgtArgs& a, hipStream_t st) {
+  constexpr int PB = 64 * NTPW, QB = 16 * NTQ;
+  const int P = a.swap ? a.K : a.N, Q = a.swap ? a.N : a.K;
+  a.ptiles = cdiv(P, PB);
+  a.qtiles = cdiv(Q, QB);
+  const int tiles = a.ptiles * a.qtiles;
+  const int dyB = a.swap ? QB : PB, aB = a.swap ? PB : QB;
+  const size_t lds = (size_t)2 * 32 * ((PB + 8) + (QB + 8)) * 2 + (size_t)(3 * dyB + 2 * aB) * 4;
+  // pixel splits: fill the chip (2 blocks per CU), but keep the partial-dW flush (S * N*K atomics) below ~8 MB
+  static const int tgt_blocks = getenv("T3D_WG_BLOCKS") ? atoi(getenv("T3D_WG_BLOCKS")) : 512;
+  static const long long cap_mb = getenv("T3D_WG_FLUSH_MB") ? atoi(getenv("T3D_WG_FLUSH_MB")) : 8;
+  int S = (tgt_blocks + tiles - 1) / tiles;
+  const long long tile_bytes = (long long)tiles * PB * QB * 4;
+  const bool use_ws = g_t3d_ws.ptr && g_t3d_ws.bytes >= tile_bytes && !getenv("T3D_WG_ATOMIC");
+  if (use_ws) {
+    const long long fit = g_t3d_ws.bytes / tile_bytes;   // partial sets the workspace holds
+    if (S > fit) S = (int)fit;
+  } else {
+    const long long flush_cap = (cap_mb << 20) / ((long long)a.N * a.K * 4 + 1);
+    if (S > flush_cap) S = (int)(flush_cap < 1 ? 1 : flush_cap);
+  }
+  const int maxs = cdiv(a.M, 32 * 4);
+  if (S > maxs) S = maxs;
+  if (S < 1) S = 1;
+  a.rows_per_split = cdiv(cdiv(a.M, S), 32) * 32;
+  S = cdiv(a.M, a.rows_per_split);
+  a.ws = use_ws ? reinterpret_cast<float*>(g_t3d_ws.ptr) : nullptr;
+  if (lds > 64 * 1024)
+    (void)hipFuncSetAttribute((const void*)pw_wgrad_tr_kernel<NTPW, NTQ, SWAP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipLaunchKernelGGL((pw_wgrad_tr_kernel<NTPW, NTQ, SWAP>), dim3(tiles, S), dim3(256), lds, st, a);
+  if (use_ws)
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(cdiv(a.N * a.K, 256), S >= 64 ? 16 : (S >= 8 ? 4 : 1)), dim3(256), 0, st, a.ws, a.dw, a.N, a.K, (int)SWAP, PB, QB,
+                       a.qtiles, tiles, S);
+  T3D_CHECK_LAUNCH();
+  return T3D_OK;
+}
+
+template <int NTPW, int NTQ>
+int launch_cfg(WgtArgs& a, hipStream_t st) {
+  return a.swap ? launch_sw<NTPW, NTQ, true>(a, st) : launch_sw<NTPW, NTQ, false>(a, st);
+}
+
+}  // namespace
+
+// bf16 path of t3d_pwconv_wgrad (pwconv_wgrad.hip keeps the fp32 parity kernel)
+int t3d_pw_wgrad_tr_entry(const void* dz, const void* y, const t3d_bnbwd* bb, const void* x, const t3d_prologue* pro,
+                          float* dw, int M, int HW, int K, int N, hipStream_t st) {
+  WgtArgs a{};
+  a.dz = dz; a.y = y; a.x = x;
+  a.alpha = bb->alpha; a.beta = bb->beta; a.gamma = bb->gamma; a.per_sample = bb->per_sample;
+  if (pro) { a.scale = pro->scale; a.shift = pro->shift; a.se = pro->se; a.act = pro->act; a.se_after = pro->se_after_act; }
+  a.dw = dw; a.M = M; a.HW = HW; a.K = K; a.N = N;
+  a.swap = K > N;
+  const int P = a.swap ? K : N, Q = a.swap ? N : K;
+  // Q side: all of Q when it fits 10 tiles, else halves / thirds ...; P side: as many 64-row groups as registers allow
+  if (Q <= 16) return P <= 64 ? launch_cfg<1, 1>(a, st) : launch_cfg<2, 1>(a, st);
+  if (Q <= 32) return P <= 64 ? launch_cfg<1, 2>(a, st) : launch_cfg<3, 2>(a, st);
+  if (Q <= 64) return P <= 192 ? launch_cfg<3, 4>(a, st) : launch_cfg<6, 4>(a, st);
+  if (Q <= 96) return launch_cfg<3, 6>(a, st);
+  return launch_cfg<3, 10>(a, st);
+}

@@ -30,6 +30,7 @@ from .arch import Arch
 
 BN_EPS, BN_MOM = 1e-5, 0.1      # PyTorch defaults the reference relies on
 NREP = 16                       # reduction replicas (include/t3d.h: t3d_set_reduction_replicas)
+WORKSPACE_BYTES = 64 << 20      # partial weight-gradient tiles (include/t3d.h: t3d_set_workspace)
 
 
 class _BN:
@@ -405,11 +406,14 @@ class Net:
 
     # ------------------------------------------------------------------ backward
     def backward(self, dkp, dlogits=None):
+        ws = self._buf('workspace', (WORKSPACE_BYTES,), torch.uint8)
         N.call('t3d_set_reduction_replicas', NREP, self._stat_stride)
+        N.call('t3d_set_workspace', N.ptr(ws), WORKSPACE_BYTES)
         try:
             return self._backward(dkp, dlogits)
         finally:
             N.call('t3d_set_reduction_replicas', 1, 0)
+            N.call('t3d_set_workspace', None, 0)
 
     def _backward(self, dkp, dlogits=None):
         """Gradient of the last train-mode forward w.r.t. every parameter -> `gflat` (overwritten).

@@ -214,6 +214,12 @@ int t3d_se_bwd(const float* ps_stats, const float* gap_sum, const float* scale, 
  * Process-wide setting (default 1 = plain behaviour); kernels that do not implement replicas use replica 0. */
 int t3d_set_reduction_replicas(int nrep, long long stats_stride);
 
+/* Optional device scratch (caller-owned, process-wide setting; NULL/0 clears it).  With a workspace the bf16
+ * pointwise weight gradient writes its per-split partial dW tiles there with plain stores and reduces them in a
+ * second, deterministic pass; without one the partials leave as fp32 atomics.  64 MB covers every layer shape of
+ * the supported models at batch 256. */
+int t3d_set_workspace(void* ptr, long long bytes);
+
 #ifdef __cplusplus
 }
 #endif
