@@ -14,7 +14,8 @@ __global__ void bn_finalize_kernel(const double* __restrict__ stats, int nrep, l
   if (c == 0 && nbt) *nbt += 1;
   if (c >= C) return;
   double s1 = 0.0, s2 = 0.0;
-  for (int r = 0; r < nrep; ++r) {
+#pragma unroll 16
+  for (int r = 0; r < nrep; ++r) {   // independent loads: all replicas in flight together
     s1 += stats[r * rstride + c];
     s2 += stats[r * rstride + C + c];
   }
@@ -53,6 +54,7 @@ __global__ void bn_bwd_finalize_kernel(const double* __restrict__ stats, int nre
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= C) return;
   double s1 = 0.0, s2 = 0.0;
+#pragma unroll 16
   for (int r = 0; r < nrep; ++r) {
     s1 += stats[r * rstride + c];
     s2 += stats[r * rstride + C + c];
@@ -75,7 +77,7 @@ extern "C" int t3d_bn_finalize(const double* stats, int C, double count, const f
                                float momentum, float eps, float* scale, float* shift, float* mean, float* invstd,
                                void* stream) {
   if (!stats || !scale || !shift || C <= 0 || count <= 0) return T3D_ERR_ARG;
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, 256)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, 64)), dim3(64), 0, reinterpret_cast<hipStream_t>(stream),
                      stats, g_t3d_reduce.nrep, g_t3d_reduce.stats_stride, C, count, gamma, beta, running_mean, running_var, num_batches_tracked, momentum, eps,
                      scale, shift, mean, invstd);
   T3D_CHECK_LAUNCH();
@@ -98,7 +100,7 @@ extern "C" int t3d_bn_bwd_finalize(const double* stats, int C, double count, con
                                    const float* invstd, float* alpha, float* beta, float* gammac, float* dgamma,
                                    float* dbeta, void* stream) {
   if (!stats || !mean || !invstd || !alpha || !beta || !gammac || C <= 0 || count <= 0) return T3D_ERR_ARG;
-  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(C, 256)), dim3(256), 0,
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(C, 64)), dim3(64), 0,
                      reinterpret_cast<hipStream_t>(stream), stats, g_t3d_reduce.nrep, g_t3d_reduce.stats_stride, C, count, gamma, mean, invstd, alpha, beta,
                      gammac, dgamma, dbeta);
   T3D_CHECK_LAUNCH();

@@ -8,6 +8,10 @@ typedef __bf16 bf16_t;
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+// packed fp32 FMA: one v_pk_fma_f32 does two lanes' worth of fused multiply-adds per issue slot (the fp32 VALU peak
+// on gfx950 is only reachable in this form); same rounding as two fmaf() calls.
+__device__ __forceinline__ f32x2 pk_fma(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
 
 #define T3D_CHECK_LAUNCH()                                  \
   do {                                                      \

@@ -166,10 +166,14 @@ __global__ __launch_bounds__(256) void dw3_fwd_kernel(const Dw3Args a) {
 #pragma unroll
               for (int c = 0; c < 3; ++c)
 #pragma unroll
-                for (int i = 0; i < CH; ++i) {
-                  accA[i] = fmaf(v[c][i], wk[6 + c][i], accA[i]);
-                  accB[i] = fmaf(v[c][i], wk[3 + c][i], accB[i]);
-                  accC[i] = fmaf(v[c][i], wk[c][i], accC[i]);
+                for (int i = 0; i < CH; i += 2) {
+                  const f32x2 vv = {v[c][i], v[c][i + 1]};
+                  f32x2 ra = pk_fma(vv, f32x2{wk[6 + c][i], wk[6 + c][i + 1]}, f32x2{accA[i], accA[i + 1]});
+                  f32x2 rb = pk_fma(vv, f32x2{wk[3 + c][i], wk[3 + c][i + 1]}, f32x2{accB[i], accB[i + 1]});
+                  f32x2 rc = pk_fma(vv, f32x2{wk[c][i], wk[c][i + 1]}, f32x2{accC[i], accC[i + 1]});
+                  accA[i] = ra[0]; accA[i + 1] = ra[1];
+                  accB[i] = rb[0]; accB[i + 1] = rb[1];
+                  accC[i] = rc[0]; accC[i + 1] = rc[1];
                 }
             }
             const int oy = iy - 1;

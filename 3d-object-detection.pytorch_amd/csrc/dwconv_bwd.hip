@@ -106,8 +106,7 @@ __global__ __launch_bounds__(256) void dw_bwd_kernel(const DwBwdArgs a) {
         float v[8];
         if (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) {
           Vec8<T>::load(xg + (((size_t)b * a.H + gy) * a.W + gx) * a.C + c0, v);
-#pragma unroll
-          for (int i = 0; i < 8; ++i) v[i] = act_apply(v[i] * sc[i] + sh[i], a.act);
+          act_affine_vec<8>(v, sc, sh, a.act);
         } else {
 #pragma unroll
           for (int i = 0; i < 8; ++i) v[i] = 0.f;
@@ -175,11 +174,8 @@ __global__ __launch_bounds__(256) void dw_bwd_kernel(const DwBwdArgs a) {
           float xv[8], o8[8];
           if (a.scale || a.stats) Vec8<T>::load(xg + off, xv);
 #pragma unroll
-          for (int i = 0; i < 8; ++i) {
-            float g = acc[o][i];
-            if (a.scale) g *= act_grad(xv[i] * sc[i] + sh[i], a.act);
-            o8[i] = g;
-          }
+          for (int i = 0; i < 8; ++i) o8[i] = acc[o][i];
+          if (a.scale) act_grad_affine_vec<8>(o8, xv, sc, sh, a.act);
           if (rg) {
             float rr[8];
             Vec8<T>::load(rg + off, rr);

@@ -93,8 +93,7 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const EwArgs a) {
   for (size_t i = g; i < nvec; i += nthr) {
     float v[8];
     Vec8<T>::load(y + i * 8, v);
-#pragma unroll
-    for (int j = 0; j < 8; ++j) v[j] = act_apply(v[j] * sc[j] + sh[j], a.act);
+    act_affine_vec<8>(v, sc, sh, a.act);
     if (r) {
       float rr[8];
       Vec8<T>::load(r + i * 8, rr);
@@ -158,8 +157,9 @@ __global__ __launch_bounds__(256) void gap_fwd_kernel(const EwArgs a) {
     for (int hw = slot; hw < a.HW; hw += 8) {
       float v[8];
       Vec8<T>::load(y + ((size_t)b * a.HW + hw) * a.C + c0, v);
+      act_affine_vec<8>(v, sc, sh, a.act);
 #pragma unroll
-      for (int j = 0; j < 8; ++j) acc[j] += act_apply(v[j] * sc[j] + sh[j], a.act);
+      for (int j = 0; j < 8; ++j) acc[j] += v[j];
     }
   }
 #pragma unroll

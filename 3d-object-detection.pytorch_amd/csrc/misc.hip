@@ -16,7 +16,33 @@ __global__ void pack_kernel(const float* __restrict__ w, T* __restrict__ out, in
   }
 }
 
+// one launch for every weight matrix of the model: desc[t] = {src, out (or 0), out_t (or 0), rows, cols} as int64
+template <typename T>
+__global__ void pack_batched_kernel(const long long* __restrict__ desc) {
+  const long long* d = desc + (size_t)blockIdx.x * 5;
+  const float* __restrict__ w = reinterpret_cast<const float*>(d[0]);
+  T* __restrict__ out = reinterpret_cast<T*>(d[1]);
+  T* __restrict__ out_t = reinterpret_cast<T*>(d[2]);
+  const int rows = (int)d[3], cols = (int)d[4];
+  const size_t n = (size_t)rows * cols;
+  for (size_t i = blockIdx.y * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.y * blockDim.x) {
+    const T v = (T)w[i];
+    if (out) out[i] = v;
+    if (out_t) out_t[(i % cols) * rows + i / cols] = v;
+  }
+}
+
 }  // namespace
+
+extern "C" int t3d_pack_weights_batched(int dtype, const long long* desc, int n, void* stream) {
+  if (!desc || n <= 0) return T3D_ERR_ARG;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (dtype == T3D_F32) hipLaunchKernelGGL(pack_batched_kernel<float>, dim3(n, 48), dim3(256), 0, st, desc);
+  else if (dtype == T3D_BF16) hipLaunchKernelGGL(pack_batched_kernel<bf16_t>, dim3(n, 48), dim3(256), 0, st, desc);
+  else return T3D_ERR_ARG;
+  T3D_CHECK_LAUNCH();
+  return T3D_OK;
+}
 
 extern "C" int t3d_pack_weight(int dtype, const float* w, void* out, int rows, int cols, int transpose,
                                void* stream) {

@@ -56,6 +56,7 @@ SIGNATURES = {
     't3d_se_bwd': [_P] * 18 + [_I, _I, _I, _I, _P],
     't3d_set_reduction_replicas': [_I, _L],
     't3d_set_workspace': [_P, _L],
+    't3d_pack_weights_batched': [_I, _P, _I, _P],
     't3d_loss_fwd_bwd': [_LP, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P],
 }
 

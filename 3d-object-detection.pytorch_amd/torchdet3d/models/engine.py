@@ -201,19 +201,23 @@ class Net:
         if not self._packed_dirty:
             return
         st = N.stream()
-        self.w, self.wt = {}, {}
-        for k, (s, kind) in self.shapes.items():
-            if kind != 'param' or len(s) != 4 or s[2] != 1:
-                continue
-            n, kk = s[0], s[1]
-            src = self.p[k]
-            if self.dt == N.F32:
-                self.w[k] = src
-            else:
-                self.w[k] = self._buf('w:' + k, (n, kk))
-                N.call('t3d_pack_weight', self.dt, N.ptr(src), N.ptr(self.w[k]), n, kk, 0, st)
-            self.wt[k] = self._buf('wt:' + k, (kk, n))
-            N.call('t3d_pack_weight', self.dt, N.ptr(src), N.ptr(self.wt[k]), n, kk, 1, st)
+        if getattr(self, '_pack_desc', None) is None:
+            # one descriptor table for every 1x1 weight: a single launch re-packs them all each step
+            self.w, self.wt, rows = {}, {}, []
+            for k, (s, kind) in self.shapes.items():
+                if kind != 'param' or len(s) != 4 or s[2] != 1:
+                    continue
+                n, kk = s[0], s[1]
+                src = self.p[k]
+                if self.dt == N.F32:
+                    self.w[k], out = src, 0
+                else:
+                    self.w[k] = self._buf('w:' + k, (n, kk))
+                    out = self.w[k].data_ptr()
+                self.wt[k] = self._buf('wt:' + k, (kk, n))
+                rows.append([src.data_ptr(), out, self.wt[k].data_ptr(), n, kk])
+            self._pack_desc = torch.tensor(rows, dtype=torch.int64, device=self.device)
+        N.call('t3d_pack_weights_batched', self.dt, N.ptr(self._pack_desc), self._pack_desc.shape[0], st)
         # stem: [C,3,3,3] -> [C,32] patch-row weights (columns 27..31 zero)
         c0 = self.arch.stem_c
         w32 = self._buf('stem32', (c0, 32), torch.float32, zero=True)

@@ -220,6 +220,10 @@ int t3d_set_reduction_replicas(int nrep, long long stats_stride);
  * the supported models at batch 256. */
 int t3d_set_workspace(void* ptr, long long bytes);
 
+/* All weight matrices of a model in ONE launch: desc is a DEVICE array of n records of 5 int64
+ * {src fp32 [rows,cols], out [rows,cols] or 0, out_t [cols,rows] or 0, rows, cols} (outputs in `dtype`). */
+int t3d_pack_weights_batched(int dtype, const long long* desc, int n, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
