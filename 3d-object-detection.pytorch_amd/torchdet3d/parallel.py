@@ -8,6 +8,8 @@ launched as soon as the backward has finished the parameters it covers (the back
 from its end to its start), so the exchange overlaps the remaining backward kernels.  Works on any
 torch.distributed backend ('nccl' = RCCL on ROCm; 'gloo' in the CPU tests).
 """
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -18,12 +20,14 @@ class GradSync:
         fully connected xGMI mesh is latency-bound below ~1 MB per message)."""
         self.g, self.min_bucket, self.group = flat_grad, min_bucket, group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        # T3D_FORCE_SYNC=1: run the collectives even on one rank (single-GPU smoke test of the RCCL path)
+        self.force = bool(os.environ.get('T3D_FORCE_SYNC')) and dist.is_initialized()
         self.hi = flat_grad.numel()
         self.works = []
 
     def broadcast(self, tensors, src=0):
         """One-time parameter / buffer sync from rank `src` (DataParallel replicates from device 0)."""
-        if self.world > 1:
+        if self.world > 1 or self.force:
             for t in tensors:
                 dist.broadcast(t, src, group=self.group)
 
@@ -33,7 +37,7 @@ class GradSync:
 
     def ready(self, lo):
         """Gradients at offsets >= lo are final."""
-        if self.world == 1:
+        if self.world == 1 and not self.force:
             return
         if lo == 0 or self.hi - lo >= self.min_bucket:
             if self.hi > lo:
@@ -43,7 +47,7 @@ class GradSync:
 
     def finish(self):
         """Wait for the buckets and turn the sums into means."""
-        if self.world == 1:
+        if self.world == 1 and not self.force:
             return
         if self.hi > 0:
             self.ready(0)

@@ -87,7 +87,7 @@ def main():
     import torch.distributed as dist
     torch.cuda.set_device(local)
     dev = torch.device('cuda', local)
-    if world > 1:
+    if world > 1 or 'RANK' in os.environ:      # launched by torch.distributed.run (also with one rank)
         dist.init_process_group('nccl', device_id=dev)
 
     from torchdet3d import _native as N
@@ -100,7 +100,7 @@ def main():
     net.reset_parameters(seed=5)
     sync = GradSync(net.gflat)
     sync.broadcast([net.flat] + [b for b in net.buffers.values()])
-    if world > 1:
+    if world > 1 or sync.force:
         net.grad_hook = sync.ready
     flat = torch.nn.Parameter(net.flat)          # one fused AdamW update over the flat master weights
     flat.grad = net.gflat
@@ -158,8 +158,8 @@ def main():
     if args.per_launch and rank == 0:
         N.timer = N.KernelTimer(set(CONV_KERNELS))
         step(0)
-        for n, sg, ms, nb in N.timer.per_launch():
-            print(f'  {n:20s} {str(sg):44s} {ms * 1e3:8.1f} us  {(nb or 0) / 1e6:8.1f} MB  {(nb or 0) / ms / 1e9:6.2f} TB/s',
+        for n, sg, ms, nby in N.timer.per_launch():
+            print(f'  {n:20s} {str(sg):44s} {ms * 1e3:8.1f} us  {(nby or 0) / 1e6:8.1f} MB  {(nby or 0) / ms / 1e9:6.2f} TB/s',
                   file=sys.stderr)
         N.timer = None
 
@@ -204,7 +204,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             res['cpu_baseline'] = cpu_baseline(args.model, S, args.cpu_batch, args.cpu_steps)
         print(json.dumps(res), flush=True)
-    if world > 1:
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 
