@@ -51,17 +51,20 @@ __device__ __forceinline__ bf16x8 tr_frag(const bf16_t* tile, int rs, int ch0, i
 }
 
 // NTPW: 16-row tiles per wave on the P side (block: 64*NTPW rows); NTQ: 16-column tiles on the Q side
-template <int NTPW, int NTQ, bool SWAP>
-__global__ __launch_bounds__(256) void pw_wgrad_tr_kernel(const WgtArgs a) {
+// G: independent 4-wave pipelines per block, taking alternate 32-pixel steps (own LDS buffers, own accumulators);
+// they are summed through LDS before the block's single flush -- twice the per-block throughput for one flush.
+template <int NTPW, int NTQ, bool SWAP, int G>
+__global__ __launch_bounds__(256 * G) void pw_wgrad_tr_kernel(const WgtArgs a) {
   constexpr int PB = 64 * NTPW, QB = 16 * NTQ;
   constexpr int RSP = PB + 8, RSQ = QB + 8;            // LDS row strides (elements): +16 B against bank conflicts
   constexpr int STEP = 32;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int BUFE = STEP * (RSP + RSQ);              // elements per buffer: P tile then Q tile
-  bf16_t* const tiles = reinterpret_cast<bf16_t*>(smem);  // (computed, not an indexed pointer array: no scratch)
-  float* coef = reinterpret_cast<float*>(tiles + 2 * BUFE);   // dy side: [3][nd]  | a side: [2][na]
+  const int grp = threadIdx.x >> 8;
+  bf16_t* const tiles = reinterpret_cast<bf16_t*>(smem) + grp * 2 * BUFE;  // this pipeline's two buffers
+  float* coef = reinterpret_cast<float*>(reinterpret_cast<bf16_t*>(smem) + G * 2 * BUFE);   // dy side [3][nd] | a side [2][na]
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x & 255, lane = tid & 63, wave = tid >> 6;
   const int P = SWAP ? a.K : a.N, Q = SWAP ? a.N : a.K;
   const int tile = blockIdx.x, pt = tile / a.qtiles, qt = tile % a.qtiles;
   const int p0 = pt * PB, q0 = qt * QB;
@@ -71,14 +74,14 @@ __global__ __launch_bounds__(256) void pw_wgrad_tr_kernel(const WgtArgs a) {
   const int dy0 = SWAP ? q0 : p0, a0c = SWAP ? p0 : q0;
   float* cdy = coef;                 // [3][dyB]
   float* ca = coef + 3 * dyB;        // [2][aB]
-  for (int i = tid; i < dyB; i += 256) {
+  for (int i = threadIdx.x; i < dyB; i += 256 * G) {
     const int n = dy0 + i;
     const bool v = n < a.N;
     cdy[i] = (v && !a.per_sample) ? a.alpha[n] : 0.f;
     cdy[dyB + i] = v ? a.beta[n] : 0.f;
     cdy[2 * dyB + i] = (v && !a.per_sample) ? a.gamma[n] : 0.f;
   }
-  for (int i = tid; i < aB; i += 256) {
+  for (int i = threadIdx.x; i < aB; i += 256 * G) {
     const int k = a0c + i;
     const bool v = k < a.K;
     ca[i] = (v && a.scale) ? a.scale[k] : 1.f;
@@ -192,15 +195,19 @@ __global__ __launch_bounds__(256) void pw_wgrad_tr_kernel(const WgtArgs a) {
     for (int j = 0; j < NTQ; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   __syncthreads();   // coefficients visible
-  if (mbeg < mend) {
-    gload(mbeg);
-    lstore(mbeg, 0);
+  const int nsteps = (mend - mbeg + STEP - 1) / STEP;
+  const int niter = (nsteps + G - 1) / G;          // same trip count for every pipeline (barriers are block-wide);
+                                                   // a step past the range loads zeros and adds nothing
+  if (niter > 0) {
+    gload(mbeg + grp * STEP);
+    lstore(mbeg + grp * STEP, 0);
   }
   __syncthreads();
   int buf = 0;
-  for (int m0 = mbeg; m0 < mend; m0 += STEP) {
-    const bool more = m0 + STEP < mend;
-    if (more) gload(m0 + STEP);
+  for (int it = 0; it < niter; ++it) {
+    const int mnext = mbeg + ((it + 1) * G + grp) * STEP;
+    const bool more = it + 1 < niter;
+    if (more) gload(mnext);
     const bf16_t* pcur = tiles + buf * BUFE;
     const bf16_t* qcur = pcur + STEP * RSP;
     bf16x8 qf[NTQ];
@@ -212,9 +219,28 @@ __global__ __launch_bounds__(256) void pw_wgrad_tr_kernel(const WgtArgs a) {
 #pragma unroll
       for (int j = 0; j < NTQ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pf, qf[j], acc[i][j], 0, 0, 0);
     }
-    if (more) lstore(m0 + STEP, buf ^ 1);
+    if (more) lstore(mnext, buf ^ 1);
     __syncthreads();
     buf ^= 1;
+  }
+
+  if constexpr (G == 2) {
+    // pipeline 1 hands its accumulators to pipeline 0 through LDS, one row-tile group at a time (lane-private slots)
+    f32x4* ex = reinterpret_cast<f32x4*>(smem);
+#pragma unroll
+    for (int i = 0; i < NTPW; ++i) {
+      if (grp == 1) {
+#pragma unroll
+        for (int j = 0; j < NTQ; ++j) ex[(tid * NTQ) + j] = acc[i][j];
+      }
+      __syncthreads();
+      if (grp == 0) {
+#pragma unroll
+        for (int j = 0; j < NTQ; ++j) acc[i][j] += ex[(tid * NTQ) + j];
+      }
+      __syncthreads();
+    }
+    if (grp == 1) return;
   }
 
   // D[row = 4*(lane>>4) + reg -> p][col = lane&15 -> q]
@@ -266,15 +292,16 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
 
 template <int NTPW, int NTQ, bool SWAP>
 int launch_sw(WgtArgs& a, hipStream_t st) {
+  constexpr int G = 2;
   constexpr int PB = 64 * NTPW, QB = 16 * NTQ;
   const int P = a.swap ? a.K : a.N, Q = a.swap ? a.N : a.K;
   a.ptiles = cdiv(P, PB);
   a.qtiles = cdiv(Q, QB);
   const int tiles = a.ptiles * a.qtiles;
   const int dyB = a.swap ? QB : PB, aB = a.swap ? PB : QB;
-  const size_t lds = (size_t)2 * 32 * ((PB + 8) + (QB + 8)) * 2 + (size_t)(3 * dyB + 2 * aB) * 4;
+  const size_t lds = (size_t)G * 2 * 32 * ((PB + 8) + (QB + 8)) * 2 + (size_t)(3 * dyB + 2 * aB) * 4;
   // pixel splits: fill the chip (2 blocks per CU), but keep the partial-dW flush (S * N*K atomics) below ~8 MB
-  static const int tgt_blocks = getenv("T3D_WG_BLOCKS") ? atoi(getenv("T3D_WG_BLOCKS")) : 512;
+  static const int tgt_blocks = getenv("T3D_WG_BLOCKS") ? atoi(getenv("T3D_WG_BLOCKS")) : 256;
   static const long long cap_mb = getenv("T3D_WG_FLUSH_MB") ? atoi(getenv("T3D_WG_FLUSH_MB")) : 8;
   int S = (tgt_blocks + tiles - 1) / tiles;
   const long long tile_bytes = (long long)tiles * PB * QB * 4;
@@ -286,15 +313,15 @@ int launch_sw(WgtArgs& a, hipStream_t st) {
     const long long flush_cap = (cap_mb << 20) / ((long long)a.N * a.K * 4 + 1);
     if (S > flush_cap) S = (int)(flush_cap < 1 ? 1 : flush_cap);
   }
-  const int maxs = cdiv(a.M, 32 * 4);
+  const int maxs = cdiv(a.M, 32 * 4 * G);
   if (S > maxs) S = maxs;
   if (S < 1) S = 1;
   a.rows_per_split = cdiv(cdiv(a.M, S), 32) * 32;
   S = cdiv(a.M, a.rows_per_split);
   a.ws = use_ws ? reinterpret_cast<float*>(g_t3d_ws.ptr) : nullptr;
   if (lds > 64 * 1024)
-    (void)hipFuncSetAttribute((const void*)pw_wgrad_tr_kernel<NTPW, NTQ, SWAP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  hipLaunchKernelGGL((pw_wgrad_tr_kernel<NTPW, NTQ, SWAP>), dim3(tiles, S), dim3(256), lds, st, a);
+    (void)hipFuncSetAttribute((const void*)pw_wgrad_tr_kernel<NTPW, NTQ, SWAP, G>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipLaunchKernelGGL((pw_wgrad_tr_kernel<NTPW, NTQ, SWAP, G>), dim3(tiles, S), dim3(256 * G), lds, st, a);
   if (use_ws)
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(cdiv(a.N * a.K, 256), S >= 64 ? 16 : (S >= 8 ? 4 : 1)), dim3(256), 0, st, a.ws, a.dw, a.N, a.K, (int)SWAP, PB, QB,
                        a.qtiles, tiles, S);
@@ -319,10 +346,24 @@ int t3d_pw_wgrad_tr_entry(const void* dz, const void* y, const t3d_bnbwd* bb, co
   a.dw = dw; a.M = M; a.HW = HW; a.K = K; a.N = N;
   a.swap = K > N;
   const int P = a.swap ? K : N, Q = a.swap ? N : K;
-  // Q side: all of Q when it fits 10 tiles, else halves / thirds ...; P side: as many 64-row groups as registers allow
-  if (Q <= 16) return P <= 64 ? launch_cfg<1, 1>(a, st) : launch_cfg<2, 1>(a, st);
-  if (Q <= 32) return P <= 64 ? launch_cfg<1, 2>(a, st) : launch_cfg<3, 2>(a, st);
-  if (Q <= 64) return P <= 192 ? launch_cfg<3, 4>(a, st) : launch_cfg<6, 4>(a, st);
-  if (Q <= 96) return launch_cfg<3, 6>(a, st);
-  return launch_cfg<3, 10>(a, st);
+  // Q side: all of Q when it fits 10 tiles, else split.  P side: the widest block tile (64*NTPW rows) that still leaves
+  // every pipeline >= ~12 steps of 32 pixels when the chip is filled -- a wide tile reads each operand once but, on the
+  // small-pixel-count layers, degenerates into a handful of steps followed by a large partial flush; a narrow tile
+  // re-reads the (small) Q-side operand through L2 instead.
+  static const int min_steps = getenv("T3D_WG_MIN_STEPS") ? atoi(getenv("T3D_WG_MIN_STEPS")) : 12;
+  auto steps_with = [&](int ntpw, int qb) {
+    const int tiles = cdiv(P, 64 * ntpw) * cdiv(Q, qb);
+    int S = cdiv(256, tiles);
+    if (S < 1) S = 1;
+    return M / (S * 2 * 32);
+  };
+  if (Q <= 16) return (P <= 64 || steps_with(2, 16) < min_steps) ? launch_cfg<1, 1>(a, st) : launch_cfg<2, 1>(a, st);
+  if (Q <= 32) return (P <= 64 || steps_with(3, 32) < min_steps) ? launch_cfg<1, 2>(a, st) : launch_cfg<3, 2>(a, st);
+  if (Q <= 64) {
+    if (P > 192 && steps_with(6, 64) >= min_steps) return launch_cfg<6, 4>(a, st);
+    if (P > 64 && steps_with(3, 64) >= min_steps) return launch_cfg<3, 4>(a, st);
+    return launch_cfg<1, 4>(a, st);
+  }
+  if (Q <= 96) return (P > 64 && steps_with(3, 96) >= min_steps) ? launch_cfg<3, 6>(a, st) : launch_cfg<1, 6>(a, st);
+  return (P > 64 && steps_with(3, 160) >= min_steps) ? launch_cfg<3, 10>(a, st) : launch_cfg<1, 10>(a, st);
 }
