@@ -40,19 +40,22 @@ def parse():
     ap.add_argument('--model', default='mobilenetv2')
     ap.add_argument('--dtype', default='bf16', choices=['bf16', 'f32'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--cpu-batch', type=int, default=32)
-    ap.add_argument('--cpu-steps', type=int, default=4)
+    ap.add_argument('--cpu-batch', type=int, default=16)
+    ap.add_argument('--cpu-steps', type=int, default=60)
+    ap.add_argument('--cpu-baseline-only', action='store_true', help=argparse.SUPPRESS)
     ap.add_argument('--per-launch', action='store_true', help='print every conv launch of one step (stderr)')
     ap.add_argument('--profile-all', action='store_true', help='time every kernel family, print a table to stderr')
     return ap.parse_args()
 
 
-def cpu_baseline(model, size, batch, steps):
-    """The oracle's train step (fwd + losses + autograd bwd + AdamW) on the host cores."""
+def cpu_baseline(model, size, batch, steps, budget_s=20.0):
+    """The oracle's train step (fwd + losses + autograd bwd + AdamW) on the host cores, on a BOUNDED sample:
+    at most `steps` steps and ~`budget_s` seconds.  Threads are capped at 32: with every hardware thread of a
+    256-thread host the small convolutions of this network oversubscribe and run ~50x slower."""
     from oracle import losses as OL
     from oracle import model as OMod
     from oracle.weights import make_inputs, make_state_dict
-    cores = os.cpu_count() or 1
+    cores = min(os.cpu_count() or 1, 32)
     torch.set_num_threads(cores)
     sd = make_state_dict(model, 9)
     params = {k: v.clone().requires_grad_(v.dtype.is_floating_point and 'running' not in k) for k, v in sd.items()}
@@ -68,18 +71,44 @@ def cpu_baseline(model, size, batch, steps):
         loss.backward()
         opt.step()
 
-    step()
     t0 = time.perf_counter()
-    for _ in range(steps):
+    step()                                   # warm-up (also the only sample if the host is very slow)
+    warm = time.perf_counter() - t0
+    done, dt = 0, 0.0
+    t0 = time.perf_counter()
+    while done < steps and warm + dt + (dt / done if done else warm) < budget_s:
         step()
-    dt = time.perf_counter() - t0
-    return dict(value=round(batch * steps / dt, 2), unit='crops/s', cores=cores, kind='port',
-                sample=f'{steps} train steps of {model} at batch {batch}, {size}x{size}, fp32, after 1 warm-up step '
-                       f'({dt:.1f} s of CPU work, torch {torch.__version__} CPU kernels, {cores} threads)')
+        done += 1
+        dt = time.perf_counter() - t0
+    if done == 0:
+        done, dt, note = 1, warm, 'the warm-up step itself (host too slow for more inside the time budget)'
+    else:
+        note = f'{done} train steps after 1 warm-up step'
+    return dict(value=round(batch * done / dt, 2), unit='crops/s', cores=cores, kind='port',
+                sample=f'{note}: {model} at batch {batch}, {size}x{size}, fp32 '
+                       f'({warm + dt:.1f} s of CPU work, torch {torch.__version__} CPU kernels, {cores} threads of '
+                       f'{os.cpu_count()})')
+
+
+def cpu_baseline_guarded(args):
+    """Runs the CPU leg in a child process with a hard wall-clock limit, so that a slow or oversubscribed host can
+    never stall the benchmark (the child never touches the GPU)."""
+    import subprocess
+    cmd = [sys.executable, os.path.abspath(__file__), '--cpu-baseline-only', '--model', args.model, '--size', str(args.size),
+           '--cpu-batch', str(args.cpu_batch), '--cpu-steps', str(args.cpu_steps)]
+    try:
+        out = subprocess.run(cmd, capture_output=True, text=True, timeout=150)
+        return json.loads(out.stdout.strip().split('\n')[-1])
+    except Exception as e:  # noqa: BLE001  (timeout, crash, unparsable output)
+        return dict(value=None, unit='crops/s', cores=min(os.cpu_count() or 1, 32), kind='port',
+                    sample=f'CPU leg did not finish within its 150 s limit ({type(e).__name__})')
 
 
 def main():
     args = parse()
+    if args.cpu_baseline_only:
+        print(json.dumps(cpu_baseline(args.model, args.size, args.cpu_batch, args.cpu_steps)), flush=True)
+        return
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
@@ -194,15 +223,23 @@ def main():
         if dominant and dominant in tsum:
             d = tsum[dominant]
             ach = d['bytes'] / (d['ms'] * 1e-3) / 1e9
+            # HBM bytes per launch from the committed rocprofv3 PMC passes (FETCH_SIZE x2 + WRITE_SIZE, gfx950 correction),
+            # valid for the default workload only; not measurable from inside this process
+            traffic = None
+            tf = os.path.join(ROOT, 'profiles', 'r1_c_hbm_traffic_pmc.json')
+            if os.path.exists(tf) and args.model == 'mobilenetv2' and S == 224 and B == 256 and args.dtype == 'bf16':
+                fam_t = json.load(open(tf))['families'].get(dominant)
+                if fam_t:
+                    traffic = round(fam_t['hbm_bytes_per_step'] / (d['launches'] // args.steps))
             res['roofline'] = {'bound': 'hbm', 'kernel': dominant, 'achieved': round(ach, 1), 'peak': HBM_PEAK / 1e9,
-                               'unit': 'GB/s', 'frac': round(ach * 1e9 / HBM_PEAK, 4), 'traffic': None,
+                               'unit': 'GB/s', 'frac': round(ach * 1e9 / HBM_PEAK, 4), 'traffic': traffic,
                                'launches_per_step': d['launches'] // args.steps,
                                'avg_launch_us': round(1e3 * d['ms'] / d['launches'], 2),
                                'algorithmic_MB_per_step': round(d['bytes'] / args.steps / 1e6, 1)}
         if args.model == 'mobilenetv2' and S == 224 and args.dtype == 'bf16':
             res['config']['step_hbm_roofline_frac'] = round(crops / world * MNV2_TRAIN_MB_PER_CROP * 1e6 / HBM_PEAK, 4)
         if world == 1 and not args.no_cpu_baseline:
-            res['cpu_baseline'] = cpu_baseline(args.model, S, args.cpu_batch, args.cpu_steps)
+            res['cpu_baseline'] = cpu_baseline_guarded(args)
         print(json.dumps(res), flush=True)
     if dist.is_initialized():
         dist.destroy_process_group()
