@@ -17,6 +17,7 @@
 //     per block: one fp64 atomic per channel per block.
 // Latency is hidden by wave-level parallelism (8-16 resident waves per CU, each with its own loads in
 // flight), not by a block-wide pipeline.
+#include <cstdlib>
 #include "pwconv_common.h"
 
 namespace t3d_pw {
@@ -33,6 +34,7 @@ __global__ __launch_bounds__(512, 2) void pw_stream_kernel(const GemmArgs a, con
   const int kpad = KS * 32;
   float* coef = reinterpret_cast<float*>(smem + (size_t)NT * KS * 1024);          // [3][kpad]
   float* lstat = coef + 3 * kpad;                                                 // [BN][2]
+  float* ecoef = lstat + BN * 2;                                                  // [2][BN] epilogue scale / shift
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int lg = lane >> 4, lc = lane & 15;
@@ -55,6 +57,12 @@ __global__ __launch_bounds__(512, 2) void pw_stream_kernel(const GemmArgs a, con
     Wf[i] = v;
   }
   for (int i = tid; i < BN * 2; i += nthr) lstat[i] = 0.f;
+  for (int i = tid; i < BN; i += nthr) {
+    const int n = n0 + i;
+    const bool v = DG && a.e_scale && n < a.Nout;
+    ecoef[i] = v ? a.e_scale[n] : 1.f;
+    ecoef[BN + i] = v ? a.e_shift[n] : 0.f;
+  }
   for (int i = tid; i < kpad; i += nthr) {
     const bool v = i < a.Kin;
     if (!DG) {
@@ -205,18 +213,17 @@ __global__ __launch_bounds__(512, 2) void pw_stream_kernel(const GemmArgs a, con
             const float* se = ok ? a.e_se + (size_t)bidx * a.Nout + n : nullptr;
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-              const float u = yv[j] * (a.e_scale ? a.e_scale[n + j] : 1.f) + (a.e_scale ? a.e_shift[n + j] : 0.f);
+              const float u = yv[j] * ecoef[n - n0 + j] + ecoef[BN + n - n0 + j];
               const float sv = se ? se[j] : 1.f;
               if (!a.e_se_after) v[j] *= act_grad(u * sv, a.e_act);
               else v[j] *= sv * act_grad(u, a.e_act);
             }
           } else if (a.e_act != T3D_ACT_NONE) {
-            float es[8], eh[8];
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-              es[j] = a.e_scale ? a.e_scale[n + j] : 1.f;
-              eh[j] = a.e_scale ? a.e_shift[n + j] : 0.f;
-            }
+            const float4 s0 = *reinterpret_cast<const float4*>(ecoef + (n - n0)), s1 = *reinterpret_cast<const float4*>(ecoef + (n - n0) + 4);
+            const float4 h0 = *reinterpret_cast<const float4*>(ecoef + BN + (n - n0)),
+                         h1 = *reinterpret_cast<const float4*>(ecoef + BN + (n - n0) + 4);
+            const float es[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
+            const float eh[8] = {h0.x, h0.y, h0.z, h0.w, h1.x, h1.y, h1.z, h1.w};
             act_grad_affine_vec<8>(v, yv, es, eh, a.e_act);
           }
         }
@@ -281,7 +288,7 @@ template <int NT, int R, bool DG, bool GEN>
 int launch_v(GemmArgs& a, int KS, hipStream_t st) {
   constexpr int BN = NT * 16;
   const int kpad = KS * 32;
-  const size_t lds = (size_t)NT * KS * 1024 + (size_t)3 * kpad * 4 + BN * 2 * 4;
+  const size_t lds = (size_t)NT * KS * 1024 + (size_t)3 * kpad * 4 + BN * 4 * 4;
   if (lds > 150 * 1024) return T3D_ERR_UNSUPPORTED;
   const int nchunks = cdiv(a.Nout, BN);
   const int ngroups = cdiv(a.M, 16 * R);
@@ -325,6 +332,10 @@ int stream_launch(GemmArgs& a, hipStream_t st) {
   // widest chunk whose weights fit ~120 KB of LDS, at most 10 tiles (register budget: 8*NT stat + 4*NT*R acc)
   int nt_cap = (120 * 1024 / 1024) / KS;
   if (nt_cap > 10) nt_cap = 10;
+  // narrow contraction (K <= 64): re-reading the activation per output chunk costs almost nothing, so trade chunks for
+  // registers / occupancy
+  static const int small_k_cap = getenv("T3D_PW_NTCAP") ? atoi(getenv("T3D_PW_NTCAP")) : 10;
+  if (a.Kin <= 64 && nt_cap > small_k_cap) nt_cap = small_k_cap;
   nt_cap &= ~1;
   if (nt_cap < 2) return T3D_ERR_UNSUPPORTED;
   int NT = 2;
