@@ -22,6 +22,7 @@ Data layout in HBM
 There is no fallback: every op goes through libt3d_hip.so or raises.
 """
 import math
+import os
 
 import torch
 
@@ -67,6 +68,8 @@ class Net:
         # end of `gflat` towards its start): lets a data-parallel wrapper start the RCCL all-reduce of that
         # tail while the rest of the backward is still being computed
         self.grad_hook = None
+        self._side = torch.cuda.Stream(device=self.device) if (self.device.type == 'cuda' and not os.environ.get('T3D_NO_SIDE_STREAM')) else None
+        self._side_busy = False
 
     # ------------------------------------------------------------------ parameters
     def _layout(self):
@@ -409,6 +412,26 @@ class Net:
         return out
 
     # ------------------------------------------------------------------ backward
+    def _wgrad(self, *args, **kw):
+        """Pointwise weight gradients are leaves of the backward graph (only the optimizer reads them), so they are
+        issued on a second HIP stream and run concurrently with the data-gradient chain of the main stream; every
+        kernel here is latency- rather than bandwidth-bound, so the two streams overlap well.  Ordering: the side
+        stream waits for everything enqueued on the main stream so far (inputs, BatchNorm-backward affine, the
+        zeroed gradient buffer); `_join_side` makes the main stream wait for the side stream."""
+        if self._side is None:
+            N.call('t3d_pwconv_wgrad', *args, N.stream(), **kw)
+            return
+        main = torch.cuda.current_stream()
+        self._side.wait_stream(main)
+        with torch.cuda.stream(self._side):
+            N.call('t3d_pwconv_wgrad', *args, N.stream(), **kw)
+        self._side_busy = True
+
+    def _join_side(self):
+        if self._side is not None and self._side_busy:
+            torch.cuda.current_stream().wait_stream(self._side)
+            self._side_busy = False
+
     def backward(self, dkp, dlogits=None):
         ws = self._buf('workspace', (WORKSPACE_BYTES,), torch.uint8)
         N.call('t3d_set_reduction_replicas', NREP, self._stat_stride)
@@ -467,15 +490,17 @@ class Net:
         N.call('t3d_gap_bwd', dt, N.ptr(dpooled), N.ptr(sv['yl']), sv['prol'], N.ptr(dzl), N.ptr(bnl.bstats),
                B, HW, a.last_c, st)
         bb = self._bn_bwd(bnl)
-        N.call('t3d_pwconv_wgrad', dt, N.ptr(dzl), N.ptr(sv['yl']), bb, N.ptr(x.t), x.pro,
-               N.ptr(self.g[ln + '.0.weight']), M, HW, x.C, a.last_c, st, nbytes=M * (x.C + a.last_c) * self.esz)
+        self._wgrad(dt, N.ptr(dzl), N.ptr(sv['yl']), bb, N.ptr(x.t), x.pro,
+                    N.ptr(self.g[ln + '.0.weight']), M, HW, x.C, a.last_c, nbytes=M * (x.C + a.last_c) * self.esz)
         dz = self._pw_dgrad(dzl, sv['yl'], bb, self.wt[ln + '.0.weight'], x, None, M, HW, x.C, a.last_c, 'dz:lastin')
 
         if self.grad_hook:
+            self._join_side()
             self.grad_hook(self.offsets[ln + '.0.weight'][0])
         for rec in reversed(sv['blocks']):
             dz = self._block_bwd(rec, dz)
             if self.grad_hook:
+                self._join_side()
                 self.grad_hook(self.offsets[f"features.{rec['idx'] + 1}.conv.0.weight"][0])
 
         # ---- stem weight gradient
@@ -484,8 +509,9 @@ class Net:
         bb = self._bn_bwd(bn0)
         M = s0.B * s0.H * s0.W
         dw32 = self._buf('dstem32', (a.stem_c, 32), torch.float32, zero=True)
-        N.call('t3d_pwconv_wgrad', dt, N.ptr(dz), N.ptr(s0.raw), bb, N.ptr(sv['col']), None, N.ptr(dw32),
-               M, s0.H * s0.W, 32, a.stem_c, st, nbytes=M * (32 + a.stem_c) * self.esz)
+        self._wgrad(dt, N.ptr(dz), N.ptr(s0.raw), bb, N.ptr(sv['col']), None, N.ptr(dw32),
+                    M, s0.H * s0.W, 32, a.stem_c, nbytes=M * (32 + a.stem_c) * self.esz)
+        self._join_side()
         self.g['features.0.0.weight'].view(a.stem_c, 27).copy_(dw32[:, :27])
         if self.grad_hook:
             self.grad_hook(0)
@@ -520,8 +546,8 @@ class Net:
         B = x.B
         M2, HW2 = s2.B * s2.H * s2.W, s2.H * s2.W
         bb3 = self._bn_bwd(rec['bn3'])
-        N.call('t3d_pwconv_wgrad', dt, N.ptr(dz), N.ptr(rec['y3']), bb3, N.ptr(s2.t), s2.pro, N.ptr(self.g[pwn]),
-               M2, HW2, blk.cexp, blk.cout, st, nbytes=M2 * (blk.cexp + blk.cout) * self.esz)
+        self._wgrad(dt, N.ptr(dz), N.ptr(rec['y3']), bb3, N.ptr(s2.t), s2.pro, N.ptr(self.g[pwn]),
+                    M2, HW2, blk.cexp, blk.cout, nbytes=M2 * (blk.cexp + blk.cout) * self.esz)
         se = rec.get('se')
         if se is None:
             dv2 = self._pw_dgrad(dz, rec['y3'], bb3, self.wt[pwn], s2, None, M2, HW2, blk.cexp, blk.cout, f'dv2:{i}')
@@ -561,9 +587,9 @@ class Net:
             torch.sum(dwrep, 0, out=self.g[dwn].view(-1))
             bb1 = self._bn_bwd(s1.bn)
             p = f'features.{i + 1}.conv'
-            N.call('t3d_pwconv_wgrad', dt, N.ptr(d1), N.ptr(s1.raw), bb1, N.ptr(x.t), x.pro,
-                   N.ptr(self.g[p + '.0.weight']), M1, x.H * x.W, blk.cin, blk.cexp, st,
-                   nbytes=M1 * (blk.cin + blk.cexp) * self.esz)
+            self._wgrad(dt, N.ptr(d1), N.ptr(s1.raw), bb1, N.ptr(x.t), x.pro,
+                        N.ptr(self.g[p + '.0.weight']), M1, x.H * x.W, blk.cin, blk.cexp,
+                        nbytes=M1 * (blk.cin + blk.cexp) * self.esz)
             return self._pw_dgrad(d1, s1.raw, bb1, self.wt[p + '.0.weight'], x, res, M1, x.H * x.W, blk.cin,
                                   blk.cexp, f'dzin:{i}')
         # no-expand layout: the depthwise conv reads the block input directly
