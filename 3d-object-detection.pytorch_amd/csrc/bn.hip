@@ -6,19 +6,35 @@
 
 namespace {
 
+// Replica-parallel load of the two per-channel sums: a block is 16 channels x 16 "replica lanes"; lane rl loads
+// replicas rl, rl+16, ... (all loads of a channel are in flight at once) and the 16 partial sums meet through DPP-free
+// shuffles inside the 16-lane row.
+__device__ __forceinline__ void load_sums(const double* __restrict__ stats, int nrep, long long rstride, int C, int c, int rl,
+                                          double& s1, double& s2) {
+  s1 = 0.0;
+  s2 = 0.0;
+  if (c < C) {
+    for (int r = rl; r < nrep; r += 16) {
+      s1 += stats[r * rstride + c];
+      s2 += stats[r * rstride + C + c];
+    }
+  }
+#pragma unroll
+  for (int o = 8; o > 0; o >>= 1) {
+    s1 += __shfl_xor(s1, o, 16);
+    s2 += __shfl_xor(s2, o, 16);
+  }
+}
+
 __global__ void bn_finalize_kernel(const double* __restrict__ stats, int nrep, long long rstride, int C, double count,
                                    const float* __restrict__ gamma, const float* __restrict__ beta,
                                    float* running_mean, float* running_var, int64_t* nbt, float momentum,
                                    float eps, float* scale, float* shift, float* mean_out, float* invstd_out) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c == 0 && nbt) *nbt += 1;
-  if (c >= C) return;
-  double s1 = 0.0, s2 = 0.0;
-#pragma unroll 16
-  for (int r = 0; r < nrep; ++r) {   // independent loads: all replicas in flight together
-    s1 += stats[r * rstride + c];
-    s2 += stats[r * rstride + C + c];
-  }
+  const int c = blockIdx.x * 16 + (threadIdx.x >> 4), rl = threadIdx.x & 15;
+  if (c == 0 && rl == 0 && nbt) *nbt += 1;
+  double s1, s2;
+  load_sums(stats, nrep, rstride, C, c, rl, s1, s2);
+  if (c >= C || rl != 0) return;
   const double mean = s1 / count;
   double var = s2 / count - mean * mean;  // biased
   if (var < 0.0) var = 0.0;
@@ -51,14 +67,10 @@ __global__ void bn_bwd_finalize_kernel(const double* __restrict__ stats, int nre
                                        const float* __restrict__ gamma, const float* __restrict__ mean,
                                        const float* __restrict__ invstd, float* alpha, float* beta, float* gammac,
                                        float* dgamma, float* dbeta) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
-  double s1 = 0.0, s2 = 0.0;
-#pragma unroll 16
-  for (int r = 0; r < nrep; ++r) {
-    s1 += stats[r * rstride + c];
-    s2 += stats[r * rstride + C + c];
-  }
+  const int c = blockIdx.x * 16 + (threadIdx.x >> 4), rl = threadIdx.x & 15;
+  double s1, s2;
+  load_sums(stats, nrep, rstride, C, c, rl, s1, s2);
+  if (c >= C || rl != 0) return;
   const double mu = (double)mean[c], is = (double)invstd[c];
   const double dg = is * (s2 - mu * s1);
   const double a = (double)(gamma ? gamma[c] : 1.f) * is;
@@ -77,7 +89,7 @@ extern "C" int t3d_bn_finalize(const double* stats, int C, double count, const f
                                float momentum, float eps, float* scale, float* shift, float* mean, float* invstd,
                                void* stream) {
   if (!stats || !scale || !shift || C <= 0 || count <= 0) return T3D_ERR_ARG;
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, 64)), dim3(64), 0, reinterpret_cast<hipStream_t>(stream),
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, 16)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
                      stats, g_t3d_reduce.nrep, g_t3d_reduce.stats_stride, C, count, gamma, beta, running_mean, running_var, num_batches_tracked, momentum, eps,
                      scale, shift, mean, invstd);
   T3D_CHECK_LAUNCH();
@@ -100,7 +112,7 @@ extern "C" int t3d_bn_bwd_finalize(const double* stats, int C, double count, con
                                    const float* invstd, float* alpha, float* beta, float* gammac, float* dgamma,
                                    float* dbeta, void* stream) {
   if (!stats || !mean || !invstd || !alpha || !beta || !gammac || C <= 0 || count <= 0) return T3D_ERR_ARG;
-  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(C, 64)), dim3(64), 0,
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(C, 16)), dim3(256), 0,
                      reinterpret_cast<hipStream_t>(stream), stats, g_t3d_reduce.nrep, g_t3d_reduce.stats_stride, C, count, gamma, mean, invstd, alpha, beta,
                      gammac, dgamma, dbeta);
   T3D_CHECK_LAUNCH();
