@@ -235,6 +235,197 @@ __global__ __launch_bounds__(256) void dw3_fwd_kernel(const Dw3Args a) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Stride-1 variant with TWO output columns per thread.  The kernel above is VALU-bound (PMC: SIMD VALU ~60 % busy at
+// 2.6 TB/s): every input element is converted + activated by the three threads whose 3-tap windows contain it.
+// Here a thread owns columns (2p, 2p+1): four column loads feed two outputs (each element is activated twice instead
+// of three times, address / loop overhead is shared), and all multiply-adds are packed (v_pk_fma_f32: two channels per
+// issue slot).  Zero padding: a 0/1 mask per out-of-image column (per item), skipped rows.
+template <typename T, int PF>
+__global__ __launch_bounds__(256) void dw3_fwd2_kernel(const Dw3Args a) {
+  constexpr int CH = 4, H2 = CH / 2;
+  extern __shared__ float lstat[];  // [2][C]
+  using RV = rawvec<T, CH>;
+  const int CG = a.C / CH, Wp = (a.Wo + 1) / 2;
+  int cg, xp_fixed = 0, q0, qstride;
+  bool on;
+  if (!a.slab) {
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    on = j < Wp * CG;
+    cg = on ? j % CG : 0;
+    xp_fixed = on ? j / CG : 0;
+    q0 = blockIdx.y;
+    qstride = gridDim.y;
+  } else {
+    cg = blockIdx.y * 64 + (threadIdx.x & 63);
+    on = cg < CG;
+    if (!on) cg = 0;
+    q0 = blockIdx.x * 4 + (threadIdx.x >> 6);
+    qstride = gridDim.x * 4;
+  }
+  const int c0 = cg * CH;
+  const bool affine = a.scale != nullptr || a.act != T3D_ACT_NONE;
+
+  f32x2 w2[9][H2], sc2[H2], sh2[H2];
+  float psum[CH], psq[CH];
+  {
+    float wb[CH * 9];
+    const float4* wp = reinterpret_cast<const float4*>(a.w + (size_t)c0 * 9);
+#pragma unroll
+    for (int i = 0; i < CH * 9 / 4; ++i) {
+      const float4 q = wp[i];
+      wb[4 * i] = q.x; wb[4 * i + 1] = q.y; wb[4 * i + 2] = q.z; wb[4 * i + 3] = q.w;
+    }
+#pragma unroll
+    for (int h = 0; h < H2; ++h) {
+      sc2[h] = f32x2{a.scale ? a.scale[c0 + 2 * h] : 1.f, a.scale ? a.scale[c0 + 2 * h + 1] : 1.f};
+      sh2[h] = f32x2{a.scale ? a.shift[c0 + 2 * h] : 0.f, a.scale ? a.shift[c0 + 2 * h + 1] : 0.f};
+#pragma unroll
+      for (int t = 0; t < 9; ++t) w2[t][h] = f32x2{wb[(2 * h) * 9 + t], wb[(2 * h + 1) * 9 + t]};
+    }
+#pragma unroll
+    for (int i = 0; i < CH; ++i) psum[i] = psq[i] = 0.f;
+  }
+
+  for (int q = q0; q < a.nitems && on; q += qstride) {
+    int xp, rest;
+    if (!a.slab) { xp = xp_fixed; rest = q; } else { xp = q % Wp; rest = q / Wp; }
+    const int chunk = rest % a.nchunks, b = rest / a.nchunks;
+    const T* __restrict__ x = reinterpret_cast<const T*>(a.x) + (size_t)b * a.H * a.W * a.C + c0;
+    T* __restrict__ y = reinterpret_cast<T*>(a.y) + (size_t)b * a.Ho * a.Wo * a.C + c0;
+    const int oy0 = chunk * a.rows_per_chunk, oy1 = min(a.Ho, oy0 + a.rows_per_chunk);
+    const int x0 = 2 * xp;                  // output columns x0 (always valid) and x0+1
+    const bool validB = x0 + 1 < a.W;
+    // input columns x0-1 .. x0+2; 0/1 masks for the ones outside the image (column x0 is always inside)
+    const float m0 = x0 - 1 >= 0 ? 1.f : 0.f, m2 = validB ? 1.f : 0.f, m3 = x0 + 2 < a.W ? 1.f : 0.f;
+    int coff[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) coff[c] = min(max(x0 - 1 + c, 0), a.W - 1) * a.C;
+    const int iy_first = oy0 - 1, iy_last = oy1;
+
+    RV ring[PF][4];
+    auto fetch = [&](int iy, RV* dst) {
+      const T* rp = x + (size_t)min(max(iy, 0), a.H - 1) * a.W * a.C;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) dst[c] = *reinterpret_cast<const RV*>(rp + coff[c]);
+    };
+#pragma unroll
+    for (int u = 0; u < PF; ++u) fetch(iy_first + u, ring[u]);
+
+    static_assert(PF == 3, "accumulator roles come from the unroll index");
+    f32x2 accA[3][H2], accB[3][H2];   // roles (output row iy-1, iy, iy+1) = [u%3], [(u+1)%3], [(u+2)%3]
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+      for (int h = 0; h < H2; ++h) accA[r][h] = accB[r][h] = f32x2{0.f, 0.f};
+
+    for (int base = iy_first; base <= iy_last; base += PF) {
+#pragma unroll
+      for (int u = 0; u < PF; ++u) {
+        const int iy = base + u;
+        if (iy <= iy_last) {
+          const bool rok = iy >= 0 && iy < a.H;
+          f32x2 v[4][H2];
+#pragma unroll
+          for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int h = 0; h < H2; ++h) v[c][h] = f32x2{(float)ring[u][c][2 * h], (float)ring[u][c][2 * h + 1]};
+          fetch(iy + PF, ring[u]);
+          if (affine) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+#pragma unroll
+              for (int h = 0; h < H2; ++h) v[c][h] = pk_fma(v[c][h], sc2[h], sh2[h]);
+            switch (a.act) {   // wave-uniform, once per row
+              case T3D_ACT_RELU:
+#pragma unroll
+                for (int c = 0; c < 4; ++c)
+#pragma unroll
+                  for (int h = 0; h < H2; ++h) v[c][h] = f32x2{fmaxf(v[c][h][0], 0.f), fmaxf(v[c][h][1], 0.f)};
+                break;
+              case T3D_ACT_RELU6:
+#pragma unroll
+                for (int c = 0; c < 4; ++c)
+#pragma unroll
+                  for (int h = 0; h < H2; ++h)
+                    v[c][h] = f32x2{__builtin_amdgcn_fmed3f(v[c][h][0], 0.f, 6.f), __builtin_amdgcn_fmed3f(v[c][h][1], 0.f, 6.f)};
+                break;
+              case T3D_ACT_HSWISH:
+#pragma unroll
+                for (int c = 0; c < 4; ++c)
+#pragma unroll
+                  for (int h = 0; h < H2; ++h) {
+                    const f32x2 t = v[c][h];
+                    v[c][h] = f32x2{t[0] * (__builtin_amdgcn_fmed3f(t[0] + 3.f, 0.f, 6.f) * T3D_SIXTH),
+                                    t[1] * (__builtin_amdgcn_fmed3f(t[1] + 3.f, 0.f, 6.f) * T3D_SIXTH)};
+                  }
+                break;
+              default: break;
+            }
+          }
+#pragma unroll
+          for (int h = 0; h < H2; ++h) {   // zero padding of the activated tensor
+            v[0][h] = v[0][h] * f32x2{m0, m0};
+            v[2][h] = v[2][h] * f32x2{m2, m2};
+            v[3][h] = v[3][h] * f32x2{m3, m3};
+          }
+          f32x2* aA = accA[u % 3];
+          f32x2* aB = accB[u % 3];
+          if (rok) {
+            f32x2* bA = accA[(u + 1) % 3];
+            f32x2* cA = accA[(u + 2) % 3];
+            f32x2* bB = accB[(u + 1) % 3];
+            f32x2* cB = accB[(u + 2) % 3];
+            // input row iy feeds output rows iy-1 (ky=2), iy (ky=1), iy+1 (ky=0); column A uses taps c=0..2, B c=1..3
+#pragma unroll
+            for (int h = 0; h < H2; ++h) {
+#pragma unroll
+              for (int c = 0; c < 3; ++c) {
+                aA[h] = pk_fma(v[c][h], w2[6 + c][h], aA[h]);
+                bA[h] = pk_fma(v[c][h], w2[3 + c][h], bA[h]);
+                cA[h] = pk_fma(v[c][h], w2[c][h], cA[h]);
+                aB[h] = pk_fma(v[c + 1][h], w2[6 + c][h], aB[h]);
+                bB[h] = pk_fma(v[c + 1][h], w2[3 + c][h], bB[h]);
+                cB[h] = pk_fma(v[c + 1][h], w2[c][h], cB[h]);
+              }
+            }
+          }
+          const int oy = iy - 1;
+          if (oy >= oy0 && oy < oy1) {
+            float oa[CH], ob[CH];
+#pragma unroll
+            for (int h = 0; h < H2; ++h) {
+              oa[2 * h] = aA[h][0]; oa[2 * h + 1] = aA[h][1];
+              ob[2 * h] = aB[h][0]; ob[2 * h + 1] = aB[h][1];
+            }
+            T* yp = y + ((size_t)oy * a.Wo + x0) * a.C;
+            store_round<T, CH>(yp, oa, psum, psq);
+            if (validB) store_round<T, CH>(yp + a.C, ob, psum, psq);
+          }
+#pragma unroll
+          for (int h = 0; h < H2; ++h) aA[h] = aB[h] = f32x2{0.f, 0.f};
+        }
+      }
+    }
+  }  // item loop
+
+  if (a.stats) {
+    for (int i = threadIdx.x; i < 2 * a.C; i += 256) lstat[i] = 0.f;
+    __syncthreads();
+    if (on) {
+#pragma unroll
+      for (int i = 0; i < CH; ++i) {
+        atomicAdd(lstat + c0 + i, psum[i]);
+        atomicAdd(lstat + a.C + c0 + i, psq[i]);
+      }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 2 * a.C; i += 256)
+      if (lstat[i] != 0.f)
+        atomicAdd(a.stats + (size_t)((blockIdx.x + blockIdx.y) % a.nrep) * a.rstride + i, (double)lstat[i]);
+  }
+}
+
 template <typename T, int CH>
 int launch_ch(Dw3Args& a, int s, hipStream_t st) {
   constexpr int PF = 3;
@@ -249,6 +440,9 @@ int launch_ch(Dw3Args& a, int s, hipStream_t st) {
   if (nchunks < 1) nchunks = 1;
   a.rows_per_chunk = cdiv(a.Ho, nchunks);
   a.nchunks = cdiv(a.Ho, a.rows_per_chunk);
+  static const bool two_col = !getenv("T3D_DW_1COL");
+  const bool use2 = (s == 1 && CH == 4 && two_col);
+  const int Wcols = use2 ? (a.Wo + 1) / 2 : a.Wo;     // work items per row: column pairs or columns
   dim3 grid;
   const int target_blocks = 256 * 6;   // persistent blocks: enough to fill the chip, few enough that the per-block flush stays cheap
   a.nrep = g_t3d_reduce.nrep;
@@ -256,14 +450,14 @@ int launch_ch(Dw3Args& a, int s, hipStream_t st) {
   if (CG < 64) {
     a.slab = 0;
     a.nitems = a.B * a.nchunks;
-    const int jb = cdiv(a.Wo * CG, 256);
+    const int jb = cdiv(Wcols * CG, 256);
     int gy = target_blocks / jb;
     if (gy > a.nitems) gy = a.nitems;
     if (gy < 1) gy = 1;
     grid = dim3(jb, gy);
   } else {
     a.slab = 1;
-    a.nitems = a.Wo * a.B * a.nchunks;
+    a.nitems = Wcols * a.B * a.nchunks;
     const int ns = cdiv(CG, 64);
     int gx = target_blocks / ns;
     if (gx > cdiv(a.nitems, 4)) gx = cdiv(a.nitems, 4);
@@ -271,7 +465,8 @@ int launch_ch(Dw3Args& a, int s, hipStream_t st) {
     grid = dim3(gx, ns);
   }
   const size_t lds = (size_t)2 * a.C * sizeof(float);
-  if (s == 1) hipLaunchKernelGGL((dw3_fwd_kernel<T, 1, CH, PF>), grid, dim3(256), lds, st, a);
+  if (use2) hipLaunchKernelGGL((dw3_fwd2_kernel<T, PF>), grid, dim3(256), lds, st, a);
+  else if (s == 1) hipLaunchKernelGGL((dw3_fwd_kernel<T, 1, CH, PF>), grid, dim3(256), lds, st, a);
   else hipLaunchKernelGGL((dw3_fwd_kernel<T, 2, CH, PF>), grid, dim3(256), lds, st, a);
   T3D_CHECK_LAUNCH();
   return T3D_OK;
