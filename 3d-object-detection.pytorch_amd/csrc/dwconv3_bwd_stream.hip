@@ -279,11 +279,308 @@ __global__ __launch_bounds__(256) void dw3_bwd_s1_kernel(const Dw3BArgs a) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Two columns per thread + packed fp32 math (the production stride-1 backward).  The one-column kernel above needs
+// ~310 VALU instructions per output vector and is VALU-bound at ~1.2 TB/s; here four column loads of dz / y / x feed
+// two outputs (dy and the activations are formed twice per element instead of three times), every multiply-add is a
+// v_pk_fma_f32, and the 9 x CH stencil weights are read from LDS per use (saves 36 registers for the two
+// accumulator sets).  Padding: 0/1 masks per out-of-image column, wave-uniform row skips.
+template <typename T, int PF>
+__global__ __launch_bounds__(256) void dw3_bwd2_kernel(const Dw3BArgs a) {
+  constexpr int CH = 4, H2 = 2;
+  extern __shared__ float lred[];       // [11][C] reduction scratch (end of kernel); first [9][C]: weights by tap
+  using RV = rawvec<T, CH>;
+  const int CG = a.C / CH, Wp = (a.W + 1) / 2;
+  int cg, xp_fixed = 0, q0, qstride;
+  bool on;
+  if (!a.slab) {
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    on = j < Wp * CG;
+    cg = on ? j % CG : 0;
+    xp_fixed = on ? j / CG : 0;
+    q0 = blockIdx.y;
+    qstride = gridDim.y;
+  } else {
+    cg = blockIdx.y * 64 + (threadIdx.x & 63);
+    on = cg < CG;
+    if (!on) cg = 0;
+    q0 = blockIdx.x * 4 + (threadIdx.x >> 6);
+    qstride = gridDim.x * 4;
+  }
+  const int c0 = cg * CH;
+  const bool affine = a.scale != nullptr || a.act != T3D_ACT_NONE;
+  // weights [tap][C] in LDS: a thread reads its 4 channels of one tap with one ds_read_b128
+  for (int i = threadIdx.x; i < 9 * a.C; i += 256) lred[i] = a.w[(size_t)(i % a.C) * 9 + i / a.C];
+  __syncthreads();
+  const float* wl = lred + c0;
+
+  f32x2 sc2[H2], sh2[H2], al2[H2], be2[H2], ga2[H2];
+  f32x2 wacc[9][H2];
+  float psum[CH], psq[CH];
+#pragma unroll
+  for (int h = 0; h < H2; ++h) {
+    const int c = c0 + 2 * h;
+    sc2[h] = f32x2{a.scale ? a.scale[c] : 1.f, a.scale ? a.scale[c + 1] : 1.f};
+    sh2[h] = f32x2{a.scale ? a.shift[c] : 0.f, a.scale ? a.shift[c + 1] : 0.f};
+    be2[h] = f32x2{a.beta[c], a.beta[c + 1]};
+    al2[h] = a.per_sample ? f32x2{0.f, 0.f} : f32x2{a.alpha[c], a.alpha[c + 1]};
+    ga2[h] = a.per_sample ? f32x2{0.f, 0.f} : f32x2{a.gamma[c], a.gamma[c + 1]};
+#pragma unroll
+    for (int t = 0; t < 9; ++t) wacc[t][h] = f32x2{0.f, 0.f};
+  }
+#pragma unroll
+  for (int i = 0; i < CH; ++i) psum[i] = psq[i] = 0.f;
+
+  for (int q = q0; q < a.nitems && on; q += qstride) {
+    int xp, rest;
+    if (!a.slab) { xp = xp_fixed; rest = q; } else { xp = q % Wp; rest = q / Wp; }
+    const int chunk = rest % a.nchunks, b = rest / a.nchunks;
+    const size_t img = (size_t)b * a.H * a.W * a.C + c0;
+    const T* __restrict__ zg = reinterpret_cast<const T*>(a.dz) + img;
+    const T* __restrict__ yg = reinterpret_cast<const T*>(a.y) + img;
+    const T* __restrict__ xg = reinterpret_cast<const T*>(a.x) + img;
+    const T* __restrict__ rg = a.res ? reinterpret_cast<const T*>(a.res) + img : nullptr;
+    T* __restrict__ dxg = reinterpret_cast<T*>(a.dx) + img;
+    if (a.per_sample) {
+#pragma unroll
+      for (int h = 0; h < H2; ++h) {
+        const size_t o = (size_t)b * a.C + c0 + 2 * h;
+        al2[h] = f32x2{a.alpha[o], a.alpha[o + 1]};
+        ga2[h] = f32x2{a.gamma[o], a.gamma[o + 1]};
+      }
+    }
+    const int r0 = chunk * a.rows_per_chunk, r1 = min(a.H, r0 + a.rows_per_chunk);
+    const int x0 = 2 * xp;                 // columns x0 (always inside) and x0+1
+    const bool validB = x0 + 1 < a.W;
+    const float m[4] = {x0 - 1 >= 0 ? 1.f : 0.f, 1.f, validB ? 1.f : 0.f, x0 + 2 < a.W ? 1.f : 0.f};
+    int coff[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) coff[c] = min(max(x0 - 1 + c, 0), a.W - 1) * a.C;
+
+    RV rz[PF][4], ry[PF][4], rx[PF][4];
+    auto fetch = [&](int r, int slot) {
+      const size_t ro = (size_t)min(max(r, 0), a.H - 1) * a.W * a.C;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        rz[slot][c] = *reinterpret_cast<const RV*>(zg + ro + coff[c]);
+        ry[slot][c] = *reinterpret_cast<const RV*>(yg + ro + coff[c]);
+        rx[slot][c] = *reinterpret_cast<const RV*>(xg + ro + coff[c]);
+      }
+    };
+    const int rf = r0 - 1, rl = r1;
+#pragma unroll
+    for (int u = 0; u < PF; ++u) fetch(rf + u, u);
+
+    static_assert(PF == 3, "accumulator roles come from the unroll index");
+    f32x2 accA[3][H2], accB[3][H2];     // dx rows r-1, r, r+1 of columns x0 / x0+1
+    f32x2 a_prev[4][H2], dyc_prev[2][H2], xr_prev[2][H2];
+#pragma unroll
+    for (int h = 0; h < H2; ++h) {
+#pragma unroll
+      for (int r = 0; r < 3; ++r) accA[r][h] = accB[r][h] = f32x2{0.f, 0.f};
+#pragma unroll
+      for (int c = 0; c < 4; ++c) a_prev[c][h] = f32x2{0.f, 0.f};
+      dyc_prev[0][h] = dyc_prev[1][h] = xr_prev[0][h] = xr_prev[1][h] = f32x2{0.f, 0.f};
+    }
+
+    for (int base = rf; base <= rl; base += PF) {
+#pragma unroll
+      for (int u = 0; u < PF; ++u) {
+        const int r = base + u;
+        if (r <= rl) {
+          const bool rok = r >= 0 && r < a.H;
+          f32x2 dy[4][H2], av[4][H2], xr[2][H2];
+#pragma unroll
+          for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int h = 0; h < H2; ++h) {
+              const f32x2 z = {(float)rz[u][c][2 * h], (float)rz[u][c][2 * h + 1]};
+              const f32x2 yy = {(float)ry[u][c][2 * h], (float)ry[u][c][2 * h + 1]};
+              av[c][h] = f32x2{(float)rx[u][c][2 * h], (float)rx[u][c][2 * h + 1]};
+              dy[c][h] = pk_fma(al2[h], z, pk_fma(be2[h], yy, ga2[h]));
+            }
+          fetch(r + PF, u);
+#pragma unroll
+          for (int h = 0; h < H2; ++h) {
+            xr[0][h] = av[1][h];
+            xr[1][h] = av[2][h];
+          }
+          if (affine) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+#pragma unroll
+              for (int h = 0; h < H2; ++h) av[c][h] = pk_fma(av[c][h], sc2[h], sh2[h]);
+            switch (a.act) {
+              case T3D_ACT_RELU:
+#pragma unroll
+                for (int c = 0; c < 4; ++c)
+#pragma unroll
+                  for (int h = 0; h < H2; ++h) av[c][h] = f32x2{fmaxf(av[c][h][0], 0.f), fmaxf(av[c][h][1], 0.f)};
+                break;
+              case T3D_ACT_RELU6:
+#pragma unroll
+                for (int c = 0; c < 4; ++c)
+#pragma unroll
+                  for (int h = 0; h < H2; ++h)
+                    av[c][h] = f32x2{__builtin_amdgcn_fmed3f(av[c][h][0], 0.f, 6.f), __builtin_amdgcn_fmed3f(av[c][h][1], 0.f, 6.f)};
+                break;
+              case T3D_ACT_HSWISH:
+#pragma unroll
+                for (int c = 0; c < 4; ++c)
+#pragma unroll
+                  for (int h = 0; h < H2; ++h) {
+                    const f32x2 t = av[c][h];
+                    av[c][h] = f32x2{t[0] * (__builtin_amdgcn_fmed3f(t[0] + 3.f, 0.f, 6.f) * T3D_SIXTH),
+                                     t[1] * (__builtin_amdgcn_fmed3f(t[1] + 3.f, 0.f, 6.f) * T3D_SIXTH)};
+                  }
+                break;
+              default: break;
+            }
+          }
+          const float rm = rok ? 1.f : 0.f;    // out-of-image row: everything it would contribute is zero
+#pragma unroll
+          for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int h = 0; h < H2; ++h) {
+              const f32x2 mm = {m[c] * rm, m[c] * rm};
+              dy[c][h] = dy[c][h] * mm;
+              av[c][h] = av[c][h] * mm;
+            }
+          f32x2* aA = accA[u % 3];
+          f32x2* bA = accA[(u + 1) % 3];
+          f32x2* cA = accA[(u + 2) % 3];
+          f32x2* aB = accB[u % 3];
+          f32x2* bB = accB[(u + 1) % 3];
+          f32x2* cB = accB[(u + 2) % 3];
+          const bool own = r >= r0 && r < r1;
+          const float om = own ? 1.f : 0.f;
+          f32x2 dycA[H2], dycB[H2];
+#pragma unroll
+          for (int h = 0; h < H2; ++h) {
+            dycA[h] = dy[1][h] * f32x2{om, om};
+            dycB[h] = dy[2][h] * f32x2{om, om};
+          }
+          // stencil taps, one LDS read (4 channels) per tap
+#pragma unroll
+          for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+              const float4 wq = *reinterpret_cast<const float4*>(wl + (ky * 3 + kx) * a.C);
+              const f32x2 w0 = {wq.x, wq.y}, w1 = {wq.z, wq.w};
+              // data gradient: dy row r reaches dx row r-1+ky; dy column (x + 1 - kx): local index 2-kx for A, 3-kx for B
+              f32x2* dA = ky == 0 ? aA : (ky == 1 ? bA : cA);
+              f32x2* dB = ky == 0 ? aB : (ky == 1 ? bB : cB);
+              dA[0] = pk_fma(dy[2 - kx][0], w0, dA[0]);
+              dA[1] = pk_fma(dy[2 - kx][1], w1, dA[1]);
+              dB[0] = pk_fma(dy[3 - kx][0], w0, dB[0]);
+              dB[1] = pk_fma(dy[3 - kx][1], w1, dB[1]);
+            }
+          // weight gradient: dw[ky][kx] += dy[oy][x] * a[oy+ky-1][x+kx-1]; a column of A: local kx, of B: local kx+1
+          if (a.dw) {
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+              for (int h = 0; h < H2; ++h) {
+                wacc[kx][h] = pk_fma(dycA[h], a_prev[kx][h], pk_fma(dycB[h], a_prev[kx + 1][h], wacc[kx][h]));          // ky=0
+                wacc[3 + kx][h] = pk_fma(dycA[h], av[kx][h], pk_fma(dycB[h], av[kx + 1][h], wacc[3 + kx][h]));          // ky=1
+                wacc[6 + kx][h] = pk_fma(dyc_prev[0][h], av[kx][h], pk_fma(dyc_prev[1][h], av[kx + 1][h], wacc[6 + kx][h]));  // ky=2
+              }
+          }
+          // dx row r-1 complete
+          const int iy = r - 1;
+          if (iy >= r0 && iy < r1) {
+#pragma unroll
+            for (int col = 0; col < 2; ++col) {
+              if (col == 1 && !validB) break;
+              const f32x2* acc = col == 0 ? aA : aB;
+              float g[CH], xv[CH];
+#pragma unroll
+              for (int h = 0; h < H2; ++h) {
+                g[2 * h] = acc[h][0]; g[2 * h + 1] = acc[h][1];
+                xv[2 * h] = xr_prev[col][h][0]; xv[2 * h + 1] = xr_prev[col][h][1];
+              }
+              if (affine) {
+                float scf[CH] = {sc2[0][0], sc2[0][1], sc2[1][0], sc2[1][1]}, shf[CH] = {sh2[0][0], sh2[0][1], sh2[1][0], sh2[1][1]};
+                act_grad_affine_vec<CH>(g, xv, scf, shf, a.act);
+              }
+              const size_t off = ((size_t)iy * a.W + x0 + col) * a.C;
+              if (rg) {
+                const RV rr = *reinterpret_cast<const RV*>(rg + off);
+#pragma unroll
+                for (int i = 0; i < CH; ++i) g[i] += (float)rr[i];
+              }
+              RV o;
+#pragma unroll
+              for (int i = 0; i < CH; ++i) {
+                o[i] = (T)g[i];
+                const float v = (float)o[i];
+                psum[i] += v;
+                psq[i] = fmaf(v, xv[i], psq[i]);
+              }
+              *reinterpret_cast<RV*>(dxg + off) = o;
+            }
+          }
+#pragma unroll
+          for (int h = 0; h < H2; ++h) {
+            aA[h] = aB[h] = f32x2{0.f, 0.f};
+            xr_prev[0][h] = xr[0][h];
+            xr_prev[1][h] = xr[1][h];
+            dyc_prev[0][h] = dycA[h];
+            dyc_prev[1][h] = dycB[h];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) a_prev[c][h] = av[c][h];
+          }
+        }
+      }
+    }
+  }  // item loop
+
+  // ---- block-level reduction (the weights in LDS are dead now)
+  __syncthreads();
+  const int nred = (a.dw ? 9 : 0) + (a.stats ? 2 : 0);
+  if (nred && !a.noflush) {
+    for (int i = threadIdx.x; i < 11 * a.C; i += 256) lred[i] = 0.f;
+    __syncthreads();
+    if (on) {
+#pragma unroll
+      for (int h = 0; h < H2; ++h)
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+          const int c = c0 + 2 * h + e;
+          if (a.dw) {
+#pragma unroll
+            for (int t = 0; t < 9; ++t) atomicAdd(lred + t * a.C + c, wacc[t][h][e]);
+          }
+          if (a.stats) {
+            atomicAdd(lred + 9 * a.C + c, psum[2 * h + e]);
+            atomicAdd(lred + 10 * a.C + c, psq[2 * h + e]);
+          }
+        }
+    }
+    __syncthreads();
+    const int rep = (blockIdx.x + blockIdx.y) % a.nrep;
+    if (a.dw) {
+      for (int i = threadIdx.x; i < 9 * a.C; i += 256) {
+        const float v = lred[i];
+        if (v != 0.f) unsafeAtomicAdd(a.dw + (size_t)rep * a.C * 9 + (size_t)(i % a.C) * 9 + i / a.C, v);
+      }
+    }
+    if (a.stats) {
+      for (int i = threadIdx.x; i < 2 * a.C; i += 256) {
+        const float v = lred[9 * a.C + i];
+        if (v != 0.f) atomicAdd(a.stats + (size_t)rep * a.rstride + i, (double)v);
+      }
+    }
+  }
+}
+
 template <typename T>
 int launch_s1(Dw3BArgs& a, hipStream_t st) {
   constexpr int CH = 4, PF = 3;
   const int CG = a.C / CH;
-  const long long per_row_chunk = (long long)a.B * a.W * CG;
+  static const bool two_col = !getenv("T3D_DW_BWD_1COL");
+  const int Wcols = two_col ? (a.W + 1) / 2 : a.W;
+  const long long per_row_chunk = (long long)a.B * Wcols * CG;
   int nchunks = (int)((256LL * 64 * 24 + per_row_chunk - 1) / per_row_chunk);
   int max_chunks = a.H / 8;
   if (max_chunks < 1) max_chunks = 1;
@@ -298,14 +595,14 @@ int launch_s1(Dw3BArgs& a, hipStream_t st) {
   if (CG < 64) {
     a.slab = 0;
     a.nitems = a.B * a.nchunks;
-    const int jb = cdiv(a.W * CG, 256);
+    const int jb = cdiv(Wcols * CG, 256);
     int gy = target_blocks / jb;
     if (gy > a.nitems) gy = a.nitems;
     if (gy < 1) gy = 1;
     grid = dim3(jb, gy);
   } else {
     a.slab = 1;
-    a.nitems = a.W * a.B * a.nchunks;
+    a.nitems = Wcols * a.B * a.nchunks;
     const int ns = cdiv(CG, 64);
     int gx = target_blocks / ns;
     if (gx > cdiv(a.nitems, 4)) gx = cdiv(a.nitems, 4);
@@ -314,7 +611,8 @@ int launch_s1(Dw3BArgs& a, hipStream_t st) {
   }
   const size_t lds = (size_t)11 * a.C * sizeof(float);
   a.noflush = getenv("T3D_DEBUG_NOFLUSH") ? 1 : 0;
-  hipLaunchKernelGGL((dw3_bwd_s1_kernel<T, CH, PF>), grid, dim3(256), lds, st, a);
+  if (two_col) hipLaunchKernelGGL((dw3_bwd2_kernel<T, PF>), grid, dim3(256), lds, st, a);
+  else hipLaunchKernelGGL((dw3_bwd_s1_kernel<T, CH, PF>), grid, dim3(256), lds, st, a);
   T3D_CHECK_LAUNCH();
   return T3D_OK;
 }
