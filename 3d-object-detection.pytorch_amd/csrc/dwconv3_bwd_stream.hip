@@ -309,10 +309,14 @@ __global__ __launch_bounds__(256) void dw3_bwd2_kernel(const Dw3BArgs a) {
   }
   const int c0 = cg * CH;
   const bool affine = a.scale != nullptr || a.act != T3D_ACT_NONE;
-  // weights [tap][C] in LDS: a thread reads its 4 channels of one tap with one ds_read_b128
-  for (int i = threadIdx.x; i < 9 * a.C; i += 256) lred[i] = a.w[(size_t)(i % a.C) * 9 + i / a.C];
+  // the block's own channel range: the whole tensor (flattened mapping) or one 64-group slab -- LDS staging and the
+  // final flush touch only these channels
+  const int cbase = a.slab ? blockIdx.y * 64 * CH : 0;
+  const int Cb = a.slab ? min(64 * CH, a.C - cbase) : a.C;
+  // weights [tap][Cb] in LDS: a thread reads its 4 channels of one tap with one ds_read_b128
+  for (int i = threadIdx.x; i < 9 * Cb; i += 256) lred[i] = a.w[(size_t)(cbase + i % Cb) * 9 + i / Cb];
   __syncthreads();
-  const float* wl = lred + c0;
+  const float* wl = lred + (c0 - cbase);
 
   f32x2 sc2[H2], sh2[H2], al2[H2], be2[H2], ga2[H2];
   f32x2 wacc[9][H2];
@@ -465,7 +469,7 @@ __global__ __launch_bounds__(256) void dw3_bwd2_kernel(const Dw3BArgs a) {
           for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
             for (int kx = 0; kx < 3; ++kx) {
-              const float4 wq = *reinterpret_cast<const float4*>(wl + (ky * 3 + kx) * a.C);
+              const float4 wq = *reinterpret_cast<const float4*>(wl + (ky * 3 + kx) * Cb);
               const f32x2 w0 = {wq.x, wq.y}, w1 = {wq.z, wq.w};
               // data gradient: dy row r reaches dx row r-1+ky; dy column (x + 1 - kx): local index 2-kx for A, 3-kx for B
               f32x2* dA = ky == 0 ? aA : (ky == 1 ? bA : cA);
@@ -539,36 +543,36 @@ __global__ __launch_bounds__(256) void dw3_bwd2_kernel(const Dw3BArgs a) {
   __syncthreads();
   const int nred = (a.dw ? 9 : 0) + (a.stats ? 2 : 0);
   if (nred && !a.noflush) {
-    for (int i = threadIdx.x; i < 11 * a.C; i += 256) lred[i] = 0.f;
+    for (int i = threadIdx.x; i < 11 * Cb; i += 256) lred[i] = 0.f;
     __syncthreads();
     if (on) {
 #pragma unroll
       for (int h = 0; h < H2; ++h)
 #pragma unroll
         for (int e = 0; e < 2; ++e) {
-          const int c = c0 + 2 * h + e;
+          const int c = c0 - cbase + 2 * h + e;
           if (a.dw) {
 #pragma unroll
-            for (int t = 0; t < 9; ++t) atomicAdd(lred + t * a.C + c, wacc[t][h][e]);
+            for (int t = 0; t < 9; ++t) atomicAdd(lred + t * Cb + c, wacc[t][h][e]);
           }
           if (a.stats) {
-            atomicAdd(lred + 9 * a.C + c, psum[2 * h + e]);
-            atomicAdd(lred + 10 * a.C + c, psq[2 * h + e]);
+            atomicAdd(lred + 9 * Cb + c, psum[2 * h + e]);
+            atomicAdd(lred + 10 * Cb + c, psq[2 * h + e]);
           }
         }
     }
     __syncthreads();
     const int rep = (blockIdx.x + blockIdx.y) % a.nrep;
     if (a.dw) {
-      for (int i = threadIdx.x; i < 9 * a.C; i += 256) {
+      for (int i = threadIdx.x; i < 9 * Cb; i += 256) {
         const float v = lred[i];
-        if (v != 0.f) unsafeAtomicAdd(a.dw + (size_t)rep * a.C * 9 + (size_t)(i % a.C) * 9 + i / a.C, v);
+        if (v != 0.f) unsafeAtomicAdd(a.dw + (size_t)rep * a.C * 9 + (size_t)(cbase + i % Cb) * 9 + i / Cb, v);
       }
     }
     if (a.stats) {
-      for (int i = threadIdx.x; i < 2 * a.C; i += 256) {
-        const float v = lred[9 * a.C + i];
-        if (v != 0.f) atomicAdd(a.stats + (size_t)rep * a.rstride + i, (double)v);
+      for (int i = threadIdx.x; i < 2 * Cb; i += 256) {
+        const float v = lred[9 * Cb + i];
+        if (v != 0.f) atomicAdd(a.stats + (size_t)rep * a.rstride + (size_t)(i / Cb) * a.C + cbase + i % Cb, (double)v);
       }
     }
   }

@@ -219,19 +219,23 @@ __global__ __launch_bounds__(256) void dw3_fwd_kernel(const Dw3Args a) {
   }  // item loop
 
   if (a.stats) {
-    for (int i = threadIdx.x; i < 2 * a.C; i += 256) lstat[i] = 0.f;
+    // only the block's own channel range (whole tensor, or one 64-group slab) goes through LDS and out
+    const int cbase = a.slab ? blockIdx.y * 64 * CH : 0;
+    const int Cb = a.slab ? min(64 * CH, a.C - cbase) : a.C;
+    for (int i = threadIdx.x; i < 2 * Cb; i += 256) lstat[i] = 0.f;
     __syncthreads();
     if (on) {
 #pragma unroll
       for (int i = 0; i < CH; ++i) {
-        atomicAdd(lstat + c0 + i, psum[i]);
-        atomicAdd(lstat + a.C + c0 + i, psq[i]);
+        atomicAdd(lstat + c0 - cbase + i, psum[i]);
+        atomicAdd(lstat + Cb + c0 - cbase + i, psq[i]);
       }
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < 2 * a.C; i += 256)
+    for (int i = threadIdx.x; i < 2 * Cb; i += 256)
       if (lstat[i] != 0.f)
-        atomicAdd(a.stats + (size_t)((blockIdx.x + blockIdx.y) % a.nrep) * a.rstride + i, (double)lstat[i]);
+        atomicAdd(a.stats + (size_t)((blockIdx.x + blockIdx.y) % a.nrep) * a.rstride + (size_t)(i / Cb) * a.C + cbase + i % Cb,
+                  (double)lstat[i]);
   }
 }
 
@@ -410,19 +414,23 @@ __global__ __launch_bounds__(256) void dw3_fwd2_kernel(const Dw3Args a) {
   }  // item loop
 
   if (a.stats) {
-    for (int i = threadIdx.x; i < 2 * a.C; i += 256) lstat[i] = 0.f;
+    // only the block's own channel range (whole tensor, or one 64-group slab) goes through LDS and out
+    const int cbase = a.slab ? blockIdx.y * 64 * CH : 0;
+    const int Cb = a.slab ? min(64 * CH, a.C - cbase) : a.C;
+    for (int i = threadIdx.x; i < 2 * Cb; i += 256) lstat[i] = 0.f;
     __syncthreads();
     if (on) {
 #pragma unroll
       for (int i = 0; i < CH; ++i) {
-        atomicAdd(lstat + c0 + i, psum[i]);
-        atomicAdd(lstat + a.C + c0 + i, psq[i]);
+        atomicAdd(lstat + c0 - cbase + i, psum[i]);
+        atomicAdd(lstat + Cb + c0 - cbase + i, psq[i]);
       }
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < 2 * a.C; i += 256)
+    for (int i = threadIdx.x; i < 2 * Cb; i += 256)
       if (lstat[i] != 0.f)
-        atomicAdd(a.stats + (size_t)((blockIdx.x + blockIdx.y) % a.nrep) * a.rstride + i, (double)lstat[i]);
+        atomicAdd(a.stats + (size_t)((blockIdx.x + blockIdx.y) % a.nrep) * a.rstride + (size_t)(i / Cb) * a.C + cbase + i % Cb,
+                  (double)lstat[i]);
   }
 }
 
