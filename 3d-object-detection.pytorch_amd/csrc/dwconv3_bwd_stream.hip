@@ -1,4 +1,4 @@
-// Depthwise 3x3 convolution backward, stride 1 -- data gradient, weight gradient and the producer's
+// Depthwise 3x3 convolution backward (stride 1; stride 2 at the end of the file) -- data gradient, weight gradient and the producer's
 // BatchNorm-backward sums in ONE pass, barrier-free streaming kernel for gfx950 (NHWC).
 //
 // Reads dz, y (gradient at / raw input of the following BatchNorm) and x (raw input of the conv) once,
@@ -621,19 +621,340 @@ int launch_s1(Dw3BArgs& a, hipStream_t st) {
   return T3D_OK;
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Stride 2.  A thread owns one OUTPUT column ow of a chunk of output rows and with it the 2x2 input pixels
+// (2oh..2oh+1, 2ow..2ow+1) of every step: with pad 1 each (input pixel, tap) pair then belongs to exactly one
+// thread and touches only the gradients at (oh, ow), (oh, ow+1), (oh+1, ow), (oh+1, ow+1):
+//   dx[2oh  ][2ow  ] = w11 T0                       dw11 += a00 T0
+//   dx[2oh  ][2ow+1] = w12 T0 + w10 T1              dw12 += a01 T0, dw10 += a01 T1
+//   dx[2oh+1][2ow  ] = w21 T0 + w01 N0              dw21 += a10 T0, dw01 += a10 N0
+//   dx[2oh+1][2ow+1] = w22 T0 + w20 T1 + w02 N0 + w00 N1    (and the four matching dw terms)
+// (T = gradient row oh, N = row oh+1; 0/1 = column ow / ow+1.)  9 + 9 packed FMAs per four input pixels, the full-
+// resolution x is read once and dx written once, the quarter-resolution dz / y are read twice (neighbour column; L2).
+template <typename T, int PF>
+__global__ __launch_bounds__(256) void dw3_bwd_s2_kernel(const Dw3BArgs a) {
+  constexpr int CH = 4, H2 = 2;
+  extern __shared__ float lred[];       // [11][Cb] reduction scratch
+  using RV = rawvec<T, CH>;
+  const int CG = a.C / CH, Ho = (a.H - 1) / 2 + 1, Wo = (a.W - 1) / 2 + 1;
+  int cg, ow_fixed = 0, q0, qstride;
+  bool on;
+  if (!a.slab) {
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    on = j < Wo * CG;
+    cg = on ? j % CG : 0;
+    ow_fixed = on ? j / CG : 0;
+    q0 = blockIdx.y;
+    qstride = gridDim.y;
+  } else {
+    cg = blockIdx.y * 64 + (threadIdx.x & 63);
+    on = cg < CG;
+    if (!on) cg = 0;
+    q0 = blockIdx.x * 4 + (threadIdx.x >> 6);
+    qstride = gridDim.x * 4;
+  }
+  const int c0 = cg * CH;
+  const bool affine = a.scale != nullptr || a.act != T3D_ACT_NONE;
+  const int cbase = a.slab ? blockIdx.y * 64 * CH : 0;
+  const int Cb = a.slab ? min(64 * CH, a.C - cbase) : a.C;
+
+  f32x2 sc2[H2], sh2[H2], al2[H2], be2[H2], ga2[H2];
+  f32x2 wt[9][H2], wacc[9][H2];
+  float psum[CH], psq[CH];
+  {
+    float wb[CH * 9];
+    const float4* wp = reinterpret_cast<const float4*>(a.w + (size_t)c0 * 9);
+#pragma unroll
+    for (int i = 0; i < CH * 9 / 4; ++i) {
+      const float4 q = wp[i];
+      wb[4 * i] = q.x; wb[4 * i + 1] = q.y; wb[4 * i + 2] = q.z; wb[4 * i + 3] = q.w;
+    }
+#pragma unroll
+    for (int h = 0; h < H2; ++h) {
+      const int c = c0 + 2 * h;
+      sc2[h] = f32x2{a.scale ? a.scale[c] : 1.f, a.scale ? a.scale[c + 1] : 1.f};
+      sh2[h] = f32x2{a.scale ? a.shift[c] : 0.f, a.scale ? a.shift[c + 1] : 0.f};
+      be2[h] = f32x2{a.beta[c], a.beta[c + 1]};
+      al2[h] = a.per_sample ? f32x2{0.f, 0.f} : f32x2{a.alpha[c], a.alpha[c + 1]};
+      ga2[h] = a.per_sample ? f32x2{0.f, 0.f} : f32x2{a.gamma[c], a.gamma[c + 1]};
+#pragma unroll
+      for (int t = 0; t < 9; ++t) {
+        wt[t][h] = f32x2{wb[(2 * h) * 9 + t], wb[(2 * h + 1) * 9 + t]};
+        wacc[t][h] = f32x2{0.f, 0.f};
+      }
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < CH; ++i) psum[i] = psq[i] = 0.f;
+  float scf[CH] = {sc2[0][0], sc2[0][1], sc2[1][0], sc2[1][1]}, shf[CH] = {sh2[0][0], sh2[0][1], sh2[1][0], sh2[1][1]};
+
+  for (int q = q0; q < a.nitems && on; q += qstride) {
+    int ow, rest;
+    if (!a.slab) { ow = ow_fixed; rest = q; } else { ow = q % Wo; rest = q / Wo; }
+    const int chunk = rest % a.nchunks, b = rest / a.nchunks;
+    const size_t oimg = (size_t)b * Ho * Wo * a.C + c0, iimg = (size_t)b * a.H * a.W * a.C + c0;
+    const T* __restrict__ zg = reinterpret_cast<const T*>(a.dz) + oimg;
+    const T* __restrict__ yg = reinterpret_cast<const T*>(a.y) + oimg;
+    const T* __restrict__ xg = reinterpret_cast<const T*>(a.x) + iimg;
+    const T* __restrict__ rg = a.res ? reinterpret_cast<const T*>(a.res) + iimg : nullptr;
+    T* __restrict__ dxg = reinterpret_cast<T*>(a.dx) + iimg;
+    if (a.per_sample) {
+#pragma unroll
+      for (int h = 0; h < H2; ++h) {
+        const size_t o = (size_t)b * a.C + c0 + 2 * h;
+        al2[h] = f32x2{a.alpha[o], a.alpha[o + 1]};
+        ga2[h] = f32x2{a.gamma[o], a.gamma[o + 1]};
+      }
+    }
+    const int o0 = chunk * a.rows_per_chunk, o1 = min(Ho, o0 + a.rows_per_chunk);   // output rows owned
+    const int ix = 2 * ow;
+    const bool colB = ix + 1 < a.W;
+    const float mo1 = ow + 1 < Wo ? 1.f : 0.f, mxB = colB ? 1.f : 0.f;
+    const int ocoff[2] = {ow * a.C, min(ow + 1, Wo - 1) * a.C};
+    const int icoff[2] = {ix * a.C, min(ix + 1, a.W - 1) * a.C};
+
+    auto form_dy = [&](const RV& z, const RV& yy, float mask, f32x2* out) {
+#pragma unroll
+      for (int h = 0; h < H2; ++h) {
+        const f32x2 zf = {(float)z[2 * h], (float)z[2 * h + 1]};
+        const f32x2 yf = {(float)yy[2 * h], (float)yy[2 * h + 1]};
+        out[h] = pk_fma(al2[h], zf, pk_fma(be2[h], yf, ga2[h])) * f32x2{mask, mask};
+      }
+    };
+    f32x2 T0[H2], T1[H2];
+    {
+      const size_t ro = (size_t)o0 * Wo * a.C;
+      const RV z0 = *reinterpret_cast<const RV*>(zg + ro + ocoff[0]), z1 = *reinterpret_cast<const RV*>(zg + ro + ocoff[1]);
+      const RV y0 = *reinterpret_cast<const RV*>(yg + ro + ocoff[0]), y1 = *reinterpret_cast<const RV*>(yg + ro + ocoff[1]);
+      form_dy(z0, y0, 1.f, T0);
+      form_dy(z1, y1, mo1, T1);
+    }
+    RV rz[PF][2], ry[PF][2], rx[PF][4];
+    auto fetch = [&](int o, int slot) {   // everything step `o` consumes: gradient row o+1, input rows 2o, 2o+1
+      const size_t ro = (size_t)min(o + 1, Ho - 1) * Wo * a.C;
+      const size_t ra = (size_t)min(2 * o, a.H - 1) * a.W * a.C, rb = (size_t)min(2 * o + 1, a.H - 1) * a.W * a.C;
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {
+        rz[slot][c] = *reinterpret_cast<const RV*>(zg + ro + ocoff[c]);
+        ry[slot][c] = *reinterpret_cast<const RV*>(yg + ro + ocoff[c]);
+        rx[slot][c] = *reinterpret_cast<const RV*>(xg + ra + icoff[c]);
+        rx[slot][2 + c] = *reinterpret_cast<const RV*>(xg + rb + icoff[c]);
+      }
+    };
+#pragma unroll
+    for (int u = 0; u < PF; ++u) fetch(o0 + u, u);
+
+    for (int base = o0; base < o1; base += PF) {
+#pragma unroll
+      for (int u = 0; u < PF; ++u) {
+        const int o = base + u;
+        if (o < o1) {
+          const float mrN = o + 1 < Ho ? 1.f : 0.f;
+          const bool rowB = 2 * o + 1 < a.H;
+          const float mrB = rowB ? 1.f : 0.f;
+          f32x2 N0[H2], N1[H2], xr[4][H2], av[4][H2];
+          form_dy(rz[u][0], ry[u][0], mrN, N0);
+          form_dy(rz[u][1], ry[u][1], mrN * mo1, N1);
+#pragma unroll
+          for (int p = 0; p < 4; ++p)
+#pragma unroll
+            for (int h = 0; h < H2; ++h) xr[p][h] = f32x2{(float)rx[u][p][2 * h], (float)rx[u][p][2 * h + 1]};
+          fetch(o + PF, u);
+#pragma unroll
+          for (int p = 0; p < 4; ++p)
+#pragma unroll
+            for (int h = 0; h < H2; ++h) av[p][h] = xr[p][h];
+          if (affine) {
+#pragma unroll
+            for (int p = 0; p < 4; ++p)
+#pragma unroll
+              for (int h = 0; h < H2; ++h) av[p][h] = pk_fma(av[p][h], sc2[h], sh2[h]);
+            switch (a.act) {
+              case T3D_ACT_RELU:
+#pragma unroll
+                for (int p = 0; p < 4; ++p)
+#pragma unroll
+                  for (int h = 0; h < H2; ++h) av[p][h] = f32x2{fmaxf(av[p][h][0], 0.f), fmaxf(av[p][h][1], 0.f)};
+                break;
+              case T3D_ACT_RELU6:
+#pragma unroll
+                for (int p = 0; p < 4; ++p)
+#pragma unroll
+                  for (int h = 0; h < H2; ++h)
+                    av[p][h] = f32x2{__builtin_amdgcn_fmed3f(av[p][h][0], 0.f, 6.f), __builtin_amdgcn_fmed3f(av[p][h][1], 0.f, 6.f)};
+                break;
+              case T3D_ACT_HSWISH:
+#pragma unroll
+                for (int p = 0; p < 4; ++p)
+#pragma unroll
+                  for (int h = 0; h < H2; ++h) {
+                    const f32x2 t = av[p][h];
+                    av[p][h] = f32x2{t[0] * (__builtin_amdgcn_fmed3f(t[0] + 3.f, 0.f, 6.f) * T3D_SIXTH),
+                                     t[1] * (__builtin_amdgcn_fmed3f(t[1] + 3.f, 0.f, 6.f) * T3D_SIXTH)};
+                  }
+                break;
+              default: break;
+            }
+          }
+#pragma unroll
+          for (int h = 0; h < H2; ++h) {      // pixels outside an odd-sized image
+            av[1][h] = av[1][h] * f32x2{mxB, mxB};
+            av[2][h] = av[2][h] * f32x2{mrB, mrB};
+            av[3][h] = av[3][h] * f32x2{mxB * mrB, mxB * mrB};
+          }
+          f32x2 g[4][H2];
+#pragma unroll
+          for (int h = 0; h < H2; ++h) {
+            g[0][h] = wt[4][h] * T0[h];
+            g[1][h] = pk_fma(wt[5][h], T0[h], wt[3][h] * T1[h]);
+            g[2][h] = pk_fma(wt[7][h], T0[h], wt[1][h] * N0[h]);
+            g[3][h] = pk_fma(wt[8][h], T0[h], pk_fma(wt[6][h], T1[h], pk_fma(wt[2][h], N0[h], wt[0][h] * N1[h])));
+          }
+          if (a.dw) {
+#pragma unroll
+            for (int h = 0; h < H2; ++h) {
+              wacc[4][h] = pk_fma(av[0][h], T0[h], wacc[4][h]);
+              wacc[5][h] = pk_fma(av[1][h], T0[h], wacc[5][h]);
+              wacc[3][h] = pk_fma(av[1][h], T1[h], wacc[3][h]);
+              wacc[7][h] = pk_fma(av[2][h], T0[h], wacc[7][h]);
+              wacc[1][h] = pk_fma(av[2][h], N0[h], wacc[1][h]);
+              wacc[8][h] = pk_fma(av[3][h], T0[h], wacc[8][h]);
+              wacc[6][h] = pk_fma(av[3][h], T1[h], wacc[6][h]);
+              wacc[2][h] = pk_fma(av[3][h], N0[h], wacc[2][h]);
+              wacc[0][h] = pk_fma(av[3][h], N1[h], wacc[0][h]);
+            }
+          }
+#pragma unroll
+          for (int p = 0; p < 4; ++p) {
+            if (((p & 1) && !colB) || ((p & 2) && !rowB)) continue;
+            float gv[CH], xv[CH];
+#pragma unroll
+            for (int h = 0; h < H2; ++h) {
+              gv[2 * h] = g[p][h][0]; gv[2 * h + 1] = g[p][h][1];
+              xv[2 * h] = xr[p][h][0]; xv[2 * h + 1] = xr[p][h][1];
+            }
+            if (affine) act_grad_affine_vec<CH>(gv, xv, scf, shf, a.act);
+            const size_t off = ((size_t)(2 * o + (p >> 1)) * a.W + ix + (p & 1)) * a.C;
+            if (rg) {
+              const RV rr = *reinterpret_cast<const RV*>(rg + off);
+#pragma unroll
+              for (int i = 0; i < CH; ++i) gv[i] += (float)rr[i];
+            }
+            RV ov;
+#pragma unroll
+            for (int i = 0; i < CH; ++i) {
+              ov[i] = (T)gv[i];
+              const float v = (float)ov[i];
+              psum[i] += v;
+              psq[i] = fmaf(v, xv[i], psq[i]);
+            }
+            *reinterpret_cast<RV*>(dxg + off) = ov;
+          }
+#pragma unroll
+          for (int h = 0; h < H2; ++h) {
+            T0[h] = N0[h];
+            T1[h] = N1[h];
+          }
+        }
+      }
+    }
+  }  // item loop
+
+  const int nred = (a.dw ? 9 : 0) + (a.stats ? 2 : 0);
+  if (nred && !a.noflush) {
+    for (int i = threadIdx.x; i < 11 * Cb; i += 256) lred[i] = 0.f;
+    __syncthreads();
+    if (on) {
+#pragma unroll
+      for (int h = 0; h < H2; ++h)
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+          const int c = c0 - cbase + 2 * h + e;
+          if (a.dw) {
+#pragma unroll
+            for (int t = 0; t < 9; ++t) atomicAdd(lred + t * Cb + c, wacc[t][h][e]);
+          }
+          if (a.stats) {
+            atomicAdd(lred + 9 * Cb + c, psum[2 * h + e]);
+            atomicAdd(lred + 10 * Cb + c, psq[2 * h + e]);
+          }
+        }
+    }
+    __syncthreads();
+    const int rep = (blockIdx.x + blockIdx.y) % a.nrep;
+    if (a.dw) {
+      for (int i = threadIdx.x; i < 9 * Cb; i += 256) {
+        const float v = lred[i];
+        if (v != 0.f) unsafeAtomicAdd(a.dw + (size_t)rep * a.C * 9 + (size_t)(cbase + i % Cb) * 9 + i / Cb, v);
+      }
+    }
+    if (a.stats) {
+      for (int i = threadIdx.x; i < 2 * Cb; i += 256) {
+        const float v = lred[9 * Cb + i];
+        if (v != 0.f) atomicAdd(a.stats + (size_t)rep * a.rstride + (size_t)(i / Cb) * a.C + cbase + i % Cb, (double)v);
+      }
+    }
+  }
+}
+
+template <typename T>
+int launch_s2(Dw3BArgs& a, hipStream_t st) {
+  constexpr int CH = 4, PF = 3;
+  const int CG = a.C / CH, Ho = (a.H - 1) / 2 + 1, Wo = (a.W - 1) / 2 + 1;
+  const long long per_row_chunk = (long long)a.B * Wo * CG;
+  int nchunks = (int)((256LL * 64 * 24 + per_row_chunk - 1) / per_row_chunk);
+  int max_chunks = Ho / 4;
+  if (max_chunks < 1) max_chunks = 1;
+  if (nchunks > max_chunks) nchunks = max_chunks;
+  if (nchunks < 1) nchunks = 1;
+  a.rows_per_chunk = cdiv(Ho, nchunks);
+  a.nchunks = cdiv(Ho, a.rows_per_chunk);
+  dim3 grid;
+  static const int target_blocks = getenv("T3D_DWB2_BLOCKS") ? atoi(getenv("T3D_DWB2_BLOCKS")) : 512;
+  a.nrep = g_t3d_reduce.nrep;
+  a.rstride = g_t3d_reduce.stats_stride;
+  if (CG < 64) {
+    a.slab = 0;
+    a.nitems = a.B * a.nchunks;
+    const int jb = cdiv(Wo * CG, 256);
+    int gy = target_blocks / jb;
+    if (gy > a.nitems) gy = a.nitems;
+    if (gy < 1) gy = 1;
+    grid = dim3(jb, gy);
+  } else {
+    a.slab = 1;
+    a.nitems = Wo * a.B * a.nchunks;
+    const int ns = cdiv(CG, 64);
+    int gx = target_blocks / ns;
+    if (gx > cdiv(a.nitems, 4)) gx = cdiv(a.nitems, 4);
+    if (gx < 1) gx = 1;
+    grid = dim3(gx, ns);
+  }
+  const size_t lds = (size_t)11 * (a.slab ? 64 * CH : a.C) * sizeof(float);
+  a.noflush = getenv("T3D_DEBUG_NOFLUSH") ? 1 : 0;
+  hipLaunchKernelGGL((dw3_bwd_s2_kernel<T, PF>), grid, dim3(256), lds, st, a);
+  T3D_CHECK_LAUNCH();
+  return T3D_OK;
+}
+
 }  // namespace
 
-// Called by t3d_dwconv_bwd for k == 3, stride 1.
+// Called by t3d_dwconv_bwd for k == 3, stride 1 or 2.
 int t3d_dw3_bwd_stream(int dtype, const void* dz, const void* y, const t3d_bnbwd* bb, const float* w, const void* x,
                        const t3d_prologue* pro, const void* residual, void* dx, double* stats, float* dw, int B, int H,
                        int W, int C, int stride, hipStream_t st) {
-  if (stride != 1) return T3D_ERR_UNSUPPORTED;
+  if (stride != 1 && stride != 2) return T3D_ERR_UNSUPPORTED;
   Dw3BArgs a{};
   a.dz = dz; a.y = y; a.x = x; a.res = residual; a.dx = dx; a.w = w;
   a.alpha = bb->alpha; a.beta = bb->beta; a.gamma = bb->gamma; a.per_sample = bb->per_sample;
   if (pro) { a.scale = pro->scale; a.shift = pro->shift; a.act = pro->act; }
   a.stats = stats; a.dw = dw;
   a.B = B; a.H = H; a.W = W; a.C = C;
+  if (stride == 2) {
+    if (dtype == T3D_F32) return launch_s2<float>(a, st);
+    if (dtype == T3D_BF16) return launch_s2<bf16_t>(a, st);
+    return T3D_ERR_ARG;
+  }
   if (dtype == T3D_F32) return launch_s1<float>(a, st);
   if (dtype == T3D_BF16) return launch_s1<bf16_t>(a, st);
   return T3D_ERR_ARG;
