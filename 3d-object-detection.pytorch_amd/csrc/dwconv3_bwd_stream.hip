@@ -285,8 +285,8 @@ __global__ __launch_bounds__(256) void dw3_bwd_s1_kernel(const Dw3BArgs a) {
 // two outputs (dy and the activations are formed twice per element instead of three times), every multiply-add is a
 // v_pk_fma_f32, and the 9 x CH stencil weights are read from LDS per use (saves 36 registers for the two
 // accumulator sets).  Padding: 0/1 masks per out-of-image column, wave-uniform row skips.
-template <typename T, int PF>
-__global__ __launch_bounds__(256) void dw3_bwd2_kernel(const Dw3BArgs a) {
+template <typename T, int PF, int NTH>
+__global__ __launch_bounds__(NTH) void dw3_bwd2_kernel(const Dw3BArgs a) {
   constexpr int CH = 4, H2 = 2;
   extern __shared__ float lred[];       // [11][C] reduction scratch (end of kernel); first [9][C]: weights by tap
   using RV = rawvec<T, CH>;
@@ -294,7 +294,7 @@ __global__ __launch_bounds__(256) void dw3_bwd2_kernel(const Dw3BArgs a) {
   int cg, xp_fixed = 0, q0, qstride;
   bool on;
   if (!a.slab) {
-    const int j = blockIdx.x * 256 + threadIdx.x;
+    const int j = blockIdx.x * NTH + threadIdx.x;
     on = j < Wp * CG;
     cg = on ? j % CG : 0;
     xp_fixed = on ? j / CG : 0;
@@ -304,8 +304,8 @@ __global__ __launch_bounds__(256) void dw3_bwd2_kernel(const Dw3BArgs a) {
     cg = blockIdx.y * 64 + (threadIdx.x & 63);
     on = cg < CG;
     if (!on) cg = 0;
-    q0 = blockIdx.x * 4 + (threadIdx.x >> 6);
-    qstride = gridDim.x * 4;
+    q0 = blockIdx.x * (NTH / 64) + (threadIdx.x >> 6);
+    qstride = gridDim.x * (NTH / 64);
   }
   const int c0 = cg * CH;
   const bool affine = a.scale != nullptr || a.act != T3D_ACT_NONE;
@@ -314,7 +314,7 @@ __global__ __launch_bounds__(256) void dw3_bwd2_kernel(const Dw3BArgs a) {
   const int cbase = a.slab ? blockIdx.y * 64 * CH : 0;
   const int Cb = a.slab ? min(64 * CH, a.C - cbase) : a.C;
   // weights [tap][Cb] in LDS: a thread reads its 4 channels of one tap with one ds_read_b128
-  for (int i = threadIdx.x; i < 9 * Cb; i += 256) lred[i] = a.w[(size_t)(cbase + i % Cb) * 9 + i / Cb];
+  for (int i = threadIdx.x; i < 9 * Cb; i += NTH) lred[i] = a.w[(size_t)(cbase + i % Cb) * 9 + i / Cb];
   __syncthreads();
   const float* wl = lred + (c0 - cbase);
 
@@ -543,7 +543,7 @@ __global__ __launch_bounds__(256) void dw3_bwd2_kernel(const Dw3BArgs a) {
   __syncthreads();
   const int nred = (a.dw ? 9 : 0) + (a.stats ? 2 : 0);
   if (nred && !a.noflush) {
-    for (int i = threadIdx.x; i < 11 * Cb; i += 256) lred[i] = 0.f;
+    for (int i = threadIdx.x; i < 11 * Cb; i += NTH) lred[i] = 0.f;
     __syncthreads();
     if (on) {
 #pragma unroll
@@ -564,13 +564,13 @@ __global__ __launch_bounds__(256) void dw3_bwd2_kernel(const Dw3BArgs a) {
     __syncthreads();
     const int rep = (blockIdx.x + blockIdx.y) % a.nrep;
     if (a.dw) {
-      for (int i = threadIdx.x; i < 9 * Cb; i += 256) {
+      for (int i = threadIdx.x; i < 9 * Cb; i += NTH) {
         const float v = lred[i];
         if (v != 0.f) unsafeAtomicAdd(a.dw + (size_t)rep * a.C * 9 + (size_t)(cbase + i % Cb) * 9 + i / Cb, v);
       }
     }
     if (a.stats) {
-      for (int i = threadIdx.x; i < 2 * Cb; i += 256) {
+      for (int i = threadIdx.x; i < 2 * Cb; i += NTH) {
         const float v = lred[9 * Cb + i];
         if (v != 0.f) atomicAdd(a.stats + (size_t)rep * a.rstride + (size_t)(i / Cb) * a.C + cbase + i % Cb, (double)v);
       }
@@ -593,13 +593,15 @@ int launch_s1(Dw3BArgs& a, hipStream_t st) {
   a.rows_per_chunk = cdiv(a.H, nchunks);
   a.nchunks = cdiv(a.H, a.rows_per_chunk);
   dim3 grid;
-  const int target_blocks = 256 * 2;   // 2 resident blocks per CU at this register budget; every extra block is one more flush
+  // one block per CU measured best on every MobileNet layer (tools/sweep_dwb.sh): every extra block is one more flush
+  static const int target_blocks = getenv("T3D_DWB1_BLOCKS") ? atoi(getenv("T3D_DWB1_BLOCKS")) : 256;
   a.nrep = g_t3d_reduce.nrep;
   a.rstride = g_t3d_reduce.stats_stride;
+  const int nth = 256;   // 512-thread blocks measured 4-5x slower (register budget)
   if (CG < 64) {
     a.slab = 0;
     a.nitems = a.B * a.nchunks;
-    const int jb = cdiv(Wcols * CG, 256);
+    const int jb = cdiv(Wcols * CG, nth);
     int gy = target_blocks / jb;
     if (gy > a.nitems) gy = a.nitems;
     if (gy < 1) gy = 1;
@@ -609,13 +611,13 @@ int launch_s1(Dw3BArgs& a, hipStream_t st) {
     a.nitems = Wcols * a.B * a.nchunks;
     const int ns = cdiv(CG, 64);
     int gx = target_blocks / ns;
-    if (gx > cdiv(a.nitems, 4)) gx = cdiv(a.nitems, 4);
+    if (gx > cdiv(a.nitems, nth / 64)) gx = cdiv(a.nitems, nth / 64);
     if (gx < 1) gx = 1;
     grid = dim3(gx, ns);
   }
   const size_t lds = (size_t)11 * a.C * sizeof(float);
   a.noflush = getenv("T3D_DEBUG_NOFLUSH") ? 1 : 0;
-  if (two_col) hipLaunchKernelGGL((dw3_bwd2_kernel<T, PF>), grid, dim3(256), lds, st, a);
+  if (two_col) hipLaunchKernelGGL((dw3_bwd2_kernel<T, PF, 256>), grid, dim3(256), lds, st, a);
   else hipLaunchKernelGGL((dw3_bwd_s1_kernel<T, CH, PF>), grid, dim3(256), lds, st, a);
   T3D_CHECK_LAUNCH();
   return T3D_OK;
@@ -631,8 +633,8 @@ int launch_s1(Dw3BArgs& a, hipStream_t st) {
 //   dx[2oh+1][2ow+1] = w22 T0 + w20 T1 + w02 N0 + w00 N1    (and the four matching dw terms)
 // (T = gradient row oh, N = row oh+1; 0/1 = column ow / ow+1.)  9 + 9 packed FMAs per four input pixels, the full-
 // resolution x is read once and dx written once, the quarter-resolution dz / y are read twice (neighbour column; L2).
-template <typename T, int PF>
-__global__ __launch_bounds__(256) void dw3_bwd_s2_kernel(const Dw3BArgs a) {
+template <typename T, int PF, int NTH>
+__global__ __launch_bounds__(NTH) void dw3_bwd_s2_kernel(const Dw3BArgs a) {
   constexpr int CH = 4, H2 = 2;
   extern __shared__ float lred[];       // [11][Cb] reduction scratch
   using RV = rawvec<T, CH>;
@@ -640,7 +642,7 @@ __global__ __launch_bounds__(256) void dw3_bwd_s2_kernel(const Dw3BArgs a) {
   int cg, ow_fixed = 0, q0, qstride;
   bool on;
   if (!a.slab) {
-    const int j = blockIdx.x * 256 + threadIdx.x;
+    const int j = blockIdx.x * NTH + threadIdx.x;
     on = j < Wo * CG;
     cg = on ? j % CG : 0;
     ow_fixed = on ? j / CG : 0;
@@ -650,8 +652,8 @@ __global__ __launch_bounds__(256) void dw3_bwd_s2_kernel(const Dw3BArgs a) {
     cg = blockIdx.y * 64 + (threadIdx.x & 63);
     on = cg < CG;
     if (!on) cg = 0;
-    q0 = blockIdx.x * 4 + (threadIdx.x >> 6);
-    qstride = gridDim.x * 4;
+    q0 = blockIdx.x * (NTH / 64) + (threadIdx.x >> 6);
+    qstride = gridDim.x * (NTH / 64);
   }
   const int c0 = cg * CH;
   const bool affine = a.scale != nullptr || a.act != T3D_ACT_NONE;
@@ -862,7 +864,7 @@ __global__ __launch_bounds__(256) void dw3_bwd_s2_kernel(const Dw3BArgs a) {
 
   const int nred = (a.dw ? 9 : 0) + (a.stats ? 2 : 0);
   if (nred && !a.noflush) {
-    for (int i = threadIdx.x; i < 11 * Cb; i += 256) lred[i] = 0.f;
+    for (int i = threadIdx.x; i < 11 * Cb; i += NTH) lred[i] = 0.f;
     __syncthreads();
     if (on) {
 #pragma unroll
@@ -883,13 +885,13 @@ __global__ __launch_bounds__(256) void dw3_bwd_s2_kernel(const Dw3BArgs a) {
     __syncthreads();
     const int rep = (blockIdx.x + blockIdx.y) % a.nrep;
     if (a.dw) {
-      for (int i = threadIdx.x; i < 9 * Cb; i += 256) {
+      for (int i = threadIdx.x; i < 9 * Cb; i += NTH) {
         const float v = lred[i];
         if (v != 0.f) unsafeAtomicAdd(a.dw + (size_t)rep * a.C * 9 + (size_t)(cbase + i % Cb) * 9 + i / Cb, v);
       }
     }
     if (a.stats) {
-      for (int i = threadIdx.x; i < 2 * Cb; i += 256) {
+      for (int i = threadIdx.x; i < 2 * Cb; i += NTH) {
         const float v = lred[9 * Cb + i];
         if (v != 0.f) atomicAdd(a.stats + (size_t)rep * a.rstride + (size_t)(i / Cb) * a.C + cbase + i % Cb, (double)v);
       }
@@ -910,13 +912,15 @@ int launch_s2(Dw3BArgs& a, hipStream_t st) {
   a.rows_per_chunk = cdiv(Ho, nchunks);
   a.nchunks = cdiv(Ho, a.rows_per_chunk);
   dim3 grid;
-  static const int target_blocks = getenv("T3D_DWB2_BLOCKS") ? atoi(getenv("T3D_DWB2_BLOCKS")) : 512;
+  static const int tb_env = getenv("T3D_DWB2_BLOCKS") ? atoi(getenv("T3D_DWB2_BLOCKS")) : 0;
+  const int target_blocks = tb_env ? tb_env : (Ho >= 28 ? 512 : 384);   // tools/sweep_dwb.sh
   a.nrep = g_t3d_reduce.nrep;
   a.rstride = g_t3d_reduce.stats_stride;
+  const int nth = 256;
   if (CG < 64) {
     a.slab = 0;
     a.nitems = a.B * a.nchunks;
-    const int jb = cdiv(Wo * CG, 256);
+    const int jb = cdiv(Wo * CG, nth);
     int gy = target_blocks / jb;
     if (gy > a.nitems) gy = a.nitems;
     if (gy < 1) gy = 1;
@@ -926,13 +930,13 @@ int launch_s2(Dw3BArgs& a, hipStream_t st) {
     a.nitems = Wo * a.B * a.nchunks;
     const int ns = cdiv(CG, 64);
     int gx = target_blocks / ns;
-    if (gx > cdiv(a.nitems, 4)) gx = cdiv(a.nitems, 4);
+    if (gx > cdiv(a.nitems, nth / 64)) gx = cdiv(a.nitems, nth / 64);
     if (gx < 1) gx = 1;
     grid = dim3(gx, ns);
   }
   const size_t lds = (size_t)11 * (a.slab ? 64 * CH : a.C) * sizeof(float);
   a.noflush = getenv("T3D_DEBUG_NOFLUSH") ? 1 : 0;
-  hipLaunchKernelGGL((dw3_bwd_s2_kernel<T, PF>), grid, dim3(256), lds, st, a);
+  hipLaunchKernelGGL((dw3_bwd_s2_kernel<T, PF, 256>), grid, dim3(256), lds, st, a);
   T3D_CHECK_LAUNCH();
   return T3D_OK;
 }

@@ -452,7 +452,9 @@ int launch_ch(Dw3Args& a, int s, hipStream_t st) {
   const bool use2 = (s == 1 && CH == 4 && two_col);
   const int Wcols = use2 ? (a.Wo + 1) / 2 : a.Wo;     // work items per row: column pairs or columns
   dim3 grid;
-  const int target_blocks = 256 * 6;   // persistent blocks: enough to fill the chip, few enough that the per-block flush stays cheap
+  // persistent blocks: enough to fill the chip, few enough that the per-block flush stays cheap (tools/sweep_dwf.sh)
+  static const int tb_env = getenv("T3D_DWF_BLOCKS") ? atoi(getenv("T3D_DWF_BLOCKS")) : 0;
+  const int target_blocks = tb_env ? tb_env : (s == 1 ? 512 : 768);
   a.nrep = g_t3d_reduce.nrep;
   a.rstride = g_t3d_reduce.stats_stride;
   if (CG < 64) {
