@@ -53,7 +53,7 @@ __device__ __forceinline__ bf16x8 tr_frag(const bf16_t* tile, int rs, int ch0, i
 // NTPW: 16-row tiles per wave on the P side (block: 64*NTPW rows); NTQ: 16-column tiles on the Q side
 // G: independent 4-wave pipelines per block, taking alternate 32-pixel steps (own LDS buffers, own accumulators);
 // they are summed through LDS before the block's single flush -- twice the per-block throughput for one flush.
-template <int NTPW, int NTQ, bool SWAP, int G>
+template <int NTPW, int NTQ, bool SWAP, int G, int D, bool GEN>
 __global__ __launch_bounds__(256 * G) void pw_wgrad_tr_kernel(const WgtArgs a) {
   constexpr int PB = 64 * NTPW, QB = 16 * NTQ;
   constexpr int RSP = PB + 8, RSQ = QB + 8;            // LDS row strides (elements): +16 B against bank conflicts
@@ -96,38 +96,36 @@ __global__ __launch_bounds__(256 * G) void pw_wgrad_tr_kernel(const WgtArgs a) {
   constexpr int dyV = dyB / 8, aV = aB / 8;                  // vectors per pixel row
   constexpr int ndv = STEP * dyV, nav = STEP * aV;
   constexpr int VDY = (ndv + 255) / 256, VA = (nav + 255) / 256;   // vectors per thread and step
-  bf16x8 rz[VDY], ry[VDY], rx[VA];
+  // D register sets: the global loads of step s+D are issued while step s is being multiplied, so a load has D-1
+  // whole iterations to land (one iteration ~= one MFMA burst, far shorter than the HBM round trip)
+  struct Regs { bf16x8 rz[VDY], ry[VDY], rx[VA]; };
+  Regs rr[D];
 
-  auto gload = [&](int m0) {
+  auto gload = [&](Regs& R, int m0) {
+    // branch-free: out-of-range vectors read a clamped (valid) address and are zeroed when they are staged
 #pragma unroll
     for (int i = 0; i < VDY; ++i) {
-      const int v = tid + 256 * i;
-      bf16x8 z;
-#pragma unroll
-      for (int j = 0; j < 8; ++j) z[j] = (bf16_t)0.f;
-      rz[i] = ry[i] = z;
-      if (v < ndv) {
-        const int row = v / dyV, n = dy0 + (v % dyV) * 8, m = m0 + row;
-        if (m < mend && n < a.N) {
-          rz[i] = *reinterpret_cast<const bf16x8*>(dz + (size_t)m * a.N + n);
-          ry[i] = *reinterpret_cast<const bf16x8*>(yy + (size_t)m * a.N + n);
-        }
-      }
+      const int v = min(tid + 256 * i, ndv - 1);
+      const int row = v / dyV, n = min(dy0 + (v % dyV) * 8, a.N - 8), m = min(m0 + row, a.M - 1);
+      R.rz[i] = *reinterpret_cast<const bf16x8*>(dz + (size_t)m * a.N + n);
+      R.ry[i] = *reinterpret_cast<const bf16x8*>(yy + (size_t)m * a.N + n);
     }
 #pragma unroll
     for (int i = 0; i < VA; ++i) {
-      const int v = tid + 256 * i;
-      bf16x8 z;
-#pragma unroll
-      for (int j = 0; j < 8; ++j) z[j] = (bf16_t)0.f;
-      rx[i] = z;
-      if (v < nav) {
-        const int row = v / aV, k = a0c + (v % aV) * 8, m = m0 + row;
-        if (m < mend && k < a.K) rx[i] = *reinterpret_cast<const bf16x8*>(xx + (size_t)m * a.K + k);
-      }
+      const int v = min(tid + 256 * i, nav - 1);
+      const int row = v / aV, k = min(a0c + (v % aV) * 8, a.K - 8), m = min(m0 + row, a.M - 1);
+      R.rx[i] = *reinterpret_cast<const bf16x8*>(xx + (size_t)m * a.K + k);
     }
   };
-  auto lstore = [&](int m0, int buf) {
+  auto ld8 = [](const float* p, float* o) {     // 8 consecutive LDS floats as two 16-B reads
+    const float4 q0 = *reinterpret_cast<const float4*>(p), q1 = *reinterpret_cast<const float4*>(p + 4);
+    o[0] = q0.x; o[1] = q0.y; o[2] = q0.z; o[3] = q0.w; o[4] = q1.x; o[5] = q1.y; o[6] = q1.z; o[7] = q1.w;
+  };
+  bf16x8 zero8;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) zero8[j] = (bf16_t)0.f;
+  auto lstore = [&](const Regs& R, int m0, int buf) {
+    const auto& rz = R.rz; const auto& ry = R.ry; const auto& rx = R.rx;
     bf16_t* const pb_ = tiles + buf * BUFE;
     bf16_t* const qb_ = pb_ + STEP * RSP;
     bf16_t* dyt = SWAP ? qb_ : pb_;
@@ -140,19 +138,24 @@ __global__ __launch_bounds__(256 * G) void pw_wgrad_tr_kernel(const WgtArgs a) {
         const int row = v / dyV, cl = (v % dyV) * 8, m = m0 + row;
         const bool ok = m < mend && dy0 + cl < a.N;
         bf16x8 o;
-        float al[8], ga[8];
-        if (a.per_sample && ok) {
-          const size_t pb = (size_t)(m / a.HW) * a.N + dy0 + cl;
+        float al[8], be[8], ga[8];
+        ld8(cdy + dyB + cl, be);
+        if constexpr (GEN) {
+          if (a.per_sample) {
+            const size_t pb = (size_t)(min(m, a.M - 1) / a.HW) * a.N + min(dy0 + cl, a.N - 8);
 #pragma unroll
-          for (int j = 0; j < 8; ++j) { al[j] = a.alpha[pb + j]; ga[j] = a.gamma[pb + j]; }
+            for (int j = 0; j < 8; ++j) { al[j] = a.alpha[pb + j]; ga[j] = a.gamma[pb + j]; }
+          } else {
+            ld8(cdy + cl, al);
+            ld8(cdy + 2 * dyB + cl, ga);
+          }
         } else {
-#pragma unroll
-          for (int j = 0; j < 8; ++j) { al[j] = cdy[cl + j]; ga[j] = cdy[2 * dyB + cl + j]; }
+          ld8(cdy + cl, al);
+          ld8(cdy + 2 * dyB + cl, ga);
         }
 #pragma unroll
-        for (int j = 0; j < 8; ++j)
-          o[j] = (bf16_t)(ok ? fmaf(al[j], (float)rz[i][j], fmaf(cdy[dyB + cl + j], (float)ry[i][j], ga[j])) : 0.f);
-        *reinterpret_cast<bf16x8*>(dyt + row * rsd + cl) = o;
+        for (int j = 0; j < 8; ++j) o[j] = (bf16_t)fmaf(al[j], (float)rz[i][j], fmaf(be[j], (float)ry[i][j], ga[j]));
+        *reinterpret_cast<bf16x8*>(dyt + row * rsd + cl) = ok ? o : zero8;
       }
     }
 #pragma unroll
@@ -163,27 +166,32 @@ __global__ __launch_bounds__(256 * G) void pw_wgrad_tr_kernel(const WgtArgs a) {
         const bool ok = m < mend && a0c + cl < a.K;
         bf16x8 o = rx[i];
         if (!plain_a) {
-          float u[8];
+          float u[8], sc[8], sh[8];
+          ld8(ca + cl, sc);
+          ld8(ca + aB + cl, sh);
 #pragma unroll
           for (int j = 0; j < 8; ++j) u[j] = (float)rx[i][j];
-          if (a.se) {
-            const float* se = ok ? a.se + (size_t)(m / a.HW) * a.K + a0c + cl : nullptr;
+          bool done = false;
+          if constexpr (GEN) {
+            if (a.se) {
+              const float* se = a.se + (size_t)(min(m, a.M - 1) / a.HW) * a.K + min(a0c + cl, a.K - 8);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-              float t = fmaf(u[j], ca[cl + j], ca[aB + cl + j]);
-              const float sv = se ? se[j] : 1.f;
-              if (!a.se_after) t *= sv;
-              t = act_apply(t, a.act);
-              if (a.se_after) t *= sv;
-              u[j] = t;
+              for (int j = 0; j < 8; ++j) {
+                float t = fmaf(u[j], sc[j], sh[j]);
+                const float sv = se[j];
+                if (!a.se_after) t *= sv;
+                t = act_apply(t, a.act);
+                if (a.se_after) t *= sv;
+                u[j] = t;
+              }
+              done = true;
             }
-          } else {
-            act_affine_vec<8>(u, ca + cl, ca + aB + cl, a.act);
           }
+          if (!done) act_affine_vec<8>(u, sc, sh, a.act);
 #pragma unroll
-          for (int j = 0; j < 8; ++j) o[j] = (bf16_t)(ok ? u[j] : 0.f);
+          for (int j = 0; j < 8; ++j) o[j] = (bf16_t)u[j];
         }
-        *reinterpret_cast<bf16x8*>(at + row * rsa + cl) = o;
+        *reinterpret_cast<bf16x8*>(at + row * rsa + cl) = ok ? o : zero8;
       }
     }
   };
@@ -198,30 +206,36 @@ __global__ __launch_bounds__(256 * G) void pw_wgrad_tr_kernel(const WgtArgs a) {
   const int nsteps = (mend - mbeg + STEP - 1) / STEP;
   const int niter = (nsteps + G - 1) / G;          // same trip count for every pipeline (barriers are block-wide);
                                                    // a step past the range loads zeros and adds nothing
-  if (niter > 0) {
-    gload(mbeg + grp * STEP);
-    lstore(mbeg + grp * STEP, 0);
-  }
+  auto step_m = [&](int it) { return mbeg + (it * G + grp) * STEP; };
+  // loads and LDS stores are unconditional (rows past the range read as zeros): a branch around them would make the
+  // compiler wait for ALL outstanding loads (vmcnt(0)) instead of just the oldest set
+#pragma unroll
+  for (int u = 0; u < D; ++u) gload(rr[u], step_m(u));
+  lstore(rr[0], step_m(0), 0);
   __syncthreads();
   int buf = 0;
-  for (int it = 0; it < niter; ++it) {
-    const int mnext = mbeg + ((it + 1) * G + grp) * STEP;
-    const bool more = it + 1 < niter;
-    if (more) gload(mnext);
-    const bf16_t* pcur = tiles + buf * BUFE;
-    const bf16_t* qcur = pcur + STEP * RSP;
-    bf16x8 qf[NTQ];
+  for (int it0 = 0; it0 < niter; it0 += D) {
 #pragma unroll
-    for (int j = 0; j < NTQ; ++j) qf[j] = tr_frag(qcur, RSQ, j * 16, lane);
+    for (int u = 0; u < D; ++u) {
+      const int it = it0 + u;
+      if (it < niter) {       // block-uniform
+        gload(rr[u], step_m(it + D));
+        const bf16_t* pcur = tiles + buf * BUFE;
+        const bf16_t* qcur = pcur + STEP * RSP;
+        bf16x8 qf[NTQ];
 #pragma unroll
-    for (int i = 0; i < NTPW; ++i) {
-      const bf16x8 pf = tr_frag(pcur, RSP, (wave + 4 * i) * 16, lane);
+        for (int j = 0; j < NTQ; ++j) qf[j] = tr_frag(qcur, RSQ, j * 16, lane);
 #pragma unroll
-      for (int j = 0; j < NTQ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pf, qf[j], acc[i][j], 0, 0, 0);
+        for (int i = 0; i < NTPW; ++i) {
+          const bf16x8 pf = tr_frag(pcur, RSP, (wave + 4 * i) * 16, lane);
+#pragma unroll
+          for (int j = 0; j < NTQ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pf, qf[j], acc[i][j], 0, 0, 0);
+        }
+        lstore(rr[(u + 1) % D], step_m(it + 1), buf ^ 1);
+        __syncthreads();
+        buf ^= 1;
+      }
     }
-    if (more) lstore(mnext, buf ^ 1);
-    __syncthreads();
-    buf ^= 1;
   }
 
   if constexpr (G == 2) {
@@ -290,8 +304,8 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
   if (i0 < i1) unsafeAtomicAdd(dw + e, s);
 }
 
-template <int NTPW, int NTQ, bool SWAP>
-int launch_sw(WgtArgs& a, hipStream_t st) {
+template <int NTPW, int NTQ, bool SWAP, int D, bool GEN>
+int launch_d(WgtArgs& a, hipStream_t st) {
   constexpr int G = 2;
   constexpr int PB = 64 * NTPW, QB = 16 * NTQ;
   const int P = a.swap ? a.K : a.N, Q = a.swap ? a.N : a.K;
@@ -320,13 +334,21 @@ int launch_sw(WgtArgs& a, hipStream_t st) {
   S = cdiv(a.M, a.rows_per_split);
   a.ws = use_ws ? reinterpret_cast<float*>(g_t3d_ws.ptr) : nullptr;
   if (lds > 64 * 1024)
-    (void)hipFuncSetAttribute((const void*)pw_wgrad_tr_kernel<NTPW, NTQ, SWAP, G>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  hipLaunchKernelGGL((pw_wgrad_tr_kernel<NTPW, NTQ, SWAP, G>), dim3(tiles, S), dim3(256 * G), lds, st, a);
+    (void)hipFuncSetAttribute((const void*)pw_wgrad_tr_kernel<NTPW, NTQ, SWAP, G, D, GEN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipLaunchKernelGGL((pw_wgrad_tr_kernel<NTPW, NTQ, SWAP, G, D, GEN>), dim3(tiles, S), dim3(256 * G), lds, st, a);
   if (use_ws)
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(cdiv(a.N * a.K, 256), S >= 64 ? 16 : (S >= 8 ? 4 : 1)), dim3(256), 0, st, a.ws, a.dw, a.N, a.K, (int)SWAP, PB, QB,
                        a.qtiles, tiles, S);
   T3D_CHECK_LAUNCH();
   return T3D_OK;
+}
+
+template <int NTPW, int NTQ, bool SWAP>
+int launch_sw(WgtArgs& a, hipStream_t st) {
+  static const int depth = getenv("T3D_WG_DEPTH") ? atoi(getenv("T3D_WG_DEPTH")) : 2;   // 2 measured best (1: -12 %, 3: -2 %)
+  if (a.per_sample || a.se) return launch_d<NTPW, NTQ, SWAP, 1, true>(a, st);   // SE layers: per-sample coefficients / gates
+  if (depth == 1) return launch_d<NTPW, NTQ, SWAP, 1, false>(a, st);
+  return launch_d<NTPW, NTQ, SWAP, 2, false>(a, st);
 }
 
 template <int NTPW, int NTQ>

@@ -49,12 +49,15 @@ else:
     bb = N.bnbwd(al, be, ga, False)
     dx = torch.empty(M, K, device=dev, dtype=dt)
     nbytes = M * (K + Nn) * x.element_size()
+    ws = torch.empty(64 << 20, device=dev, dtype=torch.uint8)
+    N.call('t3d_set_workspace', N.ptr(ws), ws.numel())
+    N.call('t3d_set_reduction_replicas', nrep, 2 * max(K, Nn))
     if kind == 'pwfwd':
-        stats = torch.zeros(2 * Nn, device=dev, dtype=torch.float64)
+        stats = torch.zeros(nrep, 2 * max(K, Nn), device=dev, dtype=torch.float64)
         fn = lambda: N.call('t3d_pwconv_fwd', N.dtype_code(x), N.ptr(x), pro, N.ptr(wq), None, N.ptr(y), N.ptr(stats),
                             M, HW, K, Nn, N.stream())
     elif kind == 'pwdgrad':
-        stats = torch.zeros(2 * K, device=dev, dtype=torch.float64)
+        stats = torch.zeros(nrep, 2 * max(K, Nn), device=dev, dtype=torch.float64)
         fn = lambda: N.call('t3d_pwconv_dgrad', N.dtype_code(x), N.ptr(dz), N.ptr(yy), bb, N.ptr(wt), N.ptr(x), pro, None,
                             N.ptr(dx), N.ptr(stats), None, M, HW, K, Nn, N.stream())
     else:
