@@ -95,27 +95,25 @@ __global__ __launch_bounds__(512, 2) void pw_stream_kernel(const GemmArgs a, con
     for (int r = 0; r < R; ++r)
 #pragma unroll
       for (int t = 0; t < NT; ++t) acc[r][t] = f32x4{0.f, 0.f, 0.f, 0.f};
-    int mrow[R];
+    int mrow[R], mld[R];
     bool mok[R];
 #pragma unroll
     for (int r = 0; r < R; ++r) {
       mrow[r] = m0 + r * 16 + lc;
       mok[r] = mrow[r] < a.M;
+      mld[r] = min(mrow[r], a.M - 1);     // rows past the end re-read the last row; they are never stored or summed
     }
 
     for (int ks0 = 0; ks0 < KS; ks0 += KU) {
       bf16x8 fa[KU][R], fb[KU][R];
+      // branch-free loads: k-steps / channels past Kin read a clamped (valid) address -- their weights are zero
 #pragma unroll
       for (int u = 0; u < KU; ++u) {
-        const int k = (ks0 + u) * 32 + lg * 8;
+        const int k = min((ks0 + u) * 32 + lg * 8, a.Kin - 8);
 #pragma unroll
         for (int r = 0; r < R; ++r) {
-          const bool ok = mok[r] && (k < a.Kin);
-          bf16x8 z;
-#pragma unroll
-          for (int j = 0; j < 8; ++j) z[j] = (bf16_t)0.f;
-          fa[u][r] = ok ? *reinterpret_cast<const bf16x8*>(A0 + (size_t)mrow[r] * a.Kin + k) : z;
-          if (DG) fb[u][r] = ok ? *reinterpret_cast<const bf16x8*>(A1 + (size_t)mrow[r] * a.Kin + k) : z;
+          fa[u][r] = *reinterpret_cast<const bf16x8*>(A0 + (size_t)mld[r] * a.Kin + k);
+          if (DG) fb[u][r] = *reinterpret_cast<const bf16x8*>(A1 + (size_t)mld[r] * a.Kin + k);
         }
       }
 #pragma unroll
@@ -155,7 +153,7 @@ __global__ __launch_bounds__(512, 2) void pw_stream_kernel(const GemmArgs a, con
                   act_affine_vec<8>(x, c0, c1, a.act);
                 }
 #pragma unroll
-                for (int j = 0; j < 8; ++j) b[r][j] = (bf16_t)(ok ? x[j] : 0.f);
+                for (int j = 0; j < 8; ++j) b[r][j] = (bf16_t)x[j];
               }
             } else {
               const float4 c2a = *reinterpret_cast<const float4*>(coef + 2 * kpad + k),
@@ -169,7 +167,7 @@ __global__ __launch_bounds__(512, 2) void pw_stream_kernel(const GemmArgs a, con
                 for (int j = 0; j < 8; ++j) {
                   const float al = (GEN && a.per_sample) ? (ok ? a.p0[pb + j] : 0.f) : c0[j];
                   const float ga = (GEN && a.per_sample) ? (ok ? a.p2[pb + j] : 0.f) : c2[j];
-                  b[r][j] = (bf16_t)(ok ? (al * (float)fa[u][r][j] + c1[j] * (float)fb[u][r][j] + ga) : 0.f);
+                  b[r][j] = (bf16_t)(al * (float)fa[u][r][j] + c1[j] * (float)fb[u][r][j] + ga);
                 }
               }
             }
@@ -204,11 +202,7 @@ __global__ __launch_bounds__(512, 2) void pw_stream_kernel(const GemmArgs a, con
           for (int j = 0; j < 8; ++j) v[j] += a.bias[n + j];
         }
         if (DG && a.e_y) {
-          if (ok) Vec8<bf16_t>::load(reinterpret_cast<const bf16_t*>(a.e_y) + (size_t)m * a.Nout + n, yv);
-          else {
-#pragma unroll
-            for (int j = 0; j < 8; ++j) yv[j] = 0.f;
-          }
+          Vec8<bf16_t>::load(reinterpret_cast<const bf16_t*>(a.e_y) + (size_t)mld[r] * a.Nout + n, yv);
           if (GEN && a.e_se) {
             const float* se = ok ? a.e_se + (size_t)bidx * a.Nout + n : nullptr;
 #pragma unroll
@@ -227,9 +221,9 @@ __global__ __launch_bounds__(512, 2) void pw_stream_kernel(const GemmArgs a, con
             act_grad_affine_vec<8>(v, yv, es, eh, a.e_act);
           }
         }
-        if (DG && a.e_res && ok) {
+        if (DG && a.e_res) {
           float rr[8];
-          Vec8<bf16_t>::load(reinterpret_cast<const bf16_t*>(a.e_res) + (size_t)m * a.Nout + n, rr);
+          Vec8<bf16_t>::load(reinterpret_cast<const bf16_t*>(a.e_res) + (size_t)mld[r] * a.Nout + n, rr);
 #pragma unroll
           for (int j = 0; j < 8; ++j) v[j] += rr[j];
         }
