@@ -285,9 +285,9 @@ __global__ __launch_bounds__(256) void dw3_bwd_s1_kernel(const Dw3BArgs a) {
 // two outputs (dy and the activations are formed twice per element instead of three times), every multiply-add is a
 // v_pk_fma_f32, and the 9 x CH stencil weights are read from LDS per use (saves 36 registers for the two
 // accumulator sets).  Padding: 0/1 masks per out-of-image column, wave-uniform row skips.
-template <typename T, int PF, int NTH>
+template <typename T, int PF, int NTH, int CH>
 __global__ __launch_bounds__(NTH) void dw3_bwd2_kernel(const Dw3BArgs a) {
-  constexpr int CH = 4, H2 = 2;
+  constexpr int H2 = CH / 2;
   extern __shared__ float lred[];       // [11][C] reduction scratch (end of kernel); first [9][C]: weights by tap
   using RV = rawvec<T, CH>;
   const int CG = a.C / CH, Wp = (a.W + 1) / 2;
@@ -469,15 +469,22 @@ __global__ __launch_bounds__(NTH) void dw3_bwd2_kernel(const Dw3BArgs a) {
           for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
             for (int kx = 0; kx < 3; ++kx) {
-              const float4 wq = *reinterpret_cast<const float4*>(wl + (ky * 3 + kx) * Cb);
-              const f32x2 w0 = {wq.x, wq.y}, w1 = {wq.z, wq.w};
+              f32x2 wv[H2];
+              if constexpr (CH == 4) {
+                const float4 wq = *reinterpret_cast<const float4*>(wl + (ky * 3 + kx) * Cb);
+                wv[0] = f32x2{wq.x, wq.y}; wv[1] = f32x2{wq.z, wq.w};
+              } else {
+                const float2 wq = *reinterpret_cast<const float2*>(wl + (ky * 3 + kx) * Cb);
+                wv[0] = f32x2{wq.x, wq.y};
+              }
               // data gradient: dy row r reaches dx row r-1+ky; dy column (x + 1 - kx): local index 2-kx for A, 3-kx for B
               f32x2* dA = ky == 0 ? aA : (ky == 1 ? bA : cA);
               f32x2* dB = ky == 0 ? aB : (ky == 1 ? bB : cB);
-              dA[0] = pk_fma(dy[2 - kx][0], w0, dA[0]);
-              dA[1] = pk_fma(dy[2 - kx][1], w1, dA[1]);
-              dB[0] = pk_fma(dy[3 - kx][0], w0, dB[0]);
-              dB[1] = pk_fma(dy[3 - kx][1], w1, dB[1]);
+#pragma unroll
+              for (int h = 0; h < H2; ++h) {
+                dA[h] = pk_fma(dy[2 - kx][h], wv[h], dA[h]);
+                dB[h] = pk_fma(dy[3 - kx][h], wv[h], dB[h]);
+              }
             }
           // weight gradient: dw[ky][kx] += dy[oy][x] * a[oy+ky-1][x+kx-1]; a column of A: local kx, of B: local kx+1
           if (a.dw) {
@@ -504,7 +511,12 @@ __global__ __launch_bounds__(NTH) void dw3_bwd2_kernel(const Dw3BArgs a) {
                 xv[2 * h] = xr_prev[col][h][0]; xv[2 * h + 1] = xr_prev[col][h][1];
               }
               if (affine) {
-                float scf[CH] = {sc2[0][0], sc2[0][1], sc2[1][0], sc2[1][1]}, shf[CH] = {sh2[0][0], sh2[0][1], sh2[1][0], sh2[1][1]};
+                float scf[CH], shf[CH];
+#pragma unroll
+                for (int h = 0; h < H2; ++h) {
+                  scf[2 * h] = sc2[h][0]; scf[2 * h + 1] = sc2[h][1];
+                  shf[2 * h] = sh2[h][0]; shf[2 * h + 1] = sh2[h][1];
+                }
                 act_grad_affine_vec<CH>(g, xv, scf, shf, a.act);
               }
               const size_t off = ((size_t)iy * a.W + x0 + col) * a.C;
@@ -578,9 +590,9 @@ __global__ __launch_bounds__(NTH) void dw3_bwd2_kernel(const Dw3BArgs a) {
   }
 }
 
-template <typename T>
-int launch_s1(Dw3BArgs& a, hipStream_t st) {
-  constexpr int CH = 4, PF = 3;
+template <typename T, int CH>
+int launch_s1c(Dw3BArgs& a, hipStream_t st) {
+  constexpr int PF = 3;
   const int CG = a.C / CH;
   static const bool two_col = !getenv("T3D_DW_BWD_1COL");
   const int Wcols = two_col ? (a.W + 1) / 2 : a.W;
@@ -593,12 +605,16 @@ int launch_s1(Dw3BArgs& a, hipStream_t st) {
   a.rows_per_chunk = cdiv(a.H, nchunks);
   a.nchunks = cdiv(a.H, a.rows_per_chunk);
   dim3 grid;
-  // one block per CU measured best on every MobileNet layer (tools/sweep_dwb.sh): every extra block is one more flush
-  static const int target_blocks = getenv("T3D_DWB1_BLOCKS") ? atoi(getenv("T3D_DWB1_BLOCKS")) : 256;
+  // tools/sweep_dwb.sh: the 4-channel variant needs AGPR spill space (1 wave/SIMD) and is best with one block per CU;
+  // the 2-channel variant fits 2 waves/SIMD and is best with two (every extra block is one more flush)
+  static const int tb_env = getenv("T3D_DWB1_BLOCKS") ? atoi(getenv("T3D_DWB1_BLOCKS")) : 0;
+  const int target_blocks = tb_env ? tb_env : (CH == 2 && two_col ? 512 : 256);
   a.nrep = g_t3d_reduce.nrep;
   a.rstride = g_t3d_reduce.stats_stride;
   const int nth = 256;   // 512-thread blocks measured 4-5x slower (register budget)
-  if (CG < 64) {
+  // slab mapping (a wave = 64 consecutive channel groups of one column) only when it wastes < 8 % of the lanes
+  const bool flat = CG < 64 || (cdiv(CG, 64) * 64 - CG) * 100 > 8 * cdiv(CG, 64) * 64;
+  if (flat) {
     a.slab = 0;
     a.nitems = a.B * a.nchunks;
     const int jb = cdiv(Wcols * CG, nth);
@@ -617,10 +633,19 @@ int launch_s1(Dw3BArgs& a, hipStream_t st) {
   }
   const size_t lds = (size_t)11 * a.C * sizeof(float);
   a.noflush = getenv("T3D_DEBUG_NOFLUSH") ? 1 : 0;
-  if (two_col) hipLaunchKernelGGL((dw3_bwd2_kernel<T, PF, 256>), grid, dim3(256), lds, st, a);
+  // (forcing 3-4 waves/SIMD through launch bounds spills to scratch: 3-7x slower)
+  if (two_col) hipLaunchKernelGGL((dw3_bwd2_kernel<T, PF, 256, CH>), grid, dim3(256), lds, st, a);
   else hipLaunchKernelGGL((dw3_bwd_s1_kernel<T, CH, PF>), grid, dim3(256), lds, st, a);
   T3D_CHECK_LAUNCH();
   return T3D_OK;
+}
+
+template <typename T>
+int launch_s1(Dw3BArgs& a, hipStream_t st) {
+  // 2 channels per thread: half the live registers (no AGPR spills, twice the resident waves) beats the wider
+  // loads of 4 channels per thread by 5-30 % on every layer
+  static const int ch = getenv("T3D_DWB_CH") ? atoi(getenv("T3D_DWB_CH")) : 2;
+  return (ch == 2 && a.C % 2 == 0) ? launch_s1c<T, 2>(a, st) : launch_s1c<T, 4>(a, st);
 }
 
 // ---------------------------------------------------------------------------------------------------------------

@@ -95,8 +95,14 @@ def test_train_step_fp32_matches_oracle(name, B, HW, nc, lnames, coeffs):
         scale = max(g64.abs().max().item(), 1e-3)
         err = (got - g64).abs().max().item() / scale
         err_ref = (grads_o[k].double() - g64).abs().max().item() / scale
-        if not err < max(8e-2, 3 * err_ref):
-            bad.append((k, err, err_ref, scale))
+        # one pre-activation within rounding of a ReLU6 kink flips its derivative (the summation order of the BatchNorm
+        # atomics varies run to run): a few elements of a late, tiny-gradient tensor may then move by ~10 % of the tensor
+        # maximum.  The element-wise bound therefore is loose, the per-tensor L2 bound is the tight one.
+        nrm = max(g64.norm().item(), 1e-3 * g64.numel() ** .5)
+        l2 = (got - g64).norm().item() / nrm
+        l2_ref = (grads_o[k].double() - g64).norm().item() / nrm
+        if not (err < max(2.5e-1, 3 * err_ref) and l2 < max(5e-2, 3 * l2_ref)):
+            bad.append((k, err, err_ref, l2, l2_ref, scale))
     assert not bad, bad[:10]
     # BatchNorm running statistics
     for k in ('features.0.1', 'conv.1'):
