@@ -101,8 +101,14 @@ __global__ __launch_bounds__(256) void head_bwd_data_kernel(const HeadArgs a) {
   }
 }
 
-// weight gradient: grid (10, ceil(F/256)); blockIdx.x < 9: regressor of that class, == 9: class head
+// weight gradient: grid (10, ceil(F/256)); blockIdx.x < 9: regressor of that class, == 9: class head.
+// The samples a block needs are first compacted (in ascending order: the sum stays deterministic) into LDS, then
+// consumed eight at a time so that eight feature loads are in flight per thread (the serial one-load-per-sample loop
+// took ~1 us per sample).
 __global__ __launch_bounds__(256) void head_bwd_weight_kernel(const HeadArgs a) {
+  constexpr int CHUNK = 512, U = 8;
+  __shared__ int lst[CHUNK];
+  __shared__ int nsel;
   const int cls = blockIdx.x, j = blockIdx.y * 256 + threadIdx.x;
   const bool jon = j < a.F;
   if (cls < 9) {
@@ -110,14 +116,45 @@ __global__ __launch_bounds__(256) void head_bwd_weight_kernel(const HeadArgs a) 
 #pragma unroll
     for (int r = 0; r < NKP; ++r) acc[r] = 0.f;
     const bool bias_thread = (blockIdx.y == 0 && threadIdx.x < NKP);
-    for (int b = 0; b < a.B; ++b) {
-      int c = (int)a.cats[b];
-      c = c < 0 ? 0 : (c > 8 ? 8 : c);
-      if (c != cls) continue;  // block-uniform
-      const float x = jon ? feat(a, b, j) : 0.f;
+    for (int b0 = 0; b0 < a.B; b0 += CHUNK) {
+      __syncthreads();
+      if (threadIdx.x == 0) {
+        int n = 0;
+        const int b1 = min(a.B, b0 + CHUNK);
+        for (int b = b0; b < b1; ++b) {
+          int c = (int)a.cats[b];
+          c = c < 0 ? 0 : (c > 8 ? 8 : c);
+          if (c == cls) lst[n++] = b;
+        }
+        nsel = n;
+      }
+      __syncthreads();
+      const int n = nsel;
+      for (int i0 = 0; i0 < n; i0 += U) {
+        float x[U];
+        int bb[U];
+        const int jc = min(j, a.F - 1);
 #pragma unroll
-      for (int r = 0; r < NKP; ++r) acc[r] = fmaf(a.dpre[(size_t)b * NKP + r], x, acc[r]);
-      if (bias_thread) bacc += a.dpre[(size_t)b * NKP + threadIdx.x];
+        for (int u = 0; u < U; ++u) {       // all eight loads first, no control flow in between
+          bb[u] = lst[min(i0 + u, n - 1)];
+          x[u] = a.f[(size_t)bb[u] * a.F + jc];
+        }
+        if (a.scale) {
+          const float sc = a.scale[jc], sh = a.shift[jc];
+#pragma unroll
+          for (int u = 0; u < U; ++u) x[u] = act_apply(x[u] * sc + sh, a.act);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) x[u] = (jon && i0 + u < n) ? x[u] : 0.f;
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          if (i0 + u < n) {       // block-uniform
+#pragma unroll
+            for (int r = 0; r < NKP; ++r) acc[r] = fmaf(a.dpre[(size_t)bb[u] * NKP + r], x[u], acc[r]);
+            if (bias_thread) bacc += a.dpre[(size_t)bb[u] * NKP + threadIdx.x];
+          }
+        }
+      }
     }
     if (jon) {
 #pragma unroll
@@ -129,12 +166,33 @@ __global__ __launch_bounds__(256) void head_bwd_weight_kernel(const HeadArgs a) 
       float acc[16];
 #pragma unroll
       for (int q = 0; q < 16; ++q) acc[q] = 0.f;
-      for (int b = 0; b < a.B; ++b) {
-        float x = jon ? feat(a, b, j) : 0.f;
-        if (a.mask && jon) x *= a.mask[(size_t)b * a.F + j];
+      for (int b0 = 0; b0 < a.B; b0 += U) {
+        float x[U], mk[U];
+        const int jc = min(j, a.F - 1);
 #pragma unroll
-        for (int q = 0; q < 16; ++q)
-          if (q0 + q < a.ncls) acc[q] = fmaf(a.dlogits[(size_t)b * a.ncls + q0 + q], x, acc[q]);
+        for (int u = 0; u < U; ++u) x[u] = a.f[(size_t)min(b0 + u, a.B - 1) * a.F + jc];
+        if (a.mask) {
+#pragma unroll
+          for (int u = 0; u < U; ++u) mk[u] = a.mask[(size_t)min(b0 + u, a.B - 1) * a.F + jc];
+        } else {
+#pragma unroll
+          for (int u = 0; u < U; ++u) mk[u] = 1.f;
+        }
+        if (a.scale) {
+          const float sc = a.scale[jc], sh = a.shift[jc];
+#pragma unroll
+          for (int u = 0; u < U; ++u) x[u] = act_apply(x[u] * sc + sh, a.act);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) x[u] = (jon && b0 + u < a.B) ? x[u] * mk[u] : 0.f;
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          if (b0 + u < a.B) {
+#pragma unroll
+            for (int q = 0; q < 16; ++q)
+              if (q0 + q < a.ncls) acc[q] = fmaf(a.dlogits[(size_t)(b0 + u) * a.ncls + q0 + q], x[u], acc[q]);
+          }
+        }
       }
       if (jon) {
 #pragma unroll

@@ -20,6 +20,11 @@ struct GemmArgs {
   double* stats;      // [2][Nout]
   float* ps_stats;    // [B][Nout][2] per-sample sums (SE case)
   int M, HW, Kin, Nout, mtiles;
+  // second activation segment (y-free data gradient, streaming kernel only): k-steps >= ks1 read a2 [M][Kin2];
+  // `Kin` is then the padded total (ks1*32 + round_up(Kin2, 32)) and indexes the weight rows directly
+  const void* a2;
+  int Kin2, ks1;
+  int row0;   // row stride (= channel count) of a0 / a1; equals Kin without a second segment
 };
 
 template <typename T> __device__ __forceinline__ void ldvec(const T* p, float* v);

@@ -26,7 +26,9 @@ namespace {
 
 // DG: data-gradient variant (two input tensors, BN-backward affine, act' epilogue); GEN: squeeze-excite / per-sample
 // coefficients present (MobileNetV3 only) -- compiled out of the common variants to keep registers down.
-template <int NT, int R, bool DG, bool GEN>
+// YF (with DG): y-free data gradient -- the main loop is the plain forward loop over two raw tensors ([dz | x], no
+// transform), the epilogue is the data gradient's (activation derivative, residual, BatchNorm-backward sums).
+template <int NT, int R, bool DG, bool GEN, bool YF = false>
 __global__ __launch_bounds__(512, 2) void pw_stream_kernel(const GemmArgs a, const int nchunks, const int KS, const int nrep, const long long rstride) {
   constexpr int BN = NT * 16;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -42,6 +44,8 @@ __global__ __launch_bounds__(512, 2) void pw_stream_kernel(const GemmArgs a, con
   const int n0 = chunk * BN;
   const bf16_t* __restrict__ A0 = reinterpret_cast<const bf16_t*>(a.a0);
   const bf16_t* __restrict__ A1 = reinterpret_cast<const bf16_t*>(a.a1);
+  const bf16_t* __restrict__ A2 = reinterpret_cast<const bf16_t*>(a.a2);
+  const int ks1 = A2 ? a.ks1 : (1 << 30);   // k-steps >= ks1 read the second segment
   const bf16_t* __restrict__ Wg = reinterpret_cast<const bf16_t*>(a.w);
   bf16_t* __restrict__ out = reinterpret_cast<bf16_t*>(a.out);
 
@@ -63,9 +67,12 @@ __global__ __launch_bounds__(512, 2) void pw_stream_kernel(const GemmArgs a, con
     ecoef[i] = v ? a.e_scale[n] : 1.f;
     ecoef[BN + i] = v ? a.e_shift[n] : 0.f;
   }
+  constexpr bool DGL = DG && !YF;     // two-tensor main loop with the BatchNorm-backward affine
   for (int i = tid; i < kpad; i += nthr) {
     const bool v = i < a.Kin;
-    if (!DG) {
+    if (YF) {
+      coef[i] = 1.f; coef[kpad + i] = 0.f; coef[2 * kpad + i] = 0.f;
+    } else if (!DG) {
       coef[i] = (v && a.p0) ? a.p0[i] : 1.f;
       coef[kpad + i] = (v && a.p0) ? a.p1[i] : 0.f;
     } else {
@@ -76,7 +83,7 @@ __global__ __launch_bounds__(512, 2) void pw_stream_kernel(const GemmArgs a, con
   }
   __syncthreads();
 
-  const bool plainA = (!DG && !a.p0 && !a.p2 && a.act == T3D_ACT_NONE);
+  const bool plainA = YF || (!DG && !a.p0 && !a.p2 && a.act == T3D_ACT_NONE);
   const bool keep_stats = a.stats != nullptr;
   float st1[NT / 2][8], st2[NT / 2][8];
 #pragma unroll
@@ -109,11 +116,18 @@ __global__ __launch_bounds__(512, 2) void pw_stream_kernel(const GemmArgs a, con
       // branch-free loads: k-steps / channels past Kin read a clamped (valid) address -- their weights are zero
 #pragma unroll
       for (int u = 0; u < KU; ++u) {
-        const int k = min((ks0 + u) * 32 + lg * 8, a.Kin - 8);
+        const int ks = ks0 + u;
+        if (!DGL && ks >= ks1) {         // wave-uniform: second segment (y-free data gradient)
+          const int k = min((ks - ks1) * 32 + lg * 8, a.Kin2 - 8);
 #pragma unroll
-        for (int r = 0; r < R; ++r) {
-          fa[u][r] = *reinterpret_cast<const bf16x8*>(A0 + (size_t)mld[r] * a.Kin + k);
-          if (DG) fb[u][r] = *reinterpret_cast<const bf16x8*>(A1 + (size_t)mld[r] * a.Kin + k);
+          for (int r = 0; r < R; ++r) fa[u][r] = *reinterpret_cast<const bf16x8*>(A2 + (size_t)mld[r] * a.Kin2 + k);
+        } else {
+          const int k = min(ks * 32 + lg * 8, a.row0 - 8);
+#pragma unroll
+          for (int r = 0; r < R; ++r) {
+            fa[u][r] = *reinterpret_cast<const bf16x8*>(A0 + (size_t)mld[r] * a.row0 + k);
+            if (DGL) fb[u][r] = *reinterpret_cast<const bf16x8*>(A1 + (size_t)mld[r] * a.row0 + k);
+          }
         }
       }
 #pragma unroll
@@ -131,7 +145,7 @@ __global__ __launch_bounds__(512, 2) void pw_stream_kernel(const GemmArgs a, con
                          c1b = *reinterpret_cast<const float4*>(coef + kpad + k + 4);
             const float c0[8] = {c0a.x, c0a.y, c0a.z, c0a.w, c0b.x, c0b.y, c0b.z, c0b.w};
             const float c1[8] = {c1a.x, c1a.y, c1a.z, c1a.w, c1b.x, c1b.y, c1b.z, c1b.w};
-            if (!DG) {
+            if (!DGL) {
 #pragma unroll
               for (int r = 0; r < R; ++r) {
                 const bool ok = mok[r] && (k < a.Kin);
@@ -197,7 +211,7 @@ __global__ __launch_bounds__(512, 2) void pw_stream_kernel(const GemmArgs a, con
         float v[8], yv[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) v[j] = acc[r][2 * q + (j >> 2)][j & 3];
-        if (!DG && a.bias) {
+        if ((!DG || YF) && a.bias) {
 #pragma unroll
           for (int j = 0; j < 8; ++j) v[j] += a.bias[n + j];
         }
@@ -221,7 +235,7 @@ __global__ __launch_bounds__(512, 2) void pw_stream_kernel(const GemmArgs a, con
             act_grad_affine_vec<8>(v, yv, es, eh, a.e_act);
           }
         }
-        if (DG && a.e_res) {
+        if (a.e_res) {
           float rr[8];
           Vec8<bf16_t>::load(reinterpret_cast<const bf16_t*>(a.e_res) + (size_t)mld[r] * a.Nout + n, rr);
 #pragma unroll
@@ -278,7 +292,7 @@ __global__ __launch_bounds__(512, 2) void pw_stream_kernel(const GemmArgs a, con
   }
 }
 
-template <int NT, int R, bool DG, bool GEN>
+template <int NT, int R, bool DG, bool GEN, bool YF = false>
 int launch_v(GemmArgs& a, int KS, hipStream_t st) {
   constexpr int BN = NT * 16;
   const int kpad = KS * 32;
@@ -289,9 +303,9 @@ int launch_v(GemmArgs& a, int KS, hipStream_t st) {
   // small weight chunks: 4-wave blocks, as many per CU as registers / LDS admit (each wave hides its own
   // load latency, so resident waves per CU are what matters); big chunks: one 8-wave block shares the copy
   const int threads = lds <= 48 * 1024 ? 256 : 512;
-  const void* fn = (const void*)pw_stream_kernel<NT, R, DG, GEN>;
+  const void* fn = (const void*)pw_stream_kernel<NT, R, DG, GEN, YF>;
   if (lds > 64 * 1024) (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  static int occ_cache[2] = {0, 0};   // per instantiation, per block size
+  static int occ_cache[2] = {0, 0};   // per instantiation (function-local static of the template), per block size
   int& occ = occ_cache[threads == 512];
   if (occ == 0) {
     int n = 0;
@@ -306,7 +320,7 @@ int launch_v(GemmArgs& a, int KS, hipStream_t st) {
   const int need = cdiv(ngroups, threads / 64);
   if (nxb > need) nxb = need;
   if (nxb < 1) nxb = 1;
-  hipLaunchKernelGGL((pw_stream_kernel<NT, R, DG, GEN>), dim3(nxb * nchunks), dim3(threads), lds, st, a, nchunks, KS,
+  hipLaunchKernelGGL((pw_stream_kernel<NT, R, DG, GEN, YF>), dim3(nxb * nchunks), dim3(threads), lds, st, a, nchunks, KS,
                      g_t3d_reduce.nrep, g_t3d_reduce.stats_stride);
   T3D_CHECK_LAUNCH();
   return T3D_OK;
@@ -314,6 +328,7 @@ int launch_v(GemmArgs& a, int KS, hipStream_t st) {
 
 template <int NT, int R>
 int launch_nt(GemmArgs& a, int KS, hipStream_t st) {
+  if (a.a2) return launch_v<NT, R, true, false, true>(a, KS, st);   // y-free data gradient
   const bool gen = a.per_sample || a.ps_stats || a.e_se || (!a.dgrad && a.p2);
   if (a.dgrad) return gen ? launch_v<NT, R, true, true>(a, KS, st) : launch_v<NT, R, true, false>(a, KS, st);
   return gen ? launch_v<NT, R, false, true>(a, KS, st) : launch_v<NT, R, false, false>(a, KS, st);
@@ -322,6 +337,7 @@ int launch_nt(GemmArgs& a, int KS, hipStream_t st) {
 }  // namespace
 
 int stream_launch(GemmArgs& a, hipStream_t st) {
+  if (!a.row0) a.row0 = a.Kin;
   const int KS = cdiv(a.Kin, 32);
   // widest chunk whose weights fit ~120 KB of LDS, at most 10 tiles (register budget: 8*NT stat + 4*NT*R acc)
   int nt_cap = (120 * 1024 / 1024) / KS;

@@ -34,6 +34,7 @@ struct WgtArgs {
   int act, se_after;
   float* dw;
   int M, HW, K, N;
+  int yfree, Nz;     // y-free mode: dy side = [dz (Nz channels) | x (K channels) | 1, 0 x 7], N = Nz + K + 8 virtual channels
   int swap;          // 0: P = N (dy side), Q = K (a side); 1: P = K, Q = N
   int ptiles, qtiles, rows_per_split;
   float* ws;         // partial tiles [split][tile][PB][QB] (plain stores) or null (atomics into dw)
@@ -53,7 +54,7 @@ __device__ __forceinline__ bf16x8 tr_frag(const bf16_t* tile, int rs, int ch0, i
 // NTPW: 16-row tiles per wave on the P side (block: 64*NTPW rows); NTQ: 16-column tiles on the Q side
 // G: independent 4-wave pipelines per block, taking alternate 32-pixel steps (own LDS buffers, own accumulators);
 // they are summed through LDS before the block's single flush -- twice the per-block throughput for one flush.
-template <int NTPW, int NTQ, bool SWAP, int G, int D, bool GEN>
+template <int NTPW, int NTQ, bool SWAP, int G, int D, bool GEN, bool YF>
 __global__ __launch_bounds__(256 * G) void pw_wgrad_tr_kernel(const WgtArgs a) {
   constexpr int PB = 64 * NTPW, QB = 16 * NTQ;
   constexpr int RSP = PB + 8, RSQ = QB + 8;            // LDS row strides (elements): +16 B against bank conflicts
@@ -74,7 +75,7 @@ __global__ __launch_bounds__(256 * G) void pw_wgrad_tr_kernel(const WgtArgs a) {
   const int dy0 = SWAP ? q0 : p0, a0c = SWAP ? p0 : q0;
   float* cdy = coef;                 // [3][dyB]
   float* ca = coef + 3 * dyB;        // [2][aB]
-  for (int i = threadIdx.x; i < dyB; i += 256 * G) {
+  for (int i = threadIdx.x; i < dyB && !YF; i += 256 * G) {
     const int n = dy0 + i;
     const bool v = n < a.N;
     cdy[i] = (v && !a.per_sample) ? a.alpha[n] : 0.f;
@@ -106,9 +107,18 @@ __global__ __launch_bounds__(256 * G) void pw_wgrad_tr_kernel(const WgtArgs a) {
 #pragma unroll
     for (int i = 0; i < VDY; ++i) {
       const int v = min(tid + 256 * i, ndv - 1);
-      const int row = v / dyV, n = min(dy0 + (v % dyV) * 8, a.N - 8), m = min(m0 + row, a.M - 1);
-      R.rz[i] = *reinterpret_cast<const bf16x8*>(dz + (size_t)m * a.N + n);
-      R.ry[i] = *reinterpret_cast<const bf16x8*>(yy + (size_t)m * a.N + n);
+      const int row = v / dyV, m = min(m0 + row, a.M - 1);
+      if constexpr (YF) {
+        // virtual channel n: < Nz -> dz, < Nz + K -> the conv input itself (Gram rows), beyond -> constants (lstore)
+        const int n = dy0 + (v % dyV) * 8;
+        const bool fromz = n < a.Nz;
+        const bf16_t* src = fromz ? dz + (size_t)m * a.Nz + n : xx + (size_t)m * a.K + min(max(n - a.Nz, 0), a.K - 8);
+        R.rz[i] = *reinterpret_cast<const bf16x8*>(src);
+      } else {
+        const int n = min(dy0 + (v % dyV) * 8, a.N - 8);
+        R.rz[i] = *reinterpret_cast<const bf16x8*>(dz + (size_t)m * a.N + n);
+        R.ry[i] = *reinterpret_cast<const bf16x8*>(yy + (size_t)m * a.N + n);
+      }
     }
 #pragma unroll
     for (int i = 0; i < VA; ++i) {
@@ -138,6 +148,16 @@ __global__ __launch_bounds__(256 * G) void pw_wgrad_tr_kernel(const WgtArgs a) {
         const int row = v / dyV, cl = (v % dyV) * 8, m = m0 + row;
         const bool ok = m < mend && dy0 + cl < a.N;
         bf16x8 o;
+        if constexpr (YF) {
+          const int n = dy0 + cl;
+          o = rz[i];
+          if (n >= a.Nz + a.K) {       // the ones column (sum of the conv input) and its zero padding
+            o = zero8;
+            if (n == a.Nz + a.K) o[0] = (bf16_t)1.f;
+          }
+          *reinterpret_cast<bf16x8*>(dyt + row * rsd + cl) = ok ? o : zero8;
+          continue;
+        }
         float al[8], be[8], ga[8];
         ld8(cdy + dyB + cl, be);
         if constexpr (GEN) {
@@ -304,7 +324,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
   if (i0 < i1) unsafeAtomicAdd(dw + e, s);
 }
 
-template <int NTPW, int NTQ, bool SWAP, int D, bool GEN>
+template <int NTPW, int NTQ, bool SWAP, int D, bool GEN, bool YF = false>
 int launch_d(WgtArgs& a, hipStream_t st) {
   constexpr int G = 2;
   constexpr int PB = 64 * NTPW, QB = 16 * NTQ;
@@ -334,8 +354,8 @@ int launch_d(WgtArgs& a, hipStream_t st) {
   S = cdiv(a.M, a.rows_per_split);
   a.ws = use_ws ? reinterpret_cast<float*>(g_t3d_ws.ptr) : nullptr;
   if (lds > 64 * 1024)
-    (void)hipFuncSetAttribute((const void*)pw_wgrad_tr_kernel<NTPW, NTQ, SWAP, G, D, GEN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  hipLaunchKernelGGL((pw_wgrad_tr_kernel<NTPW, NTQ, SWAP, G, D, GEN>), dim3(tiles, S), dim3(256 * G), lds, st, a);
+    (void)hipFuncSetAttribute((const void*)pw_wgrad_tr_kernel<NTPW, NTQ, SWAP, G, D, GEN, YF>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipLaunchKernelGGL((pw_wgrad_tr_kernel<NTPW, NTQ, SWAP, G, D, GEN, YF>), dim3(tiles, S), dim3(256 * G), lds, st, a);
   if (use_ws)
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(cdiv(a.N * a.K, 256), S >= 64 ? 16 : (S >= 8 ? 4 : 1)), dim3(256), 0, st, a.ws, a.dw, a.N, a.K, (int)SWAP, PB, QB,
                        a.qtiles, tiles, S);
@@ -346,6 +366,10 @@ int launch_d(WgtArgs& a, hipStream_t st) {
 template <int NTPW, int NTQ, bool SWAP>
 int launch_sw(WgtArgs& a, hipStream_t st) {
   static const int depth = getenv("T3D_WG_DEPTH") ? atoi(getenv("T3D_WG_DEPTH")) : 2;   // 2 measured best (1: -12 %, 3: -2 %)
+  if (a.yfree) {
+    if constexpr (!SWAP) return launch_d<NTPW, NTQ, false, 2, false, true>(a, st);
+    else return T3D_ERR_UNSUPPORTED;
+  }
   if (a.per_sample || a.se) return launch_d<NTPW, NTQ, SWAP, 1, true>(a, st);   // SE layers: per-sample coefficients / gates
   if (depth == 1) return launch_d<NTPW, NTQ, SWAP, 1, false>(a, st);
   return launch_d<NTPW, NTQ, SWAP, 2, false>(a, st);
@@ -356,16 +380,10 @@ int launch_cfg(WgtArgs& a, hipStream_t st) {
   return a.swap ? launch_sw<NTPW, NTQ, true>(a, st) : launch_sw<NTPW, NTQ, false>(a, st);
 }
 
-}  // namespace
 
-// bf16 path of t3d_pwconv_wgrad (pwconv_wgrad.hip keeps the fp32 parity kernel)
-int t3d_pw_wgrad_tr_entry(const void* dz, const void* y, const t3d_bnbwd* bb, const void* x, const t3d_prologue* pro,
-                          float* dw, int M, int HW, int K, int N, hipStream_t st) {
-  WgtArgs a{};
-  a.dz = dz; a.y = y; a.x = x;
-  a.alpha = bb->alpha; a.beta = bb->beta; a.gamma = bb->gamma; a.per_sample = bb->per_sample;
-  if (pro) { a.scale = pro->scale; a.shift = pro->shift; a.se = pro->se; a.act = pro->act; a.se_after = pro->se_after_act; }
-  a.dw = dw; a.M = M; a.HW = HW; a.K = K; a.N = N;
+
+static int choose_and_launch(WgtArgs& a, hipStream_t st) {
+  const int M = a.M, K = a.K, N = a.N;
   a.swap = K > N;
   const int P = a.swap ? K : N, Q = a.swap ? N : K;
   // Q side: all of Q when it fits 10 tiles, else split.  P side: the widest block tile (64*NTPW rows) that still leaves
@@ -388,4 +406,27 @@ int t3d_pw_wgrad_tr_entry(const void* dz, const void* y, const t3d_bnbwd* bb, co
   }
   if (Q <= 96) return (P > 64 && steps_with(3, 96) >= min_steps) ? launch_cfg<3, 6>(a, st) : launch_cfg<1, 6>(a, st);
   return (P > 64 && steps_with(3, 160) >= min_steps) ? launch_cfg<3, 10>(a, st) : launch_cfg<1, 10>(a, st);
+}
+
+}  // namespace
+
+// bf16 path of t3d_pwconv_wgrad (pwconv_wgrad.hip keeps the fp32 parity kernel)
+int t3d_pw_wgrad_tr_entry(const void* dz, const void* y, const t3d_bnbwd* bb, const void* x, const t3d_prologue* pro,
+                          float* dw, int M, int HW, int K, int N, hipStream_t st) {
+  WgtArgs a{};
+  a.dz = dz; a.y = y; a.x = x;
+  a.alpha = bb->alpha; a.beta = bb->beta; a.gamma = bb->gamma; a.per_sample = bb->per_sample;
+  if (pro) { a.scale = pro->scale; a.shift = pro->shift; a.se = pro->se; a.act = pro->act; a.se_after = pro->se_after_act; }
+  a.dw = dw; a.M = M; a.HW = HW; a.K = K; a.N = N;
+  return choose_and_launch(a, st);
+}
+
+// y-free weight-gradient products (pwconv_yfree.hip):  tmp[(N + K + 8)][K] += [dz | x | 1]^T x   -- rows 0..N-1 = dz^T x,
+// rows N..N+K-1 = the Gram matrix x^T x, row N+K = the column sums of x.  Raw bf16 operands, no BatchNorm transform.
+int t3d_pw_wgrad_tr_yfree(const void* dz, const void* x, float* tmp, int M, int HW, int K, int N, hipStream_t st) {
+  WgtArgs a{};
+  a.dz = dz; a.x = x; a.y = dz;
+  a.dw = tmp; a.M = M; a.HW = HW; a.K = K;
+  a.yfree = 1; a.Nz = N; a.N = N + K + 8;
+  return choose_and_launch(a, st);
 }

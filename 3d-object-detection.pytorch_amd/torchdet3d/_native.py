@@ -44,6 +44,9 @@ SIGNATURES = {
     't3d_pack_weight': [_I, _P, _P, _I, _I, _I, _P],
     't3d_dwconv_bwd': [_I, _P, _P, _BP, _P, _P, _PP, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
     't3d_pwconv_wgrad': [_I, _P, _P, _BP, _P, _PP, _P, _I, _I, _I, _I, _P],
+    't3d_pwconv_yfree_prep': [_P, _BP, _P, _P, _I, _I, _P],
+    't3d_pwconv_dgrad_yfree': [_P, _P, _P, _P, _P, _PP, _P, _P, _P, _I, _I, _I, _I, _P],
+    't3d_pwconv_wgrad_yfree': [_P, _P, _BP, _P, _P, _I, _I, _I, _I, _P],
     't3d_bn_bwd_finalize': [_P, _I, _D, _P, _P, _P, _P, _P, _P, _P, _P, _P],
     't3d_stem_im2col': [_I, _P, _P, _I, _I, _I, _P],
     't3d_bn_apply': [_I, _P, _PP, _P, _P, _I, _I, _P],

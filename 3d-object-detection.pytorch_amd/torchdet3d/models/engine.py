@@ -32,6 +32,8 @@ from .arch import Arch
 BN_EPS, BN_MOM = 1e-5, 0.1      # PyTorch defaults the reference relies on
 NREP = 16                       # reduction replicas (include/t3d.h: t3d_set_reduction_replicas)
 WORKSPACE_BYTES = 64 << 20      # partial weight-gradient tiles (include/t3d.h: t3d_set_workspace)
+# y-free expand-layer backward (csrc/pwconv_yfree.hip): minimum M*N elements of the expanded tensor; 0 disables
+YFREE_MIN_ELEMS = int(os.environ.get('T3D_YFREE_MIN', 8 << 20))
 
 
 class _BN:
@@ -418,13 +420,14 @@ class Net:
         kernel here is latency- rather than bandwidth-bound, so the two streams overlap well.  Ordering: the side
         stream waits for everything enqueued on the main stream so far (inputs, BatchNorm-backward affine, the
         zeroed gradient buffer); `_join_side` makes the main stream wait for the side stream."""
+        entry = kw.pop('entry', 't3d_pwconv_wgrad')
         if self._side is None:
-            N.call('t3d_pwconv_wgrad', *args, N.stream(), **kw)
+            N.call(entry, *args, N.stream(), **kw)
             return
         main = torch.cuda.current_stream()
         self._side.wait_stream(main)
         with torch.cuda.stream(self._side):
-            N.call('t3d_pwconv_wgrad', *args, N.stream(), **kw)
+            N.call(entry, *args, N.stream(), **kw)
         self._side_busy = True
 
     def _join_side(self):
@@ -531,6 +534,33 @@ class Net:
             dx = self._act_bwd(dx, x, tag + ':a')
         return dx
 
+    def _yfree_ok(self, x, M, K, Nn):
+        """Expand layer on a finished bf16 input, wide enough that skipping the two extra passes over the M x N tensors
+        pays for the three tiny extra launches (csrc/pwconv_yfree.hip)."""
+        return (self.dt == N.BF16 and YFREE_MIN_ELEMS > 0 and x.pro is None and K <= 96
+                and M * Nn >= YFREE_MIN_ELEMS)
+
+    def _expand_bwd_yfree(self, d1, bb1, wname, x, res, M, K, Nn, i):
+        """Backward of the expand conv without reading its output: dx = [d1 | x] Wcat^T + c on the main stream,
+        dW from [d1 | x | 1]^T x on the side stream."""
+        st = N.stream()
+        tot = (Nn + 31) // 32 * 32 + (K + 31) // 32 * 32
+        wcat = self._buf(f'wcat:{i}', (K, tot))
+        cvec = self._buf(f'cvec:{i}', (K,), torch.float32)
+        HW = x.H * x.W
+        N.call('t3d_pwconv_yfree_prep', N.ptr(self.w[wname]), bb1, N.ptr(wcat), N.ptr(cvec), K, Nn, st)
+        self._wgrad(N.ptr(d1), N.ptr(x.t), bb1, N.ptr(self.w[wname]), N.ptr(self.g[wname]), M, HW, K, Nn,
+                    entry='t3d_pwconv_wgrad_yfree', nbytes=M * (K + Nn) * self.esz)
+        dx = self._buf(f'dzin:{i}', (M, K))
+        with_stats = x.bn is not None and not x.finished_act       # as _pw_dgrad
+        N.call('t3d_pwconv_dgrad_yfree', N.ptr(d1), N.ptr(x.t), N.ptr(wcat), N.ptr(cvec),
+               N.ptr(x.raw) if with_stats else None, x.gpro if with_stats else None,
+               N.ptr(res) if res is not None else None, N.ptr(dx),
+               N.ptr(x.bn.bstats) if with_stats else None, M, HW, K, Nn, st, nbytes=M * (K + Nn) * self.esz)
+        if x.finished_act:
+            dx = self._act_bwd(dx, x, f'dzin:{i}:a')
+        return dx
+
     def _act_bwd(self, dz, x, tag):
         M = x.B * x.H * x.W
         out = self._buf(tag, (M, x.C))
@@ -587,6 +617,8 @@ class Net:
             torch.sum(dwrep, 0, out=self.g[dwn].view(-1))
             bb1 = self._bn_bwd(s1.bn)
             p = f'features.{i + 1}.conv'
+            if self._yfree_ok(x, M1, blk.cin, blk.cexp):
+                return self._expand_bwd_yfree(d1, bb1, p + '.0.weight', x, res, M1, blk.cin, blk.cexp, i)
             self._wgrad(dt, N.ptr(d1), N.ptr(s1.raw), bb1, N.ptr(x.t), x.pro,
                         N.ptr(self.g[p + '.0.weight']), M1, x.H * x.W, blk.cin, blk.cexp,
                         nbytes=M1 * (blk.cin + blk.cexp) * self.esz)

@@ -109,6 +109,23 @@ int t3d_pack_weight(int dtype, const float* w, void* out, int rows, int cols, in
 int t3d_pwconv_wgrad(int dtype, const void* dz, const void* y, const t3d_bnbwd* bb, const void* x,
                      const t3d_prologue* pro, float* dw, int M, int HW, int K, int N, void* stream);
 
+/* "y-free" backward of a pointwise conv whose input x [M,K] is a finished (materialised) bf16 tensor -- the expand
+ * layer nn.Conv2d(K, N, 1) + nn.BatchNorm2d(N) of an inverted-residual block (models/mobilenetv3.py:148-149).
+ * Because y = x W^T, the BatchNorm-backward affine dy = alpha*dz + beta*y + gamma never needs the wide tensor y:
+ *   dx = [dz | x] Wcat^T + c,           Wcat = [alpha.W | W^T diag(beta) W] (bf16 [K][rup32(N)+rup32(K)]), c = gamma^T W
+ *   dW += alpha.(dz^T x) + beta.(W (x^T x)) + gamma (1^T x)
+ * Same sums as t3d_pwconv_dgrad / t3d_pwconv_wgrad, reassociated; bf16 storage only, per-channel bb only.
+ *   _prep: w [N,K] bf16 (the packed weights the forward used) -> wcat, cvec [K] fp32;
+ *   _dgrad_yfree: x_raw / pro_in / residual / stats exactly as in t3d_pwconv_dgrad (x itself is the finished tensor the
+ *     conv read; x_raw the raw tensor of its producer, for that producer's BatchNorm-backward sums); dx [M,K] bf16;
+ *   _wgrad_yfree: needs t3d_set_workspace (returns T3D_ERR_UNSUPPORTED without it); dw [N,K] fp32 is accumulated. */
+int t3d_pwconv_yfree_prep(const void* w, const t3d_bnbwd* bb, void* wcat, float* cvec, int K, int N, void* stream);
+int t3d_pwconv_dgrad_yfree(const void* dz, const void* x, const void* wcat, const float* cvec, const void* x_raw,
+                           const t3d_prologue* pro_in, const void* residual, void* dx, double* stats, int M, int HW,
+                           int K, int N, void* stream);
+int t3d_pwconv_wgrad_yfree(const void* dz, const void* x, const t3d_bnbwd* bb, const void* w, float* dw, int M, int HW,
+                           int K, int N, void* stream);
+
 /* Depthwise conv backward: data gradient and weight gradient in one pass.
  *   dz, y [B,Ho,Wo,C]: gradient at / raw input of the BatchNorm after the conv; bb its backward affine;
  *   w [C,k*k] fp32; x [B,H,W,C] + pro: tensor the forward conv read and how it was activated (no SE);

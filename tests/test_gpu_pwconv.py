@@ -185,3 +185,62 @@ def test_pwconv_wgrad(B, HW, K, N, dt, mode):
     torch.cuda.synchronize()
     tol = 2e-5 if dt == 'f32' else 2e-3   # operands are pre-rounded to bf16 in the reference, accumulation is fp32
     np.testing.assert_allclose(dw.cpu().numpy(), ref.float().numpy(), atol=tol * max(1., ref.abs().max().item()), rtol=tol)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('M,HW,K,N', [(4096, 64, 16, 96), (3000, 100, 24, 144), (2048, 64, 32, 192), (1024, 16, 64, 384),
+                                      (520, 8, 16, 96)])
+@pytest.mark.parametrize('res', [False, True])
+def test_pw_yfree_backward(M, HW, K, N, res):
+    """y-free expand-layer backward (t3d_pwconv_*_yfree) vs fp64 autograd of conv1x1 + the BatchNorm-backward affine,
+    and vs the regular kernels that read y: same sums, reassociated (bf16 storage)."""
+    from torchdet3d import _native as N_
+    g = torch.Generator().manual_seed(M + K)
+    bf = torch.bfloat16
+    x = torch.randn(M, K, generator=g).to(bf)
+    w = (torch.randn(N, K, generator=g) / K ** .5).to(bf)
+    y = (x.float() @ w.float().t()).to(bf)                     # what the forward stored
+    dz = torch.randn(M, N, generator=g).to(bf)
+    alpha, beta, gamma = torch.rand(N, generator=g) + .5, torch.randn(N, generator=g) * .2, torch.randn(N, generator=g) * .1
+    r = torch.randn(M, K, generator=g).to(bf)
+    # fp64 reference on the stored operands (y-free uses x W^T in place of the rounded y: bf16-rounding-level difference)
+    dy = alpha.double() * dz.double() + beta.double() * (x.double() @ w.double().t()) + gamma.double()
+    dx_ref = dy @ w.double() + (r.double() if res else 0)
+    dw_ref = dy.t() @ x.double()
+    dev = 'cuda'
+    xd, wd, yd, dzd, rd = x.to(dev), w.to(dev), y.to(dev), dz.to(dev), r.to(dev)
+    al, be, ga = alpha.to(dev), beta.to(dev), gamma.to(dev)
+    bb = N_.bnbwd(al, be, ga, False)
+    NP, KP = (N + 31) // 32 * 32, (K + 31) // 32 * 32
+    wcat = torch.empty(K, NP + KP, device=dev, dtype=bf)
+    cvec = torch.empty(K, device=dev)
+    N_.call('t3d_pwconv_yfree_prep', N_.ptr(wd), bb, N_.ptr(wcat), N_.ptr(cvec), K, N, N_.stream())
+    dx = torch.empty(M, K, device=dev, dtype=bf)
+    yraw = torch.randn(M, K, generator=g).to(bf).to(dev)      # raw tensor of x's producer (BatchNorm-backward sums)
+    st1 = torch.zeros(2 * K, device=dev, dtype=torch.float64)
+    N_.call('t3d_pwconv_dgrad_yfree', N_.ptr(dzd), N_.ptr(xd), N_.ptr(wcat), N_.ptr(cvec), N_.ptr(yraw), None,
+            N_.ptr(rd) if res else None, N_.ptr(dx), N_.ptr(st1), M, HW, K, N, N_.stream())
+    ws = torch.empty(16 << 20, device=dev, dtype=torch.uint8)
+    dw = torch.zeros(N, K, device=dev)
+    N_.call('t3d_set_workspace', N_.ptr(ws), ws.numel())
+    try:
+        N_.call('t3d_pwconv_wgrad_yfree', N_.ptr(dzd), N_.ptr(xd), bb, N_.ptr(wd), N_.ptr(dw), M, HW, K, N, N_.stream())
+        dw2 = torch.zeros(N, K, device=dev)
+        N_.call('t3d_pwconv_wgrad', N_.BF16, N_.ptr(dzd), N_.ptr(yd), bb, N_.ptr(xd), None, N_.ptr(dw2), M, HW, K, N, N_.stream())
+    finally:
+        N_.call('t3d_set_workspace', None, 0)
+    wt = wd.t().contiguous()
+    dx2 = torch.empty(M, K, device=dev, dtype=bf)
+    st2 = torch.zeros(2 * K, device=dev, dtype=torch.float64)
+    N_.call('t3d_pwconv_dgrad', N_.BF16, N_.ptr(dzd), N_.ptr(yd), bb, N_.ptr(wt), N_.ptr(yraw), None,
+            N_.ptr(rd) if res else None, N_.ptr(dx2), N_.ptr(st2), None, M, HW, K, N, N_.stream())
+    torch.cuda.synchronize()
+    for st_, d_ in ((st1, dx), (st2, dx2)):      # sums of the stored gradient, and of gradient * raw
+        ref0, ref1 = d_.double().sum(0), (d_.double() * yraw.double()).sum(0)
+        np.testing.assert_allclose(st_[:K].cpu().numpy(), ref0.cpu().numpy(), rtol=1e-4, atol=1e-3 * M ** .5)
+        np.testing.assert_allclose(st_[K:].cpu().numpy(), ref1.cpu().numpy(), rtol=1e-4, atol=1e-3 * M ** .5)
+    sx, sw = dx_ref.abs().max().item(), dw_ref.abs().max().item()
+    ex, ex2 = (dx.double().cpu() - dx_ref).abs().max().item() / sx, (dx2.double().cpu() - dx_ref).abs().max().item() / sx
+    ew, ew2 = (dw.double().cpu() - dw_ref).abs().max().item() / sw, (dw2.double().cpu() - dw_ref).abs().max().item() / sw
+    assert ex < 1.5e-2 and ex < 2 * ex2 + 4e-3, (ex, ex2)          # bf16 output rounding dominates both
+    assert ew < 1e-2 and ew < 2 * ew2 + 4e-3, (ew, ew2)
