@@ -304,7 +304,7 @@ __global__ __launch_bounds__(NTH) void dw3_bwd2_kernel(const Dw3BArgs a) {
     cg = blockIdx.y * 64 + (threadIdx.x & 63);
     on = cg < CG;
     if (!on) cg = 0;
-    q0 = blockIdx.x * (NTH / 64) + (threadIdx.x >> 6);
+    q0 = blockIdx.x * (NTH / 64) + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform: scalar item decode
     qstride = gridDim.x * (NTH / 64);
   }
   const int c0 = cg * CH;
@@ -335,16 +335,17 @@ __global__ __launch_bounds__(NTH) void dw3_bwd2_kernel(const Dw3BArgs a) {
 #pragma unroll
   for (int i = 0; i < CH; ++i) psum[i] = psq[i] = 0.f;
 
-  for (int q = q0; q < a.nitems && on; q += qstride) {
+  // Addressing: every row base is wave-uniform (scalar registers / SALU), the lane part (column, channel group) is a
+  // 32-bit element offset computed once per item -- no 64-bit vector address arithmetic in the row loop.
+  const T* __restrict__ zb = reinterpret_cast<const T*>(a.dz);
+  const T* __restrict__ yb = reinterpret_cast<const T*>(a.y);
+  const T* __restrict__ xb = reinterpret_cast<const T*>(a.x);
+  const T* __restrict__ rb = reinterpret_cast<const T*>(a.res);
+  T* __restrict__ dxb = reinterpret_cast<T*>(a.dx);
+  for (int q = q0; q < a.nitems; q += qstride) {
     int xp, rest;
     if (!a.slab) { xp = xp_fixed; rest = q; } else { xp = q % Wp; rest = q / Wp; }
-    const int chunk = rest % a.nchunks, b = rest / a.nchunks;
-    const size_t img = (size_t)b * a.H * a.W * a.C + c0;
-    const T* __restrict__ zg = reinterpret_cast<const T*>(a.dz) + img;
-    const T* __restrict__ yg = reinterpret_cast<const T*>(a.y) + img;
-    const T* __restrict__ xg = reinterpret_cast<const T*>(a.x) + img;
-    const T* __restrict__ rg = a.res ? reinterpret_cast<const T*>(a.res) + img : nullptr;
-    T* __restrict__ dxg = reinterpret_cast<T*>(a.dx) + img;
+    const int chunk = rest % a.nchunks, b = rest / a.nchunks;          // wave-uniform
     if (a.per_sample) {
 #pragma unroll
       for (int h = 0; h < H2; ++h) {
@@ -357,25 +358,30 @@ __global__ __launch_bounds__(NTH) void dw3_bwd2_kernel(const Dw3BArgs a) {
     const int x0 = 2 * xp;                 // columns x0 (always inside) and x0+1
     const bool validB = x0 + 1 < a.W;
     const float m[4] = {x0 - 1 >= 0 ? 1.f : 0.f, 1.f, validB ? 1.f : 0.f, x0 + 2 < a.W ? 1.f : 0.f};
-    int coff[4];
+    unsigned voff[4];                      // lane part of the load addresses (BYTES, unsigned: scalar base + 32-bit offset)
 #pragma unroll
-    for (int c = 0; c < 4; ++c) coff[c] = min(max(x0 - 1 + c, 0), a.W - 1) * a.C;
+    for (int c = 0; c < 4; ++c) voff[c] = (unsigned)(min(max(x0 - 1 + c, 0), a.W - 1) * a.C + c0) * (unsigned)sizeof(T);
+    const unsigned vst = (unsigned)(x0 * a.C + c0) * (unsigned)sizeof(T);   // store address, column x0 (x0+1: + C elements)
+    const size_t imgrow = (size_t)b * a.H; // rows before this image
 
     RV rz[PF][4], ry[PF][4], rx[PF][4];
     auto fetch = [&](int r, int slot) {
-      const size_t ro = (size_t)min(max(r, 0), a.H - 1) * a.W * a.C;
+      const size_t ro = (imgrow + min(max(r, 0), a.H - 1)) * a.W * a.C;    // scalar
+      const char* zr = reinterpret_cast<const char*>(zb + ro);
+      const char* yr = reinterpret_cast<const char*>(yb + ro);
+      const char* xr_ = reinterpret_cast<const char*>(xb + ro);
 #pragma unroll
       for (int c = 0; c < 4; ++c) {
-        rz[slot][c] = *reinterpret_cast<const RV*>(zg + ro + coff[c]);
-        ry[slot][c] = *reinterpret_cast<const RV*>(yg + ro + coff[c]);
-        rx[slot][c] = *reinterpret_cast<const RV*>(xg + ro + coff[c]);
+        rz[slot][c] = *reinterpret_cast<const RV*>(zr + voff[c]);
+        ry[slot][c] = *reinterpret_cast<const RV*>(yr + voff[c]);
+        rx[slot][c] = *reinterpret_cast<const RV*>(xr_ + voff[c]);
       }
     };
     const int rf = r0 - 1, rl = r1;
 #pragma unroll
     for (int u = 0; u < PF; ++u) fetch(rf + u, u);
 
-    static_assert(PF == 3, "accumulator roles come from the unroll index");
+    static_assert(PF % 3 == 0, "accumulator roles come from the unroll index (mod 3)");
     f32x2 accA[3][H2], accB[3][H2];     // dx rows r-1, r, r+1 of columns x0 / x0+1
     f32x2 a_prev[4][H2], dyc_prev[2][H2], xr_prev[2][H2];
 #pragma unroll
@@ -519,9 +525,10 @@ __global__ __launch_bounds__(NTH) void dw3_bwd2_kernel(const Dw3BArgs a) {
                 }
                 act_grad_affine_vec<CH>(g, xv, scf, shf, a.act);
               }
-              const size_t off = ((size_t)iy * a.W + x0 + col) * a.C;
-              if (rg) {
-                const RV rr = *reinterpret_cast<const RV*>(rg + off);
+              const size_t rowo = (imgrow + iy) * a.W * a.C;     // scalar
+              const unsigned lo = vst + (unsigned)(col * a.C) * (unsigned)sizeof(T);
+              if (rb) {
+                const RV rr = *reinterpret_cast<const RV*>(reinterpret_cast<const char*>(rb + rowo) + lo);
 #pragma unroll
                 for (int i = 0; i < CH; ++i) g[i] += (float)rr[i];
               }
@@ -533,7 +540,7 @@ __global__ __launch_bounds__(NTH) void dw3_bwd2_kernel(const Dw3BArgs a) {
                 psum[i] += v;
                 psq[i] = fmaf(v, xv[i], psq[i]);
               }
-              *reinterpret_cast<RV*>(dxg + off) = o;
+              if (on) *reinterpret_cast<RV*>(reinterpret_cast<char*>(dxb + rowo) + lo) = o;
             }
           }
 #pragma unroll
@@ -634,6 +641,8 @@ int launch_s1c(Dw3BArgs& a, hipStream_t st) {
   const size_t lds = (size_t)11 * a.C * sizeof(float);
   a.noflush = getenv("T3D_DEBUG_NOFLUSH") ? 1 : 0;
   // (forcing 3-4 waves/SIMD through launch bounds spills to scratch: 3-7x slower)
+  // (a 6-row prefetch ring needs AGPR spill space -> 1 wave/SIMD: 40 % slower; PMC: VALU busy 46 %, memory unit stalled
+  //  0.1 % -- the kernel is bound by the latency two resident waves per SIMD can hide)
   if (two_col) hipLaunchKernelGGL((dw3_bwd2_kernel<T, PF, 256, CH>), grid, dim3(256), lds, st, a);
   else hipLaunchKernelGGL((dw3_bwd_s1_kernel<T, CH, PF>), grid, dim3(256), lds, st, a);
   T3D_CHECK_LAUNCH();

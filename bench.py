@@ -27,7 +27,8 @@ import torch  # noqa: E402
 
 HBM_PEAK = 8.0e12          # B/s, MI355X HBM3E spec (/opt/skills/guides/MI355X_MICROARCH.md)
 MNV2_TRAIN_MB_PER_CROP = 80.66   # algorithmic bytes, bf16, fwd + dgrad + wgrad
-CONV_KERNELS = ('t3d_dwconv_fwd', 't3d_dwconv_bwd', 't3d_pwconv_fwd', 't3d_pwconv_dgrad', 't3d_pwconv_wgrad')
+CONV_KERNELS = ('t3d_dwconv_fwd', 't3d_dwconv_bwd', 't3d_pwconv_fwd', 't3d_pwconv_dgrad', 't3d_pwconv_wgrad',
+                't3d_pwconv_dgrad_yfree', 't3d_pwconv_wgrad_yfree')
 
 
 def parse():
