@@ -204,6 +204,23 @@ __global__ __launch_bounds__(512, 2) void pw_stream_kernel(const GemmArgs a, con
       const int mrow0 = m0 + r * 16, mlast = mrow0 + 15;
       const bool uni = (mlast < a.M) && (mrow0 / a.HW == mlast / a.HW);
       const int bidx = ok ? m / a.HW : 0;
+      // all epilogue loads of the row first: the stores below then issue back to back and the 16-B pieces of a line
+      // meet in L2 (interleaved with load waits they were written back separately: 1.84x HBM write traffic, PMC)
+      bf16x8 eyr[NT / 2], err[NT / 2];
+      if (DG) {
+        if (a.e_y) {
+#pragma unroll
+          for (int q = 0; q < NT / 2; ++q)
+            eyr[q] = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const bf16_t*>(a.e_y) + (size_t)mld[r] * a.Nout +
+                                                      min(nb + 8 * q, a.Nout - 8));
+        }
+        if (a.e_res) {
+#pragma unroll
+          for (int q = 0; q < NT / 2; ++q)
+            err[q] = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const bf16_t*>(a.e_res) + (size_t)mld[r] * a.Nout +
+                                                      min(nb + 8 * q, a.Nout - 8));
+        }
+      }
 #pragma unroll
       for (int q = 0; q < NT / 2; ++q) {
         const int n = nb + 8 * q;
@@ -216,7 +233,8 @@ __global__ __launch_bounds__(512, 2) void pw_stream_kernel(const GemmArgs a, con
           for (int j = 0; j < 8; ++j) v[j] += a.bias[n + j];
         }
         if (DG && a.e_y) {
-          Vec8<bf16_t>::load(reinterpret_cast<const bf16_t*>(a.e_y) + (size_t)mld[r] * a.Nout + n, yv);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) yv[j] = (float)eyr[q][j];
           if (GEN && a.e_se) {
             const float* se = ok ? a.e_se + (size_t)bidx * a.Nout + n : nullptr;
 #pragma unroll
@@ -236,10 +254,15 @@ __global__ __launch_bounds__(512, 2) void pw_stream_kernel(const GemmArgs a, con
           }
         }
         if (a.e_res) {
-          float rr[8];
-          Vec8<bf16_t>::load(reinterpret_cast<const bf16_t*>(a.e_res) + (size_t)mld[r] * a.Nout + n, rr);
+          if constexpr (DG) {
 #pragma unroll
-          for (int j = 0; j < 8; ++j) v[j] += rr[j];
+            for (int j = 0; j < 8; ++j) v[j] += (float)err[q][j];
+          } else {
+            float rr[8];
+            Vec8<bf16_t>::load(reinterpret_cast<const bf16_t*>(a.e_res) + (size_t)mld[r] * a.Nout + n, rr);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] += rr[j];
+          }
         }
 #pragma unroll
         for (int j = 0; j < 8; ++j) v[j] = ok ? Vec8<bf16_t>::round(v[j]) : 0.f;

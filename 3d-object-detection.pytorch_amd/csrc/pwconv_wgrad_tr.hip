@@ -309,10 +309,12 @@ __global__ __launch_bounds__(256 * G) void pw_wgrad_tr_kernel(const WgtArgs a) {
 // (<= 16 adds per element).
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw, int N, int K,
                                                            int swap, int PB, int QB, int qtiles, int tiles, int S) {
+  // threads run along the Q axis of the partial tiles (the contiguous one), whatever the orientation of dW: the S
+  // partial reads per element are coalesced; the transposed case pays with scattered atomics into the small dW
+  const int P = swap ? K : N, Q = swap ? N : K, Qpad = qtiles * QB;
   const int e = blockIdx.x * 256 + threadIdx.x;
-  if (e >= N * K) return;
-  const int n = e / K, k = e % K;
-  const int p = swap ? k : n, q = swap ? n : k;
+  const int p = e / Qpad, q = e % Qpad;
+  if (p >= P || q >= Q) return;
   const int tile = (p / PB) * qtiles + q / QB;
   const float* src = ws + (size_t)tile * (PB * QB) + (size_t)(p % PB) * QB + q % QB;
   const size_t stride = (size_t)tiles * PB * QB;
@@ -321,7 +323,8 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
   float s = 0.f;
 #pragma unroll 8
   for (int i = i0; i < i1; ++i) s += src[(size_t)i * stride];
-  if (i0 < i1) unsafeAtomicAdd(dw + e, s);
+  const int n = swap ? q : p, k = swap ? p : q;
+  if (i0 < i1) unsafeAtomicAdd(dw + (size_t)n * K + k, s);
 }
 
 template <int NTPW, int NTQ, bool SWAP, int D, bool GEN, bool YF = false>
@@ -357,7 +360,7 @@ int launch_d(WgtArgs& a, hipStream_t st) {
     (void)hipFuncSetAttribute((const void*)pw_wgrad_tr_kernel<NTPW, NTQ, SWAP, G, D, GEN, YF>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   hipLaunchKernelGGL((pw_wgrad_tr_kernel<NTPW, NTQ, SWAP, G, D, GEN, YF>), dim3(tiles, S), dim3(256 * G), lds, st, a);
   if (use_ws)
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(cdiv(a.N * a.K, 256), S >= 64 ? 16 : (S >= 8 ? 4 : 1)), dim3(256), 0, st, a.ws, a.dw, a.N, a.K, (int)SWAP, PB, QB,
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(cdiv((a.swap ? a.K : a.N) * a.qtiles * QB, 256), S >= 64 ? 16 : (S >= 8 ? 4 : 1)), dim3(256), 0, st, a.ws, a.dw, a.N, a.K, (int)SWAP, PB, QB,
                        a.qtiles, tiles, S);
   T3D_CHECK_LAUNCH();
   return T3D_OK;

@@ -1,0 +1,45 @@
+#!/bin/bash
+# HBM traffic per kernel family for the default bench workload: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in
+# SEPARATE passes (MI355X_MICROARCH.md: the HBM/rocprofv3 section), FETCH_SIZE doubled (gfx950 correction), units KB.
+# usage (on the GPU box): tools/pmc_traffic.sh <out.json>
+cd $GRAFT_REPO_ROOT; export TMPDIR=/tmp
+out=${1:-gpurun_out/hbm_traffic_pmc.json}
+STEPS=3; WARM=2
+for c in FETCH_SIZE WRITE_SIZE; do
+  rm -rf gpurun_out/pmc_$c
+  rocprofv3 --pmc $c --output-format csv -d gpurun_out/pmc_$c -o p -- python3 bench.py --steps $STEPS --warmup $WARM --no-cpu-baseline > /dev/null 2>&1
+done
+python3 - "$out" $((STEPS + WARM)) <<'PY'
+import sys, glob, csv, json, re, collections
+out, nsteps = sys.argv[1], int(sys.argv[2])
+def family(k):
+    if 'dw3_bwd' in k or 'dw_bwd' in k: return 't3d_dwconv_bwd'
+    if 'dw3_fwd' in k or 'dw_fwd' in k: return 't3d_dwconv_fwd'
+    m = re.search(r'pw_stream_kernel<([^>]*)>', k)
+    if m:
+        a = [v.strip() for v in m.group(1).split(',')]
+        if len(a) > 4 and a[4] == 'true': return 't3d_pwconv_dgrad_yfree'
+        return 't3d_pwconv_dgrad' if a[2] == 'true' else 't3d_pwconv_fwd'
+    m = re.search(r'pw_wgrad_tr_kernel<([^>]*)>', k)
+    if m:
+        a = [v.strip() for v in m.group(1).split(',')]
+        return 't3d_pwconv_wgrad_yfree' if len(a) > 6 and a[6] == 'true' else 't3d_pwconv_wgrad'
+    if 'wgrad_reduce' in k or 'yfree_combine' in k or 'yfree_prep' in k: return 'pw_wgrad_reduce+yfree_small'
+    if 'pw_gemm' in k or 'pwconv' in k or 'pw_' in k: return 'pw_other'
+    return None
+fam = collections.defaultdict(lambda: dict(fetch_kb=0.0, write_kb=0.0, dispatches_fetch_pass=0, dispatches_write_pass=0))
+tot = dict(FETCH_SIZE=0.0, WRITE_SIZE=0.0)
+for c, key, cnt in (('FETCH_SIZE', 'fetch_kb', 'dispatches_fetch_pass'), ('WRITE_SIZE', 'write_kb', 'dispatches_write_pass')):
+    f = glob.glob('gpurun_out/pmc_%s/**/*counter_collection.csv' % c, recursive=True)
+    for r in csv.DictReader(open(f[0])):
+        v = float(r['Counter_Value']); tot[c] += v
+        fm = family(r['Kernel_Name'])
+        if fm: fam[fm][key] += v; fam[fm][cnt] += 1
+for v in fam.values(): v['hbm_bytes_per_step'] = round((2 * v['fetch_kb'] + v['write_kb']) * 1024 / nsteps)
+res = dict(note='rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over `bench.py --steps 3 --warmup 2` (5 steps), '
+                'MobileNetV2 224^2 B=256 bf16; FETCH_SIZE doubled per the gfx950 correction; per-family sums (tools/pmc_traffic.sh)',
+           steps=nsteps, all_kernels_hbm_bytes_per_step=round((2 * tot['FETCH_SIZE'] + tot['WRITE_SIZE']) * 1024 / nsteps), families=fam)
+json.dump(res, open(out, 'w'), indent=1)
+print(json.dumps({k: v['hbm_bytes_per_step'] for k, v in fam.items()}), res['all_kernels_hbm_bytes_per_step'])
+PY
+rm -rf gpurun_out/pmc_FETCH_SIZE gpurun_out/pmc_WRITE_SIZE
