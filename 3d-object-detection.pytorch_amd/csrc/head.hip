@@ -101,7 +101,8 @@ __global__ __launch_bounds__(256) void head_bwd_data_kernel(const HeadArgs a) {
   }
 }
 
-// weight gradient: grid (10, ceil(F/256)); blockIdx.x < 9: regressor of that class, == 9: class head.
+// weight gradient: grid (10, ceil(F/256), S); blockIdx.x < 9: regressor of that class, == 9: class head; blockIdx.z
+// takes a contiguous slice of the batch and ADDS its part (the caller's gradient buffer is zeroed once per step).
 // The samples a block needs are first compacted (in ascending order: the sum stays deterministic) into LDS, then
 // consumed eight at a time so that eight feature loads are in flight per thread (the serial one-load-per-sample loop
 // took ~1 us per sample).
@@ -116,11 +117,12 @@ __global__ __launch_bounds__(256) void head_bwd_weight_kernel(const HeadArgs a) 
 #pragma unroll
     for (int r = 0; r < NKP; ++r) acc[r] = 0.f;
     const bool bias_thread = (blockIdx.y == 0 && threadIdx.x < NKP);
-    for (int b0 = 0; b0 < a.B; b0 += CHUNK) {
+    const int per = (a.B + gridDim.z - 1) / gridDim.z, zb0 = blockIdx.z * per, zb1 = min(a.B, zb0 + per);
+    for (int b0 = zb0; b0 < zb1; b0 += CHUNK) {
       __syncthreads();
       if (threadIdx.x == 0) {
         int n = 0;
-        const int b1 = min(a.B, b0 + CHUNK);
+        const int b1 = min(zb1, b0 + CHUNK);
         for (int b = b0; b < b1; ++b) {
           int c = (int)a.cats[b];
           c = c < 0 ? 0 : (c > 8 ? 8 : c);
@@ -158,15 +160,16 @@ __global__ __launch_bounds__(256) void head_bwd_weight_kernel(const HeadArgs a) 
     }
     if (jon) {
 #pragma unroll
-      for (int r = 0; r < NKP; ++r) a.dwreg[((size_t)cls * NKP + r) * a.F + j] = acc[r];
+      for (int r = 0; r < NKP; ++r) unsafeAtomicAdd(a.dwreg + ((size_t)cls * NKP + r) * a.F + j, acc[r]);
     }
-    if (bias_thread) a.dbreg[cls * NKP + threadIdx.x] = bacc;
+    if (bias_thread) unsafeAtomicAdd(a.dbreg + cls * NKP + threadIdx.x, bacc);
   } else if (a.dlogits && a.dwcls) {
     for (int q0 = 0; q0 < a.ncls; q0 += 16) {
       float acc[16];
 #pragma unroll
       for (int q = 0; q < 16; ++q) acc[q] = 0.f;
-      for (int b0 = 0; b0 < a.B; b0 += U) {
+      const int per = (a.B + gridDim.z - 1) / gridDim.z, zb0 = blockIdx.z * per, zb1 = min(a.B, zb0 + per);
+      for (int b0 = zb0; b0 < zb1; b0 += U) {
         float x[U], mk[U];
         const int jc = min(j, a.F - 1);
 #pragma unroll
@@ -184,10 +187,10 @@ __global__ __launch_bounds__(256) void head_bwd_weight_kernel(const HeadArgs a) 
           for (int u = 0; u < U; ++u) x[u] = act_apply(x[u] * sc + sh, a.act);
         }
 #pragma unroll
-        for (int u = 0; u < U; ++u) x[u] = (jon && b0 + u < a.B) ? x[u] * mk[u] : 0.f;
+        for (int u = 0; u < U; ++u) x[u] = (jon && b0 + u < zb1) ? x[u] * mk[u] : 0.f;
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-          if (b0 + u < a.B) {
+          if (b0 + u < zb1) {
 #pragma unroll
             for (int q = 0; q < 16; ++q)
               if (q0 + q < a.ncls) acc[q] = fmaf(a.dlogits[(size_t)(b0 + u) * a.ncls + q0 + q], x[u], acc[q]);
@@ -197,13 +200,13 @@ __global__ __launch_bounds__(256) void head_bwd_weight_kernel(const HeadArgs a) 
       if (jon) {
 #pragma unroll
         for (int q = 0; q < 16; ++q)
-          if (q0 + q < a.ncls) a.dwcls[(size_t)(q0 + q) * a.F + j] = acc[q];
+          if (q0 + q < a.ncls) unsafeAtomicAdd(a.dwcls + (size_t)(q0 + q) * a.F + j, acc[q]);
       }
     }
-    if (blockIdx.y == 0 && threadIdx.x < a.ncls) {
+    if (blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x < a.ncls) {
       float s = 0.f;
       for (int b = 0; b < a.B; ++b) s += a.dlogits[(size_t)b * a.ncls + threadIdx.x];
-      a.dbcls[threadIdx.x] = s;
+      unsafeAtomicAdd(a.dbcls + threadIdx.x, s);
     }
   }
 }
@@ -245,7 +248,7 @@ extern "C" int t3d_head_bwd(const float* f, const t3d_prologue* pro, const int64
   fill(a, pro);
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   hipLaunchKernelGGL(head_bwd_data_kernel, dim3(B), dim3(256), 0, st, a);
-  hipLaunchKernelGGL(head_bwd_weight_kernel, dim3(10, cdiv(F, 256)), dim3(256), 0, st, a);
+  hipLaunchKernelGGL(head_bwd_weight_kernel, dim3(10, cdiv(F, 256), B >= 64 ? 8 : 1), dim3(256), 0, st, a);
   T3D_CHECK_LAUNCH();
   return T3D_OK;
 }

@@ -185,7 +185,8 @@ int t3d_head_fwd(const float* f, const t3d_prologue* pro, const int64_t* cats, c
 
 /* Head backward.  dkp [B,18], dlogits [B,ncls] (may be NULL) -> df [B,F] (when pro is given: the gradient
  * at the BatchNorm1d OUTPUT, i.e. already multiplied by act'; then stats [2*F] fp64 += sum(df), sum(df*f)),
- * dwreg [9,18,F], dbreg [9,18], dwcls [ncls,F], dbcls [ncls] (all OVERWRITTEN, deterministic order).
+ * dwreg [9,18,F], dbreg [9,18], dwcls [ncls,F], dbcls [ncls] are ACCUMULATED (+=, batch slices in parallel): the
+ * caller zeroes them once per step, like every other weight-gradient buffer of this ABI.
  * dpre [B,18] fp32 scratch. */
 int t3d_head_bwd(const float* f, const t3d_prologue* pro, const int64_t* cats, const float* wreg,
                  const float* wcls, const float* mask, const float* kp, const float* dkp, const float* dlogits,

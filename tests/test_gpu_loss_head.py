@@ -112,7 +112,7 @@ def test_head_fwd_bwd(B, F, nc, with_pro):
         np.testing.assert_allclose(lgd.cpu().numpy(), lg.detach().numpy(), atol=2e-5)
     dpre, df = torch.empty(B, 18, device='cuda'), torch.empty(B, F, device='cuda')
     stats = torch.zeros(2 * F, device='cuda', dtype=torch.float64)
-    dwr, dbr = torch.empty_like(wr), torch.empty_like(br)
+    dwr, dbr = torch.zeros_like(wr), torch.zeros_like(br)      # accumulated into: the caller zeroes once per step
     dwc, dbc = torch.zeros_like(wc), torch.zeros_like(bc)
     dkpd, dlgd = d(dkp), d(dlg)     # keep the device copies alive across the call
     N.call('t3d_head_bwd', N.ptr(fd), pro, N.ptr(cd), N.ptr(wr), N.ptr(wc), N.ptr(md), N.ptr(kpd), N.ptr(dkpd),
