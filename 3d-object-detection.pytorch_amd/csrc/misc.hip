@@ -32,7 +32,27 @@ __global__ void pack_batched_kernel(const long long* __restrict__ desc) {
   }
 }
 
+// desc[t] = {src [nrep][count] fp32, dst [count] fp32, count}: dst = sum over the replicas (overwrites)
+__global__ void sum_replicas_batched_kernel(const long long* __restrict__ desc, int nrep) {
+  const long long* d = desc + (size_t)blockIdx.x * 3;
+  const float* __restrict__ src = reinterpret_cast<const float*>(d[0]);
+  float* __restrict__ dst = reinterpret_cast<float*>(d[1]);
+  const int n = (int)d[2];
+  for (int i = blockIdx.y * blockDim.x + threadIdx.x; i < n; i += gridDim.y * blockDim.x) {
+    float s = 0.f;
+    for (int r = 0; r < nrep; ++r) s += src[(size_t)r * n + i];
+    dst[i] = s;
+  }
+}
+
 }  // namespace
+
+extern "C" int t3d_sum_replicas_batched(const long long* desc, int n, int nrep, void* stream) {
+  if (!desc || n <= 0 || nrep < 1) return T3D_ERR_ARG;
+  hipLaunchKernelGGL(sum_replicas_batched_kernel, dim3(n, 8), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), desc, nrep);
+  T3D_CHECK_LAUNCH();
+  return T3D_OK;
+}
 
 extern "C" int t3d_pack_weights_batched(int dtype, const long long* desc, int n, void* stream) {
   if (!desc || n <= 0) return T3D_ERR_ARG;

@@ -34,12 +34,40 @@ NREP = 16                       # reduction replicas (include/t3d.h: t3d_set_red
 WORKSPACE_BYTES = 64 << 20      # partial weight-gradient tiles (include/t3d.h: t3d_set_workspace)
 # y-free expand-layer backward (csrc/pwconv_yfree.hip): minimum M*N elements of the expanded tensor; 0 disables
 YFREE_MIN_ELEMS = int(os.environ.get('T3D_YFREE_MIN', 8 << 20))
+HOOK_MIN = 1 << 20              # gradient-exchange granularity (elements): parallel.GradSync's bucket size
 
 
 class _BN:
     """Per-BatchNorm bookkeeping: parameter views + per-step scratch slices."""
     __slots__ = ('name', 'C', 'gamma', 'beta', 'dgamma', 'dbeta', 'rm', 'rv', 'nbt', 'stats', 'bstats', 'scale',
                  'shift', 'mean', 'invstd', 'alpha', 'bbeta', 'gammac', 'count', 'pro_cache')
+
+
+def _concurrent_stream(device, tries=8):
+    """A second stream that really runs beside the current one.  HIP maps streams onto a few hardware queues
+    (GPU_MAX_HW_QUEUES, default 4) round-robin; once RCCL has created its own streams a fresh stream may share the
+    main stream's queue, and everything issued on it is then serialized behind the main stream's kernels (measured:
+    +1.7 ms per step on the data-parallel path).  Probe candidates with a spin kernel on the main stream and keep the
+    first one whose work finishes while the spin is still running."""
+    main = torch.cuda.current_stream(device)
+    cands = []
+    with torch.cuda.device(device):
+        probe = torch.zeros(1, device=device)
+        for _ in range(tries):
+            st = torch.cuda.Stream(device=device)
+            cands.append(st)
+            e0, e_side, e_main = (torch.cuda.Event(enable_timing=True) for _ in range(3))
+            torch.cuda.synchronize(device)
+            e0.record(main)
+            torch.cuda._sleep(4_000_000)            # ~2 ms of spinning on the main stream
+            e_main.record(main)
+            with torch.cuda.stream(st):
+                probe.add_(1.0)
+                e_side.record(st)
+            torch.cuda.synchronize(device)
+            if e0.elapsed_time(e_side) < 0.5 * e0.elapsed_time(e_main):
+                return st
+    return cands[0]
 
 
 class _Src:
@@ -70,7 +98,9 @@ class Net:
         # end of `gflat` towards its start): lets a data-parallel wrapper start the RCCL all-reduce of that
         # tail while the rest of the backward is still being computed
         self.grad_hook = None
-        self._side = torch.cuda.Stream(device=self.device) if (self.device.type == 'cuda' and not os.environ.get('T3D_NO_SIDE_STREAM')) else None
+        self._side = None
+        if self.device.type == 'cuda' and not os.environ.get('T3D_NO_SIDE_STREAM'):
+            self._side = _concurrent_stream(self.device)
         self._side_busy = False
 
     # ------------------------------------------------------------------ parameters
@@ -452,6 +482,10 @@ class Net:
         assert sv is not None, 'backward() needs a preceding forward(train=True)'
         a, st, dt, B = self.arch, N.stream(), self.dt, sv['B']
         self.gflat.zero_()
+        if getattr(self, '_dwarena', None) is None:
+            self._dw_arena_init()
+        self._dwarena.zero_()
+        self._dwpending, self._dwflushed, self._hook_hi = 0, 0, self.gflat.numel()
         dkp = dkp.reshape(B, 18).to(torch.float32).contiguous()
         ncls = self.num_classes
         if ncls > 1:
@@ -497,14 +531,10 @@ class Net:
                     N.ptr(self.g[ln + '.0.weight']), M, HW, x.C, a.last_c, nbytes=M * (x.C + a.last_c) * self.esz)
         dz = self._pw_dgrad(dzl, sv['yl'], bb, self.wt[ln + '.0.weight'], x, None, M, HW, x.C, a.last_c, 'dz:lastin')
 
-        if self.grad_hook:
-            self._join_side()
-            self.grad_hook(self.offsets[ln + '.0.weight'][0])
+        self._maybe_hook(self.offsets[ln + '.0.weight'][0])
         for rec in reversed(sv['blocks']):
             dz = self._block_bwd(rec, dz)
-            if self.grad_hook:
-                self._join_side()
-                self.grad_hook(self.offsets[f"features.{rec['idx'] + 1}.conv.0.weight"][0])
+            self._maybe_hook(self.offsets[f"features.{rec['idx'] + 1}.conv.0.weight"][0])
 
         # ---- stem weight gradient
         s0 = sv['stem']
@@ -514,10 +544,10 @@ class Net:
         dw32 = self._buf('dstem32', (a.stem_c, 32), torch.float32, zero=True)
         self._wgrad(dt, N.ptr(dz), N.ptr(s0.raw), bb, N.ptr(sv['col']), None, N.ptr(dw32),
                     M, s0.H * s0.W, 32, a.stem_c, nbytes=M * (32 + a.stem_c) * self.esz)
+        self._flush_dw()
         self._join_side()
         self.g['features.0.0.weight'].view(a.stem_c, 27).copy_(dw32[:, :27])
-        if self.grad_hook:
-            self.grad_hook(0)
+        self._maybe_hook(0, force=True)
         self.saved = None
 
     def _pw_dgrad(self, dz, y, bb, wt, x, residual, M, HW, K, Nn, tag):
@@ -533,6 +563,46 @@ class Net:
         if x.finished_act:
             dx = self._act_bwd(dx, x, tag + ':a')
         return dx
+
+    # ---- depthwise weight-gradient replicas: one zero fill per step, one batched sum per gradient bucket
+    def _dw_arena_init(self):
+        names = [k for k, (sh, kind) in self.shapes.items() if kind == 'param' and len(sh) == 4 and sh[1] == 1 and sh[2] > 1]
+        tot = sum(NREP * self.p[k].numel() for k in names)
+        self._dwarena = torch.empty(tot, device=self.device, dtype=torch.float32)
+        self._dwviews, off = {}, 0
+        for k in names:
+            n = self.p[k].numel()
+            self._dwviews[k] = self._dwarena[off:off + NREP * n]
+            off += NREP * n
+        # descriptor rows in BACKWARD order (the order the layers finish): a flush is a contiguous row range
+        self._dworder = list(reversed(names))
+        rows = [[self._dwviews[k].data_ptr(), self.g[k].data_ptr(), self.p[k].numel()] for k in self._dworder]
+        self._dwdesc = torch.tensor(rows, dtype=torch.int64, device=self.device)
+
+    def _dw_replicas(self, name):
+        assert self._dworder[self._dwflushed + self._dwpending] == name
+        self._dwpending += 1
+        return self._dwviews[name]
+
+    def _flush_dw(self):
+        """Replica sums -> gradient buffer for every depthwise layer finished since the last flush (one launch)."""
+        if not self._dwpending:
+            return
+        N.call('t3d_sum_replicas_batched', self._dwdesc[self._dwflushed:].data_ptr(), self._dwpending, NREP, N.stream())
+        self._dwflushed += self._dwpending
+        self._dwpending = 0
+
+    def _maybe_hook(self, lo, force=False):
+        """Tell the gradient exchange that everything at flat offsets >= lo is final -- in buckets of >= HOOK_MIN
+        elements, because each call first has to wait for the side stream (weight gradients) and flush the depthwise
+        replica sums."""
+        if self.grad_hook is None:
+            return
+        if force or self._hook_hi - lo >= HOOK_MIN:
+            self._flush_dw()
+            self._join_side()
+            self.grad_hook(lo)
+            self._hook_hi = lo
 
     def _yfree_ok(self, x, M, K, Nn):
         """Expand layer on a finished bf16 input, wide enough that skipping the two extra passes over the M x N tensors
@@ -610,11 +680,10 @@ class Net:
         if blk.expand:
             s1 = rec['s1']
             d1 = self._buf(f'dz1:{i}', (M1, blk.cexp))
-            dwrep = self._buf(f'dwrep:{i}', (NREP, blk.cexp * blk.k * blk.k), torch.float32, zero=True)
+            dwrep = self._dw_replicas(dwn)
             N.call('t3d_dwconv_bwd', dt, N.ptr(dv2), N.ptr(s2.raw), bb2, N.ptr(self.p[dwn]), N.ptr(s1.t), s1.pro, None,
                    N.ptr(d1), N.ptr(s1.bn.bstats), N.ptr(dwrep), B, x.H, x.W, blk.cexp, blk.k, blk.s, st,
                    nbytes=2 * (M1 + M2) * blk.cexp * self.esz)
-            torch.sum(dwrep, 0, out=self.g[dwn].view(-1))
             bb1 = self._bn_bwd(s1.bn)
             p = f'features.{i + 1}.conv'
             if self._yfree_ok(x, M1, blk.cin, blk.cexp):
@@ -626,13 +695,12 @@ class Net:
                                   blk.cexp, f'dzin:{i}')
         # no-expand layout: the depthwise conv reads the block input directly
         dx = self._buf(f'dzin:{i}', (M1, blk.cexp))
-        dwrep = self._buf(f'dwrep:{i}', (NREP, blk.cexp * blk.k * blk.k), torch.float32, zero=True)
+        dwrep = self._dw_replicas(dwn)
         deferred = x.pro is not None           # raw producer tensor read through its prologue
         N.call('t3d_dwconv_bwd', dt, N.ptr(dv2), N.ptr(s2.raw), bb2, N.ptr(self.p[dwn]), N.ptr(x.t), x.pro,
                N.ptr(res) if res is not None else None, N.ptr(dx),
                N.ptr(x.bn.bstats) if deferred else None, N.ptr(dwrep), B, x.H, x.W, blk.cexp, blk.k, blk.s, st,
                nbytes=2 * (M1 + M2) * blk.cexp * self.esz)
-        torch.sum(dwrep, 0, out=self.g[dwn].view(-1))
         if not deferred:
             # finished input: the producer's BatchNorm sums have to be taken against its RAW tensor
             dx = self._act_bwd(dx, x, f'dzin:{i}:a')

@@ -100,6 +100,10 @@ int t3d_pwconv_dgrad(int dtype, const void* dz, const void* y, const t3d_bnbwd* 
                      const void* x_raw, const t3d_prologue* pro_in, const void* residual, void* dx,
                      double* stats, float* ps_stats, int M, int HW, int K, int N, void* stream);
 
+/* Sum of reduction replicas for several tensors in one launch (the depthwise weight gradients of every layer finished
+ * since the last call): desc = n rows of int64 {src, dst, count}, src [nrep][count] fp32 -> dst [count] fp32 (overwritten). */
+int t3d_sum_replicas_batched(const long long* desc, int n, int nrep, void* stream);
+
 /* Weight packing: fp32 master weight [rows,cols] -> storage dtype, optionally transposed to
  * [cols,rows] (the dgrad GEMM reads the transposed copy). */
 int t3d_pack_weight(int dtype, const float* w, void* out, int rows, int cols, int transpose, void* stream);
