@@ -166,16 +166,21 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    # ---- warm-up; the first half also finds the dominant kernel family (all families timed)
+    # ---- warm-up; the first half also finds the dominant kernel family: all families timed, with the weight gradients
+    # on the main stream for these steps (event pairs on the second stream would also count the time a launch waits
+    # for the main stream's persistent kernels to free registers, not just the kernel)
     N.timer = N.KernelTimer(None)
+    side, net._side = net._side, None
     for i in range(args.warmup):
         if i == max(1, args.warmup // 2):
             fam = N.timer.summary()
             N.timer = None
+            net._side = side
         step(i)
     if N.timer is not None:
         fam = N.timer.summary()
         N.timer = None
+    net._side = side
     conv = {k: v for k, v in fam.items() if k in CONV_KERNELS}
     dominant = max(conv, key=lambda k: conv[k]['ms']) if conv else None
     if args.profile_all and rank == 0:
@@ -199,6 +204,7 @@ def main():
     t0 = time.perf_counter()
     for i in range(args.steps):
         step(i)
+    t_issue = time.perf_counter() - t0        # host time to ENQUEUE the K steps (no device wait inside a step)
     barrier()
     dt = time.perf_counter() - t0
     tsum = N.timer.summary() if N.timer else {}
@@ -219,7 +225,7 @@ def main():
             'config': {'workload': f'{args.model} 9-class Objectron keypoint regression, train step (fwd + l1/add/CE losses '
                                    f'+ bwd + AdamW{" + RCCL grad all-reduce" if world > 1 else ""}), {S}x{S} crops, '
                                    f'per-GPU batch {B}', 'global_batch': B * world, 'parallelism': f'dp{world}',
-                       'final_loss': round(loss, 5)},
+                       'final_loss': round(loss, 5), 'host_issue_ms_per_step': round(t_issue / args.steps * 1e3, 3)},
         }
         if dominant and dominant in tsum:
             d = tsum[dominant]
@@ -227,7 +233,7 @@ def main():
             # HBM bytes per launch from the committed rocprofv3 PMC passes (FETCH_SIZE x2 + WRITE_SIZE, gfx950 correction),
             # valid for the default workload only; not measurable from inside this process
             traffic = None
-            tf = os.path.join(ROOT, 'profiles', 'r1_c_hbm_traffic_pmc.json')
+            tf = os.path.join(ROOT, 'profiles', 'r1_e_hbm_traffic_pmc.json')
             if os.path.exists(tf) and args.model == 'mobilenetv2' and S == 224 and B == 256 and args.dtype == 'bf16':
                 fam_t = json.load(open(tf))['families'].get(dominant)
                 if fam_t:
