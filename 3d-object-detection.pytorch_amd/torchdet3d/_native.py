@@ -97,7 +97,14 @@ def dtype_code(t):
     raise RuntimeError(f'unsupported storage dtype {t.dtype}')
 
 
+_raw_stream = getattr(torch._C, '_cuda_getCurrentRawStream', None)
+
+
 def stream():
+    """HIP stream handle of torch's current stream on the current device.  (The raw accessor costs ~0.3 us; going
+    through torch.cuda.current_stream() was 7 us a call -- 2 ms of host time per training step.)"""
+    if _raw_stream is not None:
+        return _raw_stream(torch.cuda.current_device())
     return torch.cuda.current_stream().cuda_stream
 
 

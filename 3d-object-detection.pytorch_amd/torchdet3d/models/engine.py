@@ -456,8 +456,11 @@ class Net:
             return
         main = torch.cuda.current_stream()
         self._side.wait_stream(main)
-        with torch.cuda.stream(self._side):
-            N.call(entry, *args, N.stream(), **kw)
+        if N.timer is None:
+            N.call(entry, *args, self._side.cuda_stream, **kw)     # the ABI takes the stream: no context switch needed
+        else:
+            with torch.cuda.stream(self._side):                    # timed launches: events on the launch stream
+                N.call(entry, *args, N.stream(), **kw)
         self._side_busy = True
 
     def _join_side(self):
