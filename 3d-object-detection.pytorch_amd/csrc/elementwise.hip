@@ -43,7 +43,8 @@ struct EwArgs {
   const void* res;
   void* out;
   const float *scale, *shift;
-  const float* vec;    // per-sample fp32 vector (gap bwd: dpooled)
+  const float* vec;    // per-sample fp32 vector (gap bwd: dpooled; se-after apply: gate s)
+  const float* vec2;   // se-after apply: pooled-path gradient g
   float* pooled;
   double* stats;
   int act;
@@ -137,6 +138,86 @@ __global__ __launch_bounds__(256) void bn_act_bwd_kernel(const EwArgs a) {
     }
   }
   if (a.stats) flush_stats(lstat, a.C, c0, on, s1, s2, a.stats);
+}
+
+// Squeeze-excite AFTER the activation (no-expand layout, mobilenetv3.py:138-140; MobileNetV3-small features.1):
+// v = s * a, a = act(u), u = scale*y + shift.  Backward, step 2 of 2:
+//   du = (s[b] * dv + g[b]) * act'(u),  stats += sum(du), sum(du*y)       (dv: gradient at the gated tensor)
+template <typename T>
+__global__ __launch_bounds__(256) void se_after_apply_kernel(const EwArgs a) {
+  extern __shared__ float lstat[];
+  const int CG = a.C / 8;
+  const size_t nvec = (size_t)a.M * CG;
+  const T* __restrict__ dv = reinterpret_cast<const T*>(a.a);
+  const T* __restrict__ y = reinterpret_cast<const T*>(a.b);
+  T* __restrict__ o = reinterpret_cast<T*>(a.out);
+  const size_t nthr = ((size_t)gridDim.x * 256 / CG) * CG;
+  const size_t g = blockIdx.x * (size_t)256 + threadIdx.x;
+  const bool on = g < nthr;
+  const int c0 = (int)(g % CG) * 8;
+  float sc[8], sh[8], s1[8], s2[8];
+  load_affine(a, c0, sc, sh);
+#pragma unroll
+  for (int j = 0; j < 8; ++j) s1[j] = s2[j] = 0.f;
+  if (on) {
+    for (size_t i = g; i < nvec; i += nthr) {
+      float d[8], yv[8];
+      Vec8<T>::load(dv + i * 8, d);
+      Vec8<T>::load(y + i * 8, yv);
+      const size_t bo = (i / CG / a.HW) * a.C + c0;     // sample of this pixel row
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float da = fmaf(a.vec[bo + j], d[j], a.vec2[bo + j]);
+        const float v = Vec8<T>::round(da * act_grad(yv[j] * sc[j] + sh[j], a.act));
+        d[j] = v;
+        s1[j] += v;
+        s2[j] = fmaf(v, yv[j], s2[j]);
+      }
+      Vec8<T>::store(o + i * 8, d);
+    }
+  }
+  if (a.stats) flush_stats(lstat, a.C, c0, on, s1, s2, a.stats);
+}
+
+// step 1 of 2: ps[b][c][0] = sum_hw dv * act(scale*y + shift)  (= d loss / d gate), ps[b][c][1] = 0
+// grid (B, ceil(CG/32)), block 256 = 32 groups x 8 hw slots (as gap_fwd_kernel)
+template <typename T>
+__global__ __launch_bounds__(256) void se_after_sums_kernel(const EwArgs a) {
+  __shared__ float red[8][32 * 8];
+  const int CG = a.C / 8, b = blockIdx.x;
+  const int cgl = threadIdx.x & 31, slot = threadIdx.x >> 5;
+  const int cg = blockIdx.y * 32 + cgl;
+  const bool on = cg < CG;
+  const int c0 = on ? cg * 8 : 0;
+  const T* __restrict__ dv = reinterpret_cast<const T*>(a.a);
+  const T* __restrict__ y = reinterpret_cast<const T*>(a.b);
+  float sc[8], sh[8], acc[8];
+  load_affine(a, c0, sc, sh);
+#pragma unroll
+  for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+  if (on) {
+    for (int hw = slot; hw < a.HW; hw += 8) {
+      float v[8], d[8];
+      const size_t off = ((size_t)b * a.HW + hw) * a.C + c0;
+      Vec8<T>::load(y + off, v);
+      Vec8<T>::load(dv + off, d);
+      act_affine_vec<8>(v, sc, sh, a.act);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc[j] = fmaf(d[j], v[j], acc[j]);
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 8; ++j) red[slot][cgl * 8 + j] = acc[j];
+  __syncthreads();
+  const int t = threadIdx.x;
+  const int c = blockIdx.y * 256 + t;
+  if (c < a.C) {
+    float s = 0.f;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) s += red[q][t];
+    a.pooled[((size_t)b * a.C + c) * 2] = s;
+    a.pooled[((size_t)b * a.C + c) * 2 + 1] = 0.f;
+  }
 }
 
 // pooled[b][c] = mean_hw act(scale*y + shift);   grid (B, ceil(CG/32)), block 256 = 32 groups x 8 hw slots
@@ -287,6 +368,41 @@ extern "C" int t3d_bn_act_bwd(int dtype, const void* dz, const void* y, const t3
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   if (dtype == T3D_F32) hipLaunchKernelGGL(bn_act_bwd_kernel<float>, dim3(grid), dim3(256), lds, st, a);
   else if (dtype == T3D_BF16) hipLaunchKernelGGL(bn_act_bwd_kernel<bf16_t>, dim3(grid), dim3(256), lds, st, a);
+  else return T3D_ERR_ARG;
+  T3D_CHECK_LAUNCH();
+  return T3D_OK;
+}
+
+extern "C" int t3d_se_after_sums(int dtype, const void* dv, const void* y, const t3d_prologue* pro, float* ps, int B, int HW,
+                                 int C, void* stream) {
+  if (!dv || !y || !ps || B <= 0 || HW <= 0 || C <= 0 || (C % 8)) return T3D_ERR_ARG;
+  if (pro && pro->se) return T3D_ERR_UNSUPPORTED;
+  EwArgs a{};
+  a.a = dv; a.b = y; a.pooled = ps; a.C = C; a.HW = HW;
+  fill_pro(a, pro);
+  dim3 grid(B, cdiv(C / 8, 32));
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (dtype == T3D_F32) hipLaunchKernelGGL(se_after_sums_kernel<float>, grid, dim3(256), 0, st, a);
+  else if (dtype == T3D_BF16) hipLaunchKernelGGL(se_after_sums_kernel<bf16_t>, grid, dim3(256), 0, st, a);
+  else return T3D_ERR_ARG;
+  T3D_CHECK_LAUNCH();
+  return T3D_OK;
+}
+
+extern "C" int t3d_se_after_apply(int dtype, const void* dv, const void* y, const t3d_prologue* pro, const float* s,
+                                  const float* g, void* du, double* stats, int B, int HW, int C, void* stream) {
+  if (!dv || !y || !s || !g || !du || B <= 0 || HW <= 0 || C <= 0 || (C % 8)) return T3D_ERR_ARG;
+  if (pro && pro->se) return T3D_ERR_UNSUPPORTED;
+  EwArgs a{};
+  a.a = dv; a.b = y; a.out = du; a.stats = stats; a.vec = s; a.vec2 = g; a.M = B * HW; a.C = C; a.HW = HW;
+  fill_pro(a, pro);
+  int grid = ew_grid((size_t)a.M * (C / 8));
+  if (grid > 1024) grid = 1024;
+  if ((size_t)grid * 256 < (size_t)(C / 8)) return T3D_ERR_UNSUPPORTED;
+  const size_t lds = (size_t)2 * C * sizeof(float);
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (dtype == T3D_F32) hipLaunchKernelGGL(se_after_apply_kernel<float>, dim3(grid), dim3(256), lds, st, a);
+  else if (dtype == T3D_BF16) hipLaunchKernelGGL(se_after_apply_kernel<bf16_t>, dim3(grid), dim3(256), lds, st, a);
   else return T3D_ERR_ARG;
   T3D_CHECK_LAUNCH();
   return T3D_OK;

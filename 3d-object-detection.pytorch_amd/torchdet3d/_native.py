@@ -58,6 +58,8 @@ SIGNATURES = {
     't3d_head_bwd': [_P, _PP, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P],
     't3d_se_fwd': [_P] * 11 + [_I, _I, _I, _I, _P],
     't3d_se_bwd': [_P] * 18 + [_I, _I, _I, _I, _P],
+    't3d_se_after_sums': [_I, _P, _P, _PP, _P, _I, _I, _I, _P],
+    't3d_se_after_apply': [_I, _P, _P, _PP, _P, _P, _P, _P, _I, _I, _I, _P],
     't3d_set_reduction_replicas': [_I, _L],
     't3d_set_workspace': [_P, _L],
     't3d_pack_weights_batched': [_I, _P, _I, _P],

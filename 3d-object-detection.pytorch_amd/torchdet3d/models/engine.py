@@ -282,6 +282,13 @@ class Net:
                    N.ptr(bn.scale), N.ptr(bn.shift), st)
         return self._pro(bn, act)
 
+    def _const(self, n, v):
+        key = f'const:{n}:{v}'
+        t = self._bufs.get(key)
+        if t is None:
+            t = self._bufs[key] = torch.full((n,), v, device=self.device, dtype=torch.float32)
+        return t
+
     def _pro(self, bn, act, se=None, se_after=False):
         if se is None:
             p = bn.pro_cache.get(act)
@@ -404,21 +411,35 @@ class Net:
             dwn, bnn, pwn, bn3n = p + '.3.weight', p + '.4', p + '.7.weight', p + '.8'
         else:                                                             # mobilenetv3.py:133-144
             dwn, bnn, pwn, bn3n = p + '.0.weight', p + '.1', p + '.4.weight', p + '.5'
-        if blk.se and not blk.expand:
-            raise NotImplementedError('squeeze-excite AFTER the activation (no-expand layout, mobilenetv3_small '
-                                      'features.1) is not built yet')
-        sen = (p + '.5') if blk.se else None
+        se_after = bool(blk.se and not blk.expand)         # gate AFTER the activation (mobilenetv3.py:138-140)
+        sen = ((p + '.3') if se_after else (p + '.5')) if blk.se else None
         # depthwise k x k (mobilenetv3.py:136,152)
         pad = (blk.k - 1) // 2
         Ho, Wo = (H + 2 * pad - blk.k) // blk.s + 1, (W + 2 * pad - blk.k) // blk.s + 1
         M2 = B * Ho * Wo
         bn2 = self.bns[bnn]
         y2 = self._buf(f'y2:{i}', (M2, blk.cexp))
-        gap = self._buf(f'gap:{i}', (B, blk.cexp), torch.float32, zero=True) if blk.se else None
+        gap = self._buf(f'gap:{i}', (B, blk.cexp), torch.float32, zero=True) if (blk.se and not se_after) else None
         N.call('t3d_dwconv_fwd', dt, N.ptr(src.t), src.pro, N.ptr(self.p[dwn]), N.ptr(y2), self._st(bn2), N.ptr(gap),
                B, H, W, blk.cexp, blk.k, blk.s, st, nbytes=(B * H * W + M2) * blk.cexp * self.esz)
         pro2 = self._bn_fwd(bn2, M2, blk.act)
-        if blk.se:                                                        # mobilenetv3.py:92-107,155
+        if se_after:
+            # the gate sees the ACTIVATED tensor: one pooled pass over it, then the same two FCs (scale 1, shift 0, HW 1
+            # make t3d_se_fwd take the pooled mean as it is)
+            C, R = blk.cexp, blk.se
+            pooled = self._buf(f'se_pool:{i}', (B, C), torch.float32)
+            N.call('t3d_gap_fwd', dt, N.ptr(y2), pro2, N.ptr(pooled), B, Ho * Wo, C, st)
+            se = dict(gap=pooled, m=self._buf(f'se_m:{i}', (B, C), torch.float32),
+                      h=self._buf(f'se_h:{i}', (B, R), torch.float32), q=self._buf(f'se_q:{i}', (B, C), torch.float32),
+                      s=self._buf(f'se_s:{i}', (B, C), torch.float32), name=sen, HW=Ho * Wo, after=True, pro2n=pro2)
+            ones, zeros = self._const(C, 1.0), self._const(C, 0.0)
+            N.call('t3d_se_fwd', N.ptr(pooled), N.ptr(ones), N.ptr(zeros), N.ptr(self.p[sen + '.fc.0.weight']),
+                   N.ptr(self.p[sen + '.fc.0.bias']), N.ptr(self.p[sen + '.fc.2.weight']),
+                   N.ptr(self.p[sen + '.fc.2.bias']), N.ptr(se['m']), N.ptr(se['h']), N.ptr(se['q']), N.ptr(se['s']),
+                   B, C, R, 1, st)
+            pro2 = self._pro(bn2, blk.act, se['s'], True)
+            rec['se'] = se
+        elif blk.se:                                                      # mobilenetv3.py:92-107,155
             C, R = blk.cexp, blk.se
             se = dict(gap=gap, m=self._buf(f'se_m:{i}', (B, C), torch.float32),
                       h=self._buf(f'se_h:{i}', (B, R), torch.float32), q=self._buf(f'se_q:{i}', (B, C), torch.float32),
@@ -655,6 +676,30 @@ class Net:
         if se is None:
             dv2 = self._pw_dgrad(dz, rec['y3'], bb3, self.wt[pwn], s2, None, M2, HW2, blk.cexp, blk.cout, f'dv2:{i}')
             bb2 = self._bn_bwd(s2.bn)
+        elif se.get('after'):
+            # gate after the activation: dv = gradient at the gated tensor (plain data gradient); the gate's gradient
+            # needs sum_hw dv*a, the pooled path adds g to every pixel BEFORE the activation derivative
+            C, R, sen = blk.cexp, blk.se, se['name']
+            bn2 = s2.bn
+            dv = self._buf(f'dv2g:{i}', (M2, C))
+            N.call('t3d_pwconv_dgrad', dt, N.ptr(dz), N.ptr(rec['y3']), bb3, N.ptr(self.wt[pwn]), None, None, None,
+                   N.ptr(dv), None, None, M2, HW2, C, blk.cout, st, nbytes=M2 * (C + blk.cout) * self.esz)
+            ps = self._buf(f'se_ps:{i}', (B, C, 2), torch.float32)
+            N.call('t3d_se_after_sums', dt, N.ptr(dv), N.ptr(s2.raw), se['pro2n'], N.ptr(ps), B, HW2, C, st)
+            g = self._buf(f'se_g:{i}', (B, C), torch.float32)
+            dq = self._buf(f'se_dq:{i}', (B, C), torch.float32)
+            dp = self._buf(f'se_dp:{i}', (B, R), torch.float32)
+            scratch = self._buf(f'se_scr:{i}', (2 * C,), torch.float64)      # t3d_se_bwd's before-activation sums: unused
+            ones, zeros = self._const(C, 1.0), self._const(C, 0.0)
+            N.call('t3d_se_bwd', N.ptr(ps), N.ptr(se['gap']), N.ptr(zeros), N.ptr(ones),
+                   N.ptr(self.p[sen + '.fc.0.weight']), N.ptr(self.p[sen + '.fc.2.weight']), N.ptr(se['m']),
+                   N.ptr(se['h']), N.ptr(se['q']), N.ptr(se['s']), N.ptr(g), N.ptr(dq), N.ptr(dp), N.ptr(scratch),
+                   N.ptr(self.g[sen + '.fc.0.weight']), N.ptr(self.g[sen + '.fc.0.bias']),
+                   N.ptr(self.g[sen + '.fc.2.weight']), N.ptr(self.g[sen + '.fc.2.bias']), B, C, R, se['HW'], st)
+            dv2 = self._buf(f'dv2:{i}', (M2, C))
+            N.call('t3d_se_after_apply', dt, N.ptr(dv), N.ptr(s2.raw), se['pro2n'], N.ptr(se['s']), N.ptr(g), N.ptr(dv2),
+                   N.ptr(bn2.bstats), B, HW2, C, st)
+            bb2 = self._bn_bwd(bn2)
         else:
             # gated tensor: the data gradient reports per-SAMPLE sums; the gate's backward turns them into the
             # BatchNorm sums and the per-sample affine  dy = (alpha*s) dv + beta y + (gamma + alpha*g)

@@ -218,6 +218,16 @@ int t3d_se_fwd(const float* gap_sum, const float* scale, const float* shift, con
                const float* w2, const float* b2, float* m, float* h, float* q, float* s, int B, int C, int R, int HW,
                void* stream);
 
+/* Squeeze-excite applied AFTER the activation (the no-expand block layout, mobilenetv3.py:138-140: dw -> BN -> act ->
+ * SE -> 1x1; MobileNetV3-small features.1): v = s*a, a = act(scale*y + shift).  Forward: t3d_gap_fwd gives mean_hw(a),
+ * t3d_se_fwd (scale = 1, shift = 0, HW = 1) the gate.  Backward, with dv [B*HW,C] the gradient at the gated tensor:
+ *   _sums : ps [B,C,2] = { sum_hw dv*a, 0 }   -> t3d_se_bwd with scale = 0, shift = 1 (so that ds = ps[..][0]) gives g
+ *   _apply: du = (s*dv + g) * act'(scale*y + shift) at the BatchNorm output, stats [2*C] fp64 += sum(du), sum(du*y). */
+int t3d_se_after_sums(int dtype, const void* dv, const void* y, const t3d_prologue* pro, float* ps, int B, int HW, int C,
+                      void* stream);
+int t3d_se_after_apply(int dtype, const void* dv, const void* y, const t3d_prologue* pro, const float* s, const float* g,
+                       void* du, double* stats, int B, int HW, int C, void* stream);
+
 /* Backward of the gate.  ps_stats [B,C,2] = per-sample sum_hw(dv), sum_hw(dv*y) from t3d_pwconv_dgrad
  * (dv: gradient at the gated tensor, y: raw depthwise output).  Produces g [B,C] (the pooled path's
  * per-pixel gradient, so that du = s*dv + g), accumulates the depthwise BatchNorm's backward sums

@@ -43,6 +43,7 @@ def _loss_cfg(lnames, coeffs):
 
 
 CASES = [('mobilenetv2', 4, 64, 9, ['l1', 'add_loss', 'cross_entropy'], ([1., .1], [.2])),
+         ('mobilenetv3_small', 4, 96, 9, ['l1', 'add_loss', 'cross_entropy'], ([1., .1], [.2])),
          ('mobilenetv2', 6, 128, 1, ['mse', 'diag_loss', 'add_loss'], ([1., .5, .1], [])),
          ('mobilenetv2', 2, 224, 9, ['smoothl1', 'wing', 'cross_entropy'], ([1., .3], [.5]))]
 
@@ -56,7 +57,8 @@ def test_train_step_fp32_matches_oracle(name, B, HW, nc, lnames, coeffs):
     sd = make_state_dict(name, nc)
     imgs, gt_kp, cats = make_inputs(B, HW, HW, nc)
     g = torch.Generator().manual_seed(3)
-    mask = (torch.rand(B, 1280, generator=g) >= 0.5).float() * 2 if nc > 1 else None
+    from torchdet3d.models.arch import Arch
+    mask = (torch.rand(B, Arch(name).feat_c, generator=g) >= 0.5).float() * 2 if nc > 1 else None
 
     net = Net(name, nc, 'cuda', torch.float32)
     net.load_state_dict(sd)

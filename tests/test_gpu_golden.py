@@ -15,6 +15,7 @@ import torch
 pytestmark = pytest.mark.gpu
 
 CASES = [('mnv3_large_b4_96', 'mobilenetv3_large', 4, 96, 9, ['l1', 'add_loss', 'cross_entropy'], ([1., .1], [.2])),
+         ('mnv3_small_b4_96', 'mobilenetv3_small', 4, 96, 9, ['l1', 'add_loss', 'cross_entropy'], ([1., .1], [.2])),
          ('mnv3_large_c1_b8_96', 'mobilenetv3_large', 8, 96, 1, ['mse', 'diag_loss', 'add_loss'], ([1., .5, .1], [])),
          ('mnv3_large_b2_224', 'mobilenetv3_large', 2, 224, 9, ['smoothl1', 'wing', 'cross_entropy'], ([1., .3], [.5]))]
 
