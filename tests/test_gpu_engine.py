@@ -184,3 +184,45 @@ def test_bf16_training_tracks_fp32_training():
     end32, end16 = sum(f32[-10:]) / 10, sum(b16[-10:]) / 10
     assert end32 < 0.8 * f32[0] and end16 < 0.8 * b16[0], (f32[0], end32, b16[0], end16)
     assert abs(end16 - end32) < 0.2 * end32, (end32, end16)
+
+
+def test_yfree_expand_backward_matches_regular_path(monkeypatch):
+    """bf16 engine: the y-free backward of the expand convs (csrc/pwconv_yfree.hip) against the kernels that read the
+    conv output, on the SAME saved forward (a second forward would differ by the chaotic amplification of summation-order
+    noise through ~50 bf16-rounded train-mode BatchNorm layers, which swamps what is compared here)."""
+    from oracle.weights import make_inputs
+    from torchdet3d.models import engine as E
+    from torchdet3d import _native as N
+    name, B, HW, nc = 'mobilenetv2', 16, 96, 9
+    imgs, gt_kp, cats = make_inputs(B, HW, HW, nc)
+    net = E.Net(name, nc, 'cuda', torch.bfloat16)
+    net.reset_parameters(seed=11)
+    ones = torch.ones(B, 1280, device='cuda')
+    kp, lg = net.forward(imgs.cuda(), cats.cuda(), train=True, dropout_mask=ones)
+    out = torch.zeros(16, device='cuda')
+    dkp, dlg = torch.empty(B, 18, device='cuda'), torch.empty(B, nc, device='cuda')
+    cfg = _loss_cfg(['l1', 'add_loss', 'cross_entropy'], ([1., .1], [.2]))
+    gtd, cd = gt_kp.cuda().view(B, 18).contiguous(), cats.cuda()
+    N.call('t3d_loss_fwd_bwd', cfg, N.ptr(kp.view(B, 18)), N.ptr(gtd), N.ptr(lg), N.ptr(cd), N.ptr(out), N.ptr(dkp),
+           N.ptr(dlg), B, nc, N.stream())
+    saved, grads = net.saved, []
+    for thr in (1, 0, 0):
+        monkeypatch.setattr(E, 'YFREE_MIN_ELEMS', thr)
+        net.saved = saved
+        net._statbuf[:, net._statbuf.shape[1] // 2:].zero_()      # the backward sums of the previous pass
+        net.backward(dkp, dlg)
+        torch.cuda.synchronize()
+        grads.append({k: v.detach().float().cpu().clone() for k, v in net.g.items()})
+    yf, ref, ref2 = grads
+
+    def worst(a, b):
+        w = (0.0, None)
+        for k in b:
+            # floor: projection-BatchNorm biases feeding a conv + train-mode BatchNorm have an exactly-zero true gradient
+            n = max(b[k].norm().item(), 1e-3 * b[k].numel() ** .5)
+            w = max(w, ((a[k] - b[k]).norm().item() / n, k))
+        return w
+    noise, diff = worst(ref2, ref), worst(yf, ref)
+    assert diff[0] < max(3e-2, 3 * noise[0]), (diff, noise)
+    # and the y-free path really ran: the expand weight gradients differ in the last bits
+    assert any((yf[k] != ref[k]).any() for k in ref if k.endswith('conv.0.weight'))
