@@ -2,8 +2,7 @@
 //   m = mean_hw BN(y)  ->  h = relu(W1 m + b1)  ->  q = W2 h + b2  ->  s = h_sigmoid(q),   x * s
 // The spatial mean never touches the feature map again: the depthwise kernel already emitted
 // sum_hw(y) per (sample, channel), and BN is affine, so m = scale * sum/HW + shift.
-// One workgroup per sample; every FC row is a 64-lane dot product + wave reduction (the two
-// weight matrices, <= 960x240 floats each, stay L2-resident across the 256 workgroups).
+// The two FCs run as small tiled products (64 samples x 16 outputs per workgroup, fp32 FMA).
 // Backward (same shape of work, reversed) consumes the per-sample sums  P1 = sum_hw dv,
 // P2 = sum_hw dv*y  that the projection conv's data-gradient kernel emitted (dv = gradient at the
 // gated tensor), and produces
@@ -25,78 +24,143 @@ struct SeArgs {
   int B, C, R, HW;
 };
 
-__global__ __launch_bounds__(256) void se_fwd_kernel(const SeArgs a) {
-  extern __shared__ float sm[];  // m[C], h[R]
-  float* mh = sm;
-  float* hh = sm + a.C;
-  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const float inv = 1.f / (float)a.HW;
-  for (int c = tid; c < a.C; c += 256) {
-    const float v = a.scale[c] * (a.gap[(size_t)b * a.C + c] * inv) + a.shift[c];
-    mh[c] = v;
-    a.m[(size_t)b * a.C + c] = v;
-  }
-  __syncthreads();
-  for (int r = wave; r < a.R; r += 4) {
-    const float* w = a.w1 + (size_t)r * a.C;
-    float acc = 0.f;
-    for (int c = lane; c < a.C; c += 64) acc = fmaf(w[c], mh[c], acc);
-    acc = wave_sum(acc);
-    if (lane == 0) {
-      const float v = fmaxf(acc + a.b1[r], 0.f);
-      hh[r] = v;
-      a.h[(size_t)b * a.R + r] = v;
+// ---- small dense layers as tiled products (one workgroup per sample re-read both weight matrices, 1.8 MB, 256 times:
+// 320 us forward / 210 us backward per launch; the tiles below read each weight once per 64-sample tile)
+// out[b][o] = sum_i in(b, i) * W(o, i) for a 64-sample x 16-output tile; thread = (sample bl, 4 outputs og*4..+3).
+// WT: W is stored [I][O] (the transposed products of the backward), else [O][I].
+template <bool WT, typename InF>
+__device__ __forceinline__ void fc_tile(InF in, const float* __restrict__ W, int I, int O, int b0, int o0, int B,
+                                        float acc[4], float (*lin)[65], float (*lw)[65]) {
+  const int t = threadIdx.x, bl = t & 63, og = t >> 6;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) acc[j] = 0.f;
+  for (int i0 = 0; i0 < I; i0 += 64) {
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+      const int idx = t + 256 * k, row = idx >> 6, col = idx & 63;
+      const int b = b0 + row, i = i0 + col;
+      lin[row][col] = (b < B && i < I) ? in(b, i) : 0.f;
     }
-  }
-  __syncthreads();
-  for (int c = wave; c < a.C; c += 4) {
-    const float* w = a.w2 + (size_t)c * a.R;
-    float acc = 0.f;
-    for (int r = lane; r < a.R; r += 64) acc = fmaf(w[r], hh[r], acc);
-    acc = wave_sum(acc);
-    if (lane == 0) {
-      const float v = acc + a.b2[c];
-      a.q[(size_t)b * a.C + c] = v;
-      a.s[(size_t)b * a.C + c] = hsigmoid(v);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int idx = t + 256 * k;
+      int row, col;
+      if (WT) { row = idx & 15; col = idx >> 4; } else { row = idx >> 6; col = idx & 63; }
+      const int o = o0 + row, i = i0 + col;
+      float v = 0.f;
+      if (o < O && i < I) v = WT ? W[(size_t)i * O + o] : W[(size_t)o * I + i];
+      lw[row][col] = v;
+    }
+    __syncthreads();
+#pragma unroll 8
+    for (int ii = 0; ii < 64; ++ii) {
+      const float x = lin[bl][ii];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[j] = fmaf(x, lw[og * 4 + j][ii], acc[j]);
     }
   }
 }
 
-__global__ __launch_bounds__(256) void se_bwd_kernel(const SeArgs a) {
-  extern __shared__ float sm[];  // dq[C], dp[R]
-  float* dqs = sm;
-  float* dps = sm + a.C;
-  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  for (int c = tid; c < a.C; c += 256) {
-    const size_t i = (size_t)b * a.C + c;
-    const float p1 = a.ps[2 * i], p2 = a.ps[2 * i + 1];
-    const float ds = a.scale[c] * p2 + a.shift[c] * p1;      // sum_hw dv * u,  u = scale*y + shift
-    const float q = a.q[i];
-    const float v = (q > -3.f && q < 3.f) ? ds * (1.f / 6.f) : 0.f;   // h_sigmoid' (relu6 passes strictly inside)
-    dqs[c] = v;
-    a.dq[i] = v;
-  }
-  __syncthreads();
-  // dh[r] = sum_c dq[c] * W2[c][r]   (thread r walks a column; W2 rows are R floats apart)
-  for (int r = tid; r < a.R; r += 256) {
-    float acc = 0.f;
-    for (int c = 0; c < a.C; ++c) acc = fmaf(dqs[c], a.w2[(size_t)c * a.R + r], acc);
-    const float v = a.h[(size_t)b * a.R + r] > 0.f ? acc : 0.f;
-    dps[r] = v;
-    a.dp[(size_t)b * a.R + r] = v;
-  }
-  __syncthreads();
-  // dm[c] = sum_r dp[r] * W1[r][c]  (coalesced over c)
+// grid (ceil(R/16), ceil(B/64)): h = relu(W1 m + b1), m = scale*gap/HW + shift (written by the first column of blocks)
+__global__ __launch_bounds__(256) void se_fc1_kernel(const SeArgs a) {
+  __shared__ float lin[64][65], lw[16][65];
+  const int o0 = blockIdx.x * 16, b0 = blockIdx.y * 64;
   const float inv = 1.f / (float)a.HW;
-  for (int c = tid; c < a.C; c += 256) {
-    float acc = 0.f;
-    for (int r = 0; r < a.R; ++r) acc = fmaf(dps[r], a.w1[(size_t)r * a.C + c], acc);
-    const size_t i = (size_t)b * a.C + c;
-    const float gu = acc * inv;   // m = mean_hw(u): every pixel of u receives dL/dm / HW
-    a.g[i] = gu;
-    const float s = a.s[i], p1 = a.ps[2 * i], p2 = a.ps[2 * i + 1];
-    atomicAdd(a.stats + c, (double)(s * p1 + (float)a.HW * gu));
-    atomicAdd(a.stats + a.C + c, (double)(s * p2 + gu * a.gap[i]));
+  auto in = [&](int b, int c) { return a.scale[c] * (a.gap[(size_t)b * a.C + c] * inv) + a.shift[c]; };
+  float acc[4];
+  fc_tile<false>(in, a.w1, a.C, a.R, b0, o0, a.B, acc, lin, lw);
+  const int b = b0 + (threadIdx.x & 63), og = threadIdx.x >> 6;
+  if (b < a.B) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int r = o0 + og * 4 + j;
+      if (r < a.R) a.h[(size_t)b * a.R + r] = fmaxf(acc[j] + a.b1[r], 0.f);
+    }
+  }
+  if (blockIdx.x == 0) {
+    for (int i = threadIdx.x; i < 64 * a.C; i += 256) {
+      const int bb = b0 + i / a.C, c = i % a.C;
+      if (bb < a.B) a.m[(size_t)bb * a.C + c] = in(bb, c);
+    }
+  }
+}
+
+// grid (ceil(C/16), ceil(B/64)): q = W2 h + b2, s = h_sigmoid(q)
+__global__ __launch_bounds__(256) void se_fc2_kernel(const SeArgs a) {
+  __shared__ float lin[64][65], lw[16][65];
+  const int o0 = blockIdx.x * 16, b0 = blockIdx.y * 64;
+  auto in = [&](int b, int r) { return a.h[(size_t)b * a.R + r]; };
+  float acc[4];
+  fc_tile<false>(in, a.w2, a.R, a.C, b0, o0, a.B, acc, lin, lw);
+  const int b = b0 + (threadIdx.x & 63), og = threadIdx.x >> 6;
+  if (b < a.B) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int c = o0 + og * 4 + j;
+      if (c < a.C) {
+        const float v = acc[j] + a.b2[c];
+        a.q[(size_t)b * a.C + c] = v;
+        a.s[(size_t)b * a.C + c] = hsigmoid(v);
+      }
+    }
+  }
+}
+
+// dq = h_sigmoid'(q) * ds,  ds = sum_hw dv*u = scale*P2 + shift*P1
+__global__ __launch_bounds__(256) void se_dq_kernel(const SeArgs a) {
+  const size_t i = blockIdx.x * (size_t)256 + threadIdx.x;
+  if (i >= (size_t)a.B * a.C) return;
+  const int c = (int)(i % a.C);
+  const float ds = a.scale[c] * a.ps[2 * i + 1] + a.shift[c] * a.ps[2 * i];
+  const float q = a.q[i];
+  a.dq[i] = (q > -3.f && q < 3.f) ? ds * (1.f / 6.f) : 0.f;     // relu6 passes strictly inside
+}
+
+// grid (ceil(R/16), ceil(B/64)): dp = relu'(h) * (dq W2)
+__global__ __launch_bounds__(256) void se_dh_kernel(const SeArgs a) {
+  __shared__ float lin[64][65], lw[16][65];
+  const int o0 = blockIdx.x * 16, b0 = blockIdx.y * 64;
+  auto in = [&](int b, int c) { return a.dq[(size_t)b * a.C + c]; };
+  float acc[4];
+  fc_tile<true>(in, a.w2, a.C, a.R, b0, o0, a.B, acc, lin, lw);      // W2 is [C][R] = [I][O]
+  const int b = b0 + (threadIdx.x & 63), og = threadIdx.x >> 6;
+  if (b < a.B) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int r = o0 + og * 4 + j;
+      if (r < a.R) a.dp[(size_t)b * a.R + r] = a.h[(size_t)b * a.R + r] > 0.f ? acc[j] : 0.f;
+    }
+  }
+}
+
+// grid (ceil(C/16), ceil(B/64)): g = (dp W1) / HW, and the depthwise BatchNorm's backward sums of du = s*dv + g
+__global__ __launch_bounds__(256) void se_dm_kernel(const SeArgs a) {
+  __shared__ float lin[64][65], lw[16][65];
+  const int o0 = blockIdx.x * 16, b0 = blockIdx.y * 64;
+  auto in = [&](int b, int r) { return a.dp[(size_t)b * a.R + r]; };
+  float acc[4];
+  fc_tile<true>(in, a.w1, a.R, a.C, b0, o0, a.B, acc, lin, lw);      // W1 is [R][C] = [I][O]
+  const int b = b0 + (threadIdx.x & 63), og = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const float inv = 1.f / (float)a.HW;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int c = o0 + og * 4 + j;       // wave-uniform
+    float v1 = 0.f, v2 = 0.f;
+    if (b < a.B && c < a.C) {
+      const size_t i = (size_t)b * a.C + c;
+      const float gu = acc[j] * inv;     // m = mean_hw(u): every pixel of u receives dL/dm / HW
+      a.g[i] = gu;
+      const float s = a.s[i], p1 = a.ps[2 * i], p2 = a.ps[2 * i + 1];
+      v1 = s * p1 + (float)a.HW * gu;
+      v2 = s * p2 + gu * a.gap[i];
+    }
+    v1 = wave_sum(v1);
+    v2 = wave_sum(v2);
+    if (lane == 0 && c < a.C) {
+      atomicAdd(a.stats + c, (double)v1);
+      atomicAdd(a.stats + a.C + c, (double)v2);
+    }
   }
 }
 
@@ -138,8 +202,9 @@ extern "C" int t3d_se_fwd(const float* gap_sum, const float* scale, const float*
   SeArgs a{};
   a.gap = gap_sum; a.scale = scale; a.shift = shift; a.w1 = w1; a.b1 = b1; a.w2 = w2; a.b2 = b2;
   a.m = m; a.h = h; a.q = q; a.s = s; a.B = B; a.C = C; a.R = R; a.HW = HW;
-  hipLaunchKernelGGL(se_fwd_kernel, dim3(B), dim3(256), (size_t)(C + R) * sizeof(float),
-                     reinterpret_cast<hipStream_t>(stream), a);
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  hipLaunchKernelGGL(se_fc1_kernel, dim3(cdiv(R, 16), cdiv(B, 64)), dim3(256), 0, st, a);
+  hipLaunchKernelGGL(se_fc2_kernel, dim3(cdiv(C, 16), cdiv(B, 64)), dim3(256), 0, st, a);
   T3D_CHECK_LAUNCH();
   return T3D_OK;
 }
@@ -157,7 +222,9 @@ extern "C" int t3d_se_bwd(const float* ps_stats, const float* gap_sum, const flo
   a.g = g; a.dq = dq; a.dp = dp; a.stats = stats; a.dw1 = dw1; a.db1 = db1; a.dw2 = dw2; a.db2 = db2;
   a.B = B; a.C = C; a.R = R; a.HW = HW;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-  hipLaunchKernelGGL(se_bwd_kernel, dim3(B), dim3(256), (size_t)(C + R) * sizeof(float), st, a);
+  hipLaunchKernelGGL(se_dq_kernel, dim3(cdiv(B * C, 256)), dim3(256), 0, st, a);
+  hipLaunchKernelGGL(se_dh_kernel, dim3(cdiv(R, 16), cdiv(B, 64)), dim3(256), 0, st, a);
+  hipLaunchKernelGGL(se_dm_kernel, dim3(cdiv(C, 16), cdiv(B, 64)), dim3(256), 0, st, a);
   const int n = 2 * C * R + C + R;
   hipLaunchKernelGGL(se_wgrad_kernel, dim3(cdiv(n, 256)), dim3(256), 0, st, a);
   T3D_CHECK_LAUNCH();

@@ -128,3 +128,43 @@ def test_head_fwd_bwd(B, F, nc, with_pro):
     if with_pro:
         np.testing.assert_allclose(stats[:F].cpu().numpy(), u.grad.double().sum(0).numpy(), atol=1e-5)
         np.testing.assert_allclose(stats[F:].cpu().numpy(), (u.grad.double() * f.double()).sum(0).numpy(), atol=1e-5)
+
+
+@pytest.mark.parametrize('B,C,R,HW', [(256, 960, 240, 49), (5, 72, 24, 196), (70, 16, 8, 3136)])
+def test_se_gate_fwd_bwd(B, C, R, HW):
+    """t3d_se_fwd / t3d_se_bwd (SELayer, mobilenetv3.py:92-107) against torch autograd of the same two FCs."""
+    import torch.nn.functional as F
+    from torchdet3d import _native as N
+    g = torch.Generator().manual_seed(B + C)
+    rnd = lambda *s: torch.randn(*s, generator=g)
+    gap, scale, shift = rnd(B, C) * HW ** .5, torch.rand(C, generator=g) + .5, rnd(C) * .2
+    w1, b1, w2, b2 = rnd(R, C) / C ** .5, rnd(R) * .1, rnd(C, R) / R ** .5, rnd(C) * .5
+    ps = rnd(B, C, 2)
+    w1r, b1r, w2r, b2r = (t.clone().requires_grad_(True) for t in (w1, b1, w2, b2))
+    m = (scale * gap / HW + shift).requires_grad_(True)
+    h = F.relu(F.linear(m, w1r, b1r))
+    q = F.linear(h, w2r, b2r)
+    s = F.relu6(q + 3) / 6
+    ds = scale * ps[..., 1] + shift * ps[..., 0]
+    (s * ds).sum().backward()
+    d = lambda t: t.contiguous().cuda()
+    gd, scd, shd, w1d, b1d, w2d, b2d, psd = map(d, (gap, scale, shift, w1, b1, w2, b2, ps))
+    mo, ho, qo, so = (torch.empty(B, n, device='cuda') for n in (C, R, C, C))
+    N.call('t3d_se_fwd', N.ptr(gd), N.ptr(scd), N.ptr(shd), N.ptr(w1d), N.ptr(b1d), N.ptr(w2d), N.ptr(b2d), N.ptr(mo),
+           N.ptr(ho), N.ptr(qo), N.ptr(so), B, C, R, HW, N.stream())
+    go, dq, dp = torch.empty(B, C, device='cuda'), torch.empty(B, C, device='cuda'), torch.empty(B, R, device='cuda')
+    stats = torch.zeros(2 * C, device='cuda', dtype=torch.float64)
+    dw1, db1, dw2, db2 = (torch.empty_like(t) for t in (w1d, b1d, w2d, b2d))
+    N.call('t3d_se_bwd', N.ptr(psd), N.ptr(gd), N.ptr(scd), N.ptr(shd), N.ptr(w1d), N.ptr(w2d), N.ptr(mo), N.ptr(ho),
+           N.ptr(qo), N.ptr(so), N.ptr(go), N.ptr(dq), N.ptr(dp), N.ptr(stats), N.ptr(dw1), N.ptr(db1), N.ptr(dw2),
+           N.ptr(db2), B, C, R, HW, N.stream())
+    torch.cuda.synchronize()
+    close = lambda a, b, tol=2e-5: np.testing.assert_allclose(a.cpu().numpy(), b.detach().numpy(), rtol=1e-4,
+                                                              atol=tol * max(1., b.detach().abs().max().item()))
+    close(mo, m); close(ho, h); close(qo, q); close(so, s)
+    close(go, m.grad / HW); close(dw1, w1r.grad); close(db1, b1r.grad); close(dw2, w2r.grad); close(db2, b2r.grad)
+    gref = (m.grad / HW).detach()
+    st0 = (s.detach() * ps[..., 0] + HW * gref).double().sum(0)
+    st1 = (s.detach() * ps[..., 1] + gref * gap).double().sum(0)
+    np.testing.assert_allclose(stats[:C].cpu().numpy(), st0.numpy(), rtol=1e-4, atol=1e-3 * B ** .5)
+    np.testing.assert_allclose(stats[C:].cpu().numpy(), st1.numpy(), rtol=1e-4, atol=1e-3 * B ** .5 * HW ** .5)
