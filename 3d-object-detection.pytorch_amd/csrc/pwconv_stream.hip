@@ -274,15 +274,25 @@ __global__ __launch_bounds__(512, 2) void pw_stream_kernel(const GemmArgs a, con
             st2[q][j] = fmaf(v[j], (DG && a.e_y) ? yv[j] : v[j], st2[q][j]);
           }
         } else if (GEN && a.ps_stats) {
+          // per-sample sums: the 16 pixel rows of a group span one sample, or two (HW >= 16: 7x7 maps straddle in most
+          // groups) -- two masked 16-lane reductions and one atomic pair each; more than two samples (HW < 16) falls
+          // back to one atomic pair per lane
+          const int b_first = min(mrow0, a.M - 1) / a.HW, b_last = min(mlast, a.M - 1) / a.HW;
+          const bool two = (b_last - b_first) <= 1;
 #pragma unroll
           for (int j = 0; j < 8; ++j) {
-            float s1 = v[j], s2 = v[j] * yv[j];
-            if (uni) {
-              s1 = row16_sum(s1);
-              s2 = row16_sum(s2);
+            const float s1 = v[j], s2 = v[j] * yv[j];      // v is 0 for rows past M
+            if (two) {
+              const bool in0 = bidx == b_first;
+              const float a1 = row16_sum(in0 ? s1 : 0.f), a2 = row16_sum(in0 ? s2 : 0.f);
+              const float c1 = row16_sum(in0 ? 0.f : s1), c2 = row16_sum(in0 ? 0.f : s2);
               if (lc == 0) {
-                unsafeAtomicAdd(a.ps_stats + ((size_t)bidx * a.Nout + n + j) * 2, s1);
-                unsafeAtomicAdd(a.ps_stats + ((size_t)bidx * a.Nout + n + j) * 2 + 1, s2);
+                unsafeAtomicAdd(a.ps_stats + ((size_t)b_first * a.Nout + n + j) * 2, a1);
+                unsafeAtomicAdd(a.ps_stats + ((size_t)b_first * a.Nout + n + j) * 2 + 1, a2);
+                if (b_last != b_first) {
+                  unsafeAtomicAdd(a.ps_stats + ((size_t)b_last * a.Nout + n + j) * 2, c1);
+                  unsafeAtomicAdd(a.ps_stats + ((size_t)b_last * a.Nout + n + j) * 2 + 1, c2);
+                }
               }
             } else if (ok) {
               unsafeAtomicAdd(a.ps_stats + ((size_t)bidx * a.Nout + n + j) * 2, s1);

@@ -26,27 +26,30 @@ struct SeArgs {
 
 // ---- small dense layers as tiled products (one workgroup per sample re-read both weight matrices, 1.8 MB, 256 times:
 // 320 us forward / 210 us backward per launch; the tiles below read each weight once per 64-sample tile)
-// out[b][o] = sum_i in(b, i) * W(o, i) for a 64-sample x 16-output tile; thread = (sample bl, 4 outputs og*4..+3).
+// out[b][o] = sum_i in(b, i) * W(o, i) for a 64-sample x OT-output tile; thread = (sample bl, OT/4 outputs og*PT..).
 // WT: W is stored [I][O] (the transposed products of the backward), else [O][I].
-template <bool WT, typename InF>
+// OT = 4: the layers are tiny (B = 256 samples), so what matters is enough workgroups to hide the load latency.
+constexpr int OT = 4, PT = OT / 4;
+// IT: the input is read transposed (rows of the tile are its fast axis in memory) -- the weight-gradient products.
+template <bool WT, bool IT = false, typename InF>
 __device__ __forceinline__ void fc_tile(InF in, const float* __restrict__ W, int I, int O, int b0, int o0, int B,
-                                        float acc[4], float (*lin)[65], float (*lw)[65]) {
+                                        float acc[PT], float (*lin)[65], float (*lw)[65]) {
   const int t = threadIdx.x, bl = t & 63, og = t >> 6;
 #pragma unroll
-  for (int j = 0; j < 4; ++j) acc[j] = 0.f;
+  for (int j = 0; j < PT; ++j) acc[j] = 0.f;
   for (int i0 = 0; i0 < I; i0 += 64) {
     __syncthreads();
 #pragma unroll
     for (int k = 0; k < 16; ++k) {
-      const int idx = t + 256 * k, row = idx >> 6, col = idx & 63;
+      const int idx = t + 256 * k, row = IT ? (idx & 63) : (idx >> 6), col = IT ? (idx >> 6) : (idx & 63);
       const int b = b0 + row, i = i0 + col;
       lin[row][col] = (b < B && i < I) ? in(b, i) : 0.f;
     }
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
+    for (int k = 0; k < OT / 4; ++k) {
       const int idx = t + 256 * k;
       int row, col;
-      if (WT) { row = idx & 15; col = idx >> 4; } else { row = idx >> 6; col = idx & 63; }
+      if (WT) { row = idx % OT; col = idx / OT; } else { row = idx >> 6; col = idx & 63; }
       const int o = o0 + row, i = i0 + col;
       float v = 0.f;
       if (o < O && i < I) v = WT ? W[(size_t)i * O + o] : W[(size_t)o * I + i];
@@ -57,24 +60,24 @@ __device__ __forceinline__ void fc_tile(InF in, const float* __restrict__ W, int
     for (int ii = 0; ii < 64; ++ii) {
       const float x = lin[bl][ii];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) acc[j] = fmaf(x, lw[og * 4 + j][ii], acc[j]);
+      for (int j = 0; j < PT; ++j) acc[j] = fmaf(x, lw[og * PT + j][ii], acc[j]);
     }
   }
 }
 
-// grid (ceil(R/16), ceil(B/64)): h = relu(W1 m + b1), m = scale*gap/HW + shift (written by the first column of blocks)
+// grid (ceil(R/OT), ceil(B/64)): h = relu(W1 m + b1), m = scale*gap/HW + shift (written by the first column of blocks)
 __global__ __launch_bounds__(256) void se_fc1_kernel(const SeArgs a) {
-  __shared__ float lin[64][65], lw[16][65];
-  const int o0 = blockIdx.x * 16, b0 = blockIdx.y * 64;
+  __shared__ float lin[64][65], lw[OT][65];
+  const int o0 = blockIdx.x * OT, b0 = blockIdx.y * 64;
   const float inv = 1.f / (float)a.HW;
   auto in = [&](int b, int c) { return a.scale[c] * (a.gap[(size_t)b * a.C + c] * inv) + a.shift[c]; };
-  float acc[4];
+  float acc[PT];
   fc_tile<false>(in, a.w1, a.C, a.R, b0, o0, a.B, acc, lin, lw);
   const int b = b0 + (threadIdx.x & 63), og = threadIdx.x >> 6;
   if (b < a.B) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int r = o0 + og * 4 + j;
+    for (int j = 0; j < PT; ++j) {
+      const int r = o0 + og * PT + j;
       if (r < a.R) a.h[(size_t)b * a.R + r] = fmaxf(acc[j] + a.b1[r], 0.f);
     }
   }
@@ -86,18 +89,18 @@ __global__ __launch_bounds__(256) void se_fc1_kernel(const SeArgs a) {
   }
 }
 
-// grid (ceil(C/16), ceil(B/64)): q = W2 h + b2, s = h_sigmoid(q)
+// grid (ceil(C/OT), ceil(B/64)): q = W2 h + b2, s = h_sigmoid(q)
 __global__ __launch_bounds__(256) void se_fc2_kernel(const SeArgs a) {
-  __shared__ float lin[64][65], lw[16][65];
-  const int o0 = blockIdx.x * 16, b0 = blockIdx.y * 64;
+  __shared__ float lin[64][65], lw[OT][65];
+  const int o0 = blockIdx.x * OT, b0 = blockIdx.y * 64;
   auto in = [&](int b, int r) { return a.h[(size_t)b * a.R + r]; };
-  float acc[4];
+  float acc[PT];
   fc_tile<false>(in, a.w2, a.R, a.C, b0, o0, a.B, acc, lin, lw);
   const int b = b0 + (threadIdx.x & 63), og = threadIdx.x >> 6;
   if (b < a.B) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int c = o0 + og * 4 + j;
+    for (int j = 0; j < PT; ++j) {
+      const int c = o0 + og * PT + j;
       if (c < a.C) {
         const float v = acc[j] + a.b2[c];
         a.q[(size_t)b * a.C + c] = v;
@@ -117,35 +120,35 @@ __global__ __launch_bounds__(256) void se_dq_kernel(const SeArgs a) {
   a.dq[i] = (q > -3.f && q < 3.f) ? ds * (1.f / 6.f) : 0.f;     // relu6 passes strictly inside
 }
 
-// grid (ceil(R/16), ceil(B/64)): dp = relu'(h) * (dq W2)
+// grid (ceil(R/OT), ceil(B/64)): dp = relu'(h) * (dq W2)
 __global__ __launch_bounds__(256) void se_dh_kernel(const SeArgs a) {
-  __shared__ float lin[64][65], lw[16][65];
-  const int o0 = blockIdx.x * 16, b0 = blockIdx.y * 64;
+  __shared__ float lin[64][65], lw[OT][65];
+  const int o0 = blockIdx.x * OT, b0 = blockIdx.y * 64;
   auto in = [&](int b, int c) { return a.dq[(size_t)b * a.C + c]; };
-  float acc[4];
+  float acc[PT];
   fc_tile<true>(in, a.w2, a.C, a.R, b0, o0, a.B, acc, lin, lw);      // W2 is [C][R] = [I][O]
   const int b = b0 + (threadIdx.x & 63), og = threadIdx.x >> 6;
   if (b < a.B) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int r = o0 + og * 4 + j;
+    for (int j = 0; j < PT; ++j) {
+      const int r = o0 + og * PT + j;
       if (r < a.R) a.dp[(size_t)b * a.R + r] = a.h[(size_t)b * a.R + r] > 0.f ? acc[j] : 0.f;
     }
   }
 }
 
-// grid (ceil(C/16), ceil(B/64)): g = (dp W1) / HW, and the depthwise BatchNorm's backward sums of du = s*dv + g
+// grid (ceil(C/OT), ceil(B/64)): g = (dp W1) / HW, and the depthwise BatchNorm's backward sums of du = s*dv + g
 __global__ __launch_bounds__(256) void se_dm_kernel(const SeArgs a) {
-  __shared__ float lin[64][65], lw[16][65];
-  const int o0 = blockIdx.x * 16, b0 = blockIdx.y * 64;
+  __shared__ float lin[64][65], lw[OT][65];
+  const int o0 = blockIdx.x * OT, b0 = blockIdx.y * 64;
   auto in = [&](int b, int r) { return a.dp[(size_t)b * a.R + r]; };
-  float acc[4];
+  float acc[PT];
   fc_tile<true>(in, a.w1, a.R, a.C, b0, o0, a.B, acc, lin, lw);      // W1 is [R][C] = [I][O]
   const int b = b0 + (threadIdx.x & 63), og = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const float inv = 1.f / (float)a.HW;
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const int c = o0 + og * 4 + j;       // wave-uniform
+  for (int j = 0; j < PT; ++j) {
+    const int c = o0 + og * PT + j;       // wave-uniform
     float v1 = 0.f, v2 = 0.f;
     if (b < a.B && c < a.C) {
       const size_t i = (size_t)b * a.C + c;
@@ -164,30 +167,44 @@ __global__ __launch_bounds__(256) void se_dm_kernel(const SeArgs a) {
   }
 }
 
-// weight gradients: grid.x over output elements, each thread one element, loop over the batch (deterministic)
-__global__ __launch_bounds__(256) void se_wgrad_kernel(const SeArgs a) {
-  const int n2 = a.C * a.R;
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i < n2) {                       // dW2[c][r] = sum_b dq[b][c] * h[b][r]
-    const int c = i / a.R, r = i % a.R;
-    float acc = 0.f;
-    for (int b = 0; b < a.B; ++b) acc = fmaf(a.dq[(size_t)b * a.C + c], a.h[(size_t)b * a.R + r], acc);
-    a.dw2[i] = acc;
-  } else if (i < 2 * n2) {            // dW1[r][c] = sum_b dp[b][r] * m[b][c]
-    const int j = i - n2, r = j / a.C, c = j % a.C;
-    float acc = 0.f;
-    for (int b = 0; b < a.B; ++b) acc = fmaf(a.dp[(size_t)b * a.R + r], a.m[(size_t)b * a.C + c], acc);
-    a.dw1[j] = acc;
-  } else if (i < 2 * n2 + a.C) {
-    const int c = i - 2 * n2;
-    float acc = 0.f;
-    for (int b = 0; b < a.B; ++b) acc += a.dq[(size_t)b * a.C + c];
-    a.db2[c] = acc;
-  } else if (i < 2 * n2 + a.C + a.R) {
-    const int r = i - 2 * n2 - a.C;
-    float acc = 0.f;
-    for (int b = 0; b < a.B; ++b) acc += a.dp[(size_t)b * a.R + r];
-    a.db1[r] = acc;
+// weight gradients as the same tiled products, contraction over the batch:
+//   dW2[c][r] = sum_b dq[b][c] h[b][r]   (rows c, outputs r)      dW1[r][c] = sum_b dp[b][r] m[b][c]   (rows r, outputs c)
+// which = 0: dW2, grid (ceil(R/OT), ceil(C/64));  which = 1: dW1, grid (ceil(C/OT), ceil(R/64))
+__global__ __launch_bounds__(256) void se_wgrad_tile_kernel(const SeArgs a, int which) {
+  __shared__ float lin[64][65], lw[OT][65];
+  const int o0 = blockIdx.x * OT, r0 = blockIdx.y * 64;
+  const int rows = which == 0 ? a.C : a.R, outs = which == 0 ? a.R : a.C;
+  const float* src = which == 0 ? a.dq : a.dp;        // [B][rows]
+  const float* wsrc = which == 0 ? a.h : a.m;         // [B][outs] = [I][O]
+  auto in = [&](int row, int b) { return src[(size_t)b * rows + row]; };
+  float acc[PT];
+  fc_tile<true, true>(in, wsrc, a.B, outs, r0, o0, rows, acc, lin, lw);
+  const int row = r0 + (threadIdx.x & 63), og = threadIdx.x >> 6;
+  float* dst = which == 0 ? a.dw2 : a.dw1;
+  if (row < rows) {
+#pragma unroll
+    for (int j = 0; j < PT; ++j) {
+      const int o = o0 + og * PT + j;
+      if (o < outs) dst[(size_t)row * outs + o] = acc[j];
+    }
+  }
+}
+
+// bias gradients: db2[c] = sum_b dq[b][c], db1[r] = sum_b dp[b][r]; block = 64 channels x 4 batch slices
+__global__ __launch_bounds__(256) void se_bias_kernel(const SeArgs a) {
+  __shared__ float red[4][64];
+  const int ch = blockIdx.x * 64 + (threadIdx.x & 63), sl = threadIdx.x >> 6;
+  const bool second = ch >= a.C;                       // channels [0, C): db2, [C, C+R): db1
+  const int c = second ? ch - a.C : ch, n = second ? a.R : a.C;
+  const float* src = second ? a.dp : a.dq;
+  float acc = 0.f;
+  if (c < n)
+    for (int b = sl; b < a.B; b += 4) acc += src[(size_t)b * n + c];
+  red[sl][threadIdx.x & 63] = acc;
+  __syncthreads();
+  if (sl == 0 && c < n) {
+    const float v = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+    (second ? a.db1 : a.db2)[c] = v;
   }
 }
 
@@ -203,8 +220,8 @@ extern "C" int t3d_se_fwd(const float* gap_sum, const float* scale, const float*
   a.gap = gap_sum; a.scale = scale; a.shift = shift; a.w1 = w1; a.b1 = b1; a.w2 = w2; a.b2 = b2;
   a.m = m; a.h = h; a.q = q; a.s = s; a.B = B; a.C = C; a.R = R; a.HW = HW;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-  hipLaunchKernelGGL(se_fc1_kernel, dim3(cdiv(R, 16), cdiv(B, 64)), dim3(256), 0, st, a);
-  hipLaunchKernelGGL(se_fc2_kernel, dim3(cdiv(C, 16), cdiv(B, 64)), dim3(256), 0, st, a);
+  hipLaunchKernelGGL(se_fc1_kernel, dim3(cdiv(R, OT), cdiv(B, 64)), dim3(256), 0, st, a);
+  hipLaunchKernelGGL(se_fc2_kernel, dim3(cdiv(C, OT), cdiv(B, 64)), dim3(256), 0, st, a);
   T3D_CHECK_LAUNCH();
   return T3D_OK;
 }
@@ -223,10 +240,11 @@ extern "C" int t3d_se_bwd(const float* ps_stats, const float* gap_sum, const flo
   a.B = B; a.C = C; a.R = R; a.HW = HW;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   hipLaunchKernelGGL(se_dq_kernel, dim3(cdiv(B * C, 256)), dim3(256), 0, st, a);
-  hipLaunchKernelGGL(se_dh_kernel, dim3(cdiv(R, 16), cdiv(B, 64)), dim3(256), 0, st, a);
-  hipLaunchKernelGGL(se_dm_kernel, dim3(cdiv(C, 16), cdiv(B, 64)), dim3(256), 0, st, a);
-  const int n = 2 * C * R + C + R;
-  hipLaunchKernelGGL(se_wgrad_kernel, dim3(cdiv(n, 256)), dim3(256), 0, st, a);
+  hipLaunchKernelGGL(se_dh_kernel, dim3(cdiv(R, OT), cdiv(B, 64)), dim3(256), 0, st, a);
+  hipLaunchKernelGGL(se_dm_kernel, dim3(cdiv(C, OT), cdiv(B, 64)), dim3(256), 0, st, a);
+  hipLaunchKernelGGL(se_wgrad_tile_kernel, dim3(cdiv(R, OT), cdiv(C, 64)), dim3(256), 0, st, a, 0);
+  hipLaunchKernelGGL(se_wgrad_tile_kernel, dim3(cdiv(C, OT), cdiv(R, 64)), dim3(256), 0, st, a, 1);
+  hipLaunchKernelGGL(se_bias_kernel, dim3(cdiv(C + R, 64)), dim3(256), 0, st, a);
   T3D_CHECK_LAUNCH();
   return T3D_OK;
 }
