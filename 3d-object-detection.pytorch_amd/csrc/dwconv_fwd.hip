@@ -252,12 +252,21 @@ int launch(const DwFwdArgs& a0, int k, int s, hipStream_t st) {
 int t3d_dw3_fwd_stream(int dtype, const void* x, const t3d_prologue* pro, const float* w, void* y, double* stats, int B,
                        int H, int W, int C, int stride, hipStream_t st);   // dwconv3_stream.hip
 
+int t3d_dwk_fwd_stream(int dtype, const void* x, const t3d_prologue* pro, const float* w, void* y, double* stats,
+                       float* gap_sum, int B, int H, int W, int C, int k, int stride, hipStream_t st);   // dwconvk_stream.hip
+
 extern "C" int t3d_dwconv_fwd(int dtype, const void* x, const t3d_prologue* pro, const float* w, void* y,
                               double* stats, float* gap_sum, int B, int H, int W, int C, int k, int stride,
                               void* stream) {
   if (!x || !w || !y || B <= 0 || H <= 0 || W <= 0 || C <= 0 || (C % 8)) return T3D_ERR_ARG;
   if (k == 3 && (stride == 1 || stride == 2) && !gap_sum && !(pro && pro->se) && !getenv("T3D_DW_TILED"))
     return t3d_dw3_fwd_stream(dtype, x, pro, w, y, stats, B, H, W, C, stride, reinterpret_cast<hipStream_t>(stream));
+  if ((k == 3 || k == 5) && (stride == 1 || stride == 2) && !(pro && pro->se) && !getenv("T3D_DW_TILED")) {
+    // 5x5 layers and the squeeze-excite blocks (per-sample pooled sums): generic streaming kernel
+    const int rc = t3d_dwk_fwd_stream(dtype, x, pro, w, y, stats, gap_sum, B, H, W, C, k, stride,
+                                      reinterpret_cast<hipStream_t>(stream));
+    if (rc != T3D_ERR_UNSUPPORTED) return rc;
+  }
   DwFwdArgs a{};
   a.x = x; a.y = y; a.w = w;
   if (pro) { a.scale = pro->scale; a.shift = pro->shift; a.se = pro->se; a.act = pro->act; a.se_after = pro->se_after_act; }
