@@ -95,7 +95,30 @@ __global__ __launch_bounds__(512, 2) void pw_stream_kernel(const GemmArgs a, con
   const int nb = n0 + lg * 4 * NT;
   constexpr int KU = 2;  // k-steps whose loads are issued together
 
-  for (int g = xb * WAVES + wave; g < ngroups; g += nxb * WAVES) {
+  // per-sample sums (squeeze-excite blocks): a wave walks a CONTIGUOUS range of pixel groups, so consecutive groups
+  // mostly belong to one sample and its sums stay in st1/st2 until the sample changes (cur_b)
+  const bool ps_mode = GEN && a.ps_stats != nullptr;
+  int cur_b = -1;
+  auto ps_flush = [&](int b) {
+#pragma unroll
+    for (int q = 0; q < NT / 2; ++q) {
+      const int n = nb + 8 * q;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float s1 = row16_sum(st1[q][j]), s2 = row16_sum(st2[q][j]);
+        st1[q][j] = st2[q][j] = 0.f;
+        if (lc == 0 && n < a.Nout) {
+          unsafeAtomicAdd(a.ps_stats + ((size_t)b * a.Nout + n + j) * 2, s1);
+          unsafeAtomicAdd(a.ps_stats + ((size_t)b * a.Nout + n + j) * 2 + 1, s2);
+        }
+      }
+    }
+  };
+  const int wv = xb * WAVES + wave, nwv = nxb * WAVES;
+  const int per_w = (ngroups + nwv - 1) / nwv;
+  const int g_begin = ps_mode ? wv * per_w : wv, g_end = ps_mode ? min(ngroups, (wv + 1) * per_w) : ngroups;
+  const int g_step = ps_mode ? 1 : nwv;
+  for (int g = g_begin; g < g_end; g += g_step) {
     const int m0 = g * 16 * R;
     f32x4 acc[R][NT];
 #pragma unroll
@@ -202,8 +225,18 @@ __global__ __launch_bounds__(512, 2) void pw_stream_kernel(const GemmArgs a, con
       const int m = mrow[r];
       const bool ok = mok[r];
       const int mrow0 = m0 + r * 16, mlast = mrow0 + 15;
-      const bool uni = (mlast < a.M) && (mrow0 / a.HW == mlast / a.HW);
       const int bidx = ok ? m / a.HW : 0;
+      const int b_first = min(mrow0, a.M - 1) / a.HW, b_last = min(mlast, a.M - 1) / a.HW;
+      const bool two = (b_last - b_first) <= 1;
+      if (ps_mode && two) {
+        if (cur_b != b_first) {
+          if (cur_b >= 0) ps_flush(cur_b);
+          cur_b = b_first;
+        }
+      } else if (ps_mode && cur_b >= 0) {
+        ps_flush(cur_b);
+        cur_b = -1;
+      }
       // all epilogue loads of the row first: the stores below then issue back to back and the 16-B pieces of a line
       // meet in L2 (interleaved with load waits they were written back separately: 1.84x HBM write traffic, PMC)
       bf16x8 eyr[NT / 2], err[NT / 2];
@@ -274,22 +307,18 @@ __global__ __launch_bounds__(512, 2) void pw_stream_kernel(const GemmArgs a, con
             st2[q][j] = fmaf(v[j], (DG && a.e_y) ? yv[j] : v[j], st2[q][j]);
           }
         } else if (GEN && a.ps_stats) {
-          // per-sample sums: the 16 pixel rows of a group span one sample, or two (HW >= 16: 7x7 maps straddle in most
-          // groups) -- two masked 16-lane reductions and one atomic pair each; more than two samples (HW < 16) falls
-          // back to one atomic pair per lane
-          const int b_first = min(mrow0, a.M - 1) / a.HW, b_last = min(mlast, a.M - 1) / a.HW;
-          const bool two = (b_last - b_first) <= 1;
+          // rows of the group's FIRST sample go to the running registers; the rows of a second sample (straddling group)
+          // take one masked 16-lane reduction + atomic pair; more than two samples (HW < 16): one atomic pair per lane
 #pragma unroll
           for (int j = 0; j < 8; ++j) {
             const float s1 = v[j], s2 = v[j] * yv[j];      // v is 0 for rows past M
             if (two) {
               const bool in0 = bidx == b_first;
-              const float a1 = row16_sum(in0 ? s1 : 0.f), a2 = row16_sum(in0 ? s2 : 0.f);
-              const float c1 = row16_sum(in0 ? 0.f : s1), c2 = row16_sum(in0 ? 0.f : s2);
-              if (lc == 0) {
-                unsafeAtomicAdd(a.ps_stats + ((size_t)b_first * a.Nout + n + j) * 2, a1);
-                unsafeAtomicAdd(a.ps_stats + ((size_t)b_first * a.Nout + n + j) * 2 + 1, a2);
-                if (b_last != b_first) {
+              st1[q][j] += in0 ? s1 : 0.f;
+              st2[q][j] += in0 ? s2 : 0.f;
+              if (b_last != b_first) {                     // wave-uniform
+                const float c1 = row16_sum(in0 ? 0.f : s1), c2 = row16_sum(in0 ? 0.f : s2);
+                if (lc == 0) {
                   unsafeAtomicAdd(a.ps_stats + ((size_t)b_last * a.Nout + n + j) * 2, c1);
                   unsafeAtomicAdd(a.ps_stats + ((size_t)b_last * a.Nout + n + j) * 2 + 1, c2);
                 }
@@ -301,8 +330,13 @@ __global__ __launch_bounds__(512, 2) void pw_stream_kernel(const GemmArgs a, con
           }
         }
       }
+      if (ps_mode && two && b_last != b_first) {   // the first sample ended inside this group
+        ps_flush(b_first);
+        cur_b = -1;
+      }
     }
   }
+  if (ps_mode && cur_b >= 0) ps_flush(cur_b);
 
   if (keep_stats) {
 #pragma unroll
