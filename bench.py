@@ -239,7 +239,7 @@ def main():
             # HBM bytes per launch from the committed rocprofv3 PMC passes (FETCH_SIZE x2 + WRITE_SIZE, gfx950 correction),
             # valid for the default workload only; not measurable from inside this process
             traffic = None
-            tf = os.path.join(ROOT, 'profiles', 'r1_e_hbm_traffic_pmc.json')
+            tf = os.path.join(ROOT, 'profiles', 'r1_f_hbm_traffic_pmc.json')
             if os.path.exists(tf) and args.model == 'mobilenetv2' and S == 224 and B == 256 and args.dtype == 'bf16':
                 fam_t = json.load(open(tf))['families'].get(dominant)
                 if fam_t:
