@@ -285,7 +285,9 @@ __global__ __launch_bounds__(256) void dw3_bwd_s1_kernel(const Dw3BArgs a) {
 // two outputs (dy and the activations are formed twice per element instead of three times), every multiply-add is a
 // v_pk_fma_f32, and the 9 x CH stencil weights are read from LDS per use (saves 36 registers for the two
 // accumulator sets).  Padding: 0/1 masks per out-of-image column, wave-uniform row skips.
-template <typename T, int PF, int NTH, int CH>
+// ACT: the input's activation as a compile-time constant (a runtime switch in the row loop costs a scalar branch chain
+// and a register-merge of all variants per row: ~10 % of the instructions)
+template <typename T, int PF, int NTH, int CH, int ACT>
 __global__ __launch_bounds__(NTH) void dw3_bwd2_kernel(const Dw3BArgs a) {
   constexpr int H2 = CH / 2;
   extern __shared__ float lred[];       // [11][C] reduction scratch (end of kernel); first [9][C]: weights by tap
@@ -308,7 +310,7 @@ __global__ __launch_bounds__(NTH) void dw3_bwd2_kernel(const Dw3BArgs a) {
     qstride = gridDim.x * (NTH / 64);
   }
   const int c0 = cg * CH;
-  const bool affine = a.scale != nullptr || a.act != T3D_ACT_NONE;
+  const bool affine = a.scale != nullptr || ACT != T3D_ACT_NONE;
   // the block's own channel range: the whole tensor (flattened mapping) or one 64-group slab -- LDS staging and the
   // final flush touch only these channels
   const int cbase = a.slab ? blockIdx.y * 64 * CH : 0;
@@ -420,7 +422,7 @@ __global__ __launch_bounds__(NTH) void dw3_bwd2_kernel(const Dw3BArgs a) {
             for (int c = 0; c < 4; ++c)
 #pragma unroll
               for (int h = 0; h < H2; ++h) av[c][h] = pk_fma(av[c][h], sc2[h], sh2[h]);
-            switch (a.act) {
+            switch (ACT) {
               case T3D_ACT_RELU:
 #pragma unroll
                 for (int c = 0; c < 4; ++c)
@@ -523,7 +525,7 @@ __global__ __launch_bounds__(NTH) void dw3_bwd2_kernel(const Dw3BArgs a) {
                   scf[2 * h] = sc2[h][0]; scf[2 * h + 1] = sc2[h][1];
                   shf[2 * h] = sh2[h][0]; shf[2 * h + 1] = sh2[h][1];
                 }
-                act_grad_affine_vec<CH>(g, xv, scf, shf, a.act);
+                act_grad_affine_vec<CH>(g, xv, scf, shf, ACT);
               }
               const size_t rowo = (imgrow + iy) * a.W * a.C;     // scalar
               const unsigned lo = vst + (unsigned)(col * a.C) * (unsigned)sizeof(T);
@@ -643,7 +645,14 @@ int launch_s1c(Dw3BArgs& a, hipStream_t st) {
   // (forcing 3-4 waves/SIMD through launch bounds spills to scratch: 3-7x slower)
   // (a 6-row prefetch ring needs AGPR spill space -> 1 wave/SIMD: 40 % slower; PMC: VALU busy 46 %, memory unit stalled
   //  0.1 % -- the kernel is bound by the latency two resident waves per SIMD can hide)
-  if (two_col) hipLaunchKernelGGL((dw3_bwd2_kernel<T, PF, 256, CH>), grid, dim3(256), lds, st, a);
+  if (two_col) {
+    switch (a.act) {
+      case T3D_ACT_RELU: hipLaunchKernelGGL((dw3_bwd2_kernel<T, PF, 256, CH, T3D_ACT_RELU>), grid, dim3(256), lds, st, a); break;
+      case T3D_ACT_RELU6: hipLaunchKernelGGL((dw3_bwd2_kernel<T, PF, 256, CH, T3D_ACT_RELU6>), grid, dim3(256), lds, st, a); break;
+      case T3D_ACT_HSWISH: hipLaunchKernelGGL((dw3_bwd2_kernel<T, PF, 256, CH, T3D_ACT_HSWISH>), grid, dim3(256), lds, st, a); break;
+      default: hipLaunchKernelGGL((dw3_bwd2_kernel<T, PF, 256, CH, T3D_ACT_NONE>), grid, dim3(256), lds, st, a); break;
+    }
+  }
   else hipLaunchKernelGGL((dw3_bwd_s1_kernel<T, CH, PF>), grid, dim3(256), lds, st, a);
   T3D_CHECK_LAUNCH();
   return T3D_OK;
@@ -970,6 +979,7 @@ int launch_s2(Dw3BArgs& a, hipStream_t st) {
   }
   const size_t lds = (size_t)11 * (a.slab ? 64 * CH : a.C) * sizeof(float);
   a.noflush = getenv("T3D_DEBUG_NOFLUSH") ? 1 : 0;
+  // (a compile-time activation, as in the stride-1 kernel, pushes this one over 256 VGPRs -> 1 wave/SIMD: slower)
   hipLaunchKernelGGL((dw3_bwd_s2_kernel<T, PF, 256>), grid, dim3(256), lds, st, a);
   T3D_CHECK_LAUNCH();
   return T3D_OK;
