@@ -9,7 +9,7 @@ for c in FETCH_SIZE WRITE_SIZE; do
   rm -rf gpurun_out/pmc_$c
   rocprofv3 --pmc $c --output-format csv -d gpurun_out/pmc_$c -o p -- python3 bench.py --steps $STEPS --warmup $WARM --no-cpu-baseline > /dev/null 2>&1
 done
-python3 - "$out" $((STEPS + WARM)) <<'PY'
+python3 - "$out" $((STEPS + WARM + 2)) <<'PY'
 import sys, glob, csv, json, re, collections
 out, nsteps = sys.argv[1], int(sys.argv[2])
 def family(k):
@@ -36,7 +36,7 @@ for c, key, cnt in (('FETCH_SIZE', 'fetch_kb', 'dispatches_fetch_pass'), ('WRITE
         fm = family(r['Kernel_Name'])
         if fm: fam[fm][key] += v; fam[fm][cnt] += 1
 for v in fam.values(): v['hbm_bytes_per_step'] = round((2 * v['fetch_kb'] + v['write_kb']) * 1024 / nsteps)
-res = dict(note='rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over `bench.py --steps 3 --warmup 2` (5 steps), '
+res = dict(note='rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over `bench.py --steps 3 --warmup 2` (7 steps: 2 warm-up, 2 host-issue probes, 3 timed), '
                 'MobileNetV2 224^2 B=256 bf16; FETCH_SIZE doubled per the gfx950 correction; per-family sums (tools/pmc_traffic.sh)',
            steps=nsteps, all_kernels_hbm_bytes_per_step=round((2 * tot['FETCH_SIZE'] + tot['WRITE_SIZE']) * 1024 / nsteps), families=fam)
 json.dump(res, open(out, 'w'), indent=1)
