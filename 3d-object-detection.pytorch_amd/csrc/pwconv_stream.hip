@@ -140,6 +140,7 @@ __global__ __launch_bounds__(512, 2) void pw_stream_kernel(const GemmArgs a, con
 #pragma unroll
       for (int u = 0; u < KU; ++u) {
         const int ks = ks0 + u;
+        if (ks >= KS) continue;          // wave-uniform (K <= 32: one k-step, no second load)
         if (!DGL && ks >= ks1) {         // wave-uniform: second segment (y-free data gradient)
           const int k = min((ks - ks1) * 32 + lg * 8, a.Kin2 - 8);
 #pragma unroll
