@@ -18,7 +18,6 @@
 // Latency is hidden by wave-level parallelism (8-16 resident waves per CU, each with its own loads in
 // flight), not by a block-wide pipeline.
 #include <cstdlib>
-#include <type_traits>
 #include "pwconv_common.h"
 
 namespace t3d_pw {
@@ -122,6 +121,10 @@ __global__ __launch_bounds__(512, 2) void pw_stream_kernel(const GemmArgs a, con
   for (int g = g_begin; g < g_end; g += g_step) {
     const int m0 = g * 16 * R;
     f32x4 acc[R][NT];
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+#pragma unroll
+      for (int t = 0; t < NT; ++t) acc[r][t] = f32x4{0.f, 0.f, 0.f, 0.f};
     int mrow[R], mld[R];
     bool mok[R];
 #pragma unroll
@@ -131,9 +134,7 @@ __global__ __launch_bounds__(512, 2) void pw_stream_kernel(const GemmArgs a, con
       mld[r] = min(mrow[r], a.M - 1);     // rows past the end re-read the last row; they are never stored or summed
     }
 
-    // the first k-step multiplies into a literal zero (C = 0 inline operand) instead of cleared registers
-    auto kblock = [&](int ks0, auto FIRSTT) {
-      constexpr bool FIRST = decltype(FIRSTT)::value;
+    for (int ks0 = 0; ks0 < KS; ks0 += KU) {
       bf16x8 fa[KU][R], fb[KU][R];
       // branch-free loads: k-steps / channels past Kin read a clamped (valid) address -- their weights are zero
 #pragma unroll
@@ -213,24 +214,17 @@ __global__ __launch_bounds__(512, 2) void pw_stream_kernel(const GemmArgs a, con
           for (int t = 0; t < NT; ++t) {
             const bf16x8 wf = Wf[(t * KS + ks) * 64 + lane];
 #pragma unroll
-            for (int r = 0; r < R; ++r)
-              acc[r][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, b[r], (FIRST && u == 0) ? f32x4{0.f, 0.f, 0.f, 0.f} : acc[r][t],
-                                                                   0, 0, 0);
+            for (int r = 0; r < R; ++r) acc[r][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, b[r], acc[r][t], 0, 0, 0);
           }
         }
       }
-    };
-    kblock(0, std::true_type{});
-    for (int ks0 = KU; ks0 < KS; ks0 += KU) kblock(ks0, std::false_type{});
+    }
 
     // ---------------- epilogue: lane holds channels nb .. nb+4*NT-1 of pixel mrow[r] ----------
-    // two versions: FULL groups (every row < M; all but the last group of a tensor) carry no per-row predicates
-    auto epilogue = [&](auto FULLT) {
-    constexpr bool FULL = decltype(FULLT)::value;
 #pragma unroll
     for (int r = 0; r < R; ++r) {
       const int m = mrow[r];
-      const bool ok = FULL || mok[r];
+      const bool ok = mok[r];
       const int mrow0 = m0 + r * 16, mlast = mrow0 + 15;
       const int bidx = ok ? m / a.HW : 0;
       const int b_first = min(mrow0, a.M - 1) / a.HW, b_last = min(mlast, a.M - 1) / a.HW;
@@ -342,9 +336,6 @@ __global__ __launch_bounds__(512, 2) void pw_stream_kernel(const GemmArgs a, con
         cur_b = -1;
       }
     }
-    };
-    if (m0 + 16 * R <= a.M) epilogue(std::true_type{});
-    else epilogue(std::false_type{});
   }
   if (ps_mode && cur_b >= 0) ps_flush(cur_b);
 

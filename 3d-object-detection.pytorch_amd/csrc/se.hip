@@ -33,17 +33,18 @@ constexpr int OT = 4, PT = OT / 4;
 // IT: the input is read transposed (rows of the tile are its fast axis in memory) -- the weight-gradient products.
 template <bool WT, bool IT = false, typename InF>
 __device__ __forceinline__ void fc_tile(InF in, const float* __restrict__ W, int I, int O, int b0, int o0, int B,
-                                        float acc[PT], float (*lin)[65], float (*lw)[65]) {
+                                        float acc[PT], float (*lin)[65], float (*lw)[65], int ibeg = 0, int iend = 1 << 30) {
   const int t = threadIdx.x, bl = t & 63, og = t >> 6;
 #pragma unroll
   for (int j = 0; j < PT; ++j) acc[j] = 0.f;
-  for (int i0 = 0; i0 < I; i0 += 64) {
+  iend = min(iend, I);
+  for (int i0 = ibeg; i0 < iend; i0 += 64) {
     __syncthreads();
 #pragma unroll
     for (int k = 0; k < 16; ++k) {
       const int idx = t + 256 * k, row = IT ? (idx & 63) : (idx >> 6), col = IT ? (idx >> 6) : (idx & 63);
       const int b = b0 + row, i = i0 + col;
-      lin[row][col] = (b < B && i < I) ? in(b, i) : 0.f;
+      lin[row][col] = (b < B && i < iend) ? in(b, i) : 0.f;
     }
 #pragma unroll
     for (int k = 0; k < OT / 4; ++k) {
@@ -52,7 +53,7 @@ __device__ __forceinline__ void fc_tile(InF in, const float* __restrict__ W, int
       if (WT) { row = idx % OT; col = idx / OT; } else { row = idx >> 6; col = idx & 63; }
       const int o = o0 + row, i = i0 + col;
       float v = 0.f;
-      if (o < O && i < I) v = WT ? W[(size_t)i * O + o] : W[(size_t)o * I + i];
+      if (o < O && i < iend) v = WT ? W[(size_t)i * O + o] : W[(size_t)o * I + i];
       lw[row][col] = v;
     }
     __syncthreads();
@@ -65,28 +66,39 @@ __device__ __forceinline__ void fc_tile(InF in, const float* __restrict__ W, int
   }
 }
 
-// grid (ceil(R/OT), ceil(B/64)): h = relu(W1 m + b1), m = scale*gap/HW + shift (written by the first column of blocks)
+// The contraction over C (<= 960: 15 serial 64-chunks, each a global-load round trip) is split over blockIdx.z; the
+// partial products are added into a zeroed h, bias + ReLU follow in se_relu_bias_kernel.
+// grid (ceil(R/OT), ceil(B/64), KSPLIT): h_raw += W1[:, slice] m[slice], m = scale*gap/HW + shift (written by the
+// first column of blocks of split 0)
+constexpr int KSPLIT = 4;
 __global__ __launch_bounds__(256) void se_fc1_kernel(const SeArgs a) {
   __shared__ float lin[64][65], lw[OT][65];
   const int o0 = blockIdx.x * OT, b0 = blockIdx.y * 64;
   const float inv = 1.f / (float)a.HW;
   auto in = [&](int b, int c) { return a.scale[c] * (a.gap[(size_t)b * a.C + c] * inv) + a.shift[c]; };
+  const int per = ((a.C + KSPLIT - 1) / KSPLIT + 63) / 64 * 64;
   float acc[PT];
-  fc_tile<false>(in, a.w1, a.C, a.R, b0, o0, a.B, acc, lin, lw);
+  fc_tile<false>(in, a.w1, a.C, a.R, b0, o0, a.B, acc, lin, lw, blockIdx.z * per, (blockIdx.z + 1) * per);
   const int b = b0 + (threadIdx.x & 63), og = threadIdx.x >> 6;
   if (b < a.B) {
 #pragma unroll
     for (int j = 0; j < PT; ++j) {
       const int r = o0 + og * PT + j;
-      if (r < a.R) a.h[(size_t)b * a.R + r] = fmaxf(acc[j] + a.b1[r], 0.f);
+      if (r < a.R) unsafeAtomicAdd(a.h + (size_t)b * a.R + r, acc[j]);
     }
   }
-  if (blockIdx.x == 0) {
+  if (blockIdx.x == 0 && blockIdx.z == 0) {
     for (int i = threadIdx.x; i < 64 * a.C; i += 256) {
       const int bb = b0 + i / a.C, c = i % a.C;
       if (bb < a.B) a.m[(size_t)bb * a.C + c] = in(bb, c);
     }
   }
+}
+
+// h = relu(h_raw + b1)
+__global__ __launch_bounds__(256) void se_relu_bias_kernel(const SeArgs a) {
+  const size_t i = blockIdx.x * (size_t)256 + threadIdx.x;
+  if (i < (size_t)a.B * a.R) a.h[i] = fmaxf(a.h[i] + a.b1[i % a.R], 0.f);
 }
 
 // grid (ceil(C/OT), ceil(B/64)): q = W2 h + b2, s = h_sigmoid(q)
@@ -120,21 +132,28 @@ __global__ __launch_bounds__(256) void se_dq_kernel(const SeArgs a) {
   a.dq[i] = (q > -3.f && q < 3.f) ? ds * (1.f / 6.f) : 0.f;     // relu6 passes strictly inside
 }
 
-// grid (ceil(R/OT), ceil(B/64)): dp = relu'(h) * (dq W2)
+// grid (ceil(R/OT), ceil(B/64), KSPLIT): dp_raw += dq[:, slice] W2[slice, :]; relu'(h) follows in se_relu_mask_kernel
 __global__ __launch_bounds__(256) void se_dh_kernel(const SeArgs a) {
   __shared__ float lin[64][65], lw[OT][65];
   const int o0 = blockIdx.x * OT, b0 = blockIdx.y * 64;
   auto in = [&](int b, int c) { return a.dq[(size_t)b * a.C + c]; };
+  const int per = ((a.C + KSPLIT - 1) / KSPLIT + 63) / 64 * 64;
   float acc[PT];
-  fc_tile<true>(in, a.w2, a.C, a.R, b0, o0, a.B, acc, lin, lw);      // W2 is [C][R] = [I][O]
+  fc_tile<true>(in, a.w2, a.C, a.R, b0, o0, a.B, acc, lin, lw, blockIdx.z * per, (blockIdx.z + 1) * per);   // W2: [C][R] = [I][O]
   const int b = b0 + (threadIdx.x & 63), og = threadIdx.x >> 6;
   if (b < a.B) {
 #pragma unroll
     for (int j = 0; j < PT; ++j) {
       const int r = o0 + og * PT + j;
-      if (r < a.R) a.dp[(size_t)b * a.R + r] = a.h[(size_t)b * a.R + r] > 0.f ? acc[j] : 0.f;
+      if (r < a.R) unsafeAtomicAdd(a.dp + (size_t)b * a.R + r, acc[j]);
     }
   }
+}
+
+// dp = relu'(h) * dp_raw
+__global__ __launch_bounds__(256) void se_relu_mask_kernel(const SeArgs a) {
+  const size_t i = blockIdx.x * (size_t)256 + threadIdx.x;
+  if (i < (size_t)a.B * a.R) a.dp[i] = a.h[i] > 0.f ? a.dp[i] : 0.f;
 }
 
 // grid (ceil(C/OT), ceil(B/64)): g = (dp W1) / HW, and the depthwise BatchNorm's backward sums of du = s*dv + g
@@ -220,7 +239,9 @@ extern "C" int t3d_se_fwd(const float* gap_sum, const float* scale, const float*
   a.gap = gap_sum; a.scale = scale; a.shift = shift; a.w1 = w1; a.b1 = b1; a.w2 = w2; a.b2 = b2;
   a.m = m; a.h = h; a.q = q; a.s = s; a.B = B; a.C = C; a.R = R; a.HW = HW;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-  hipLaunchKernelGGL(se_fc1_kernel, dim3(cdiv(R, OT), cdiv(B, 64)), dim3(256), 0, st, a);
+  if (hipMemsetAsync(h, 0, (size_t)B * R * sizeof(float), st) != hipSuccess) return T3D_ERR_LAUNCH;
+  hipLaunchKernelGGL(se_fc1_kernel, dim3(cdiv(R, OT), cdiv(B, 64), KSPLIT), dim3(256), 0, st, a);
+  hipLaunchKernelGGL(se_relu_bias_kernel, dim3(cdiv(B * R, 256)), dim3(256), 0, st, a);
   hipLaunchKernelGGL(se_fc2_kernel, dim3(cdiv(C, OT), cdiv(B, 64)), dim3(256), 0, st, a);
   T3D_CHECK_LAUNCH();
   return T3D_OK;
@@ -240,7 +261,9 @@ extern "C" int t3d_se_bwd(const float* ps_stats, const float* gap_sum, const flo
   a.B = B; a.C = C; a.R = R; a.HW = HW;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   hipLaunchKernelGGL(se_dq_kernel, dim3(cdiv(B * C, 256)), dim3(256), 0, st, a);
-  hipLaunchKernelGGL(se_dh_kernel, dim3(cdiv(R, OT), cdiv(B, 64)), dim3(256), 0, st, a);
+  if (hipMemsetAsync(dp, 0, (size_t)B * R * sizeof(float), st) != hipSuccess) return T3D_ERR_LAUNCH;
+  hipLaunchKernelGGL(se_dh_kernel, dim3(cdiv(R, OT), cdiv(B, 64), KSPLIT), dim3(256), 0, st, a);
+  hipLaunchKernelGGL(se_relu_mask_kernel, dim3(cdiv(B * R, 256)), dim3(256), 0, st, a);
   hipLaunchKernelGGL(se_dm_kernel, dim3(cdiv(C, OT), cdiv(B, 64)), dim3(256), 0, st, a);
   hipLaunchKernelGGL(se_wgrad_tile_kernel, dim3(cdiv(R, OT), cdiv(C, 64)), dim3(256), 0, st, a, 0);
   hipLaunchKernelGGL(se_wgrad_tile_kernel, dim3(cdiv(C, OT), cdiv(R, 64)), dim3(256), 0, st, a, 1);
