@@ -414,6 +414,9 @@ int stream_launch(GemmArgs& a, hipStream_t st) {
   // registers / occupancy
   static const int small_k_cap = getenv("T3D_PW_NTCAP") ? atoi(getenv("T3D_PW_NTCAP")) : 10;
   if (a.Kin <= 64 && nt_cap > small_k_cap) nt_cap = small_k_cap;
+  // squeeze-excite data gradient (per-sample sums / gates in registers): wider tiles spill (NT = 8: 216 B, 10: 412 B)
+  static const int gen_cap = getenv("T3D_PW_GEN_NTCAP") ? atoi(getenv("T3D_PW_GEN_NTCAP")) : 6;
+  if (a.dgrad && (a.per_sample || a.ps_stats || a.e_se) && nt_cap > gen_cap) nt_cap = gen_cap;
   nt_cap &= ~1;
   if (nt_cap < 2) return T3D_ERR_UNSUPPORTED;
   int NT = 2;
