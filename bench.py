@@ -44,6 +44,8 @@ def parse():
     ap.add_argument('--cpu-batch', type=int, default=16)
     ap.add_argument('--cpu-steps', type=int, default=60)
     ap.add_argument('--cpu-baseline-only', action='store_true', help=argparse.SUPPRESS)
+    ap.add_argument('--eval', action='store_true', help='time the inference forward (Evaluator.val_step: running BatchNorm '
+                    'statistics, values-only losses + metrics) instead of the train step')
     ap.add_argument('--per-launch', action='store_true', help='print every conv launch of one step (stderr)')
     ap.add_argument('--profile-all', action='store_true', help='time every kernel family, print a table to stderr')
     return ap.parse_args()
@@ -150,7 +152,15 @@ def main():
     out = torch.zeros(16, device=dev)
     dkp, dlg = torch.empty(B, 18, device=dev), torch.empty(B, 9, device=dev)
 
+    def eval_step(i):
+        j = i % nb
+        kp, lg = net.forward(imgs[j], cats[j], train=False)
+        N.call('t3d_loss_fwd_bwd', cfg, N.ptr(kp), N.ptr(gts[j]), N.ptr(lg), N.ptr(cats[j]), N.ptr(out), None, None, B, 9,
+               N.stream())
+
     def step(i):
+        if args.eval:
+            return eval_step(i)
         j = i % nb
         kp, lg = net.forward(imgs[j], cats[j], train=True)
         N.call('t3d_loss_fwd_bwd', cfg, N.ptr(kp), N.ptr(gts[j]), N.ptr(lg), N.ptr(cats[j]), N.ptr(out), N.ptr(dkp),
@@ -225,12 +235,14 @@ def main():
     if rank == 0:
         crops = B * world * args.steps / dt
         res = {
-            'metric': f'regression train crops/sec @{S}^2 bs{B} ' + {'mobilenetv2': 'MobileNetV2', 'mobilenetv3_large': 'MobileNetV3-large', 'mobilenetv3_small': 'MobileNetV3-small'}.get(args.model, args.model), 'value': round(crops, 1), 'unit': 'crops/s',
+            'metric': f'regression {"eval" if args.eval else "train"} crops/sec @{S}^2 bs{B} ' + {'mobilenetv2': 'MobileNetV2', 'mobilenetv3_large': 'MobileNetV3-large', 'mobilenetv3_small': 'MobileNetV3-small'}.get(args.model, args.model), 'value': round(crops, 1), 'unit': 'crops/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(dt / args.steps * 1e3, 3),
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': args.dtype, 'data': 'synthetic',
-            'config': {'workload': f'{args.model} 9-class Objectron keypoint regression, train step (fwd + l1/add/CE losses '
-                                   f'+ bwd + AdamW{" + RCCL grad all-reduce" if world > 1 else ""}), {S}x{S} crops, '
-                                   f'per-GPU batch {B}', 'global_batch': B * world, 'parallelism': f'dp{world}',
+            'config': {'workload': f'{args.model} 9-class Objectron keypoint regression, '
+                                   + ('inference forward (running BatchNorm statistics) + loss / metric values'
+                                      if args.eval else
+                                      f'train step (fwd + l1/add/CE losses + bwd + AdamW{" + RCCL grad all-reduce" if world > 1 else ""})')
+                                   + f', {S}x{S} crops, per-GPU batch {B}', 'global_batch': B * world, 'parallelism': f'dp{world}',
                        'final_loss': round(loss, 5), 'host_issue_ms_per_step': round(t_issue * 1e3, 3)},
         }
         if dominant and dominant in tsum:
@@ -250,7 +262,8 @@ def main():
                                'avg_launch_us': round(1e3 * d['ms'] / d['launches'], 2),
                                'algorithmic_MB_per_step': round(d['bytes'] / args.steps / 1e6, 1)}
         if args.model == 'mobilenetv2' and S == 224 and args.dtype == 'bf16':
-            res['config']['step_hbm_roofline_frac'] = round(crops / world * MNV2_TRAIN_MB_PER_CROP * 1e6 / HBM_PEAK, 4)
+            per_crop = 26.89 if args.eval else MNV2_TRAIN_MB_PER_CROP     # forward / train MB per crop
+            res['config']['step_hbm_roofline_frac'] = round(crops / world * per_crop * 1e6 / HBM_PEAK, 4)
         if world == 1 and not args.no_cpu_baseline:
             res['cpu_baseline'] = cpu_baseline_guarded(args)
         print(json.dumps(res), flush=True)
