@@ -285,6 +285,31 @@ __global__ __launch_bounds__(256) void dw3_bwd_s1_kernel(const Dw3BArgs a) {
 // two outputs (dy and the activations are formed twice per element instead of three times), every multiply-add is a
 // v_pk_fma_f32, and the 9 x CH stencil weights are read from LDS per use (saves 36 registers for the two
 // accumulator sets).  Padding: 0/1 masks per out-of-image column, wave-uniform row skips.
+// raw buffer load of one register vector: scalar descriptor + scalar byte offset + per-lane byte offset
+template <typename RV>
+__device__ __forceinline__ RV bufload(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+  if constexpr (sizeof(RV) == 4) {
+    return __builtin_bit_cast(RV, __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
+  } else if constexpr (sizeof(RV) == 8) {
+    return __builtin_bit_cast(RV, __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0));
+  } else {
+    return __builtin_bit_cast(RV, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
+  }
+}
+
+template <typename RV>
+__device__ __forceinline__ void bufstore(const RV& v, __amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+  if constexpr (sizeof(RV) == 4) {
+    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, voff, soff, 0);
+  } else if constexpr (sizeof(RV) == 8) {
+    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, v), r, voff, soff, 0);
+  } else {
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, voff, soff, 0);
+  }
+}
+
 // ACT: the input's activation as a compile-time constant (a runtime switch in the row loop costs a scalar branch chain
 // and a register-merge of all variants per row: ~10 % of the instructions)
 template <typename T, int PF, int NTH, int CH, int ACT>
@@ -344,6 +369,11 @@ __global__ __launch_bounds__(NTH) void dw3_bwd2_kernel(const Dw3BArgs a) {
   const T* __restrict__ xb = reinterpret_cast<const T*>(a.x);
   const T* __restrict__ rb = reinterpret_cast<const T*>(a.res);
   T* __restrict__ dxb = reinterpret_cast<T*>(a.dx);
+  const size_t tbytes = (size_t)a.B * a.H * a.W * a.C * sizeof(T);
+  const __amdgpu_buffer_rsrc_t rsz = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(zb), 0, (int)tbytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsy = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(yb), 0, (int)tbytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsx = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(xb), 0, (int)tbytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsd = __builtin_amdgcn_make_buffer_rsrc(dxb, 0, (int)tbytes, 0x00020000);
   for (int q = q0; q < a.nitems; q += qstride) {
     int xp, rest;
     if (!a.slab) { xp = xp_fixed; rest = q; } else { xp = q % Wp; rest = q / Wp; }
@@ -367,16 +397,14 @@ __global__ __launch_bounds__(NTH) void dw3_bwd2_kernel(const Dw3BArgs a) {
     const size_t imgrow = (size_t)b * a.H; // rows before this image
 
     RV rz[PF][4], ry[PF][4], rx[PF][4];
+    // buffer loads: descriptor (scalar) + 32-bit scalar row offset + 32-bit lane offset -- no vector address arithmetic
     auto fetch = [&](int r, int slot) {
-      const size_t ro = (imgrow + min(max(r, 0), a.H - 1)) * a.W * a.C;    // scalar
-      const char* zr = reinterpret_cast<const char*>(zb + ro);
-      const char* yr = reinterpret_cast<const char*>(yb + ro);
-      const char* xr_ = reinterpret_cast<const char*>(xb + ro);
+      const unsigned so = (unsigned)((imgrow + min(max(r, 0), a.H - 1)) * a.W * a.C * sizeof(T));   // scalar; tensors < 4 GB
 #pragma unroll
       for (int c = 0; c < 4; ++c) {
-        rz[slot][c] = *reinterpret_cast<const RV*>(zr + voff[c]);
-        ry[slot][c] = *reinterpret_cast<const RV*>(yr + voff[c]);
-        rx[slot][c] = *reinterpret_cast<const RV*>(xr_ + voff[c]);
+        rz[slot][c] = bufload<RV>(rsz, voff[c], so);
+        ry[slot][c] = bufload<RV>(rsy, voff[c], so);
+        rx[slot][c] = bufload<RV>(rsx, voff[c], so);
       }
     };
     const int rf = r0 - 1, rl = r1;
@@ -542,7 +570,7 @@ __global__ __launch_bounds__(NTH) void dw3_bwd2_kernel(const Dw3BArgs a) {
                 psum[i] += v;
                 psq[i] = fmaf(v, xv[i], psq[i]);
               }
-              if (on) *reinterpret_cast<RV*>(reinterpret_cast<char*>(dxb + rowo) + lo) = o;
+              if (on) bufstore<RV>(o, rsd, lo, (unsigned)(rowo * sizeof(T)));
             }
           }
 #pragma unroll
@@ -645,6 +673,7 @@ int launch_s1c(Dw3BArgs& a, hipStream_t st) {
   // (forcing 3-4 waves/SIMD through launch bounds spills to scratch: 3-7x slower)
   // (a 6-row prefetch ring needs AGPR spill space -> 1 wave/SIMD: 40 % slower; PMC: VALU busy 46 %, memory unit stalled
   //  0.1 % -- the kernel is bound by the latency two resident waves per SIMD can hide)
+  if (two_col && (size_t)a.B * a.H * a.W * a.C * sizeof(T) >= (1ull << 32)) return T3D_ERR_UNSUPPORTED;   // 32-bit buffer offsets
   if (two_col) {
     switch (a.act) {
       case T3D_ACT_RELU: hipLaunchKernelGGL((dw3_bwd2_kernel<T, PF, 256, CH, T3D_ACT_RELU>), grid, dim3(256), lds, st, a); break;
