@@ -10,8 +10,9 @@
 //     B operand (pixel = lane&15, k = 8*(lane>>4)..+8) is exactly a 16-B global load per lane, so the
 //     producer's BatchNorm affine + activation (forward) or the BatchNorm-backward affine
 //     dy = alpha*dz + beta*y + gamma (data gradient) is applied in registers on the way to the MFMA;
-//   * the product is computed transposed (D = W * A^T) with permuted weight rows, so every lane ends up
-//     with 4*NT CONSECUTIVE output channels of one pixel: 16-B stores, no accumulator transpose;
+//   * the product is computed transposed (D = W * A^T) with permuted weight rows, so every lane ends up with 8
+//     consecutive output channels of one pixel per 32-channel block and the four lane groups of a row write 64
+//     contiguous bytes per store instruction: 16-B stores, no accumulator transpose;
 //   * BatchNorm sums (sum y, sum y^2 | sum dx, sum dx*x) live in per-lane registers across the wave's
 //     whole persistent loop (2 VALU ops per output element) and are reduced across lanes / waves once
 //     per block: one fp64 atomic per channel per block.
@@ -49,11 +50,11 @@ __global__ __launch_bounds__(512, 2) void pw_stream_kernel(const GemmArgs a, con
   const bf16_t* __restrict__ Wg = reinterpret_cast<const bf16_t*>(a.w);
   bf16_t* __restrict__ out = reinterpret_cast<bf16_t*>(a.out);
 
-  // ---- stage the weight chunk in fragment order: MFMA row lc of tile t <-> n_local = (lc>>2)*4*NT + 4*t + (lc&3)
+  // ---- stage the weight chunk in fragment order: MFMA row lc of tile t <-> n_local = (t>>1)*32 + (lc>>2)*8 + (t&1)*4 + (lc&3)
   const int nthr = blockDim.x, WAVES = nthr >> 6;
   for (int i = tid; i < NT * KS * 64; i += nthr) {
     const int l = i & 63, ks = (i >> 6) % KS, t = (i >> 6) / KS;
-    const int n = n0 + ((l & 15) >> 2) * 4 * NT + 4 * t + (l & 3), k = ks * 32 + (l >> 4) * 8;
+    const int n = n0 + (t >> 1) * 32 + ((l & 15) >> 2) * 8 + (t & 1) * 4 + (l & 3), k = ks * 32 + (l >> 4) * 8;
     bf16x8 v;
 #pragma unroll
     for (int j = 0; j < 8; ++j) v[j] = (bf16_t)0.f;
@@ -92,7 +93,7 @@ __global__ __launch_bounds__(512, 2) void pw_stream_kernel(const GemmArgs a, con
     for (int j = 0; j < 8; ++j) st1[q][j] = st2[q][j] = 0.f;
 
   const int ngroups = (a.M + 16 * R - 1) / (16 * R);
-  const int nb = n0 + lg * 4 * NT;
+  const int nb = n0 + lg * 8;     // lane group lg owns channels nb + 32*q .. +7 of every 32-channel block q
   constexpr int KU = 2;  // k-steps whose loads are issued together
 
   // per-sample sums (squeeze-excite blocks): a wave walks a CONTIGUOUS range of pixel groups, so consecutive groups
@@ -102,7 +103,7 @@ __global__ __launch_bounds__(512, 2) void pw_stream_kernel(const GemmArgs a, con
   auto ps_flush = [&](int b) {
 #pragma unroll
     for (int q = 0; q < NT / 2; ++q) {
-      const int n = nb + 8 * q;
+      const int n = nb + 32 * q;
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
         const float s1 = row16_sum(st1[q][j]), s2 = row16_sum(st2[q][j]);
@@ -246,18 +247,18 @@ __global__ __launch_bounds__(512, 2) void pw_stream_kernel(const GemmArgs a, con
 #pragma unroll
           for (int q = 0; q < NT / 2; ++q)
             eyr[q] = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const bf16_t*>(a.e_y) + (size_t)mld[r] * a.Nout +
-                                                      min(nb + 8 * q, a.Nout - 8));
+                                                      min(nb + 32 * q, a.Nout - 8));
         }
         if (a.e_res) {
 #pragma unroll
           for (int q = 0; q < NT / 2; ++q)
             err[q] = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const bf16_t*>(a.e_res) + (size_t)mld[r] * a.Nout +
-                                                      min(nb + 8 * q, a.Nout - 8));
+                                                      min(nb + 32 * q, a.Nout - 8));
         }
       }
 #pragma unroll
       for (int q = 0; q < NT / 2; ++q) {
-        const int n = nb + 8 * q;
+        const int n = nb + 32 * q;
         if (n >= a.Nout) continue;  // whole 8-channel groups are in or out (Nout % 8 == 0)
         float v[8], yv[8];
 #pragma unroll
@@ -342,7 +343,7 @@ __global__ __launch_bounds__(512, 2) void pw_stream_kernel(const GemmArgs a, con
   if (keep_stats) {
 #pragma unroll
     for (int q = 0; q < NT / 2; ++q) {
-      const int n = nb + 8 * q;
+      const int n = nb + 32 * q;
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
         const float s1 = row16_sum(st1[q][j]), s2 = row16_sum(st2[q][j]);
