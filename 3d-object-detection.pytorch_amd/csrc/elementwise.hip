@@ -50,6 +50,8 @@ struct EwArgs {
   int act;
   int M, C, HW;
   float inv_hw;
+  int mode;            // global pool: T3D_POOL_AVG / _MAX / _AVGMAX
+  int* argmax;         // [B,C] position (hw) of the per-sample maximum, written by the forward, read by the backward
 };
 
 __device__ __forceinline__ void load_affine(const EwArgs& a, int c0, float sc[8], float sh[8]) {
@@ -220,31 +222,43 @@ __global__ __launch_bounds__(256) void se_after_sums_kernel(const EwArgs a) {
   }
 }
 
-// pooled[b][c] = mean_hw act(scale*y + shift);   grid (B, ceil(CG/32)), block 256 = 32 groups x 8 hw slots
+// pooled[b][c] = mean_hw a (avg) | max_hw a (max) | both added (avg+max), a = act(scale*y + shift);
+// grid (B, ceil(CG/32)), block 256 = 32 groups x 8 hw slots.  The maximum keeps the FIRST position in (h,w) scan order
+// among equal values (what F.adaptive_max_pool2d's backward routes the gradient to).
 template <typename T>
 __global__ __launch_bounds__(256) void gap_fwd_kernel(const EwArgs a) {
   __shared__ float red[8][32 * 8];
+  __shared__ float redm[8][32 * 8];
+  __shared__ int redi[8][32 * 8];
   const int CG = a.C / 8, b = blockIdx.x;
   const int cgl = threadIdx.x & 31, slot = threadIdx.x >> 5;
   const int cg = blockIdx.y * 32 + cgl;
   const bool on = cg < CG;
   const int c0 = on ? cg * 8 : 0;
+  const bool want_max = a.mode != T3D_POOL_AVG;
   const T* __restrict__ y = reinterpret_cast<const T*>(a.a);
-  float sc[8], sh[8], acc[8];
+  float sc[8], sh[8], acc[8], mx[8];
+  int mi[8];
   load_affine(a, c0, sc, sh);
 #pragma unroll
-  for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+  for (int j = 0; j < 8; ++j) { acc[j] = 0.f; mx[j] = -INFINITY; mi[j] = 0; }
   if (on) {
     for (int hw = slot; hw < a.HW; hw += 8) {
       float v[8];
       Vec8<T>::load(y + ((size_t)b * a.HW + hw) * a.C + c0, v);
       act_affine_vec<8>(v, sc, sh, a.act);
 #pragma unroll
-      for (int j = 0; j < 8; ++j) acc[j] += v[j];
+      for (int j = 0; j < 8; ++j) {
+        acc[j] += v[j];
+        if (v[j] > mx[j]) { mx[j] = v[j]; mi[j] = hw; }      // strict: first position wins inside a slot
+      }
     }
   }
 #pragma unroll
-  for (int j = 0; j < 8; ++j) red[slot][cgl * 8 + j] = acc[j];
+  for (int j = 0; j < 8; ++j) {
+    red[slot][cgl * 8 + j] = acc[j];
+    if (want_max) { redm[slot][cgl * 8 + j] = mx[j]; redi[slot][cgl * 8 + j] = mi[j]; }
+  }
   __syncthreads();
   const int t = threadIdx.x;  // 256 = 32 groups x 8 channels
   const int c = blockIdx.y * 256 + t;
@@ -252,7 +266,20 @@ __global__ __launch_bounds__(256) void gap_fwd_kernel(const EwArgs a) {
     float s = 0.f;
 #pragma unroll
     for (int q = 0; q < 8; ++q) s += red[q][t];
-    a.pooled[(size_t)b * a.C + c] = s * a.inv_hw;
+    float out = s * a.inv_hw;
+    if (want_max) {
+      float m = redm[0][t];
+      int im = redi[0][t];
+#pragma unroll
+      for (int q = 1; q < 8; ++q) {
+        const float mq = redm[q][t];
+        const int iq = redi[q][t];
+        if (mq > m || (mq == m && iq < im)) { m = mq; im = iq; }
+      }
+      if (a.argmax) a.argmax[(size_t)b * a.C + c] = im;
+      out = (a.mode == T3D_POOL_MAX) ? m : out + m;
+    }
+    a.pooled[(size_t)b * a.C + c] = out;
   }
 }
 
@@ -273,16 +300,23 @@ __global__ __launch_bounds__(256) void gap_bwd_kernel(const EwArgs a, int B) {
   for (int j = 0; j < 8; ++j) s1[j] = s2[j] = 0.f;
   if (on) {
     for (int b = blockIdx.x; b < B; b += gridDim.x) {
-      float dp[8];
+      float dp[8], dm[8];
+      int am[8];
 #pragma unroll
-      for (int j = 0; j < 8; ++j) dp[j] = a.vec[(size_t)b * a.C + c0 + j] * a.inv_hw;
+      for (int j = 0; j < 8; ++j) {
+        const float g = a.vec[(size_t)b * a.C + c0 + j];
+        dp[j] = (a.mode == T3D_POOL_MAX) ? 0.f : g * a.inv_hw;       // the mean's share, every position
+        dm[j] = (a.mode == T3D_POOL_AVG) ? 0.f : g;                  // the maximum's share, its position only
+        am[j] = (a.mode == T3D_POOL_AVG) ? -1 : a.argmax[(size_t)b * a.C + c0 + j];
+      }
       for (int hw = slot; hw < a.HW; hw += 8) {
         const size_t off = ((size_t)b * a.HW + hw) * a.C + c0;
         float v[8], d[8];
         Vec8<T>::load(y + off, v);
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-          d[j] = Vec8<T>::round(dp[j] * act_grad(v[j] * sc[j] + sh[j], a.act));
+          const float gin = dp[j] + (hw == am[j] ? dm[j] : 0.f);
+          d[j] = Vec8<T>::round(gin * act_grad(v[j] * sc[j] + sh[j], a.act));
           s1[j] += d[j];
           s2[j] = fmaf(d[j], v[j], s2[j]);
         }
@@ -408,12 +442,13 @@ extern "C" int t3d_se_after_apply(int dtype, const void* dv, const void* y, cons
   return T3D_OK;
 }
 
-extern "C" int t3d_gap_fwd(int dtype, const void* y, const t3d_prologue* pro, float* pooled, int B, int HW, int C,
-                           void* stream) {
+extern "C" int t3d_pool_fwd(int dtype, const void* y, const t3d_prologue* pro, int mode, float* pooled, int* argmax,
+                            int B, int HW, int C, void* stream) {
   if (!y || !pooled || B <= 0 || HW <= 0 || C <= 0 || (C % 8)) return T3D_ERR_ARG;
+  if (mode != T3D_POOL_AVG && mode != T3D_POOL_MAX && mode != T3D_POOL_AVGMAX) return T3D_ERR_ARG;
   if (pro && pro->se) return T3D_ERR_UNSUPPORTED;
   EwArgs a{};
-  a.a = y; a.pooled = pooled; a.C = C; a.HW = HW; a.inv_hw = 1.f / (float)HW;
+  a.a = y; a.pooled = pooled; a.C = C; a.HW = HW; a.inv_hw = 1.f / (float)HW; a.mode = mode; a.argmax = argmax;
   fill_pro(a, pro);
   dim3 grid(B, cdiv(C / 8, 32));
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
@@ -424,12 +459,20 @@ extern "C" int t3d_gap_fwd(int dtype, const void* y, const t3d_prologue* pro, fl
   return T3D_OK;
 }
 
-extern "C" int t3d_gap_bwd(int dtype, const float* dpooled, const void* y, const t3d_prologue* pro, void* dz,
-                           double* stats, int B, int HW, int C, void* stream) {
+extern "C" int t3d_gap_fwd(int dtype, const void* y, const t3d_prologue* pro, float* pooled, int B, int HW, int C,
+                           void* stream) {
+  return t3d_pool_fwd(dtype, y, pro, T3D_POOL_AVG, pooled, nullptr, B, HW, C, stream);
+}
+
+extern "C" int t3d_pool_bwd(int dtype, const float* dpooled, const void* y, const t3d_prologue* pro, int mode,
+                            const int* argmax, void* dz, double* stats, int B, int HW, int C, void* stream) {
   if (!dpooled || !y || !dz || B <= 0 || HW <= 0 || C <= 0 || (C % 8)) return T3D_ERR_ARG;
+  if (mode != T3D_POOL_AVG && mode != T3D_POOL_MAX && mode != T3D_POOL_AVGMAX) return T3D_ERR_ARG;
+  if (mode != T3D_POOL_AVG && !argmax) return T3D_ERR_ARG;
   if (pro && pro->se) return T3D_ERR_UNSUPPORTED;
   EwArgs a{};
   a.a = y; a.vec = dpooled; a.out = dz; a.stats = stats; a.C = C; a.HW = HW; a.inv_hw = 1.f / (float)HW;
+  a.mode = mode; a.argmax = const_cast<int*>(argmax);
   fill_pro(a, pro);
   dim3 grid(B < 256 ? B : 256, cdiv(C / 8, 32));
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
@@ -438,4 +481,9 @@ extern "C" int t3d_gap_bwd(int dtype, const float* dpooled, const void* y, const
   else return T3D_ERR_ARG;
   T3D_CHECK_LAUNCH();
   return T3D_OK;
+}
+
+extern "C" int t3d_gap_bwd(int dtype, const float* dpooled, const void* y, const t3d_prologue* pro, void* dz,
+                           double* stats, int B, int HW, int C, void* stream) {
+  return t3d_pool_bwd(dtype, dpooled, y, pro, T3D_POOL_AVG, nullptr, dz, stats, B, HW, C, stream);
 }

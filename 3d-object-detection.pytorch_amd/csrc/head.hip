@@ -26,6 +26,7 @@ struct HeadArgs {
   double* stats;
   float *dwreg, *dbreg, *dwcls, *dbcls;
   int B, F, ncls;
+  int all_heads;   // export mode (forward_to_onnx): every one of the 9 regressors for every sample, kp [9,B,18]
 };
 
 __device__ __forceinline__ float feat(const HeadArgs& a, int b, int j) {
@@ -43,22 +44,25 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(const HeadArgs a) {
     fm[j] = a.mask ? v * a.mask[(size_t)b * a.F + j] : v;
   }
   __syncthreads();
-  int c = (int)a.cats[b];
-  c = c < 0 ? 0 : (c > 8 ? 8 : c);
-  const int nrows = NKP + (a.logits ? a.ncls : 0);
+  int cb = a.all_heads ? 0 : (int)a.cats[b];
+  cb = cb < 0 ? 0 : (cb > 8 ? 8 : cb);
+  const int nreg = a.all_heads ? 9 * NKP : NKP;
+  const int nrows = nreg + (a.logits ? a.ncls : 0);
   for (int r = wave; r < nrows; r += 4) {
-    const bool reg = r < NKP;
-    const float* w = reg ? a.wreg + ((size_t)c * NKP + r) * a.F : a.wcls + (size_t)(r - NKP) * a.F;
+    const bool reg = r < nreg;
+    const int c = a.all_heads ? r / NKP : cb, rr = a.all_heads ? r % NKP : r;      // (class, row) of a regressor row
+    const float* w = reg ? a.wreg + ((size_t)c * NKP + rr) * a.F : a.wcls + (size_t)(r - nreg) * a.F;
     const float* x = reg ? fs : fm;
     float s = 0.f;
     for (int j = lane; j < a.F; j += 64) s = fmaf(w[j], x[j], s);
     s = wave_sum(s);
     if (lane == 0) {
       if (reg) {
-        s += a.breg[c * NKP + r];
-        a.kp[(size_t)b * NKP + r] = 1.f / (1.f + expf(-s));
+        s += a.breg[c * NKP + rr];
+        const size_t o = a.all_heads ? ((size_t)c * a.B + b) * NKP + rr : (size_t)b * NKP + rr;
+        a.kp[o] = 1.f / (1.f + expf(-s));
       } else {
-        a.logits[(size_t)b * a.ncls + (r - NKP)] = s + a.bcls[r - NKP];
+        a.logits[(size_t)b * a.ncls + (r - nreg)] = s + a.bcls[r - nreg];
       }
     }
   }
@@ -211,6 +215,22 @@ __global__ __launch_bounds__(256) void head_bwd_weight_kernel(const HeadArgs a) 
   }
 }
 
+// y[m][n] = sum_k x[m][k] w[n][k] + bias[n]: one wave per output element (any N, K; the heads' N = 18 / num_classes
+// are not multiples of 8, which the MFMA 1x1 kernels require)
+__global__ __launch_bounds__(256) void linear_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                         const float* __restrict__ bias, float* __restrict__ y, int M,
+                                                         int K, int Nn) {
+  const int lane = threadIdx.x & 63;
+  const long long total = (long long)M * Nn;
+  for (long long o = blockIdx.x * 4ll + (threadIdx.x >> 6); o < total; o += gridDim.x * 4ll) {
+    const int m = (int)(o / Nn), n = (int)(o % Nn);
+    float s = 0.f;
+    for (int k = lane; k < K; k += 64) s = fmaf(x[(size_t)m * K + k], w[(size_t)n * K + k], s);
+    s = wave_sum(s);
+    if (lane == 0) y[o] = s + (bias ? bias[n] : 0.f);
+  }
+}
+
 inline void fill(HeadArgs& a, const t3d_prologue* pro) {
   if (pro) { a.scale = pro->scale; a.shift = pro->shift; a.act = pro->act; }
 }
@@ -226,6 +246,33 @@ extern "C" int t3d_head_fwd(const float* f, const t3d_prologue* pro, const int64
   HeadArgs a{};
   a.f = f; a.cats = cats; a.wreg = wreg; a.breg = breg; a.wcls = wcls; a.bcls = bcls; a.mask = mask;
   a.kp = kp; a.logits = logits; a.B = B; a.F = F; a.ncls = ncls;
+  fill(a, pro);
+  hipLaunchKernelGGL(head_fwd_kernel, dim3(B), dim3(256), (size_t)2 * F * sizeof(float),
+                     reinterpret_cast<hipStream_t>(stream), a);
+  T3D_CHECK_LAUNCH();
+  return T3D_OK;
+}
+
+extern "C" int t3d_linear_fwd(const float* x, const float* w, const float* bias, float* y, int M, int K, int N,
+                              void* stream) {
+  if (!x || !w || !y || M <= 0 || K <= 0 || N <= 0) return T3D_ERR_ARG;
+  const long long total = (long long)M * N;
+  const int grid = (int)((total + 3) / 4 < 4096 ? (total + 3) / 4 : 4096);
+  hipLaunchKernelGGL(linear_fwd_kernel, dim3(grid), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), x, w, bias, y,
+                     M, K, N);
+  T3D_CHECK_LAUNCH();
+  return T3D_OK;
+}
+
+extern "C" int t3d_head_fwd_all(const float* f, const t3d_prologue* pro, const float* wreg, const float* breg,
+                                const float* wcls, const float* bcls, float* kp_all, float* logits, int B, int F,
+                                int ncls, void* stream) {
+  if (!f || !wreg || !breg || !kp_all || B <= 0 || F <= 0) return T3D_ERR_ARG;
+  if (logits && (!wcls || !bcls || ncls <= 0 || ncls > 64)) return T3D_ERR_ARG;
+  if (pro && pro->se) return T3D_ERR_UNSUPPORTED;
+  HeadArgs a{};
+  a.f = f; a.wreg = wreg; a.breg = breg; a.wcls = wcls; a.bcls = bcls;
+  a.kp = kp_all; a.logits = logits; a.B = B; a.F = F; a.ncls = ncls; a.all_heads = 1;
   fill(a, pro);
   hipLaunchKernelGGL(head_fwd_kernel, dim3(B), dim3(256), (size_t)2 * F * sizeof(float),
                      reinterpret_cast<hipStream_t>(stream), a);

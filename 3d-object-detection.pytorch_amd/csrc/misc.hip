@@ -45,7 +45,171 @@ __global__ void sum_replicas_batched_kernel(const long long* __restrict__ desc, 
   }
 }
 
+// AdamW over one flat fp32 buffer (torch.optim.AdamW semantics, decoupled weight decay, no amsgrad):
+//   p *= 1 - lr*wd;  m = lerp(m, g, 1-b1);  v = b2*v + (1-b2)*g*g;  p -= (lr/bc1) * m / (sqrt(v)/sqrt(bc2) + eps)
+// 16 B per lane per array; the bias corrections are computed on the host in fp64.
+__global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                    float* __restrict__ m, float* __restrict__ v, long long n4,
+                                                    float decay, float b1, float b2, float step_size,
+                                                    float inv_sqrt_bc2, float eps, float gscale) {
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
+    float4 pp = reinterpret_cast<float4*>(p)[i];
+    const float4 gg4 = reinterpret_cast<const float4*>(g)[i];
+    float4 mm = reinterpret_cast<float4*>(m)[i];
+    float4 vv = reinterpret_cast<float4*>(v)[i];
+    float* pe = reinterpret_cast<float*>(&pp);
+    const float* ge = reinterpret_cast<const float*>(&gg4);
+    float* me = reinterpret_cast<float*>(&mm);
+    float* ve = reinterpret_cast<float*>(&vv);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float gj = ge[j] * gscale;
+      const float pj = pe[j] * decay;
+      const float mj = me[j] + (gj - me[j]) * (1.f - b1);
+      const float vj = ve[j] * b2 + (1.f - b2) * gj * gj;
+      const float denom = sqrtf(vj) * inv_sqrt_bc2 + eps;
+      pe[j] = pj - step_size * (mj / denom);
+      me[j] = mj;
+      ve[j] = vj;
+    }
+    reinterpret_cast<float4*>(p)[i] = pp;
+    reinterpret_cast<float4*>(m)[i] = mm;
+    reinterpret_cast<float4*>(v)[i] = vv;
+  }
+}
+
+// dst [rows][cd] <- src [rows][cs]: the leading min(cs, cd) columns are copied, further dst columns zeroed
+__global__ void copy_cols_kernel(const float* __restrict__ src, float* __restrict__ dst, int rows, int cs, int cd) {
+  const int n = rows * cd;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    const int r = i / cd, c = i % cd;
+    dst[i] = c < cs ? src[(size_t)r * cs + c] : 0.f;
+  }
+}
+
+// Linear bias gradient under a train-mode BatchNorm: sum_b dy = alpha*sum(dz) + beta*sum(y) + count*gamma
+__global__ void bn_bias_grad_kernel(const double* __restrict__ fstats, const double* __restrict__ bstats, int nrep,
+                                    long long rstride, int C, double count, const float* __restrict__ alpha,
+                                    const float* __restrict__ beta, const float* __restrict__ gammac, float* dbias) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  double sy = 0.0, sdz = 0.0;
+  for (int r = 0; r < nrep; ++r) {
+    sy += fstats[r * rstride + c];
+    sdz += bstats[r * rstride + c];
+  }
+  dbias[c] = (float)((double)alpha[c] * sdz + (double)beta[c] * sy + count * (double)gammac[c]);
+}
+
+// squeeze-excite gate between a BatchNorm and its consumer: per-sample backward affine
+//   aps[b][c] = s[b][c]*alpha[c],  gps[b][c] = gammac[c] + g[b][c]*alpha[c]
+__global__ void se_bwd_affine_kernel(const float* __restrict__ s, const float* __restrict__ g,
+                                     const float* __restrict__ alpha, const float* __restrict__ gammac,
+                                     float* __restrict__ aps, float* __restrict__ gps, int B, int C) {
+  const int n = B * C;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    const int c = i % C;
+    aps[i] = s[i] * alpha[c];
+    gps[i] = gammac[c] + g[i] * alpha[c];
+  }
+}
+
+// Dropout(0.5) keep/scale factors {0, 2} from a counter-based generator (Philox-4x32-10 keyed by `seed`, counter =
+// (element index / 4, offset)): one launch, no state on the device, reproducible for a given (seed, offset).
+__device__ __forceinline__ void philox_round(uint32_t c[4], uint32_t k0, uint32_t k1) {
+  const uint64_t p0 = (uint64_t)0xD2511F53u * c[0], p1 = (uint64_t)0xCD9E8D57u * c[2];
+  const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c[1] ^ k0, n2 = (uint32_t)(p0 >> 32) ^ c[3] ^ k1;
+  c[1] = (uint32_t)p1; c[3] = (uint32_t)p0; c[0] = n0; c[2] = n2;
+}
+__global__ void dropout_mask_kernel(float* __restrict__ mask, long long n, unsigned long long seed,
+                                    unsigned long long offset, float keep, float scale) {
+  const long long n4 = (n + 3) / 4;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
+    uint32_t c[4] = {(uint32_t)i, (uint32_t)(i >> 32), (uint32_t)offset, (uint32_t)(offset >> 32)};
+    uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+      philox_round(c, k0, k1);
+      k0 += 0x9E3779B9u;
+      k1 += 0xBB67AE85u;
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const long long e = i * 4 + j;
+      if (e < n) mask[e] = ((float)(c[j] >> 8) * (1.f / 16777216.f) < keep) ? scale : 0.f;
+    }
+  }
+}
+
+// desc[t] = {ptr, bytes (multiple of 16)}: zero fill of several buffers in one launch
+__global__ void zero_batched_kernel(const long long* __restrict__ desc) {
+  const long long* d = desc + (size_t)blockIdx.x * 2;
+  float4* __restrict__ dst = reinterpret_cast<float4*>(d[0]);
+  const long long n = d[1] / 16;
+  for (long long i = blockIdx.y * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.y * blockDim.x)
+    dst[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+}
+
 }  // namespace
+
+extern "C" int t3d_adamw_step(float* p, const float* g, float* m, float* v, long long n, float lr, float beta1,
+                              float beta2, float eps, float weight_decay, long long step, float grad_scale,
+                              void* stream) {
+  if (!p || !g || !m || !v || n <= 0 || (n % 4) || step <= 0) return T3D_ERR_ARG;
+  const double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
+  const long long n4 = n / 4;
+  const int grid = (int)((n4 + 255) / 256 < 2048 ? (n4 + 255) / 256 : 2048);
+  hipLaunchKernelGGL(adamw_kernel, dim3(grid), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), p, g, m, v, n4,
+                     (float)(1.0 - (double)lr * (double)weight_decay), beta1, beta2, (float)((double)lr / bc1),
+                     (float)(1.0 / sqrt(bc2)), eps, grad_scale);
+  T3D_CHECK_LAUNCH();
+  return T3D_OK;
+}
+
+extern "C" int t3d_copy_cols(const float* src, float* dst, int rows, int cols_src, int cols_dst, void* stream) {
+  if (!src || !dst || rows <= 0 || cols_src <= 0 || cols_dst <= 0) return T3D_ERR_ARG;
+  hipLaunchKernelGGL(copy_cols_kernel, dim3(cdiv(rows * cols_dst, 256) < 256 ? cdiv(rows * cols_dst, 256) : 256),
+                     dim3(256), 0, reinterpret_cast<hipStream_t>(stream), src, dst, rows, cols_src, cols_dst);
+  T3D_CHECK_LAUNCH();
+  return T3D_OK;
+}
+
+extern "C" int t3d_bn_bias_grad(const double* fwd_stats, const double* bwd_stats, int C, double count,
+                                const float* alpha, const float* beta, const float* gammac, float* dbias,
+                                void* stream) {
+  if (!fwd_stats || !bwd_stats || !alpha || !beta || !gammac || !dbias || C <= 0) return T3D_ERR_ARG;
+  hipLaunchKernelGGL(bn_bias_grad_kernel, dim3(cdiv(C, 256)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                     fwd_stats, bwd_stats, g_t3d_reduce.nrep, g_t3d_reduce.stats_stride, C, count, alpha, beta, gammac,
+                     dbias);
+  T3D_CHECK_LAUNCH();
+  return T3D_OK;
+}
+
+extern "C" int t3d_se_bwd_affine(const float* s, const float* g, const float* alpha, const float* gammac, float* aps,
+                                 float* gps, int B, int C, void* stream) {
+  if (!s || !g || !alpha || !gammac || !aps || !gps || B <= 0 || C <= 0) return T3D_ERR_ARG;
+  hipLaunchKernelGGL(se_bwd_affine_kernel, dim3(cdiv(B * C, 256) < 512 ? cdiv(B * C, 256) : 512), dim3(256), 0,
+                     reinterpret_cast<hipStream_t>(stream), s, g, alpha, gammac, aps, gps, B, C);
+  T3D_CHECK_LAUNCH();
+  return T3D_OK;
+}
+
+extern "C" int t3d_dropout_mask(float* mask, long long n, unsigned long long seed, unsigned long long offset, float p,
+                                void* stream) {
+  if (!mask || n <= 0 || !(p >= 0.f && p < 1.f)) return T3D_ERR_ARG;
+  const long long n4 = (n + 3) / 4;
+  hipLaunchKernelGGL(dropout_mask_kernel, dim3((int)((n4 + 255) / 256 < 1024 ? (n4 + 255) / 256 : 1024)), dim3(256), 0,
+                     reinterpret_cast<hipStream_t>(stream), mask, n, seed, offset, 1.f - p, 1.f / (1.f - p));
+  T3D_CHECK_LAUNCH();
+  return T3D_OK;
+}
+
+extern "C" int t3d_zero_batched(const long long* desc, int n, void* stream) {
+  if (!desc || n <= 0) return T3D_ERR_ARG;
+  hipLaunchKernelGGL(zero_batched_kernel, dim3(n, 64), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), desc);
+  T3D_CHECK_LAUNCH();
+  return T3D_OK;
+}
 
 extern "C" int t3d_sum_replicas_batched(const long long* desc, int n, int nrep, void* stream) {
   if (!desc || n <= 0 || nrep < 1) return T3D_ERR_ARG;

@@ -13,6 +13,7 @@ LIB_PATH = os.path.join(os.path.dirname(_HERE), 'libt3d_hip.so')
 
 F32, BF16 = 0, 1
 ACT = {'none': 0, 'relu': 1, 'relu6': 2, 'hswish': 3}
+POOL = {'avg': 0, 'max': 1, 'avg+max': 2}
 _P, _I, _F, _D, _L = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_double, ctypes.c_longlong
 
 
@@ -54,7 +55,11 @@ SIGNATURES = {
     't3d_bn_act_bwd': [_I, _P, _P, _PP, _P, _P, _I, _I, _P],
     't3d_gap_fwd': [_I, _P, _PP, _P, _I, _I, _I, _P],
     't3d_gap_bwd': [_I, _P, _P, _PP, _P, _P, _I, _I, _I, _P],
+    't3d_pool_fwd': [_I, _P, _PP, _I, _P, _P, _I, _I, _I, _P],
+    't3d_pool_bwd': [_I, _P, _P, _PP, _I, _P, _P, _P, _I, _I, _I, _P],
     't3d_head_fwd': [_P, _PP, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P],
+    't3d_linear_fwd': [_P, _P, _P, _P, _I, _I, _I, _P],
+    't3d_head_fwd_all': [_P, _PP, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P],
     't3d_head_bwd': [_P, _PP, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P],
     't3d_se_fwd': [_P] * 11 + [_I, _I, _I, _I, _P],
     't3d_se_bwd': [_P] * 18 + [_I, _I, _I, _I, _P],
@@ -63,6 +68,12 @@ SIGNATURES = {
     't3d_set_reduction_replicas': [_I, _L],
     't3d_set_workspace': [_P, _L],
     't3d_pack_weights_batched': [_I, _P, _I, _P],
+    't3d_adamw_step': [_P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _L, _F, _P],
+    't3d_zero_batched': [_P, _I, _P],
+    't3d_copy_cols': [_P, _P, _I, _I, _I, _P],
+    't3d_bn_bias_grad': [_P, _P, _I, _D, _P, _P, _P, _P, _P],
+    't3d_se_bwd_affine': [_P, _P, _P, _P, _P, _P, _I, _I, _P],
+    't3d_dropout_mask': [_P, _L, ctypes.c_ulonglong, ctypes.c_ulonglong, _F, _P],
     't3d_loss_fwd_bwd': [_LP, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P],
 }
 

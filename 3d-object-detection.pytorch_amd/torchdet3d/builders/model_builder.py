@@ -10,8 +10,15 @@ reference's).  Differences a caller can observe:
   * the forward runs on the GPU only ('--device cuda'); there is no CPU fallback;
   * extra model names: 'mobilenetv2' (north-star throughput model).  The timm / efficientnet-lite names of the
     reference need un-vendored third-party packages and are not built.
+  * `regressors`, `cls_fc`, `sigmoid` (model_builder.py:79-87) are views onto the flat buffer, `extract_features`
+    (mobilenetv3.py:199-203) and `_glob_feature_vector` (:96-110) are callable but inference-only: training goes
+    through `forward`, whose whole graph is one autograd node;
+  * train-mode BatchNorm / Dropout are applied only when a backward can follow (`model.train()` AND grad mode on);
+    a train-mode model called under `torch.no_grad()` evaluates with the running statistics and leaves them alone,
+    where the reference would still use (and update) batch statistics.
 Config keys read: model.name, model.num_classes, model.pretrained (ignored: no network), model.load_weights,
-model.storage_dtype ('f32' default for parity | 'bf16' throughput mode)."""
+model.storage_dtype ('f32' default for parity | 'bf16' throughput mode), model.pooling_mode ('avg' | 'max' |
+'avg+max'; the reference fixes this at its default 'avg', model_builder.py:73-74)."""
 import torch
 from torch import nn
 
@@ -27,7 +34,7 @@ class _Run(torch.autograd.Function):
     def forward(ctx, flat, wrapper, x, cats, mask, train):
         net = wrapper.net
         kp, logits = net.forward(x, cats, train=train, dropout_mask=mask)
-        ctx.wrapper, ctx.train = wrapper, train
+        ctx.wrapper, ctx.train, ctx.generation = wrapper, train, net.generation
         if logits is None:
             logits = torch.empty(0, device=kp.device)
             ctx.mark_non_differentiable(logits)
@@ -38,6 +45,11 @@ class _Run(torch.autograd.Function):
         net = ctx.wrapper.net
         if not ctx.train:
             raise RuntimeError('backward through an eval-mode forward is not supported (BatchNorm uses running stats)')
+        if net.saved is None or net.saved.get('generation') != ctx.generation:
+            # the engine keeps the activations of ONE train-mode forward (the latest); back-propagating an older
+            # forward through them would silently produce the wrong gradients
+            raise RuntimeError('backward() of a forward whose activations were overwritten by a later train-mode '
+                               'forward (or already consumed): run forward -> backward one batch at a time')
         if dkp is None:
             dkp = torch.zeros(net.saved['B'], 9, 2, device=net.device)
         if net.num_classes > 1 and dlogits is None:
@@ -51,22 +63,105 @@ class _Run(torch.autograd.Function):
         return net.gflat, None, None, None, None, None
 
 
+class _HeadView(nn.Module):
+    """`regressors[k][0]` / `cls_fc[1]` as a caller of the reference sees them (model_builder.py:79-85): a Linear whose
+    weight / bias are VIEWS into the engine's flat master buffer (not separately registered parameters: the optimizer
+    keeps seeing the one flat tensor).  Calling it runs the product's GEMM kernel."""
+
+    def __init__(self, wrapper, wkey, bkey):
+        super().__init__()
+        object.__setattr__(self, '_w', wrapper)
+        self._wkey, self._bkey = wkey, bkey
+
+    @property
+    def weight(self):
+        return self._w.net.p[self._wkey]
+
+    @property
+    def bias(self):
+        return self._w.net.p[self._bkey]
+
+    @property
+    def in_features(self):
+        return self.weight.shape[1]
+
+    @property
+    def out_features(self):
+        return self.weight.shape[0]
+
+    @torch.no_grad()
+    def forward(self, x):
+        from .. import _native as N
+        squeeze = x.dim() == 1
+        x2 = x.reshape(-1, x.shape[-1]).float().contiguous()
+        if not x2.is_cuda:
+            raise RuntimeError('the HIP path needs its inputs on the GPU (no CPU fallback)')
+        w, b = self.weight, self.bias
+        y = torch.empty(x2.shape[0], w.shape[0], device=x2.device)
+        N.call('t3d_linear_fwd', N.ptr(x2), N.ptr(w.contiguous()), N.ptr(b.contiguous()), N.ptr(y), x2.shape[0],
+               w.shape[1], w.shape[0], N.stream())
+        return y[0] if squeeze else y.view(*x.shape[:-1], w.shape[0])
+
+
+class _Sigmoid(nn.Module):
+    """`self.sigmoid` (model_builder.py:87); inside `forward` the sigmoid is fused into the head kernel."""
+
+    def forward(self, x):
+        return torch.sigmoid(x)
+
+
 class ModelWrapper(nn.Module):
-    def __init__(self, name, num_classes=9, export_mode=False, storage_dtype='f32', device='cpu'):
+    def __init__(self, name, num_classes=9, export_mode=False, storage_dtype='f32', device='cpu', pooling_mode='avg'):
         super().__init__()
         assert name in AVAILABLE_MODELS, f'Wrong model name parameter. Expected one of {AVAILABLE_MODELS}'
-        self.name, self.num_classes, self.export_mode = name, num_classes, export_mode
+        if pooling_mode not in ('avg', 'max', 'avg+max'):
+            raise ValueError(f'Unknown pooling mode: {pooling_mode}')          # model_builder.py:105-106
+        self.name, self.num_classes, self.export_mode, self.pooling_mode = name, num_classes, export_mode, pooling_mode
         self.storage_dtype = torch.bfloat16 if storage_dtype in ('bf16', torch.bfloat16) else torch.float32
         self.grad_sync = None          # optional torchdet3d.parallel.GradSync (one process per GPU)
         self._make(torch.device(device))
+        # the reference's head attributes (model_builder.py:79-87) as views; kept out of `_modules` / `_parameters`
+        # so that parameters() stays the single flat tensor
+        regs = [nn.Sequential(_HeadView(self, f'regressors.{k}.0.weight', f'regressors.{k}.0.bias')) for k in range(9)]
+        object.__setattr__(self, '_regressors', nn.ModuleList(regs))
+        object.__setattr__(self, '_cls_fc', nn.Sequential(nn.Dropout(0.5), _HeadView(self, 'cls_fc.1.weight', 'cls_fc.1.bias')))
+        object.__setattr__(self, '_sigmoid', _Sigmoid())
+
+    regressors = property(lambda self: self._regressors)
+    cls_fc = property(lambda self: self._cls_fc)
+    sigmoid = property(lambda self: self._sigmoid)
 
     def _make(self, device, state=None):
-        self.net = Net(self.name, self.num_classes, device, self.storage_dtype)
+        self.net = Net(self.name, self.num_classes, device, self.storage_dtype, self.pooling_mode)
         if state is not None:
             self.net.load_state_dict(state)
         self.flat = nn.Parameter(self.net.flat)     # shares storage with the engine's master weights
         if self.grad_sync is not None:
             self.attach_grad_sync(self.grad_sync)
+
+    @torch.no_grad()
+    def extract_features(self, x):
+        """mobilenetv3.py:199-203: activated last feature map, fp32 NCHW [B, C, H/32, W/32] (inference)."""
+        if not x.is_cuda:
+            raise RuntimeError('the HIP path needs the model and the crops on the GPU (no CPU fallback)')
+        return self.net.extract_features(x.float())
+
+    @staticmethod
+    @torch.no_grad()
+    def _glob_feature_vector(x, mode, reduce_dims=True):
+        """model_builder.py:96-110 on an NCHW feature map: 'avg' | 'max' | 'avg+max', ValueError otherwise."""
+        from .. import _native as N
+        if mode not in N.POOL:
+            raise ValueError(f'Unknown pooling mode: {mode}')
+        if not x.is_cuda:
+            raise RuntimeError('the HIP path needs its inputs on the GPU (no CPU fallback)')
+        B, C, H, W = x.shape
+        if C % 8:
+            raise RuntimeError('channel count must be a multiple of 8')
+        nhwc = x.float().permute(0, 2, 3, 1).contiguous()
+        out = torch.empty(B, C, device=x.device)
+        N.call('t3d_pool_fwd', N.F32, N.ptr(nhwc), None, N.POOL[mode], N.ptr(out), None, B, H * W, C, N.stream())
+        return out if reduce_dims else out.view(B, C, 1, 1)
 
     def attach_grad_sync(self, sync_cls_or_obj):
         from ..parallel import GradSync
@@ -106,20 +201,19 @@ class ModelWrapper(nn.Module):
 
     @torch.no_grad()
     def forward_to_onnx(self, x):
-        """All 9 heads (model_builder.py:112-124): kp [9,B,9,2] (sigmoid), class logits (or zeros(B))."""
-        outs, logits = [], None
-        for k in range(9):
-            kp, lg = self.net.forward(x.float(), torch.full((x.shape[0],), k, dtype=torch.int64, device=x.device),
-                                      train=False)
-            outs.append(kp.clone().view(1, x.shape[0], 9, 2))
-            logits = lg
-        return torch.cat(outs), (logits if self.num_classes > 1 else torch.zeros(x.shape[0], device=x.device))
+        """All 9 heads (model_builder.py:112-124): kp [9,B,9,2] (sigmoid), class logits (or zeros(B)) -- ONE pass over
+        the backbone, then every regressor on every sample in one launch (`t3d_head_fwd_all`)."""
+        if not x.is_cuda:
+            raise RuntimeError('the HIP path needs the model and the crops on the GPU (no CPU fallback)')
+        kp, logits = self.net.forward(x.float(), None, train=False, all_heads=True)
+        return kp, (logits if self.num_classes > 1 else torch.zeros(x.shape[0], device=x.device))
 
 
 def build_model(config, export_mode=False, weights_path=''):
     name = config.model.name
     assert name in AVAILABLE_MODELS, f'Wrong model name parameter. Expected one of {AVAILABLE_MODELS}'
-    model = ModelWrapper(name, config.model.num_classes or 9, export_mode, config.model.storage_dtype or 'f32')
+    model = ModelWrapper(name, config.model.num_classes or 9, export_mode, config.model.storage_dtype or 'f32',
+                         pooling_mode=config.model.pooling_mode or 'avg')
     weights = config.model.load_weights or weights_path
     if weights:
         load_pretrained_weights(model, weights)

@@ -1,19 +1,75 @@
 """Validation loop (torchdet3d/evaluation/evaluate.py:73-149): eval-mode forward with the ground-truth class
 selecting the regression head (:92), per-class meters weighted by the whole batch size (:96-100, as the reference
-does), TensorBoard scalars `Val/{ADD,SADD,ACC,IOU}`, a plain-text table in place of PrettyTable."""
+does), TensorBoard scalars `Val/{ADD,SADD,ACC,IOU}`, a plain-text table in place of PrettyTable; and `visual_test`
+(:31-72): per-sample forward + metrics on a few test samples (the jpg drawing needs cv2 + objectron.graphics, which
+this image does not have: the predicted / true keypoints are saved as .npy next to where the jpgs would go)."""
+import os.path as osp
+
+import numpy as np
 import torch
 
-from ..utils import AverageMeter, put_on_device, OBJECTRON_CLASSES
-from .metrics import compute_metrics_per_cls
+from ..utils import AverageMeter, put_on_device, mkdir_if_missing, OBJECTRON_CLASSES
+from .metrics import compute_accuracy, compute_average_distance, compute_metrics_per_cls
 
 
 class Evaluator:
     def __init__(self, model, val_loader, test_loader=None, cfg=None, writer=None, max_epoch=1, device='cuda',
-                 debug=False, debug_steps=30, path_to_save_imgs='./testing_images', num_classes=9):
+                 num_classes=9, samples='random', num_samples=10, path_to_save_imgs='./testing_images', debug=False,
+                 debug_steps=30):
         self.model, self.val_loader, self.test_loader, self.cfg, self.writer = model, val_loader, test_loader, cfg, writer
         self.max_epoch, self.device, self.debug, self.debug_steps = max_epoch, device, debug, debug_steps
-        self.path_to_save_imgs = path_to_save_imgs
+        self.path_to_save_imgs, self.samples, self.num_samples = path_to_save_imgs, samples, num_samples
         self.num_classes = cfg.model.num_classes if cfg is not None and cfg.model.num_classes else num_classes
+
+    @torch.no_grad()
+    def visual_test(self):
+        """evaluate.py:31-72 over the TEST loader's dataset (the reference rebuilds `Objectron(root, mode='test')`,
+        which is the dataset behind `test_loader`, loader_builder.py:31-34): forward one sample at a time with the
+        ground-truth class selecting the head, print ADD / SADD / accuracy, store the keypoints."""
+        ds = getattr(self.test_loader, 'dataset', None)
+        if ds is None or len(ds) == 0:
+            print('visual_test: no test dataset, nothing to do')
+            return []
+        mkdir_if_missing(self.path_to_save_imgs)
+        if self.samples == 'random':
+            indexes = np.random.choice(len(ds), min(self.num_samples, len(ds)), replace=False)
+        else:
+            assert isinstance(self.samples, list)
+            indexes = self.samples
+        self.model.eval()
+        results = []
+        for idx in indexes:
+            item = ds[int(idx)]
+            crop_cords = None
+            if len(item) == 5:                     # test-mode Objectron item (objectron_main.py:93-94)
+                _, img, gt_kp, gt_cat, crop_cords = item
+            else:
+                img, gt_kp, gt_cat = item
+            img, gt_kp = put_on_device([torch.as_tensor(img), torch.as_tensor(gt_kp)], self.device)
+            cat = torch.as_tensor(gt_cat).view(-1).to(self.device)
+            pred_kp, pred_cat = self.model(torch.unsqueeze(img, 0), cat)
+            ADD, SADD = compute_average_distance(pred_kp, torch.unsqueeze(gt_kp, 0))
+            accuracy = compute_accuracy(pred_cat, cat)
+            print(f"\nimage №{idx}.\nComputed metrics:\n"
+                  f"ADD ---> {ADD}\n"
+                  f"SADD ---> {SADD}\n"
+                  f"classification accuracy ---> {accuracy}")
+            pk, gk = pred_kp[0].detach().cpu().numpy(), gt_kp.detach().cpu().numpy()
+            if crop_cords is not None:
+                pk, gk = self.transform_kp(pk, crop_cords), self.transform_kp(gk.copy(), crop_cords)
+            label = OBJECTRON_CLASSES[int(torch.argmax(pred_cat, dim=1))] if pred_cat.dtype.is_floating_point else None
+            np.save(osp.join(self.path_to_save_imgs, f'tested_image_{idx}_predicted.npy'), pk)
+            np.save(osp.join(self.path_to_save_imgs, f'tested_image_{idx}_true.npy'), gk)
+            results.append(dict(idx=int(idx), ADD=ADD, SADD=SADD, accuracy=accuracy, label=label))
+        return results
+
+    @staticmethod
+    def transform_kp(kp, crop_cords):
+        """evaluate.py:141-149: crop-normalised keypoints -> pixel coordinates of the original frame."""
+        x0, y0, x1, y1 = crop_cords
+        kp[:, 0] = kp[:, 0] * (x1 - x0) + x0
+        kp[:, 1] = kp[:, 1] * (y1 - y0) + y0
+        return kp
 
     @torch.no_grad()
     def val_step(self, imgs, gt_kp, gt_cats, compute_iou=True):
@@ -54,6 +110,10 @@ class Evaluator:
         return dict(ADD=meters[0].avg, SADD=meters[1].avg, ACC=meters[2].avg, IOU=meters[3].avg)
 
     def run_eval_pipe(self, visual_only=False):
+        """evaluate.py:135-139."""
+        print('.' * 10, 'Run evaluating protocol', '.' * 10)
+        res = None
         if not visual_only:
-            return self.val(compute_iou=True)
-        raise NotImplementedError('visual_test draws jpgs with cv2 (evaluate.py:31-72): out of scope')
+            res = self.val(compute_iou=True)
+        self.visual_test()
+        return res

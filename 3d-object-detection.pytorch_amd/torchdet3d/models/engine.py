@@ -82,7 +82,10 @@ class _Src:
 
 
 class Net:
-    def __init__(self, name, num_classes=9, device='cuda', dtype=torch.float32):
+    def __init__(self, name, num_classes=9, device='cuda', dtype=torch.float32, pooling_mode='avg'):
+        if pooling_mode not in N.POOL:                 # model_builder.py:105-106
+            raise ValueError(f'Unknown pooling mode: {pooling_mode}')
+        self.pooling_mode, self.pool = pooling_mode, N.POOL[pooling_mode]
         self.arch = Arch(name)
         self.name, self.num_classes = name, num_classes
         self.device = torch.device(device)
@@ -93,7 +96,9 @@ class Net:
         self._layout()
         self._bufs = {}
         self._packed_dirty = True
+        self._packed_version = -1
         self.saved = None
+        self.generation = 0           # id of the latest train-mode forward (whose activations `saved` holds)
         # called as grad_hook(lo) once every gradient at flat offsets >= lo is final (backward runs from the
         # end of `gflat` towards its start): lets a data-parallel wrapper start the RCCL all-reduce of that
         # tail while the rest of the backward is still being computed
@@ -232,8 +237,11 @@ class Net:
         return t
 
     def _pack(self):
-        """fp32 master weights -> storage dtype (+ transposed copies for the data-gradient GEMMs)."""
-        if not self._packed_dirty:
+        """fp32 master weights -> storage dtype (+ transposed copies for the data-gradient GEMMs).  Re-done whenever
+        the master weights may have moved: `flat`, its views `p[...]` and the nn.Parameter the optimizer updates share
+        one version counter, which every in-place update bumps (the hand-written optimizer kernel bumps it
+        explicitly), so an eval forward right after `optimizer.step()` sees the new weights."""
+        if not self._packed_dirty and self._packed_version == self.flat._version:
             return
         st = N.stream()
         if getattr(self, '_pack_desc', None) is None:
@@ -255,8 +263,8 @@ class Net:
         N.call('t3d_pack_weights_batched', self.dt, N.ptr(self._pack_desc), self._pack_desc.shape[0], st)
         # stem: [C,3,3,3] -> [C,32] patch-row weights (columns 27..31 zero)
         c0 = self.arch.stem_c
-        w32 = self._buf('stem32', (c0, 32), torch.float32, zero=True)
-        w32[:, :27] = self.p['features.0.0.weight'].view(c0, 27)
+        w32 = self._buf('stem32', (c0, 32), torch.float32)
+        N.call('t3d_copy_cols', N.ptr(self.p['features.0.0.weight']), N.ptr(w32), c0, 27, 32, st)
         if self.dt == N.F32:
             self.w['stem'] = w32
         else:
@@ -267,6 +275,7 @@ class Net:
             self.wt['classifier'] = self._buf('wt:cls', (wc.shape[1], wc.shape[0]), torch.float32)
             N.call('t3d_pack_weight', N.F32, N.ptr(wc), N.ptr(self.wt['classifier']), wc.shape[0], wc.shape[1], 1, st)
         self._packed_dirty = False
+        self._packed_version = self.flat._version
 
     # ------------------------------------------------------------------ BatchNorm helpers
     def _bn_fwd(self, bn, count, act):
@@ -307,28 +316,99 @@ class Net:
         return N.ptr(bn.stats) if self.training else None
 
     # ------------------------------------------------------------------ forward
-    def forward(self, imgs, cats, train=False, dropout_mask=None):
+    def forward(self, imgs, cats, train=False, dropout_mask=None, all_heads=False):
         N.call('t3d_set_reduction_replicas', NREP, self._stat_stride)
         try:
-            return self._forward(imgs, cats, train, dropout_mask)
+            return self._forward(imgs, cats, train, dropout_mask, all_heads)
         finally:
             N.call('t3d_set_reduction_replicas', 1, 0)
 
-    def _forward(self, imgs, cats, train=False, dropout_mask=None):
+    def _forward(self, imgs, cats, train=False, dropout_mask=None, all_heads=False):
         """imgs [B,3,H,W] fp32 NCHW (the reference's input contract), cats int64 [B] ->
-        kp [B,9,2] fp32 in (0,1), logits [B,num_classes] fp32 (None when num_classes == 1)."""
+        kp [B,9,2] fp32 in (0,1), logits [B,num_classes] fp32 (None when num_classes == 1).
+        all_heads (export mode, model_builder.py:112-124): kp [9,B,9,2], every regressor on every sample."""
+        a, st = self.arch, N.stream()
+        sv = self._features(imgs, train)
+        B = sv['B']
+        pooled, cur, yl, prol = sv['pooled'], sv['last_in'], sv['yl'], sv['prol']
+        if not all_heads:
+            cats = cats.to(self.device, torch.int64).contiguous()
+        sv['cats'] = cats
+        # ---- global pool of the activated last feature map (model_builder.py:96-110)
+        amax = None
+        if self.pool != N.POOL['avg']:
+            amax = self._buf('pool_argmax', (B, a.last_c), torch.int32)
+        N.call('t3d_pool_fwd', self.dt, N.ptr(yl), prol, self.pool, N.ptr(pooled), N.ptr(amax), B, cur.H * cur.W,
+               a.last_c, st)
+        sv['pool_argmax'] = amax
+
+        # ---- classifier Linear + BatchNorm1d + h_swish, MobileNetV3 only (mobilenetv3.py:191-195)
+        f, fpro = pooled, None
+        if a.classifier:
+            bnc = self.bns['classifier.1']
+            yc = self._buf('y:cls', (B, a.classifier), torch.float32)
+            N.call('t3d_pwconv_fwd', N.F32, N.ptr(pooled), None, N.ptr(self.p['classifier.0.weight']),
+                   N.ptr(self.p['classifier.0.bias']), N.ptr(yc), self._st(bnc), B, 1, a.last_c, a.classifier, st)
+            fpro = self._bn_fwd(bnc, B, 'hswish')
+            f = yc
+        # ---- heads (model_builder.py:137-144)
+        ncls = self.num_classes
+        logits = torch.empty(B, ncls, device=self.device) if ncls > 1 else None
+        if all_heads:
+            kp = torch.empty(9, B, 18, device=self.device)
+            N.call('t3d_head_fwd_all', N.ptr(f), fpro, N.ptr(self.wreg), N.ptr(self.breg),
+                   N.ptr(self.p['cls_fc.1.weight']) if ncls > 1 else None,
+                   N.ptr(self.p['cls_fc.1.bias']) if ncls > 1 else None, N.ptr(kp), N.ptr(logits), B, a.feat_c, ncls, st)
+            self.saved = None
+            return kp.view(9, B, 9, 2), logits
+        mask = None
+        if train and ncls > 1:
+            mask = dropout_mask
+            if mask is None:        # nn.Dropout(0.5): keep with p = .5, scale by 2 (model_builder.py:83)
+                mask = self._buf('dropout', (B, a.feat_c), torch.float32)
+                self._dropout_calls = getattr(self, '_dropout_calls', 0) + 1
+                N.call('t3d_dropout_mask', N.ptr(mask), B * a.feat_c, torch.initial_seed() & ((1 << 64) - 1),
+                       self._dropout_calls, 0.5, st)
+            else:
+                mask = mask.to(self.device, torch.float32).contiguous()
+        kp = torch.empty(B, 18, device=self.device)
+        N.call('t3d_head_fwd', N.ptr(f), fpro, N.ptr(cats), N.ptr(self.wreg), N.ptr(self.breg),
+               N.ptr(self.p['cls_fc.1.weight']), N.ptr(self.p['cls_fc.1.bias']), N.ptr(mask), N.ptr(kp),
+               N.ptr(logits), B, a.feat_c, ncls, st)
+        sv.update(f=f, fpro=fpro, mask=mask, kp=kp)
+        if train:
+            self.generation += 1
+            sv['generation'] = self.generation
+        self.saved = sv if train else None
+        return kp.view(B, 9, 2), logits
+
+    def extract_features(self, imgs):
+        """`MobileNetV3.extract_features` (mobilenetv3.py:199-203) as a caller sees it: the activated last feature map,
+        fp32 NCHW [B, C, H/32, W/32].  Inference only (running BatchNorm statistics); the layout conversion from the
+        engine's NHWC storage is a convenience for the API, not part of the hot path."""
+        N.call('t3d_set_reduction_replicas', NREP, self._stat_stride)
+        try:
+            sv = self._features(imgs, False)
+        finally:
+            N.call('t3d_set_reduction_replicas', 1, 0)
+        cur, a = sv['last_in'], self.arch
+        M = sv['B'] * cur.H * cur.W
+        z = torch.empty(M, a.last_c, device=self.device, dtype=self.dtype)
+        N.call('t3d_bn_apply', self.dt, N.ptr(sv['yl']), sv['prol'], None, N.ptr(z), M, a.last_c, N.stream())
+        return z.float().view(sv['B'], cur.H, cur.W, a.last_c).permute(0, 3, 1, 2).contiguous()
+
+    def _features(self, imgs, train):
+        """Stem + inverted-residual blocks + last 1x1 conv (`extract_features`): fills and returns the saved-state
+        dict with the RAW last feature map `yl` and its BatchNorm/activation prologue `prol`."""
         a, st, dt = self.arch, N.stream(), self.dt
         assert imgs.is_cuda and imgs.dtype == torch.float32 and imgs.dim() == 4 and imgs.shape[1] == 3
         imgs = imgs.contiguous()
-        cats = cats.to(self.device, torch.int64).contiguous()
         self.training = bool(train)
-        if train:
-            self._packed_dirty = True     # the optimizer has (possibly) moved the master weights
         self._pack()
         B, _, H, W = imgs.shape
         if train:
             self._statbuf.zero_()
-        sv = dict(B=B, imgs=imgs, cats=cats, blocks=[])
+        sv = dict(B=B, imgs=imgs, blocks=[])
 
         # ---- stem: patch gather + GEMM (mobilenetv3.py:110-115,178)
         Ho, Wo = (H + 2 - 3) // 2 + 1, (W + 2 - 3) // 2 + 1
@@ -355,34 +435,8 @@ class Net:
                self._st(bnl), M, cur.H * cur.W, cur.C, a.last_c, st, nbytes=M * (cur.C + a.last_c) * self.esz)
         prol = self._bn_fwd(bnl, M, a.last_act)
         pooled = self._buf('pooled', (B, a.last_c), torch.float32)
-        N.call('t3d_gap_fwd', dt, N.ptr(yl), prol, N.ptr(pooled), B, cur.H * cur.W, a.last_c, st)
         sv.update(last_in=cur, yl=yl, prol=prol, pooled=pooled, HWl=cur.H * cur.W)
-
-        # ---- classifier Linear + BatchNorm1d + h_swish, MobileNetV3 only (mobilenetv3.py:191-195)
-        f, fpro = pooled, None
-        if a.classifier:
-            bnc = self.bns['classifier.1']
-            yc = self._buf('y:cls', (B, a.classifier), torch.float32)
-            N.call('t3d_pwconv_fwd', N.F32, N.ptr(pooled), None, N.ptr(self.p['classifier.0.weight']),
-                   N.ptr(self.p['classifier.0.bias']), N.ptr(yc), self._st(bnc), B, 1, a.last_c, a.classifier, st)
-            fpro = self._bn_fwd(bnc, B, 'hswish')
-            f = yc
-        # ---- heads (model_builder.py:137-144)
-        ncls = self.num_classes
-        mask = None
-        if train and ncls > 1:
-            mask = dropout_mask
-            if mask is None:        # nn.Dropout(0.5): keep with p = .5, scale by 2 (model_builder.py:83)
-                mask = (torch.rand(B, a.feat_c, device=self.device) >= 0.5).float() * 2.0
-            mask = mask.to(self.device, torch.float32).contiguous()
-        kp = torch.empty(B, 18, device=self.device)
-        logits = torch.empty(B, ncls, device=self.device) if ncls > 1 else None
-        N.call('t3d_head_fwd', N.ptr(f), fpro, N.ptr(cats), N.ptr(self.wreg), N.ptr(self.breg),
-               N.ptr(self.p['cls_fc.1.weight']), N.ptr(self.p['cls_fc.1.bias']), N.ptr(mask), N.ptr(kp),
-               N.ptr(logits), B, a.feat_c, ncls, st)
-        sv.update(f=f, fpro=fpro, mask=mask, kp=kp)
-        self.saved = sv if train else None
-        return kp.view(B, 9, 2), logits
+        return sv
 
     def _finish(self, src, tag):
         """Materialise act(BN(y)) (needed when a deferred tensor also feeds a skip connection)."""
@@ -505,10 +559,15 @@ class Net:
         sv = self.saved
         assert sv is not None, 'backward() needs a preceding forward(train=True)'
         a, st, dt, B = self.arch, N.stream(), self.dt, sv['B']
-        self.gflat.zero_()
         if getattr(self, '_dwarena', None) is None:
             self._dw_arena_init()
-        self._dwarena.zero_()
+        # one launch clears every accumulate-into buffer of the backward: gradients, depthwise replicas, stem patch-row dW
+        dw32 = self._buf('dstem32', (a.stem_c, 32), torch.float32)
+        if getattr(self, '_zero_desc', None) is None:
+            rows = [[t.data_ptr(), t.numel() * t.element_size()] for t in (self.gflat, self._dwarena, dw32)]
+            assert all(r[1] % 16 == 0 for r in rows)
+            self._zero_desc = torch.tensor(rows, dtype=torch.int64, device=self.device)
+        N.call('t3d_zero_batched', N.ptr(self._zero_desc), self._zero_desc.shape[0], st)
         self._dwpending, self._dwflushed, self._hook_hi = 0, 0, self.gflat.numel()
         dkp = dkp.reshape(B, 18).to(torch.float32).contiguous()
         ncls = self.num_classes
@@ -532,13 +591,8 @@ class Net:
             N.call('t3d_pwconv_wgrad', N.F32, N.ptr(df), N.ptr(yc), bb, N.ptr(pooled), None,
                    N.ptr(self.g['classifier.0.weight']), B, 1, a.last_c, a.classifier, st)
             # bias gradient = sum_b dy = alpha*sum(dz) + beta*sum(y) + B*gamma (exactly 0 in exact arithmetic)
-            C = a.classifier
-            o = bnc.stats.storage_offset()
-            tot2 = self._stat_stride // 2
-            sy = self._statbuf[:, o:o + C].sum(0)
-            sdz = self._statbuf[:, o + tot2:o + tot2 + C].sum(0)
-            self.g['classifier.0.bias'].copy_((bnc.alpha.double() * sdz + bnc.bbeta.double() * sy
-                                               + B * bnc.gammac.double()).float())
+            N.call('t3d_bn_bias_grad', N.ptr(bnc.stats), N.ptr(bnc.bstats), a.classifier, float(B), N.ptr(bnc.alpha),
+                   N.ptr(bnc.bbeta), N.ptr(bnc.gammac), N.ptr(self.g['classifier.0.bias']), st)
             dpooled = self._buf('dpooled', (B, a.last_c), torch.float32)
             N.call('t3d_pwconv_dgrad', N.F32, N.ptr(df), N.ptr(yc), bb, N.ptr(self.wt['classifier']), None, None,
                    None, N.ptr(dpooled), None, None, B, 1, a.last_c, a.classifier, st)
@@ -548,8 +602,8 @@ class Net:
         x = sv['last_in']
         M, HW = B * sv['HWl'], sv['HWl']
         dzl = self._buf('dz:last', (M, a.last_c))
-        N.call('t3d_gap_bwd', dt, N.ptr(dpooled), N.ptr(sv['yl']), sv['prol'], N.ptr(dzl), N.ptr(bnl.bstats),
-               B, HW, a.last_c, st)
+        N.call('t3d_pool_bwd', dt, N.ptr(dpooled), N.ptr(sv['yl']), sv['prol'], self.pool, N.ptr(sv['pool_argmax']),
+               N.ptr(dzl), N.ptr(bnl.bstats), B, HW, a.last_c, st)
         bb = self._bn_bwd(bnl)
         self._wgrad(dt, N.ptr(dzl), N.ptr(sv['yl']), bb, N.ptr(x.t), x.pro,
                     N.ptr(self.g[ln + '.0.weight']), M, HW, x.C, a.last_c, nbytes=M * (x.C + a.last_c) * self.esz)
@@ -565,12 +619,11 @@ class Net:
         bn0 = s0.bn
         bb = self._bn_bwd(bn0)
         M = s0.B * s0.H * s0.W
-        dw32 = self._buf('dstem32', (a.stem_c, 32), torch.float32, zero=True)
         self._wgrad(dt, N.ptr(dz), N.ptr(s0.raw), bb, N.ptr(sv['col']), None, N.ptr(dw32),
                     M, s0.H * s0.W, 32, a.stem_c, nbytes=M * (32 + a.stem_c) * self.esz)
         self._flush_dw()
         self._join_side()
-        self.g['features.0.0.weight'].view(a.stem_c, 27).copy_(dw32[:, :27])
+        N.call('t3d_copy_cols', N.ptr(dw32), N.ptr(self.g['features.0.0.weight']), a.stem_c, 32, 27, st)
         self._maybe_hook(0, force=True)
         self.saved = None
 
@@ -720,8 +773,8 @@ class Net:
             self._bn_bwd(bn2)
             aps = self._buf(f'se_aps:{i}', (B, C), torch.float32)
             gps = self._buf(f'se_gps:{i}', (B, C), torch.float32)
-            torch.mul(se['s'], bn2.alpha, out=aps)
-            torch.addcmul(bn2.gammac.expand(B, C), g, bn2.alpha.expand(B, C), out=gps)
+            N.call('t3d_se_bwd_affine', N.ptr(se['s']), N.ptr(g), N.ptr(bn2.alpha), N.ptr(bn2.gammac), N.ptr(aps),
+                   N.ptr(gps), B, C, st)
             bb2 = N.bnbwd(aps, bn2.bbeta, gps, True)
         M1 = B * x.H * x.W
         res = dz if blk.res else None

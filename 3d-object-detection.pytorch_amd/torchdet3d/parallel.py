@@ -45,8 +45,9 @@ class GradSync:
                                                   async_op=True))
             self.hi = lo
 
-    def finish(self):
-        """Wait for the buckets and turn the sums into means."""
+    def finish(self, scale=True):
+        """Wait for the buckets and turn the sums into means (scale=False: the caller's optimizer kernel applies the
+        1/world factor while it reads the gradient, `FusedAdamW.grad_scale`)."""
         if self.world == 1 and not self.force:
             return
         if self.hi > 0:
@@ -54,4 +55,5 @@ class GradSync:
         for w in self.works:
             w.wait()
         self.works = []
-        self.g.mul_(1.0 / self.world)
+        if scale:
+            self.g.mul_(1.0 / self.world)

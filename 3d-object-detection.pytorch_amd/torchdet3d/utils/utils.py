@@ -1,11 +1,14 @@
 """Host-side glue of the hot path's callers, behaviour of torchdet3d/utils/utils.py restated without its absent
-third-party imports (cv2, addict, objectron.graphics): seeds (:24-31), checkpoint save / load / resume
-(:56-64, :86-112, :127-208), python-file config reader (:66-84), `put_on_device` (:242-245), `AverageMeter`
-(:272-287)."""
+third-party imports (cv2, addict, objectron.graphics): seeds (:24-31), `check_isfile` / `mkdir_if_missing`
+(:33-54), checkpoint save / load / resume (:56-64, :86-112, :127-208), python-file config reader (:66-84),
+`put_on_device` (:242-245), `AverageMeter` (:272-287), `Logger` (:289-333)."""
+import errno
 import importlib.util
 import os
 import os.path as osp
 import random
+import sys
+import warnings
 from collections import OrderedDict
 
 import numpy as np
@@ -34,7 +37,8 @@ class AttrDict(dict):
 def read_py_config(filename):
     """utils.py:66-84: import a python file as a module, return its public globals as an attribute dict."""
     filename = osp.abspath(osp.expanduser(filename))
-    check_isfile(filename)
+    if not check_isfile(filename):
+        raise RuntimeError("config not found")
     assert filename.endswith('.py')
     module_name = osp.basename(filename)[:-3]
     if '.' in module_name:
@@ -46,9 +50,21 @@ def read_py_config(filename):
 
 
 def check_isfile(fpath):
-    if not osp.isfile(fpath):
-        raise RuntimeError(f'No file found at "{fpath}"')
-    return True
+    """utils.py:33-45: warns (does not raise) and returns whether `fpath` is a file."""
+    isfile = osp.isfile(fpath)
+    if not isfile:
+        warnings.warn(f'No file found at "{fpath}"')
+    return isfile
+
+
+def mkdir_if_missing(dirname):
+    """utils.py:47-54."""
+    if not osp.exists(dirname):
+        try:
+            os.makedirs(dirname)
+        except OSError as e:
+            if e.errno != errno.EEXIST:
+                raise
 
 
 def set_random_seed(seed, deterministic=False):
@@ -64,7 +80,7 @@ def save_snap(model, optimizer, scheduler, epoch, log_path):
     """utils.py:56-64 (`snap_{epoch}.pth` with state_dict / optimizer / scheduler / epoch)."""
     snap = {'state_dict': model.state_dict(), 'optimizer': optimizer.state_dict(),
             'scheduler': scheduler.state_dict() if scheduler is not None else None, 'epoch': epoch}
-    os.makedirs(log_path, exist_ok=True)
+    mkdir_if_missing(log_path)
     name = osp.join(log_path, f'snap_{epoch}.pth')
     print(f'==> saving checkpoint to {name}')
     torch.save(snap, name)
@@ -74,7 +90,8 @@ def load_checkpoint(fpath, map_location=None):
     """utils.py:86-112."""
     if fpath is None:
         raise ValueError('File path is None')
-    check_isfile(fpath)
+    if not osp.exists(fpath):
+        raise FileNotFoundError(f'File is not found at "{fpath}"')
     return torch.load(fpath, map_location=map_location or 'cpu', weights_only=False)
 
 
@@ -133,3 +150,42 @@ class AverageMeter:
         self.sum += val * n
         self.count += n
         self.avg = self.sum / self.count
+
+
+class Logger:
+    """utils.py:289-333: tee of the console into a text file (`sys.stdout = Logger(path)`, scripts/main.py:39);
+    creates the directory of `fpath`, `flush` also fsyncs the file."""
+
+    def __init__(self, fpath=None):
+        self.console = sys.stdout
+        self.file = None
+        if fpath is not None:
+            mkdir_if_missing(osp.dirname(fpath))
+            self.file = open(fpath, 'w')      # noqa: SIM115  (lives as long as the logger)
+
+    def __del__(self):
+        self.close()
+
+    def __enter__(self):
+        pass
+
+    def __exit__(self, *args):
+        self.close()
+
+    def write(self, msg):
+        self.console.write(msg)
+        if self.file is not None and not self.file.closed:
+            self.file.write(msg)
+
+    def flush(self):
+        self.console.flush()
+        if self.file is not None:
+            self.file.flush()
+            os.fsync(self.file.fileno())
+
+    def close(self):
+        # the reference also closes the console stream here (:330); closing the process's stdout from a destructor
+        # is an accident, not a contract, so only the file is closed
+        if self.file is not None:
+            self.file.close()
+            self.file = None

@@ -9,8 +9,10 @@ One "step" = one full train iteration of the hot path over one synthetic batch t
 in HBM: forward (train-mode BatchNorm) -> fused losses l1 + 0.1*add_loss + 0.2*cross_entropy and their
 gradients -> hand-derived backward -> (N > 1: bucketed RCCL all-reduce overlapped with the backward) ->
 AdamW update.  Prints ONE JSON line (rank 0).  Also reported on the same line:
-  roofline      the dominant kernel family (by device time, measured with HIP events on the launch
-                stream inside the timed steps): algorithmic HBM bytes / measured time vs 8 TB/s
+  roofline      the depthwise kernels (the ones the north-star names), each family -- forward / backward x
+                stride 1 / 2, by its rocprof kernel name -- timed with HIP events on the launch stream inside
+                the timed steps: algorithmic HBM bytes / measured time vs 8 TB/s; the headline entry is the
+                family with the most device time (MobileNetV2: the stride-1 backward, `dw3_bwd2_kernel`)
   cpu_baseline  the CPU oracle (oracle/, a torch-CPU restatement pinned to the reference) running the same
                 train step on this host's cores, on a bounded sample (rank 0, N == 1 only)
 """
@@ -29,6 +31,28 @@ HBM_PEAK = 8.0e12          # B/s, MI355X HBM3E spec (/opt/skills/guides/MI355X_M
 MNV2_TRAIN_MB_PER_CROP = 80.66   # algorithmic bytes, bf16, fwd + dgrad + wgrad
 CONV_KERNELS = ('t3d_dwconv_fwd', 't3d_dwconv_bwd', 't3d_pwconv_fwd', 't3d_pwconv_dgrad', 't3d_pwconv_wgrad',
                 't3d_pwconv_dgrad_yfree', 't3d_pwconv_wgrad_yfree')
+DW_ENTRIES = ('t3d_dwconv_fwd', 't3d_dwconv_bwd')
+# (entry point, k, stride) -> kernel name as rocprofv3 prints it (csrc/dwconv3_stream.hip, dwconv3_bwd_stream.hip,
+# dwconvk_stream.hip, dwconv5_bwd_stream.hip, dwconv_bwd.hip), bf16 storage
+DW_KERNEL_NAMES = {('t3d_dwconv_fwd', 3, 1): 'dw3_fwd2_kernel', ('t3d_dwconv_fwd', 3, 2): 'dw3_fwd_kernel',
+                   ('t3d_dwconv_bwd', 3, 1): 'dw3_bwd2_kernel', ('t3d_dwconv_bwd', 3, 2): 'dw3_bwd_s2_kernel',
+                   ('t3d_dwconv_fwd', 5, 1): 'dwk_fwd_kernel<5,1>', ('t3d_dwconv_fwd', 5, 2): 'dwk_fwd_kernel<5,2>',
+                   ('t3d_dwconv_bwd', 5, 1): 'dw_bwd_kernel (LDS tiles)', ('t3d_dwconv_bwd', 5, 2): 'dw5_bwd_s2_kernel'}
+
+
+def spawn_ranks(args):
+    """`python bench.py --gpus N` run plainly (no launcher environment): start the N ranks ourselves as a CHILD
+    process (`python -m torch.distributed.run`, one rank per GPU over RCCL) before anything in this process touches
+    the GPU, pass its output through and exit with its code."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(('127.0.0.1', 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={args.gpus}',
+           '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'))
+    sys.exit(subprocess.run(cmd, env=env).returncode)
 
 
 def parse():
@@ -112,10 +136,15 @@ def main():
     if args.cpu_baseline_only:
         print(json.dumps(cpu_baseline(args.model, args.size, args.cpu_batch, args.cpu_steps)), flush=True)
         return
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        spawn_ranks(args)
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
-    assert world == args.gpus or world == 1, f'--gpus {args.gpus} but WORLD_SIZE={world}'
+    if world != args.gpus:
+        raise SystemExit(f'bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks')
+    if torch.cuda.device_count() < world:
+        raise SystemExit(f'bench.py: --gpus {args.gpus} but only {torch.cuda.device_count()} GPU(s) visible')
     import torch.distributed as dist
     torch.cuda.set_device(local)
     dev = torch.device('cuda', local)
@@ -123,6 +152,7 @@ def main():
         dist.init_process_group('nccl', device_id=dev)
 
     from torchdet3d import _native as N
+    from torchdet3d.builders.optim_builder import FusedAdamW
     from torchdet3d.models.engine import Net
     from torchdet3d.parallel import GradSync
 
@@ -134,12 +164,10 @@ def main():
     sync.broadcast([net.flat] + [b for b in net.buffers.values()])
     if world > 1 or sync.force:
         net.grad_hook = sync.ready
-    flat = torch.nn.Parameter(net.flat)          # one fused AdamW update over the flat master weights
+    flat = torch.nn.Parameter(net.flat)          # one hand-written AdamW launch over the flat master weights
     flat.grad = net.gflat
-    try:
-        opt = torch.optim.AdamW([flat], lr=1e-3, weight_decay=1e-4, fused=True)
-    except Exception:                            # noqa: BLE001
-        opt = torch.optim.AdamW([flat], lr=1e-3, weight_decay=1e-4)
+    # default_config.py:18 (lr 1e-3, wd 1e-4); the 1/world of the gradient average rides on the optimizer's gradient load
+    opt = FusedAdamW([flat], lr=1e-3, weight_decay=1e-4, grad_scale=1.0 / world)
 
     g = torch.Generator(device=dev).manual_seed(5 + rank)
     nb = 2                                       # synthetic batches resident in HBM, cycled
@@ -167,7 +195,7 @@ def main():
                N.ptr(dlg), B, 9, N.stream())
         sync.start()
         net.backward(dkp, dlg)
-        sync.finish()
+        sync.finish(scale=False)
         opt.step()
 
     def barrier():
@@ -176,16 +204,15 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    # ---- warm-up; the first half also finds the dominant kernel family: all families timed, with the weight gradients
-    # on the main stream for these steps (event pairs on the second stream would also count the time a launch waits
+    # ---- warm-up (untimed).  With --profile-all the second half of it times every kernel family, the weight gradients
+    # on the main stream for those steps (event pairs on the second stream would also count the time a launch waits
     # for the main stream's persistent kernels to free registers, not just the kernel)
-    N.timer = N.KernelTimer(None)
-    side, net._side = net._side, None
+    fam = {}
+    side = net._side
     for i in range(args.warmup):
-        if i == max(1, args.warmup // 2):
-            fam = N.timer.summary()
-            N.timer = None
-            net._side = side
+        if args.profile_all and i == max(1, args.warmup // 2):
+            N.timer = N.KernelTimer(None)
+            net._side = None
         step(i)
     if N.timer is not None:
         fam = N.timer.summary()
@@ -198,8 +225,6 @@ def main():
     step(0)
     step(1)
     t_issue = (time.perf_counter() - t0) / 2
-    conv = {k: v for k, v in fam.items() if k in CONV_KERNELS}
-    dominant = max(conv, key=lambda k: conv[k]['ms']) if conv else None
     if args.profile_all and rank == 0:
         tot = sum(v['ms'] for v in fam.values())
         for k, v in sorted(fam.items(), key=lambda kv: -kv[1]['ms']):
@@ -215,15 +240,15 @@ def main():
                   file=sys.stderr)
         N.timer = None
 
-    # ---- timed region: exactly K steps, only the dominant family carries event pairs
-    N.timer = N.KernelTimer({dominant}) if dominant else None
+    # ---- timed region: exactly K steps; the depthwise launches (main stream) carry HIP-event pairs
+    N.timer = N.KernelTimer(set(DW_ENTRIES))
     barrier()
     t0 = time.perf_counter()
     for i in range(args.steps):
         step(i)
     barrier()
     dt = time.perf_counter() - t0
-    tsum = N.timer.summary() if N.timer else {}
+    launches = N.timer.per_launch() if N.timer else []
     N.timer = None
     if world > 1:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
@@ -243,24 +268,47 @@ def main():
                                       if args.eval else
                                       f'train step (fwd + l1/add/CE losses + bwd + AdamW{" + RCCL grad all-reduce" if world > 1 else ""})')
                                    + f', {S}x{S} crops, per-GPU batch {B}', 'global_batch': B * world, 'parallelism': f'dp{world}',
-                       'final_loss': round(loss, 5), 'host_issue_ms_per_step': round(t_issue * 1e3, 3)},
+                       'final_loss': round(loss, 5), 'host_issue_ms_per_step': round(t_issue * 1e3, 3),
+                       'rccl_ranks': world if dist.is_initialized() else 0},
         }
-        if dominant and dominant in tsum:
-            d = tsum[dominant]
+        # per depthwise family: (entry, k, stride) from the launch's integer arguments (..., B, H, W, C, k, stride)
+        groups = {}
+        for name, sig, ms, nby in launches:
+            key = (name, sig[-2], sig[-1])
+            d = groups.setdefault(key, dict(launches=0, ms=0.0, bytes=0))
+            d['launches'] += 1
+            d['ms'] += ms
+            d['bytes'] += nby or 0
+        rows = []
+        for key, d in sorted(groups.items(), key=lambda kv: -kv[1]['ms']):
             ach = d['bytes'] / (d['ms'] * 1e-3) / 1e9
-            # HBM bytes per launch from the committed rocprofv3 PMC passes (FETCH_SIZE x2 + WRITE_SIZE, gfx950 correction),
-            # valid for the default workload only; not measurable from inside this process
-            traffic = None
-            tf = os.path.join(ROOT, 'profiles', 'r1_f_hbm_traffic_pmc.json')
-            if os.path.exists(tf) and args.model == 'mobilenetv2' and S == 224 and B == 256 and args.dtype == 'bf16':
-                fam_t = json.load(open(tf))['families'].get(dominant)
+            rows.append({'kernel': DW_KERNEL_NAMES.get(key, '?') if args.dtype == 'bf16' else f'{key[0]} k{key[1]} s{key[2]} (fp32)',
+                         'entry': key[0], 'k': key[1], 'stride': key[2],
+                         'launches_per_step': d['launches'] // args.steps,
+                         'avg_launch_us': round(1e3 * d['ms'] / d['launches'], 2),
+                         'ms_per_step': round(d['ms'] / args.steps, 4),
+                         'algorithmic_MB_per_step': round(d['bytes'] / args.steps / 1e6, 1),
+                         'achieved': round(ach, 1), 'frac': round(ach * 1e9 / HBM_PEAK, 4)})
+        if rows:
+            top = rows[0]
+            # HBM bytes per launch of that family from the committed rocprofv3 PMC passes (FETCH_SIZE x2 + WRITE_SIZE,
+            # gfx950 correction): not measurable from inside this process, so it is quoted with its source, and only
+            # for the workload the passes were collected on
+            traffic, tsrc = None, None
+            tf = os.path.join(ROOT, 'profiles', 'r2_hbm_traffic_pmc.json')
+            if os.path.exists(tf) and args.model == 'mobilenetv2' and S == 224 and B == 256 and args.dtype == 'bf16' and not args.eval:
+                pm = json.load(open(tf))
+                fam_t = pm.get('kernels', {}).get(top['kernel'])
                 if fam_t:
-                    traffic = round(fam_t['hbm_bytes_per_step'] / (d['launches'] // args.steps))
-            res['roofline'] = {'bound': 'hbm', 'kernel': dominant, 'achieved': round(ach, 1), 'peak': HBM_PEAK / 1e9,
-                               'unit': 'GB/s', 'frac': round(ach * 1e9 / HBM_PEAK, 4), 'traffic': traffic,
-                               'launches_per_step': d['launches'] // args.steps,
-                               'avg_launch_us': round(1e3 * d['ms'] / d['launches'], 2),
-                               'algorithmic_MB_per_step': round(d['bytes'] / args.steps / 1e6, 1)}
+                    traffic = round(fam_t['hbm_bytes_per_step'] / top['launches_per_step'])
+                    tsrc = f"profiles/r2_hbm_traffic_pmc.json (committed rocprofv3 --pmc pass at {pm.get('commit', '?')})"
+            res['roofline'] = {'bound': 'hbm', 'kernel': top['kernel'], 'entry': top['entry'], 'achieved': top['achieved'],
+                               'peak': HBM_PEAK / 1e9, 'unit': 'GB/s', 'frac': top['frac'], 'traffic': traffic,
+                               'traffic_source': tsrc, 'launches_per_step': top['launches_per_step'],
+                               'avg_launch_us': top['avg_launch_us'],
+                               'algorithmic_MB_per_step': top['algorithmic_MB_per_step'],
+                               'selection': 'depthwise family with the most device time over the timed steps',
+                               'depthwise': rows}
         if args.model == 'mobilenetv2' and S == 224 and args.dtype == 'bf16':
             per_crop = 26.89 if args.eval else MNV2_TRAIN_MB_PER_CROP     # forward / train MB per crop
             res['config']['step_hbm_roofline_frac'] = round(crops / world * per_crop * 1e6 / HBM_PEAK, 4)

@@ -177,6 +177,16 @@ int t3d_gap_fwd(int dtype, const void* y, const t3d_prologue* pro, float* pooled
 int t3d_gap_bwd(int dtype, const float* dpooled, const void* y, const t3d_prologue* pro, void* dz, double* stats,
                 int B, int HW, int C, void* stream);
 
+/* The other pooling modes of ModelWrapper._glob_feature_vector (model_builder.py:96-110): 'max'
+ * (F.adaptive_max_pool2d(x, 1)) and 'avg+max' (their sum).  argmax [B,C] int32 receives the (h*W + w) position of
+ * each maximum -- the first one in scan order among equal values, which is where PyTorch's backward routes the
+ * gradient -- and is what t3d_pool_bwd reads back (may be NULL for T3D_POOL_AVG). */
+enum { T3D_POOL_AVG = 0, T3D_POOL_MAX = 1, T3D_POOL_AVGMAX = 2 };
+int t3d_pool_fwd(int dtype, const void* y, const t3d_prologue* pro, int mode, float* pooled, int* argmax, int B,
+                 int HW, int C, void* stream);
+int t3d_pool_bwd(int dtype, const float* dpooled, const void* y, const t3d_prologue* pro, int mode, const int* argmax,
+                 void* dz, double* stats, int B, int HW, int C, void* stream);
+
 /* Regression + class heads (ModelWrapper.forward, model_builder.py:126-146):
  *   f' = act(scale*f + shift)                       (classifier BatchNorm1d + h_swish, or identity: pro NULL)
  *   kp[b]     = sigmoid(Wreg[cats[b]] f'[b] + breg[cats[b]])      [B,18]   (:137-139, class-gathered GEMV)
@@ -186,6 +196,15 @@ int t3d_gap_bwd(int dtype, const float* dpooled, const void* y, const t3d_prolog
 int t3d_head_fwd(const float* f, const t3d_prologue* pro, const int64_t* cats, const float* wreg,
                  const float* breg, const float* wcls, const float* bcls, const float* mask, float* kp,
                  float* logits, int B, int F, int ncls, void* stream);
+
+/* Export-mode heads (ModelWrapper.forward_to_onnx, model_builder.py:112-124): EVERY one of the 9 regressors applied
+ * to every sample in one launch, kp_all [9,B,18] = sigmoid(Wreg[k] f'[b] + breg[k]); logits as above (eval: no mask). */
+int t3d_head_fwd_all(const float* f, const t3d_prologue* pro, const float* wreg, const float* breg, const float* wcls,
+                     const float* bcls, float* kp_all, float* logits, int B, int F, int ncls, void* stream);
+
+/* A single head applied on its own -- `model.regressors[k](f)` / `model.cls_fc[1](f)` for callers that use the
+ * reference's attributes directly (model_builder.py:79-85): y [M,N] = x [M,K] w[N,K]^T + bias, fp32, any N. */
+int t3d_linear_fwd(const float* x, const float* w, const float* bias, float* y, int M, int K, int N, void* stream);
 
 /* Head backward.  dkp [B,18], dlogits [B,ncls] (may be NULL) -> df [B,F] (when pro is given: the gradient
  * at the BatchNorm1d OUTPUT, i.e. already multiplied by act'; then stats [2*F] fp64 += sum(df), sum(df*f)),
@@ -255,6 +274,34 @@ int t3d_set_workspace(void* ptr, long long bytes);
 /* All weight matrices of a model in ONE launch: desc is a DEVICE array of n records of 5 int64
  * {src fp32 [rows,cols], out [rows,cols] or 0, out_t [cols,rows] or 0, rows, cols} (outputs in `dtype`). */
 int t3d_pack_weights_batched(int dtype, const long long* desc, int n, void* stream);
+
+/* Optimizer step: torch.optim.AdamW as build_optimizer(name='adam') constructs it
+ * (torchdet3d/builders/optim_builder.py:10-12; stepped at trainer/train.py:50-52) over ONE flat fp32 buffer of n
+ * elements (n % 4 == 0): decoupled weight decay, no amsgrad.  `step` is the 1-based step count (bias corrections are
+ * computed on the host in fp64), g is read as grad_scale * g (1/world for summed data-parallel gradients), m / v are the
+ * caller-owned moment buffers (zeroed before the first step). */
+int t3d_adamw_step(float* p, const float* g, float* m, float* v, long long n, float lr, float beta1, float beta2,
+                   float eps, float weight_decay, long long step, float grad_scale, void* stream);
+
+/* Small bookkeeping kernels that keep the step free of framework arithmetic:
+ *  _copy_cols   dst [rows,cols_dst] <- leading columns of src [rows,cols_src], rest zero (the stem's [C,27] <-> [C,32]
+ *               patch-row weights and their gradient, mobilenetv3.py:110-115);
+ *  _bn_bias_grad gradient of the bias of a Linear that feeds a train-mode BatchNorm1d (classifier, mobilenetv3.py:191-194):
+ *               sum_b dy = alpha*sum(dz) + beta*sum(y) + count*gammac from the forward / backward sum replicas;
+ *  _se_bwd_affine the per-sample BatchNorm-backward affine behind a squeeze-excite gate: aps = s*alpha, gps = gammac + g*alpha
+ *               ([B,C]; what t3d_bnbwd.per_sample reads);
+ *  _dropout_mask nn.Dropout(p) keep/scale factors {0, 1/(1-p)} (model_builder.py:83) from Philox-4x32-10 keyed by
+ *               (seed, offset): stateless and reproducible. */
+int t3d_copy_cols(const float* src, float* dst, int rows, int cols_src, int cols_dst, void* stream);
+int t3d_bn_bias_grad(const double* fwd_stats, const double* bwd_stats, int C, double count, const float* alpha,
+                     const float* beta, const float* gammac, float* dbias, void* stream);
+int t3d_se_bwd_affine(const float* s, const float* g, const float* alpha, const float* gammac, float* aps, float* gps,
+                      int B, int C, void* stream);
+int t3d_dropout_mask(float* mask, long long n, unsigned long long seed, unsigned long long offset, float p, void* stream);
+
+/* Zero fill of several device buffers in one launch: desc = n rows of int64 {ptr, bytes}, bytes % 16 == 0, DEVICE array
+ * (the per-step clears of the gradient buffer, the BatchNorm sum replicas and the depthwise weight-gradient replicas). */
+int t3d_zero_batched(const long long* desc, int n, void* stream);
 
 #ifdef __cplusplus
 }

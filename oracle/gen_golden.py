@@ -98,7 +98,7 @@ def checks(t):
     return np.array([t.mean().item(), t.abs().mean().item()] + [t[i].item() for i in idx])
 
 
-def model_golden(td3, name, B, HW, num_classes, loss_names, coeffs, tag):
+def model_golden(td3, name, B, HW, num_classes, loss_names, coeffs, tag, big=False):
     from oracle.weights import make_state_dict, make_inputs
     from torchdet3d.builders import build_model, build_loss
     from torchdet3d.losses import LossManager
@@ -154,6 +154,13 @@ def model_golden(td3, name, B, HW, num_classes, loss_names, coeffs, tag):
         out['dtargets'] = tg.grad.numpy()
     for k, v in taps.items():
         out['tap:' + k] = checks(v)
+    if big:
+        # production-resolution fixture (B >= 32 @ 224^2): also the reference's own metrics of its eval outputs, so the
+        # bf16 throughput mode can be gated on ADD / SADD / accuracy (evaluation/metrics.py:10-37) against the reference
+        from torchdet3d.evaluation.metrics import compute_average_distance, compute_accuracy
+        ekp, etg = torch.from_numpy(out['eval_kp']), torch.from_numpy(out['eval_targets'])
+        out['eval_add_sadd'] = np.array(compute_average_distance(ekp, gt_kp))
+        out['eval_acc'] = np.array(compute_accuracy(etg, cats))
     full = {'features.0.0.weight', 'conv.0.weight', 'cls_fc.1.weight', 'cls_fc.1.bias',
             'regressors.0.0.weight', 'regressors.4.0.weight', 'regressors.4.0.bias'}
     for k, p in net.named_parameters():
@@ -282,6 +289,7 @@ def main():
                  ([1., .5, .1], []), tag='mnv3_large_c1_b8_96')
     model_golden(td3, 'mobilenetv3_large', 2, 224, 9, ['smoothl1', 'wing', 'cross_entropy'],
                  ([1., .3], [.5]), tag='mnv3_large_b2_224')
+    model_golden(td3, 'mobilenetv3_large', 32, 224, 9, *default, tag='mnv3_large_b32_224', big=True)
     losses_golden(td3)
     metrics_golden(td3)
     alwa_golden(td3)

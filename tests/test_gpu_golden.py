@@ -17,7 +17,11 @@ pytestmark = pytest.mark.gpu
 CASES = [('mnv3_large_b4_96', 'mobilenetv3_large', 4, 96, 9, ['l1', 'add_loss', 'cross_entropy'], ([1., .1], [.2])),
          ('mnv3_small_b4_96', 'mobilenetv3_small', 4, 96, 9, ['l1', 'add_loss', 'cross_entropy'], ([1., .1], [.2])),
          ('mnv3_large_c1_b8_96', 'mobilenetv3_large', 8, 96, 1, ['mse', 'diag_loss', 'add_loss'], ([1., .5, .1], [])),
-         ('mnv3_large_b2_224', 'mobilenetv3_large', 2, 224, 9, ['smoothl1', 'wing', 'cross_entropy'], ([1., .3], [.5]))]
+         ('mnv3_large_b2_224', 'mobilenetv3_large', 2, 224, 9, ['smoothl1', 'wing', 'cross_entropy'], ([1., .3], [.5])),
+         # production resolution, 32 crops: 1568+ samples behind every BatchNorm channel, so a single activation-kink
+         # flip no longer moves the gradients visibly -> the gradient bound for this case is 1e-2 (typically ~1e-4)
+         ('mnv3_large_b32_224', 'mobilenetv3_large', 32, 224, 9, ['l1', 'add_loss', 'cross_entropy'], ([1., .1], [.2]))]
+GRAD_TOL = {'mnv3_large_b32_224': 1e-2}
 
 
 @pytest.mark.parametrize('tag,name,B,HW,nc,lnames,coeffs', CASES)
@@ -37,10 +41,14 @@ def test_hip_path_matches_reference_golden(golden_dir, tag, name, B, HW, nc, lna
     if nc > 1:
         np.testing.assert_allclose(lg.cpu().numpy(), g['eval_targets'], atol=1e-4)
         assert (lg.argmax(1).cpu().numpy() == g['eval_argmax']).all()
-    # export-mode forward: all 9 heads (model_builder.py:112-124)
-    for k in range(9):
+    # export-mode forward: all 9 heads in one backbone pass (model_builder.py:112-124)
+    kpa, lga = net.forward(im, None, train=False, all_heads=True)
+    np.testing.assert_allclose(kpa.cpu().numpy(), g['onnx_kp'], atol=1e-4)
+    if nc > 1:
+        np.testing.assert_allclose(lga.cpu().numpy(), g['onnx_targets'], atol=1e-4)
+    for k in (0, 5):                                  # ... bit-identical to the class-selected head kernel
         kpk, _ = net.forward(im, torch.full_like(ca, k), train=False)
-        np.testing.assert_allclose(kpk.cpu().numpy(), g['onnx_kp'][k], atol=1e-4)
+        assert torch.equal(kpk, kpa[k])
     mask = torch.from_numpy(g['dropout_mask'].astype(np.float32)).cuda() if 'dropout_mask' in g.files else None
     kp, lg = net.forward(im, ca, train=True, dropout_mask=mask)
     np.testing.assert_allclose(kp.cpu().numpy(), g['train_kp'], atol=1e-4)
@@ -68,12 +76,12 @@ def test_hip_path_matches_reference_golden(golden_dir, tag, name, B, HW, nc, lna
             got = got[:6]
         scale = max(np.abs(ref).max(), 1e-3)
         err = np.abs(got - ref).max() / scale
-        if not err < 5e-2:
+        if not err < GRAD_TOL.get(tag, 5e-2):
             bad.append((name_, err))
     for k in [f for f in g.files if f.startswith('gsum:')]:
         ref = g[k][1]
         got = net.g[k[5:]].double().abs().sum().item()
-        if abs(got - ref) > 5e-2 * max(ref, 1e-2):
+        if abs(got - ref) > GRAD_TOL.get(tag, 5e-2) * max(ref, 1e-2):
             bad.append((k, got, ref))
     assert not bad, bad[:10]
     for k in [f for f in g.files if f.startswith('rm:')]:

@@ -2,7 +2,7 @@
 # kernel trace of the default bench (one GPU): per-kernel totals per step + idle-gap analysis of the timed region
 cd $GRAFT_REPO_ROOT; export TMPDIR=/tmp
 d=gpurun_out/trace
-python3 tools/trace_streams.py $(find $d -name "*kernel_trace.csv") | tee gpurun_out/trace_streams.txt; rm -rf $d
+rm -rf $d
 rocprofv3 --kernel-trace --stats --output-format csv -d $d -o t -- python3 bench.py --steps 10 --warmup 5 --no-cpu-baseline > gpurun_out/trace_bench.json 2> gpurun_out/trace_err.txt
 tail -1 gpurun_out/trace_bench.json
 python3 - $d <<'PY'
