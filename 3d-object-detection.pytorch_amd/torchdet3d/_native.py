@@ -68,6 +68,8 @@ SIGNATURES = {
     't3d_set_reduction_replicas': [_I, _L],
     't3d_set_workspace': [_P, _L],
     't3d_pack_weights_batched': [_I, _P, _I, _P],
+    't3d_iou3d': [_P, _P, _I, _I, _P, _P, _P, _P, _P],
+    't3d_box_iou3d': [_P, _I, _P, _P, _P],
     't3d_adamw_step': [_P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _L, _F, _P],
     't3d_zero_batched': [_P, _I, _P],
     't3d_copy_cols': [_P, _P, _I, _I, _I, _P],

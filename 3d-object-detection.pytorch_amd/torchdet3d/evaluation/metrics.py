@@ -2,15 +2,12 @@
 accuracy (:31-37), per-class aggregation (:39-68) and the 2-D based 3-D IoU (:70-89).
 
 ADD / SADD / accuracy come out of the single-launch wavefront-reduction kernel `t3d_loss_fwd_bwd`
-(csrc/loss.hip) instead of the reference's 9x9 Python loop of tiny kernels; the 3-D IoU stays on the host in
-numpy fp64 exactly like the reference (lift_2d + box IoU per sample)."""
-import numpy as np
-import scipy.spatial
+(csrc/loss.hip) instead of the reference's 9x9 Python loop of tiny kernels; the 3-D IoU (lift_2d of both keypoint
+sets + objectron box fit + box-box IoU per sample, a serial numpy / scipy loop with a device-to-host copy in the
+reference) is ONE launch of `t3d_iou3d` (csrc/geometry.hip, fp64, one workgroup per sample) and one read-back."""
 import torch
 
 from .. import _native as N
-from ..utils.geometry import lift_2d
-from .box_iou import Box, IoU
 
 _METRIC_CFG = None
 
@@ -59,20 +56,30 @@ def compute_accuracy(pred_cats, gt_cats, reduce_mean=True):
     return hit.mean().item() if reduce_mean else hit.sum().item()
 
 
+def iou3d_per_sample(pred_kp, gt_kp, portrait=True, return_lifted=False):
+    """Per-sample 2-D based 3-D IoU [B] fp64 on the device (degenerate hulls / singular fits give 0, metrics.py:82-86);
+    with return_lifted also the lifted boxes [B,2,9,3] fp64 (= lift_2d of both keypoint sets)."""
+    B = pred_kp.shape[0]
+    dev = pred_kp.device
+    if not pred_kp.is_cuda:
+        raise RuntimeError('the 3-D IoU runs on the HIP path only (no CPU fallback)')
+    p = pred_kp.detach().reshape(B, 18).float().contiguous()
+    g = gt_kp.detach().reshape(B, 18).to(dev).float().contiguous()
+    iou = torch.empty(B, device=dev, dtype=torch.float64)
+    lifted = torch.empty(B, 2, 9, 3, device=dev, dtype=torch.float64) if return_lifted else None
+    if B:
+        N.call('t3d_iou3d', N.ptr(p), N.ptr(g), B, int(bool(portrait)), None, N.ptr(iou), None, N.ptr(lifted), N.stream())
+    return (iou, lifted) if return_lifted else iou
+
+
+@torch.no_grad()
 def compute_2d_based_iou(pred_kp, gt_kp, reduce_mean=True):
-    """metrics.py:70-89: degenerate hulls / singular fits contribute 0."""
-    p = pred_kp.detach().cpu().numpy().astype(np.float64)
-    g = gt_kp.detach().cpu().numpy().astype(np.float64)
-    total = 0.
-    for i in range(p.shape[0]):
-        k3 = lift_2d([p[i], g[i]], portrait=True)
-        try:
-            total += IoU(Box(k3[0]), Box(k3[1])).iou()
-        except (scipy.spatial.QhullError, np.linalg.LinAlgError):
-            pass
-    if reduce_mean:
-        return total / p.shape[0] if p.shape[0] else 0
-    return total
+    """metrics.py:70-89."""
+    B = pred_kp.shape[0]
+    if B == 0:
+        return 0
+    total = sum(iou3d_per_sample(pred_kp, gt_kp).tolist())
+    return total / B if reduce_mean else total
 
 
 @torch.no_grad()
@@ -81,10 +88,12 @@ def compute_metrics_per_cls(pred_kp, gt_kp, pred_cats, gt_cats, compute_iou=True
     out = []
     tA = tS = tI = tC = 0.
     bs = pred_kp.shape[0]
+    # one IoU launch + one read-back for the whole batch; the per-class sums are taken from it on the host
+    ious = iou3d_per_sample(pred_kp, gt_kp).cpu() if compute_iou and bs else None
     for cl in torch.unique(gt_cats):
         m = gt_cats == cl
         A, S = compute_average_distance(pred_kp[m], gt_kp[m], reduce_mean=False)
-        I = compute_2d_based_iou(pred_kp[m], gt_kp[m], reduce_mean=False) if compute_iou else 0.
+        I = float(ious[m.cpu()].sum()) if compute_iou else 0.
         C = compute_accuracy(pred_cats[m], gt_cats[m], reduce_mean=False)
         n = int(m.sum())
         out.append((int(cl), A / n, S / n, I / n, C / n))

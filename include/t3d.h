@@ -230,6 +230,20 @@ typedef struct {
 int t3d_loss_fwd_bwd(const t3d_loss_cfg* cfg, const float* kp, const float* gt_kp, const float* logits,
                      const int64_t* cats, float* out, float* dkp, float* dlogits, int B, int ncls, void* stream);
 
+/* 2-D based 3-D IoU of the validation loop, batched on the device (torchdet3d/evaluation/metrics.py:70-89 with
+ * torchdet3d/utils/geometry.py:51-108 `lift_2d(..., portrait)` and the objectron box fit + box-box IoU it calls):
+ *   pred_kp, gt_kp [B,9,2] fp32 normalised keypoints (the centre keypoint 0 is not used by the lift, :71-72);
+ *   camera_ndc: NULL for the default camera (geometry.py:16-19,29-37: fx = fy = 2, cx = cy = 0) or {fx, fy, cx, cy} fp64 (HOST);
+ *   iou [B] fp64 per-sample IoU (0 where the reference swallows a QhullError / LinAlgError, metrics.py:82-86), may be
+ *   NULL when only `lifted` is wanted; total: fp64 scalar += sum(iou) (may be NULL; caller zeroes);
+ *   lifted [B,2,9,3] fp64 or NULL: the lifted vertices of (pred, gt) -- what lift_2d returns. */
+int t3d_iou3d(const float* pred_kp, const float* gt_kp, int B, int portrait, const double* camera_ndc, double* iou,
+              double* total, double* lifted, void* stream);
+
+/* The box-box part alone: verts [B,2,9,3] fp64 = B pairs of 9-vertex boxes in objectron's vertex order (centre, then
+ * the 8 corners), as `box.Box(vertices)` takes them (metrics.py:79-81) -> iou [B] fp64. */
+int t3d_box_iou3d(const double* verts, int B, double* iou, double* total, void* stream);
+
 /* Squeeze-excite gate (SELayer, mobilenetv3.py:92-107) from the depthwise kernel's per-sample sums:
  *   m = scale*gap_sum/HW + shift (= mean_hw of the BatchNorm output), h = relu(W1 m + b1), q = W2 h + b2,
  *   s = h_sigmoid(q).  gap_sum, m, q, s [B,C]; h [B,R]; W1 [R,C]; W2 [C,R]; all fp32. */

@@ -42,7 +42,8 @@ def to_ndc(points, portrait=False):                            # geometry.py:40-
 def lift_system(kp_set, portrait, fx, fy, cx, cy):
     """The 16x12 matrix of geometry.py:65-88 (centre keypoint kp_set[0] unused)."""
     m = np.zeros((16, 12))
-    uv = to_ndc(np.asarray(kp_set, dtype=np.float64)[1:], portrait)
+    # NDC in the keypoints' OWN dtype, like the reference's element-wise `kp[1] * 2 - 1` on float32 rows (:73-78)
+    uv = to_ndc(np.asarray(kp_set)[1:], portrait).astype(np.float64)
     for i in range(8):
         u, v = uv[i]
         for j in range(4):

@@ -46,9 +46,9 @@ def test_hip_path_matches_reference_golden(golden_dir, tag, name, B, HW, nc, lna
     np.testing.assert_allclose(kpa.cpu().numpy(), g['onnx_kp'], atol=1e-4)
     if nc > 1:
         np.testing.assert_allclose(lga.cpu().numpy(), g['onnx_targets'], atol=1e-4)
-    for k in (0, 5):                                  # ... bit-identical to the class-selected head kernel
-        kpk, _ = net.forward(im, torch.full_like(ca, k), train=False)
-        assert torch.equal(kpk, kpa[k])
+    for k in (0, 5):          # ... and equal to the class-selected head kernel (same dot-product order; the backbone's
+        kpk, _ = net.forward(im, torch.full_like(ca, k), train=False)      # SE sums are float atomics: 1-ulp run-to-run noise)
+        np.testing.assert_allclose(kpk.cpu().numpy(), kpa[k].cpu().numpy(), atol=1e-6)
     mask = torch.from_numpy(g['dropout_mask'].astype(np.float32)).cuda() if 'dropout_mask' in g.files else None
     kp, lg = net.forward(im, ca, train=True, dropout_mask=mask)
     np.testing.assert_allclose(kp.cpu().numpy(), g['train_kp'], atol=1e-4)
