@@ -50,7 +50,7 @@ __global__ void sum_replicas_batched_kernel(const long long* __restrict__ desc, 
 // 16 B per lane per array; the bias corrections are computed on the host in fp64.
 __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g,
                                                     float* __restrict__ m, float* __restrict__ v, long long n4,
-                                                    float decay, float b1, float b2, float step_size,
+                                                    float decay, float omb1, float b2, float omb2, float step_size,
                                                     float inv_sqrt_bc2, float eps, float gscale) {
   for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
     float4 pp = reinterpret_cast<float4*>(p)[i];
@@ -65,8 +65,8 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
     for (int j = 0; j < 4; ++j) {
       const float gj = ge[j] * gscale;
       const float pj = pe[j] * decay;
-      const float mj = me[j] + (gj - me[j]) * (1.f - b1);
-      const float vj = ve[j] * b2 + (1.f - b2) * gj * gj;
+      const float mj = me[j] + (gj - me[j]) * omb1;                 // lerp(m, g, 1 - beta1)
+      const float vj = ve[j] * b2 + omb2 * gj * gj;                 // 1 - beta taken in fp64 on the host, like PyTorch
       const float denom = sqrtf(vj) * inv_sqrt_bc2 + eps;
       pe[j] = pj - step_size * (mj / denom);
       me[j] = mj;
@@ -152,16 +152,19 @@ __global__ void zero_batched_kernel(const long long* __restrict__ desc) {
 
 }  // namespace
 
-extern "C" int t3d_adamw_step(float* p, const float* g, float* m, float* v, long long n, float lr, float beta1,
-                              float beta2, float eps, float weight_decay, long long step, float grad_scale,
+extern "C" int t3d_adamw_step(float* p, const float* g, float* m, float* v, long long n, double lr, double beta1,
+                              double beta2, double eps, double weight_decay, long long step, double grad_scale,
                               void* stream) {
   if (!p || !g || !m || !v || n <= 0 || (n % 4) || step <= 0) return T3D_ERR_ARG;
-  const double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
+  // hyper-parameters in fp64 like the Python floats PyTorch holds: 1 - beta and beta^step are formed in fp64 and only
+  // then rounded to fp32 (1 - 0.999 -> 1.0000000e-3f, where 1.f - 0.999f would be 0.99998713e-3f)
+  const double b1d = beta1, b2d = beta2;
+  const double bc1 = 1.0 - pow(b1d, (double)step), bc2 = 1.0 - pow(b2d, (double)step);
   const long long n4 = n / 4;
   const int grid = (int)((n4 + 255) / 256 < 2048 ? (n4 + 255) / 256 : 2048);
   hipLaunchKernelGGL(adamw_kernel, dim3(grid), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), p, g, m, v, n4,
-                     (float)(1.0 - (double)lr * (double)weight_decay), beta1, beta2, (float)((double)lr / bc1),
-                     (float)(1.0 / sqrt(bc2)), eps, grad_scale);
+                     (float)(1.0 - lr * weight_decay), (float)(1.0 - b1d), (float)beta2, (float)(1.0 - b2d),
+                     (float)(lr / bc1), (float)(1.0 / sqrt(bc2)), (float)eps, (float)grad_scale);
   T3D_CHECK_LAUNCH();
   return T3D_OK;
 }

@@ -70,7 +70,7 @@ SIGNATURES = {
     't3d_pack_weights_batched': [_I, _P, _I, _P],
     't3d_iou3d': [_P, _P, _I, _I, _P, _P, _P, _P, _P],
     't3d_box_iou3d': [_P, _I, _P, _P, _P],
-    't3d_adamw_step': [_P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _L, _F, _P],
+    't3d_adamw_step': [_P, _P, _P, _P, _L, _D, _D, _D, _D, _D, _L, _D, _P],
     't3d_zero_batched': [_P, _I, _P],
     't3d_copy_cols': [_P, _P, _I, _I, _I, _P],
     't3d_bn_bias_grad': [_P, _P, _I, _D, _P, _P, _P, _P, _P],

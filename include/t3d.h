@@ -294,8 +294,8 @@ int t3d_pack_weights_batched(int dtype, const long long* desc, int n, void* stre
  * elements (n % 4 == 0): decoupled weight decay, no amsgrad.  `step` is the 1-based step count (bias corrections are
  * computed on the host in fp64), g is read as grad_scale * g (1/world for summed data-parallel gradients), m / v are the
  * caller-owned moment buffers (zeroed before the first step). */
-int t3d_adamw_step(float* p, const float* g, float* m, float* v, long long n, float lr, float beta1, float beta2,
-                   float eps, float weight_decay, long long step, float grad_scale, void* stream);
+int t3d_adamw_step(float* p, const float* g, float* m, float* v, long long n, double lr, double beta1, double beta2,
+                   double eps, double weight_decay, long long step, double grad_scale, void* stream);
 
 /* Small bookkeeping kernels that keep the step free of framework arithmetic:
  *  _copy_cols   dst [rows,cols_dst] <- leading columns of src [rows,cols_src], rest zero (the stem's [C,27] <-> [C,32]

@@ -32,7 +32,7 @@ def _metrics(kp, gt, logits, cats):
 
 def _iou(kp, gt):
     from torchdet3d.evaluation.metrics import compute_2d_based_iou
-    return compute_2d_based_iou(kp, gt)
+    return compute_2d_based_iou(kp.cuda(), gt.cuda())
 
 
 def _gt_star(ref_kp, sigma, seed=3):
@@ -78,7 +78,7 @@ def test_bf16_mnv3_large_b32_224_metrics_vs_reference_golden(golden_dir):
     assert abs(acc - float(g['eval_acc'])) <= 1.0 / B + 1e-9      # at most one near-tie flips
     # ---- 3-D IoU against informative ground truths
     _iou_gate(ref_kp, kp.cpu(), 'reference')
-    # ---- train step: loss within 1e-3 (absolute) of the reference's
+    # ---- train step: loss within 2e-3 (absolute) of the reference's
     from test_gpu_engine import _loss_cfg
     from torchdet3d import _native as N
     mask = torch.from_numpy(g['dropout_mask'].astype(np.float32)).cuda()
@@ -90,21 +90,6 @@ def test_bf16_mnv3_large_b32_224_metrics_vs_reference_golden(golden_dir):
            N.ptr(lgt), N.ptr(cd), N.ptr(out), N.ptr(dkp), N.ptr(dlg), B, nc, N.stream())
     print(f'   train loss bf16 {out[0].item():.6f} reference {g["loss"][0]:.6f}')
     assert abs(out[0].item() - g['loss'][0]) < 2e-3
-    net.backward(dkp, dlg)
-    torch.cuda.synchronize()
-    worst = []
-    for k in [f for f in g.files if f.startswith('grad:')]:
-        ref = g[k].astype(np.float64).ravel()
-        got = net.g[k[5:]].cpu().double().numpy().ravel()
-        l2 = np.linalg.norm(got - ref) / max(np.linalg.norm(ref), 1e-3 * ref.size ** .5)
-        worst.append((l2, k))
-    worst.sort(reverse=True)
-    med = worst[len(worst) // 2][0]
-    print('   bf16 gradient relative L2 vs reference, worst tensors:', [(f'{l:.3f}', k) for l, k in worst[:4]], 'median',
-          f'{med:.3f}', 'all', [f'{l:.2f}' for l, _ in worst])
-    # bf16 storage of ~60 layers of activations and gradients: direction and scale, not digits; the BatchNorm / conv
-    # parameters of the first blocks sum 4e5 rounded terms per channel with heavy cancellation and are the noisiest
-    assert worst[0][0] < 1.0 and med < 0.15, worst[:5]
 
 
 def test_bf16_mnv2_b256_224_eval_metrics_vs_cpu_oracle():
@@ -143,9 +128,89 @@ def test_bf16_mnv2_b256_224_eval_metrics_vs_cpu_oracle():
     _iou_gate(ref_kp, kp.cpu(), 'oracle', kp32.cpu())
 
 
-def test_bf16_mnv2_b64_224_train_step_vs_fp32_engine():
-    """Train step at production resolution, bf16 vs the fp32 HIP engine on the same crops / weights / dropout mask:
-    loss within 1e-3, every parameter gradient within a per-tensor relative L2 bound."""
+FWD_TAGS = ('col', 'y:', 'y1:', 'y2:', 'y3:', 'z:', 'pooled', 'gap:', 'se_', 'pool_argmax')
+
+
+def _round_1x1(sd):
+    """1x1 / stem conv weights rounded to bf16-representable values: the throughput mode computes with exactly these,
+    so an fp32 engine loaded with them runs the same network."""
+    out = {}
+    for k, v in sd.items():
+        is_pw = v.dim() == 4 and (v.shape[2] == 1 or k == 'features.0.0.weight')
+        out[k] = v.to(torch.bfloat16).float() if is_pw else v.clone()
+    return out
+
+
+def _adopt_forward(src, dst):
+    """Overwrite the saved train-mode forward of `dst` (fp32 storage) with `src`'s (bf16 storage): raw activation
+    tensors, BatchNorm batch statistics / affines, head outputs.  Afterwards both engines back-propagate through the
+    SAME forward, so their gradients differ only by what the bf16 backward kernels do."""
+    dmap = {(k[0], k[1]): t for k, t in dst._bufs.items() if isinstance(k, tuple)}
+    n = 0
+    for k, t in src._bufs.items():
+        if isinstance(k, tuple) and k[0].startswith(FWD_TAGS):
+            dmap[(k[0], k[1])].copy_(t)
+            n += 1
+    assert n > 40
+    dst._aff.copy_(src._aff)
+    dst._statbuf.copy_(src._statbuf)
+    for k, b in src.bns.items():
+        dst.bns[k].count = b.count
+    dst.saved['kp'].copy_(src.saved['kp'])
+
+
+@pytest.mark.parametrize('name,B', [('mobilenetv2', 64), ('mobilenetv3_large', 32)])
+def test_bf16_backward_vs_fp32_backward_on_the_same_forward_224(name, B):
+    """The bf16 backward kernels at production resolution (streaming depthwise backward, bf16 MFMA data / weight
+    gradients incl. the y-free expand pair and the workspace-split reduce, SE chain for MobileNetV3) against the fp32
+    parity-mode backward THROUGH IDENTICAL ACTIVATIONS: the bf16 engine's saved forward is copied into an fp32 engine
+    (same weights, 1x1 weights on the bf16 grid), then both back-propagate the same d loss / d outputs.
+
+    Why not simply compare two independent train steps: with random weights and train-mode BatchNorm the network is in
+    the chaotic regime of deep BN-ReLU nets at initialisation -- a 0.3 % perturbation (one bf16 rounding) of the stem
+    output grows ~9 % per layer to 34 % at the last block (tools/debug_bf16_grads.py prints the layer-by-layer table),
+    so two forwards that differ by rounding have unrelated gradients whatever the backward does."""
+    from oracle.weights import make_inputs, make_state_dict
+    from test_gpu_engine import _loss_cfg
+    from torchdet3d import _native as N
+    from torchdet3d.models.engine import Net
+    HW, nc = 224, 9
+    imgs, gt_kp, cats = make_inputs(B, HW, HW, nc)
+    sd = _round_1x1(make_state_dict(name, nc))
+    feat = 1280
+    mask = ((torch.rand(B, feat, generator=torch.Generator().manual_seed(2)) >= 0.5).float() * 2).cuda()
+    cfg = _loss_cfg(['l1', 'add_loss', 'cross_entropy'], ([1., .1], [.2]))
+    gtd, cd, im = gt_kp.cuda().view(B, 18).contiguous(), cats.cuda(), imgs.cuda()
+    nb = Net(name, nc, 'cuda', torch.bfloat16)
+    nf = Net(name, nc, 'cuda', torch.float32)
+    nb.load_state_dict(sd)
+    nf.load_state_dict(sd)
+    kp, lg = nb.forward(im, cd, train=True, dropout_mask=mask)
+    nf.forward(im, cd, train=True, dropout_mask=mask)
+    _adopt_forward(nb, nf)
+    out = torch.zeros(16, device='cuda')
+    dkp, dlg = torch.empty(B, 18, device='cuda'), torch.empty(B, nc, device='cuda')
+    N.call('t3d_loss_fwd_bwd', cfg, N.ptr(kp), N.ptr(gtd), N.ptr(lg), N.ptr(cd), N.ptr(out), N.ptr(dkp), N.ptr(dlg), B, nc,
+           N.stream())
+    nb.backward(dkp, dlg)
+    nf.backward(dkp, dlg)
+    torch.cuda.synchronize()
+    rows = []
+    for k, gf in nf.g.items():
+        a, b = nb.g[k].double().flatten(), gf.double().flatten()
+        nrm = max(b.norm().item(), 1e-3 * b.numel() ** .5)
+        rows.append(((a - b).norm().item() / nrm, ((a @ b) / (a.norm() * b.norm() + 1e-300)).item(), k))
+    rows.sort(reverse=True)
+    print(f'{name} b{B}@224 bf16 vs fp32 backward on the same forward: relative L2 worst',
+          [(f'{l:.4f}', f'{c:.5f}', k) for l, c, k in rows[:6]], 'quartiles',
+          [f'{rows[int(len(rows) * q)][0]:.4f}' for q in (0.25, 0.5, 0.75)])
+    # bf16 storage of every gradient tensor on the way down (2^-9 per element per layer, ~60 layers deep)
+    assert rows[0][0] < 0.10 and rows[len(rows) // 2][0] < 0.03, rows[:8]
+
+
+def test_bf16_mnv2_b64_224_train_loss_vs_fp32_engine():
+    """Two independent train steps (bf16 vs fp32 storage) at production resolution: the loss (what the optimizer follows)
+    within 5e-3; gradient-level agreement is the subject of the same-forward test above."""
     from oracle.weights import make_inputs, make_state_dict
     from test_gpu_engine import _loss_cfg
     from torchdet3d import _native as N
@@ -156,35 +221,14 @@ def test_bf16_mnv2_b64_224_train_step_vs_fp32_engine():
     mask = ((torch.rand(B, 1280, generator=torch.Generator().manual_seed(2)) >= 0.5).float() * 2).cuda()
     cfg = _loss_cfg(['l1', 'add_loss', 'cross_entropy'], ([1., .1], [.2]))
     gtd, cd, im = gt_kp.cuda().view(B, 18).contiguous(), cats.cuda(), imgs.cuda()
-    grads, losses = {}, {}
+    losses = {}
     for dt in (torch.float32, torch.bfloat16):
         net = Net('mobilenetv2', nc, 'cuda', dt)
         net.load_state_dict(sd)
         kp, lg = net.forward(im, cd, train=True, dropout_mask=mask)
         out = torch.zeros(16, device='cuda')
-        dkp, dlg = torch.empty(B, 18, device='cuda'), torch.empty(B, nc, device='cuda')
-        N.call('t3d_loss_fwd_bwd', cfg, N.ptr(kp), N.ptr(gtd), N.ptr(lg), N.ptr(cd), N.ptr(out), N.ptr(dkp), N.ptr(dlg),
-               B, nc, N.stream())
-        net.backward(dkp, dlg)
-        torch.cuda.synchronize()
+        N.call('t3d_loss_fwd_bwd', cfg, N.ptr(kp), N.ptr(gtd), N.ptr(lg), N.ptr(cd), N.ptr(out), None, None, B, nc, N.stream())
         losses[dt] = out[0].item()
-        grads[dt] = {k: v.detach().cpu().double().clone() for k, v in net.g.items()}
         del net
     print(f'mnv2 b64@224 train loss fp32 {losses[torch.float32]:.6f} bf16 {losses[torch.bfloat16]:.6f}')
-    rows = []
-    for k, g32 in grads[torch.float32].items():
-        gb = grads[torch.bfloat16][k]
-        nrm = max(g32.norm().item(), 1e-3 * g32.numel() ** .5)
-        rows.append(((gb - g32).norm().item() / nrm, k))
-    rows.sort(reverse=True)
-    print('   bf16 vs fp32 gradient relative L2, worst tensors:', [(f'{l:.3f}', k) for l, k in rows[:5]],
-          'median', f'{rows[len(rows) // 2][0]:.3f}')
-    cos = []
-    for k in ('regressors.0.0.weight', 'cls_fc.1.weight', 'conv.0.weight', 'features.17.conv.3.weight', 'features.9.conv.0.weight',
-              'features.2.conv.3.weight', 'features.0.0.weight'):
-        a, b = grads[torch.bfloat16][k].flatten(), grads[torch.float32][k].flatten()
-        cos.append((k, round(((a @ b) / (a.norm() * b.norm() + 1e-30)).item(), 4)))
-    print('   cosines', cos, 'quartiles', [f'{rows[int(len(rows) * q)][0]:.3f}' for q in (0.25, 0.5, 0.75)])
-    assert abs(losses[torch.float32] - losses[torch.bfloat16]) < 5e-3      # train-mode BatchNorm over bf16-rounded tensors
-    assert rows[0][0] < 1.0 and rows[len(rows) // 2][0] < 0.15, rows[:8]
-    assert all(c > 0.9 for _, c in cos), cos
+    assert abs(losses[torch.float32] - losses[torch.bfloat16]) < 5e-3
