@@ -32,6 +32,104 @@ extern T3dReduceCfg g_t3d_reduce;
 struct T3dWorkspace { void* ptr; long long bytes; };
 extern T3dWorkspace g_t3d_ws;
 
+// BatchNorm finalize folded into the LAST workgroup of the kernel that produced the sums (t3d_fold_request, misc.hip;
+// descriptor: t3d_bn_fold in include/t3d.h, in DEVICE memory -- the kernels take one pointer, not the ~130 bytes: the
+// streaming kernels sit at the SGPR limit and the by-value form spilled scalars into their row loops, -40 %).
+// Every workgroup ends with: its stat atomics -> wait for them -> barrier -> one ticket from a device counter; the
+// workgroup that draws the last ticket knows all sums are complete, acquires, and does what t3d_bn_finalize /
+// t3d_bn_bwd_finalize would have done in a launch of their own (~5 us each, ~100 of them per training step, all on the
+// critical stream).
+typedef t3d_bn_fold T3dFold;
+struct T3dFoldReq { const T3dFold* desc; const double* stats; };
+extern T3dFoldReq g_t3d_fold;
+// host side: the pending request if it is for the sums this launch accumulates (consumes it), else null
+inline const T3dFold* t3d_take_fold(const double* stats) {
+  if (!stats || !g_t3d_fold.desc || g_t3d_fold.stats != stats) return nullptr;
+  const T3dFold* d = g_t3d_fold.desc;
+  g_t3d_fold.desc = nullptr;
+  return d;
+}
+
+// called by ALL threads of every workgroup, after the workgroup's stat atomics have been issued
+__device__ __forceinline__ void t3d_fold_tail(const T3dFold* __restrict__ fp, int nrep, long long rstride) {
+  if (fp == nullptr) return;
+  // 16 bytes, 16-aligned: the kernels' dynamic LDS starts behind this static block, and an odd 4-byte shift of that
+  // base turned their 8- / 16-byte LDS reads (stencil weights) into misaligned ones: the depthwise backward lost 40 %
+  __shared__ __attribute__((aligned(16))) int s_lastv[4];
+  int& s_last = s_lastv[0];
+  // The sums leave as device-scope atomics, which are performed at the memory side: waiting for them (vmcnt) orders
+  // them before the ticket.  NOT __threadfence(): its release half writes back the XCD's dirty L2 lines -- after a
+  // kernel that has just stored hundreds of MB that made every workgroup's exit cost more than the finalize launch
+  // it replaces (measured: step 9.4 -> 15.9 ms).
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const unsigned nblk = gridDim.x * gridDim.y * gridDim.z;
+    s_last = atomicAdd(fp->counter, 1u) == nblk - 1;
+  }
+  __syncthreads();
+  if (!s_last) return;
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  const T3dFold f = *fp;
+  if (threadIdx.x == 0) {
+    *f.counter = 0;
+    if (f.kind == 1 && f.nbt) *f.nbt += 1;
+  }
+  // 16 replica lanes per channel (all replica loads of a channel in flight at once), 4 channel groups unrolled
+  const int rl = threadIdx.x & 15, cl = threadIdx.x >> 4, cpp = blockDim.x >> 4;     // channels per pass
+  for (int c0 = 0; c0 < f.C; c0 += 4 * cpp) {
+    double s1[4], s2[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int c = c0 + u * cpp + cl;
+      s1[u] = s2[u] = 0.0;
+      if (c < f.C) {
+        for (int r = rl; r < nrep; r += 16) {
+          s1[u] += f.stats[r * rstride + c];
+          s2[u] += f.stats[r * rstride + f.C + c];
+        }
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+#pragma unroll
+      for (int o = 8; o > 0; o >>= 1) {
+        s1[u] += __shfl_xor(s1[u], o, 16);
+        s2[u] += __shfl_xor(s2[u], o, 16);
+      }
+      const int c = c0 + u * cpp + cl;
+      if (c >= f.C || rl != 0) continue;
+      if (f.kind == 1) {
+        const double mean = s1[u] / f.count;
+        double var = s2[u] / f.count - mean * mean;  // biased
+        if (var < 0.0) var = 0.0;
+        const float invstd = (float)(1.0 / sqrt(var + (double)f.eps));
+        const float g = f.gamma ? f.gamma[c] : 1.f, b = f.beta ? f.beta[c] : 0.f;
+        const float sc = g * invstd;
+        f.o0[c] = sc;
+        f.o1[c] = b - (float)mean * sc;
+        if (f.o2) f.o2[c] = (float)mean;
+        if (f.o3) f.o3[c] = invstd;
+        if (f.rm) f.rm[c] = (1.f - f.momentum) * f.rm[c] + f.momentum * (float)mean;
+        if (f.rv) {
+          const double unbiased = f.count > 1.0 ? var * f.count / (f.count - 1.0) : var;
+          f.rv[c] = (1.f - f.momentum) * f.rv[c] + f.momentum * (float)unbiased;
+        }
+      } else {
+        const double mu = (double)f.mean[c], is = (double)f.invstd[c];
+        const double dg = is * (s2[u] - mu * s1[u]);
+        const double al = (double)(f.gamma ? f.gamma[c] : 1.f) * is;
+        const double be = -al * is * dg / f.count;
+        f.o0[c] = (float)al;
+        f.o1[c] = (float)be;
+        f.o2[c] = (float)(-al * s1[u] / f.count - be * mu);
+        if (f.o3) f.o3[c] = (float)dg;
+        if (f.o4) f.o4[c] = (float)s1[u];
+      }
+    }
+  }
+}
+
 // ---- 8-channel vector load/store, storage type T, math in fp32 ------------
 template <typename T> struct Vec8;
 template <> struct Vec8<float> {

@@ -36,6 +36,7 @@ struct Dw3BArgs {
   int nrep;
   long long rstride;
   int noflush;   // profiling ablation only (T3D_DEBUG_NOFLUSH): skip the end-of-block reduction
+  const T3dFold* fold;  // BatchNorm backward finalize folded into the last workgroup (common.h)
 };
 
 template <typename T, int CH> using rawvec = T __attribute__((ext_vector_type(CH)));
@@ -277,6 +278,7 @@ __global__ __launch_bounds__(256) void dw3_bwd_s1_kernel(const Dw3BArgs a) {
       }
     }
   }
+  t3d_fold_tail(a.fold, a.nrep, a.rstride);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -409,7 +411,11 @@ __global__ __launch_bounds__(NTH) void dw3_bwd2_kernel(const Dw3BArgs a) {
     };
     const int rf = r0 - 1, rl = r1;
 #pragma unroll
-    for (int u = 0; u < PF; ++u) fetch(rf + u, u);
+    for (int u = 0; u < PF; ++u) {      // ring fill in slot order, pinned (see the note at the row loop)
+      __builtin_amdgcn_sched_barrier(0);
+      fetch(rf + u, u);
+    }
+    __builtin_amdgcn_sched_barrier(0);
 
     static_assert(PF % 3 == 0, "accumulator roles come from the unroll index (mod 3)");
     f32x2 accA[3][H2], accB[3][H2];     // dx rows r-1, r, r+1 of columns x0 / x0+1
@@ -423,12 +429,24 @@ __global__ __launch_bounds__(NTH) void dw3_bwd2_kernel(const Dw3BArgs a) {
       dyc_prev[0][h] = dyc_prev[1][h] = xr_prev[0][h] = xr_prev[1][h] = f32x2{0.f, 0.f};
     }
 
-    for (int base = rf; base <= rl; base += PF) {
+    // Keeping the prefetch ring really PF rows deep takes three things the compiler does not do by itself (all found
+    // in the ISA: the ring was drained by `s_waitcnt vmcnt(0..8)` once per PF rows):
+    //  * the walk is padded to whole PF-row groups and the unrolled body carries no `if (r <= rl)` guard -- with
+    //    several paths to the loop latch the register allocator reconciles the ring registers by v_mov copies there,
+    //    i.e. copies of registers whose loads are still in flight, each behind a wait;
+    //  * every read of a slot's registers is pinned ABOVE its refill (empty volatile asm + scheduling barriers):
+    //    otherwise the conversions of the two edge columns are sunk below the loads, the new loads get fresh
+    //    registers and are copied back later;
+    //  * the ring is filled in slot order before the loop: the wait at the loop header is the more conservative of
+    //    the two ways into the loop, and a reordered prologue made it a full drain.
+    // Rows past rl contribute nothing (rok = false).  Worth 4-6 % on the 112x112 / 56x56 layers (isolated launches).
+    const int rend = rf + (rl - rf + PF) / PF * PF;
+    for (int base = rf; base < rend; base += PF) {
 #pragma unroll
       for (int u = 0; u < PF; ++u) {
         const int r = base + u;
-        if (r <= rl) {
-          const bool rok = r >= 0 && r < a.H;
+        {
+          const bool rok = r >= 0 && r < a.H && r <= rl;
           f32x2 dy[4][H2], av[4][H2], xr[2][H2];
 #pragma unroll
           for (int c = 0; c < 4; ++c)
@@ -439,7 +457,13 @@ __global__ __launch_bounds__(NTH) void dw3_bwd2_kernel(const Dw3BArgs a) {
               av[c][h] = f32x2{(float)rx[u][c][2 * h], (float)rx[u][c][2 * h + 1]};
               dy[c][h] = pk_fma(al2[h], z, pk_fma(be2[h], yy, ga2[h]));
             }
+#pragma unroll
+          for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int h = 0; h < H2; ++h) asm volatile("" : "+v"(dy[c][h]), "+v"(av[c][h]));
+          __builtin_amdgcn_sched_barrier(0);
           fetch(r + PF, u);
+          __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
           for (int h = 0; h < H2; ++h) {
             xr[0][h] = av[1][h];
@@ -625,6 +649,7 @@ __global__ __launch_bounds__(NTH) void dw3_bwd2_kernel(const Dw3BArgs a) {
       }
     }
   }
+  t3d_fold_tail(a.fold, a.nrep, a.rstride);
 }
 
 template <typename T, int CH>
@@ -670,6 +695,7 @@ int launch_s1c(Dw3BArgs& a, hipStream_t st) {
   }
   const size_t lds = (size_t)11 * a.C * sizeof(float);
   a.noflush = getenv("T3D_DEBUG_NOFLUSH") ? 1 : 0;
+  a.fold = t3d_take_fold(a.stats);
   // (forcing 3-4 waves/SIMD through launch bounds spills to scratch: 3-7x slower)
   // (a 6-row prefetch ring needs AGPR spill space -> 1 wave/SIMD: 40 % slower; PMC: VALU busy 46 %, memory unit stalled
   //  0.1 % -- the kernel is bound by the latency two resident waves per SIMD can hide)
@@ -969,6 +995,7 @@ __global__ __launch_bounds__(NTH) void dw3_bwd_s2_kernel(const Dw3BArgs a) {
       }
     }
   }
+  t3d_fold_tail(a.fold, a.nrep, a.rstride);
 }
 
 template <typename T>
@@ -1008,6 +1035,7 @@ int launch_s2(Dw3BArgs& a, hipStream_t st) {
   }
   const size_t lds = (size_t)11 * (a.slab ? 64 * CH : a.C) * sizeof(float);
   a.noflush = getenv("T3D_DEBUG_NOFLUSH") ? 1 : 0;
+  a.fold = t3d_take_fold(a.stats);
   // (a compile-time activation, as in the stride-1 kernel, pushes this one over 256 VGPRs -> 1 wave/SIMD: slower)
   hipLaunchKernelGGL((dw3_bwd_s2_kernel<T, PF, 256>), grid, dim3(256), lds, st, a);
   T3D_CHECK_LAUNCH();

@@ -32,6 +32,7 @@ struct Dw3Args {
   int nitems;      // work items a thread walks: flattened: B*nchunks; slab: Wo*B*nchunks
   int nrep;        // reduction replicas (common.h)
   long long rstride;
+  const T3dFold* fold;    // BatchNorm finalize folded into the last workgroup (common.h)
 };
 
 template <typename T, int CH> using rawvec = T __attribute__((ext_vector_type(CH)));
@@ -237,6 +238,7 @@ __global__ __launch_bounds__(256) void dw3_fwd_kernel(const Dw3Args a) {
         atomicAdd(a.stats + (size_t)((blockIdx.x + blockIdx.y) % a.nrep) * a.rstride + (size_t)(i / Cb) * a.C + cbase + i % Cb,
                   (double)lstat[i]);
   }
+  t3d_fold_tail(a.fold, a.nrep, a.rstride);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -314,7 +316,11 @@ __global__ __launch_bounds__(256) void dw3_fwd2_kernel(const Dw3Args a) {
       for (int c = 0; c < 4; ++c) dst[c] = *reinterpret_cast<const RV*>(rp + coff[c]);
     };
 #pragma unroll
-    for (int u = 0; u < PF; ++u) fetch(iy_first + u, ring[u]);
+    for (int u = 0; u < PF; ++u) {      // ring fill in slot order, pinned (see dw3_bwd2_kernel's row loop)
+      __builtin_amdgcn_sched_barrier(0);
+      fetch(iy_first + u, ring[u]);
+    }
+    __builtin_amdgcn_sched_barrier(0);
 
     static_assert(PF == 3, "accumulator roles come from the unroll index");
     f32x2 accA[3][H2], accB[3][H2];   // roles (output row iy-1, iy, iy+1) = [u%3], [(u+1)%3], [(u+2)%3]
@@ -323,18 +329,26 @@ __global__ __launch_bounds__(256) void dw3_fwd2_kernel(const Dw3Args a) {
 #pragma unroll
       for (int h = 0; h < H2; ++h) accA[r][h] = accB[r][h] = f32x2{0.f, 0.f};
 
-    for (int base = iy_first; base <= iy_last; base += PF) {
+    // padded walk without a guard, reads pinned above the refill: keeps the ring PF rows deep in the generated code
+    // (dw3_bwd2_kernel in dwconv3_bwd_stream.hip has the full note); rows past iy_last contribute nothing
+    const int iy_end = iy_first + (iy_last - iy_first + PF) / PF * PF;
+    for (int base = iy_first; base < iy_end; base += PF) {
 #pragma unroll
       for (int u = 0; u < PF; ++u) {
         const int iy = base + u;
-        if (iy <= iy_last) {
-          const bool rok = iy >= 0 && iy < a.H;
+        {
+          const bool rok = iy >= 0 && iy < a.H && iy <= iy_last;
           f32x2 v[4][H2];
 #pragma unroll
           for (int c = 0; c < 4; ++c)
 #pragma unroll
-            for (int h = 0; h < H2; ++h) v[c][h] = f32x2{(float)ring[u][c][2 * h], (float)ring[u][c][2 * h + 1]};
+            for (int h = 0; h < H2; ++h) {
+              v[c][h] = f32x2{(float)ring[u][c][2 * h], (float)ring[u][c][2 * h + 1]};
+              asm volatile("" : "+v"(v[c][h]));
+            }
+          __builtin_amdgcn_sched_barrier(0);
           fetch(iy + PF, ring[u]);
+          __builtin_amdgcn_sched_barrier(0);
           if (affine) {
 #pragma unroll
             for (int c = 0; c < 4; ++c)
@@ -432,6 +446,7 @@ __global__ __launch_bounds__(256) void dw3_fwd2_kernel(const Dw3Args a) {
         atomicAdd(a.stats + (size_t)((blockIdx.x + blockIdx.y) % a.nrep) * a.rstride + (size_t)(i / Cb) * a.C + cbase + i % Cb,
                   (double)lstat[i]);
   }
+  t3d_fold_tail(a.fold, a.nrep, a.rstride);
 }
 
 template <typename T, int CH>
@@ -475,6 +490,7 @@ int launch_ch(Dw3Args& a, int s, hipStream_t st) {
     grid = dim3(gx, ns);
   }
   const size_t lds = (size_t)2 * a.C * sizeof(float);
+  a.fold = t3d_take_fold(a.stats);
   if (use2) hipLaunchKernelGGL((dw3_fwd2_kernel<T, PF>), grid, dim3(256), lds, st, a);
   else if (s == 1) hipLaunchKernelGGL((dw3_fwd_kernel<T, 1, CH, PF>), grid, dim3(256), lds, st, a);
   else hipLaunchKernelGGL((dw3_fwd_kernel<T, 2, CH, PF>), grid, dim3(256), lds, st, a);

@@ -50,6 +50,7 @@ struct EwArgs {
   int act;
   int M, C, HW;
   float inv_hw;
+  const T3dFold* fold;        // BatchNorm backward finalize folded into the last workgroup (common.h)
   int mode;            // global pool: T3D_POOL_AVG / _MAX / _AVGMAX
   int* argmax;         // [B,C] position (hw) of the per-sample maximum, written by the forward, read by the backward
 };
@@ -140,6 +141,7 @@ __global__ __launch_bounds__(256) void bn_act_bwd_kernel(const EwArgs a) {
     }
   }
   if (a.stats) flush_stats(lstat, a.C, c0, on, s1, s2, a.stats);
+  t3d_fold_tail(a.fold, 1, 0);
 }
 
 // Squeeze-excite AFTER the activation (no-expand layout, mobilenetv3.py:138-140; MobileNetV3-small features.1):
@@ -343,6 +345,7 @@ __global__ __launch_bounds__(256) void gap_bwd_kernel(const EwArgs a, int B) {
       atomicAdd(a.stats + a.C + c, u2);
     }
   }
+  t3d_fold_tail(a.fold, 1, 0);
 }
 
 inline void fill_pro(EwArgs& a, const t3d_prologue* pro) {
@@ -395,6 +398,7 @@ extern "C" int t3d_bn_act_bwd(int dtype, const void* dz, const void* y, const t3
   EwArgs a{};
   a.a = dz; a.b = y; a.out = dzp; a.stats = stats; a.M = M; a.C = C;
   fill_pro(a, pro);
+  a.fold = t3d_take_fold(stats);
   int grid = ew_grid((size_t)M * (C / 8));
   if (grid > 1024) grid = 1024;
   if ((size_t)grid * 256 < (size_t)(C / 8)) return T3D_ERR_UNSUPPORTED;
@@ -473,6 +477,7 @@ extern "C" int t3d_pool_bwd(int dtype, const float* dpooled, const void* y, cons
   EwArgs a{};
   a.a = y; a.vec = dpooled; a.out = dz; a.stats = stats; a.C = C; a.HW = HW; a.inv_hw = 1.f / (float)HW;
   a.mode = mode; a.argmax = const_cast<int*>(argmax);
+  a.fold = t3d_take_fold(stats);
   fill_pro(a, pro);
   dim3 grid(B < 256 ? B : 256, cdiv(C / 8, 32));
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);

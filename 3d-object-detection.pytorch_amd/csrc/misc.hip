@@ -256,6 +256,22 @@ extern "C" int t3d_set_reduction_replicas(int nrep, long long stats_stride) {
   return T3D_OK;
 }
 
+T3dFoldReq g_t3d_fold = {nullptr, nullptr};
+
+extern "C" int t3d_fold_request(const t3d_bn_fold* desc_device, const double* stats) {
+  if (!desc_device || !stats) return T3D_ERR_ARG;
+  g_t3d_fold.desc = desc_device;
+  g_t3d_fold.stats = stats;
+  return T3D_OK;
+}
+
+/* 1: a fold request is still pending (the last launch did not implement the tail); clears it either way */
+extern "C" int t3d_fold_pending(void) {
+  const int p = g_t3d_fold.desc != nullptr;
+  g_t3d_fold.desc = nullptr;
+  return p;
+}
+
 T3dWorkspace g_t3d_ws = {nullptr, 0};
 
 extern "C" int t3d_set_workspace(void* ptr, long long bytes) {

@@ -25,6 +25,7 @@ struct GemmArgs {
   const void* a2;
   int Kin2, ks1;
   int row0;   // row stride (= channel count) of a0 / a1; equals Kin without a second segment
+  const T3dFold* fold;   // BatchNorm finalize folded into the last workgroup (streaming kernel only)
 };
 
 template <typename T> __device__ __forceinline__ void ldvec(const T* p, float* v);

@@ -29,7 +29,7 @@ namespace {
 // coefficients present (MobileNetV3 only) -- compiled out of the common variants to keep registers down.
 // YF (with DG): y-free data gradient -- the main loop is the plain forward loop over two raw tensors ([dz | x], no
 // transform), the epilogue is the data gradient's (activation derivative, residual, BatchNorm-backward sums).
-template <int NT, int R, bool DG, bool GEN, bool YF = false>
+template <int NT, int R, bool DG, bool GEN, bool YF = false, int KU = 2>
 __global__ __launch_bounds__(512, 2) void pw_stream_kernel(const GemmArgs a, const int nchunks, const int KS, const int nrep, const long long rstride) {
   constexpr int BN = NT * 16;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -52,14 +52,31 @@ __global__ __launch_bounds__(512, 2) void pw_stream_kernel(const GemmArgs a, con
 
   // ---- stage the weight chunk in fragment order: MFMA row lc of tile t <-> n_local = (t>>1)*32 + (lc>>2)*8 + (t&1)*4 + (lc&3)
   const int nthr = blockDim.x, WAVES = nthr >> 6;
-  for (int i = tid; i < NT * KS * 64; i += nthr) {
-    const int l = i & 63, ks = (i >> 6) % KS, t = (i >> 6) / KS;
-    const int n = n0 + (t >> 1) * 32 + ((l & 15) >> 2) * 8 + (t & 1) * 4 + (l & 3), k = ks * 32 + (l >> 4) * 8;
-    bf16x8 v;
+  // (eight independent loads in flight per thread, branch-free: a block of the 7x7 stage stages up to 120 KB before it
+  // can start, and with one dependent load -> store round per 8 KB that prologue WAS most of those launches)
+  {
+    constexpr int SU = 8;
+    const int total = NT * KS * 64;
+    for (int i0 = tid; i0 < total; i0 += nthr * SU) {
+      bf16x8 v[SU];
+      bool ok[SU];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) v[j] = (bf16_t)0.f;
-    if (n < a.Nout && k < a.Kin) v = *reinterpret_cast<const bf16x8*>(Wg + (size_t)n * a.Kin + k);
-    Wf[i] = v;
+      for (int u = 0; u < SU; ++u) {
+        const int i = min(i0 + u * nthr, total - 1);
+        const int l = i & 63, ks = (i >> 6) % KS, t = (i >> 6) / KS;
+        const int n = n0 + (t >> 1) * 32 + ((l & 15) >> 2) * 8 + (t & 1) * 4 + (l & 3), k = ks * 32 + (l >> 4) * 8;
+        ok[u] = n < a.Nout && k < a.Kin;
+        v[u] = *reinterpret_cast<const bf16x8*>(Wg + (size_t)min(n, a.Nout - 1) * a.Kin + min(k, a.Kin - 8));
+      }
+#pragma unroll
+      for (int u = 0; u < SU; ++u) {
+        if (!ok[u]) {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) v[u][j] = (bf16_t)0.f;
+        }
+        if (i0 + u * nthr < total) Wf[i0 + u * nthr] = v[u];
+      }
+    }
   }
   for (int i = tid; i < BN * 2; i += nthr) lstat[i] = 0.f;
   for (int i = tid; i < BN; i += nthr) {
@@ -94,7 +111,10 @@ __global__ __launch_bounds__(512, 2) void pw_stream_kernel(const GemmArgs a, con
 
   const int ngroups = (a.M + 16 * R - 1) / (16 * R);
   const int nb = n0 + lg * 8;     // lane group lg owns channels nb + 32*q .. +7 of every 32-channel block q
-  constexpr int KU = 2;  // k-steps whose loads are issued together
+  // KU = k-steps whose loads are issued together.  2 for the wide, shallow layers (K <= 160: the whole contraction is
+  // one or two rounds anyway); 4 / 6 for the deep contractions of the 14x14 and 7x7 stages (K = 384 .. 960): those
+  // launches have fewer pixel groups than the chip has wave slots, so a wave's own serial load -> wait -> multiply
+  // rounds ARE the kernel's duration (K = 960: 15 rounds of ~1.5 us with KU = 2).
 
   // per-sample sums (squeeze-excite blocks): a wave walks a CONTIGUOUS range of pixel groups, so consecutive groups
   // mostly belong to one sample and its sums stay in st1/st2 until the sample changes (cur_b)
@@ -359,9 +379,10 @@ __global__ __launch_bounds__(512, 2) void pw_stream_kernel(const GemmArgs a, con
       if (n < a.Nout) atomicAdd(a.stats + (size_t)(xb % nrep) * rstride + (size_t)(i & 1) * a.Nout + n, (double)lstat[i]);
     }
   }
+  t3d_fold_tail(a.fold, nrep, rstride);
 }
 
-template <int NT, int R, bool DG, bool GEN, bool YF = false>
+template <int NT, int R, bool DG, bool GEN, bool YF = false, int KU = 2>
 int launch_v(GemmArgs& a, int KS, hipStream_t st) {
   constexpr int BN = NT * 16;
   const int kpad = KS * 32;
@@ -372,7 +393,7 @@ int launch_v(GemmArgs& a, int KS, hipStream_t st) {
   // small weight chunks: 4-wave blocks, as many per CU as registers / LDS admit (each wave hides its own
   // load latency, so resident waves per CU are what matters); big chunks: one 8-wave block shares the copy
   const int threads = lds <= 48 * 1024 ? 256 : 512;
-  const void* fn = (const void*)pw_stream_kernel<NT, R, DG, GEN, YF>;
+  const void* fn = (const void*)pw_stream_kernel<NT, R, DG, GEN, YF, KU>;
   if (lds > 64 * 1024) (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   static int occ_cache[2] = {0, 0};   // per instantiation (function-local static of the template), per block size
   int& occ = occ_cache[threads == 512];
@@ -389,7 +410,9 @@ int launch_v(GemmArgs& a, int KS, hipStream_t st) {
   const int need = cdiv(ngroups, threads / 64);
   if (nxb > need) nxb = need;
   if (nxb < 1) nxb = 1;
-  hipLaunchKernelGGL((pw_stream_kernel<NT, R, DG, GEN, YF>), dim3(nxb * nchunks), dim3(threads), lds, st, a, nchunks, KS,
+  // a pending BatchNorm-finalize fold belongs to this launch when it produces that BatchNorm's sums
+  a.fold = t3d_take_fold(a.stats);
+  hipLaunchKernelGGL((pw_stream_kernel<NT, R, DG, GEN, YF, KU>), dim3(nxb * nchunks), dim3(threads), lds, st, a, nchunks, KS,
                      g_t3d_reduce.nrep, g_t3d_reduce.stats_stride);
   T3D_CHECK_LAUNCH();
   return T3D_OK;
@@ -399,7 +422,13 @@ template <int NT, int R>
 int launch_nt(GemmArgs& a, int KS, hipStream_t st) {
   if (a.a2) return launch_v<NT, R, true, false, true>(a, KS, st);   // y-free data gradient
   const bool gen = a.per_sample || a.ps_stats || a.e_se || (!a.dgrad && a.p2);
-  if (a.dgrad) return gen ? launch_v<NT, R, true, true>(a, KS, st) : launch_v<NT, R, true, false>(a, KS, st);
+  static const int ku_env = getenv("T3D_PW_KU") ? atoi(getenv("T3D_PW_KU")) : 0;   // 2: the shallow variant everywhere
+  const bool deep = KS >= 6 && !gen && ku_env != 2;
+  if (a.dgrad) {
+    if (deep) return launch_v<NT, R, true, false, false, (R == 1 ? 6 : 4)>(a, KS, st);    // two tensors per k-step in flight
+    return gen ? launch_v<NT, R, true, true>(a, KS, st) : launch_v<NT, R, true, false>(a, KS, st);
+  }
+  if (deep) return launch_v<NT, R, false, false, false, 6>(a, KS, st);
   return gen ? launch_v<NT, R, false, true>(a, KS, st) : launch_v<NT, R, false, false>(a, KS, st);
 }
 
@@ -407,6 +436,7 @@ int launch_nt(GemmArgs& a, int KS, hipStream_t st) {
 
 int stream_launch(GemmArgs& a, hipStream_t st) {
   if (!a.row0) a.row0 = a.Kin;
+
   const int KS = cdiv(a.Kin, 32);
   // widest chunk whose weights fit ~120 KB of LDS, at most 10 tiles (register budget: 8*NT stat + 4*NT*R acc)
   int nt_cap = (120 * 1024 / 1024) / KS;

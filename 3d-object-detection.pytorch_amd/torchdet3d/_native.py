@@ -30,6 +30,12 @@ class LossCfg(ctypes.Structure):
                                   'wing_w', 'wing_eps', 'c_ce', 'lam_reg', 'lam_cls')]
 
 
+class BnFold(ctypes.Structure):          # t3d_bn_fold (include/t3d.h); lives in device memory
+    _fields_ = [('kind', _I), ('C', _I), ('counter', _P), ('stats', _P), ('count', _D), ('gamma', _P), ('beta', _P),
+                ('rm', _P), ('rv', _P), ('nbt', _P), ('momentum', _F), ('eps', _F), ('o0', _P), ('o1', _P), ('o2', _P),
+                ('o3', _P), ('o4', _P), ('mean', _P), ('invstd', _P)]
+
+
 _PP = ctypes.POINTER(Prologue)
 _BP = ctypes.POINTER(BnBwd)
 _LP = ctypes.POINTER(LossCfg)
@@ -67,6 +73,8 @@ SIGNATURES = {
     't3d_se_after_apply': [_I, _P, _P, _PP, _P, _P, _P, _P, _I, _I, _I, _P],
     't3d_set_reduction_replicas': [_I, _L],
     't3d_set_workspace': [_P, _L],
+    't3d_fold_request': [_P, _P],
+    't3d_fold_pending': [],
     't3d_pack_weights_batched': [_I, _P, _I, _P],
     't3d_iou3d': [_P, _P, _I, _I, _P, _P, _P, _P, _P],
     't3d_box_iou3d': [_P, _I, _P, _P, _P],

@@ -40,7 +40,7 @@ HOOK_MIN = 1 << 20              # gradient-exchange granularity (elements): para
 class _BN:
     """Per-BatchNorm bookkeeping: parameter views + per-step scratch slices."""
     __slots__ = ('name', 'C', 'gamma', 'beta', 'dgamma', 'dbeta', 'rm', 'rv', 'nbt', 'stats', 'bstats', 'scale',
-                 'shift', 'mean', 'invstd', 'alpha', 'bbeta', 'gammac', 'count', 'pro_cache')
+                 'shift', 'mean', 'invstd', 'alpha', 'bbeta', 'gammac', 'count', 'pro_cache', 'ctr', 'folded', 'desc')
 
 
 def _concurrent_stream(device, tries=8):
@@ -171,6 +171,14 @@ class Net:
             self.bns[k] = b
             o += C
         self._bn_total = tot
+        # ticket counters of the folded BatchNorm finalizes (include/t3d.h: t3d_fold_bn_*): forward / backward per layer
+        self._foldctr = torch.zeros(2 * len(self.bns), device=dev, dtype=torch.int32)
+        for i, b in enumerate(self.bns.values()):
+            b.ctr = (self._foldctr[2 * i:2 * i + 1], self._foldctr[2 * i + 1:2 * i + 2])
+            b.folded = [False, False]
+            b.desc = {}
+        # opt-in (T3D_FOLD=1): measured SLOWER than the standalone finalize launches on MI355X (findings)
+        self._fold = bool(os.environ.get('T3D_FOLD'))
         self.reset_parameters()
 
     def _view(self, key, shape, n=None, g=False):
@@ -278,14 +286,50 @@ class Net:
         self._packed_version = self.flat._version
 
     # ------------------------------------------------------------------ BatchNorm helpers
+    def _fold_desc(self, bn, which, count):
+        """Device-resident t3d_bn_fold descriptor of one BatchNorm (0: forward, 1: backward finalize), rebuilt only when
+        the element count behind the sums changes (a new batch size / resolution)."""
+        key = (which, float(count))
+        d = bn.desc.get(key)
+        if d is None:
+            f = N.BnFold()
+            f.kind, f.C, f.counter, f.count = which + 1, bn.C, N.ptr(bn.ctr[which]), float(count)
+            f.gamma = N.ptr(bn.gamma)
+            if which == 0:
+                f.stats, f.beta, f.rm, f.rv, f.nbt = N.ptr(bn.stats), N.ptr(bn.beta), N.ptr(bn.rm), N.ptr(bn.rv), N.ptr(bn.nbt)
+                f.momentum, f.eps = BN_MOM, BN_EPS
+                f.o0, f.o1, f.o2, f.o3 = N.ptr(bn.scale), N.ptr(bn.shift), N.ptr(bn.mean), N.ptr(bn.invstd)
+            else:
+                f.stats, f.mean, f.invstd = N.ptr(bn.bstats), N.ptr(bn.mean), N.ptr(bn.invstd)
+                f.o0, f.o1, f.o2 = N.ptr(bn.alpha), N.ptr(bn.bbeta), N.ptr(bn.gammac)
+                f.o3, f.o4 = N.ptr(bn.dgamma), N.ptr(bn.dbeta)
+            host = torch.frombuffer(bytearray(bytes(f)), dtype=torch.uint8)
+            d = bn.desc[key] = host.to(self.device)
+        return d
+
+    def _fold_fwd(self, bn, count):
+        """Ask the NEXT launch that accumulates bn's batch sums to finalize them in its last workgroup (train mode);
+        `_bn_fwd` then has nothing left to launch -- unless that kernel does not implement the fold."""
+        if self.training and self._fold:
+            N.call('t3d_fold_request', N.ptr(self._fold_desc(bn, 0, count)), N.ptr(bn.stats))
+            bn.folded[0] = True
+
+    def _fold_bwd(self, bn):
+        if self._fold:
+            N.call('t3d_fold_request', N.ptr(self._fold_desc(bn, 1, bn.count)), N.ptr(bn.bstats))
+            bn.folded[1] = True
+
     def _bn_fwd(self, bn, count, act):
         """Batch sums -> consumer affine (train) or running estimates -> affine (eval)."""
         st = N.stream()
         if self.training:
             bn.count = float(count)
-            N.call('t3d_bn_finalize', N.ptr(bn.stats), bn.C, float(count), N.ptr(bn.gamma), N.ptr(bn.beta),
-                   N.ptr(bn.rm), N.ptr(bn.rv), N.ptr(bn.nbt), BN_MOM, BN_EPS, N.ptr(bn.scale), N.ptr(bn.shift),
-                   N.ptr(bn.mean), N.ptr(bn.invstd), st)
+            done = bn.folded[0] and not N.lib().t3d_fold_pending()
+            bn.folded[0] = False
+            if not done:
+                N.call('t3d_bn_finalize', N.ptr(bn.stats), bn.C, float(count), N.ptr(bn.gamma), N.ptr(bn.beta),
+                       N.ptr(bn.rm), N.ptr(bn.rv), N.ptr(bn.nbt), BN_MOM, BN_EPS, N.ptr(bn.scale), N.ptr(bn.shift),
+                       N.ptr(bn.mean), N.ptr(bn.invstd), st)
         else:
             N.call('t3d_bn_eval_affine', bn.C, N.ptr(bn.gamma), N.ptr(bn.beta), N.ptr(bn.rm), N.ptr(bn.rv), BN_EPS,
                    N.ptr(bn.scale), N.ptr(bn.shift), st)
@@ -306,10 +350,18 @@ class Net:
             return p
         return N.prologue(bn.scale, bn.shift, se, act, se_after)
 
+    def _fold_done(self, bn):
+        """Right after the launch a backward fold was requested for: did that kernel take it?"""
+        if bn.folded[1] and N.lib().t3d_fold_pending():
+            bn.folded[1] = False
+
     def _bn_bwd(self, bn):
-        N.call('t3d_bn_bwd_finalize', N.ptr(bn.bstats), bn.C, bn.count, N.ptr(bn.gamma), N.ptr(bn.mean),
-               N.ptr(bn.invstd), N.ptr(bn.alpha), N.ptr(bn.bbeta), N.ptr(bn.gammac), N.ptr(bn.dgamma),
-               N.ptr(bn.dbeta), N.stream())
+        done = bn.folded[1]
+        bn.folded[1] = False
+        if not done:
+            N.call('t3d_bn_bwd_finalize', N.ptr(bn.bstats), bn.C, bn.count, N.ptr(bn.gamma), N.ptr(bn.mean),
+                   N.ptr(bn.invstd), N.ptr(bn.alpha), N.ptr(bn.bbeta), N.ptr(bn.gammac), N.ptr(bn.dgamma),
+                   N.ptr(bn.dbeta), N.stream())
         return N.bnbwd(bn.alpha, bn.bbeta, bn.gammac, False)
 
     def _st(self, bn):
@@ -417,6 +469,7 @@ class Net:
         N.call('t3d_stem_im2col', dt, N.ptr(imgs), N.ptr(col), B, H, W, st)
         bn0 = self.bns['features.0.1']
         y0 = self._buf('y:stem', (M, a.stem_c))
+        self._fold_fwd(bn0, M)
         N.call('t3d_pwconv_fwd', dt, N.ptr(col), None, N.ptr(self.w['stem']), None, N.ptr(y0), self._st(bn0),
                M, Ho * Wo, 32, a.stem_c, st, nbytes=M * (32 + a.stem_c) * self.esz)
         pro0 = self._bn_fwd(bn0, M, a.stem_act)
@@ -431,6 +484,7 @@ class Net:
         bnl = self.bns[ln + '.1']
         M = cur.B * cur.H * cur.W
         yl = self._buf('y:last', (M, a.last_c))
+        self._fold_fwd(bnl, M)
         N.call('t3d_pwconv_fwd', dt, N.ptr(cur.t), cur.pro, N.ptr(self.w[ln + '.0.weight']), None, N.ptr(yl),
                self._st(bnl), M, cur.H * cur.W, cur.C, a.last_c, st, nbytes=M * (cur.C + a.last_c) * self.esz)
         prol = self._bn_fwd(bnl, M, a.last_act)
@@ -457,6 +511,7 @@ class Net:
             bn1 = self.bns[p + '.1']
             M = B * H * W
             y1 = self._buf(f'y1:{i}', (M, blk.cexp))
+            self._fold_fwd(bn1, M)
             N.call('t3d_pwconv_fwd', dt, N.ptr(x.t), x.pro, N.ptr(self.w[p + '.0.weight']), None, N.ptr(y1),
                    self._st(bn1), M, H * W, blk.cin, blk.cexp, st, nbytes=M * (blk.cin + blk.cexp) * self.esz)
             pro1 = self._bn_fwd(bn1, M, blk.act)
@@ -474,6 +529,7 @@ class Net:
         bn2 = self.bns[bnn]
         y2 = self._buf(f'y2:{i}', (M2, blk.cexp))
         gap = self._buf(f'gap:{i}', (B, blk.cexp), torch.float32, zero=True) if (blk.se and not se_after) else None
+        self._fold_fwd(bn2, M2)
         N.call('t3d_dwconv_fwd', dt, N.ptr(src.t), src.pro, N.ptr(self.p[dwn]), N.ptr(y2), self._st(bn2), N.ptr(gap),
                B, H, W, blk.cexp, blk.k, blk.s, st, nbytes=(B * H * W + M2) * blk.cexp * self.esz)
         pro2 = self._bn_fwd(bn2, M2, blk.act)
@@ -508,6 +564,7 @@ class Net:
         # linear 1x1 projection (mobilenetv3.py:142-143,158-159)
         bn3 = self.bns[bn3n]
         y3 = self._buf(f'y3:{i}', (M2, blk.cout))
+        self._fold_fwd(bn3, M2)
         N.call('t3d_pwconv_fwd', dt, N.ptr(y2), pro2, N.ptr(self.w[pwn]), None, N.ptr(y3), self._st(bn3),
                M2, Ho * Wo, blk.cexp, blk.cout, st, nbytes=M2 * (blk.cexp + blk.cout) * self.esz)
         pro3 = self._bn_fwd(bn3, M2, 'none')
@@ -602,8 +659,10 @@ class Net:
         x = sv['last_in']
         M, HW = B * sv['HWl'], sv['HWl']
         dzl = self._buf('dz:last', (M, a.last_c))
+        self._fold_bwd(bnl)
         N.call('t3d_pool_bwd', dt, N.ptr(dpooled), N.ptr(sv['yl']), sv['prol'], self.pool, N.ptr(sv['pool_argmax']),
                N.ptr(dzl), N.ptr(bnl.bstats), B, HW, a.last_c, st)
+        self._fold_done(bnl)
         bb = self._bn_bwd(bnl)
         self._wgrad(dt, N.ptr(dzl), N.ptr(sv['yl']), bb, N.ptr(x.t), x.pro,
                     N.ptr(self.g[ln + '.0.weight']), M, HW, x.C, a.last_c, nbytes=M * (x.C + a.last_c) * self.esz)
@@ -632,11 +691,15 @@ class Net:
         of x's producer, with that BatchNorm's backward sums accumulated."""
         dx = self._buf(tag, (M, K))
         with_stats = x.bn is not None and not x.finished_act
+        if with_stats:
+            self._fold_bwd(x.bn)
         N.call('t3d_pwconv_dgrad', self.dt, N.ptr(dz), N.ptr(y), bb, N.ptr(wt),
                N.ptr(x.raw) if with_stats else None, x.gpro if with_stats else None,
                N.ptr(residual) if residual is not None else None, N.ptr(dx),
                N.ptr(x.bn.bstats) if with_stats else None, None, M, HW, K, Nn, N.stream(),
                nbytes=M * (K + Nn) * self.esz)
+        if with_stats:
+            self._fold_done(x.bn)
         if x.finished_act:
             dx = self._act_bwd(dx, x, tag + ':a')
         return dx
@@ -700,10 +763,14 @@ class Net:
                     entry='t3d_pwconv_wgrad_yfree', nbytes=M * (K + Nn) * self.esz)
         dx = self._buf(f'dzin:{i}', (M, K))
         with_stats = x.bn is not None and not x.finished_act       # as _pw_dgrad
+        if with_stats:
+            self._fold_bwd(x.bn)
         N.call('t3d_pwconv_dgrad_yfree', N.ptr(d1), N.ptr(x.t), N.ptr(wcat), N.ptr(cvec),
                N.ptr(x.raw) if with_stats else None, x.gpro if with_stats else None,
                N.ptr(res) if res is not None else None, N.ptr(dx),
                N.ptr(x.bn.bstats) if with_stats else None, M, HW, K, Nn, st, nbytes=M * (K + Nn) * self.esz)
+        if with_stats:
+            self._fold_done(x.bn)
         if x.finished_act:
             dx = self._act_bwd(dx, x, f'dzin:{i}:a')
         return dx
@@ -711,8 +778,10 @@ class Net:
     def _act_bwd(self, dz, x, tag):
         M = x.B * x.H * x.W
         out = self._buf(tag, (M, x.C))
+        self._fold_bwd(x.bn)
         N.call('t3d_bn_act_bwd', self.dt, N.ptr(dz), N.ptr(x.raw), x.gpro, N.ptr(out), N.ptr(x.bn.bstats), M, x.C,
                N.stream())
+        self._fold_done(x.bn)
         return out
 
     def _block_bwd(self, rec, dz):
@@ -782,9 +851,11 @@ class Net:
             s1 = rec['s1']
             d1 = self._buf(f'dz1:{i}', (M1, blk.cexp))
             dwrep = self._dw_replicas(dwn)
+            self._fold_bwd(s1.bn)
             N.call('t3d_dwconv_bwd', dt, N.ptr(dv2), N.ptr(s2.raw), bb2, N.ptr(self.p[dwn]), N.ptr(s1.t), s1.pro, None,
                    N.ptr(d1), N.ptr(s1.bn.bstats), N.ptr(dwrep), B, x.H, x.W, blk.cexp, blk.k, blk.s, st,
                    nbytes=2 * (M1 + M2) * blk.cexp * self.esz)
+            self._fold_done(s1.bn)
             bb1 = self._bn_bwd(s1.bn)
             p = f'features.{i + 1}.conv'
             if self._yfree_ok(x, M1, blk.cin, blk.cexp):
@@ -798,10 +869,14 @@ class Net:
         dx = self._buf(f'dzin:{i}', (M1, blk.cexp))
         dwrep = self._dw_replicas(dwn)
         deferred = x.pro is not None           # raw producer tensor read through its prologue
+        if deferred:
+            self._fold_bwd(x.bn)
         N.call('t3d_dwconv_bwd', dt, N.ptr(dv2), N.ptr(s2.raw), bb2, N.ptr(self.p[dwn]), N.ptr(x.t), x.pro,
                N.ptr(res) if res is not None else None, N.ptr(dx),
                N.ptr(x.bn.bstats) if deferred else None, N.ptr(dwrep), B, x.H, x.W, blk.cexp, blk.k, blk.s, st,
                nbytes=2 * (M1 + M2) * blk.cexp * self.esz)
+        if deferred:
+            self._fold_done(x.bn)
         if not deferred:
             # finished input: the producer's BatchNorm sums have to be taken against its RAW tensor
             dx = self._act_bwd(dx, x, f'dzin:{i}:a')

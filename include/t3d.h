@@ -279,6 +279,32 @@ int t3d_se_bwd(const float* ps_stats, const float* gap_sum, const float* scale, 
  * Process-wide setting (default 1 = plain behaviour); kernels that do not implement replicas use replica 0. */
 int t3d_set_reduction_replicas(int nrep, long long stats_stride);
 
+/* BatchNorm finalize folded into its producer.  t3d_bn_finalize / t3d_bn_bwd_finalize are 5-us launches that sit
+ * between every convolution and its consumer (~100 per training step, all on the critical stream).  A fold request
+ * names the sums (`stats`, replica 0) and a DEVICE-resident descriptor of everything the finalize would compute; the
+ * NEXT launch that accumulates into exactly those sums consumes the request and lets its last workgroup (device ticket
+ * counter, zero before and after) do the finalize.  Implemented by the bf16 streaming kernels (t3d_pwconv_fwd /
+ * _dgrad / _dgrad_yfree, t3d_dwconv_fwd / _bwd with k = 3) and by t3d_bn_act_bwd / t3d_pool_bwd; other launches
+ * leave the request pending: t3d_fold_pending() returns 1 (and clears it) and the caller runs the standalone
+ * finalize.
+ *   kind 1 (forward, = t3d_bn_finalize):      stats = sum(y), sum(y^2); o0..o3 = scale, shift, mean, invstd
+ *   kind 2 (backward, = t3d_bn_bwd_finalize): stats = sum(dz), sum(dz*y); o0..o4 = alpha, beta, gammac, dgamma, dbeta */
+typedef struct {
+  int kind;
+  int C;
+  unsigned* counter;
+  const double* stats;
+  double count;
+  const float *gamma, *beta;
+  float *rm, *rv;            /* kind 1: running estimates (may be NULL) */
+  long long* nbt;            /* kind 1: num_batches_tracked (may be NULL) */
+  float momentum, eps;
+  float *o0, *o1, *o2, *o3, *o4;
+  const float *mean, *invstd; /* kind 2: the forward's batch mean / invstd */
+} t3d_bn_fold;
+int t3d_fold_request(const t3d_bn_fold* desc_device, const double* stats);
+int t3d_fold_pending(void);
+
 /* Optional device scratch (caller-owned, process-wide setting; NULL/0 clears it).  With a workspace the bf16
  * pointwise weight gradient writes its per-split partial dW tiles there with plain stores and reduces them in a
  * second, deterministic pass; without one the partials leave as fp32 atomics.  64 MB covers every layer shape of
