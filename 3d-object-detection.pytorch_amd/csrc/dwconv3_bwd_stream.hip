@@ -17,6 +17,7 @@
 // wave-uniform skips.  Block-level reduction of dw (9*C) and the sums (2*C) through LDS, then fp32 / fp64
 // atomics once per block.
 #include <cstdlib>
+#include <type_traits>
 #include "common.h"
 
 namespace {
@@ -342,10 +343,18 @@ __global__ __launch_bounds__(NTH) void dw3_bwd2_kernel(const Dw3BArgs a) {
   // final flush touch only these channels
   const int cbase = a.slab ? blockIdx.y * 64 * CH : 0;
   const int Cb = a.slab ? min(64 * CH, a.C - cbase) : a.C;
-  // weights [tap][Cb] in LDS: a thread reads its 4 channels of one tap with one ds_read_b128
-  for (int i = threadIdx.x; i < 9 * Cb; i += NTH) lred[i] = a.w[(size_t)(cbase + i % Cb) * 9 + i / Cb];
-  __syncthreads();
+  // stencil weights: the 2-channel variant keeps its 9 x 2 in registers for the thread's whole life (18 VGPRs; read
+  // from LDS per tap they cost 9 ds_read + ~8 lgkmcnt waits per row, 7 % of the row loop's instructions); the
+  // 4-channel variant has no registers to spare and reads [tap][Cb] from LDS, one ds_read_b128 per tap
+  f32x2 wreg[9];
   const float* wl = lred + (c0 - cbase);
+  if constexpr (CH == 2) {
+#pragma unroll
+    for (int t = 0; t < 9; ++t) wreg[t] = f32x2{a.w[(size_t)c0 * 9 + t], a.w[(size_t)(c0 + 1) * 9 + t]};
+  } else {
+    for (int i = threadIdx.x; i < 9 * Cb; i += NTH) lred[i] = a.w[(size_t)(cbase + i % Cb) * 9 + i / Cb];
+    __syncthreads();
+  }
 
   f32x2 sc2[H2], sh2[H2], al2[H2], be2[H2], ga2[H2];
   f32x2 wacc[9][H2];
@@ -392,6 +401,17 @@ __global__ __launch_bounds__(NTH) void dw3_bwd2_kernel(const Dw3BArgs a) {
     const int x0 = 2 * xp;                 // columns x0 (always inside) and x0+1
     const bool validB = x0 + 1 < a.W;
     const float m[4] = {x0 - 1 >= 0 ? 1.f : 0.f, 1.f, validB ? 1.f : 0.f, x0 + 2 < a.W ? 1.f : 0.f};
+    // zero padding folded into the coefficients: a column outside the image gets alpha = beta = gamma = 0 (dy = 0) and
+    // scale = shift = 0 (act(0) = 0 for every supported activation) -- no mask multiplies in the row loop
+    f32x2 alm[4][H2], bem[4][H2], gam[4][H2], scm[4][H2], shm[4][H2];
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+      for (int h = 0; h < H2; ++h) {
+        const f32x2 mm = {m[c], m[c]};
+        alm[c][h] = al2[h] * mm; bem[c][h] = be2[h] * mm; gam[c][h] = ga2[h] * mm;
+        scm[c][h] = sc2[h] * mm; shm[c][h] = sh2[h] * mm;
+      }
     unsigned voff[4];                      // lane part of the load addresses (BYTES, unsigned: scalar base + 32-bit offset)
 #pragma unroll
     for (int c = 0; c < 4; ++c) voff[c] = (unsigned)(min(max(x0 - 1 + c, 0), a.W - 1) * a.C + c0) * (unsigned)sizeof(T);
@@ -440,13 +460,21 @@ __global__ __launch_bounds__(NTH) void dw3_bwd2_kernel(const Dw3BArgs a) {
     //  * the ring is filled in slot order before the loop: the wait at the loop header is the more conservative of
     //    the two ways into the loop, and a reordered prologue made it a full drain.
     // Rows past rl contribute nothing (rok = false).  Worth 4-6 % on the 112x112 / 56x56 layers (isolated launches).
-    const int rend = rf + (rl - rf + PF) / PF * PF;
-    for (int base = rf; base < rend; base += PF) {
+    // Two versions of a PF-row group (generic lambda, FAST = compile-time): the general one carries every row / halo /
+    // store predicate; the FAST one is for groups whose rows are all owned, inside the image and past the two warm-up
+    // rows -- no predicates, no exec-mask branches (out-of-tile lanes are steered to an out-of-range buffer offset,
+    // which the hardware drops).  The predicates were a third of the row loop's instructions (SALU compares / selects
+    // / branches); an item walks one general group, then FAST groups, then one or two general groups.
+    const unsigned OOB = 0x80000000u;                        // beyond num_records of every tensor here (< 2 GB)
+    const unsigned stA = on ? vst : OOB, stB = (on && validB) ? vst + (unsigned)(a.C * sizeof(T)) : OOB;
+    const float mA = on ? 1.f : 0.f, mB = (on && validB) ? 1.f : 0.f;
+    auto group = [&](auto fast_tag, const int base) {
+      constexpr bool FAST = decltype(fast_tag)::value;
 #pragma unroll
       for (int u = 0; u < PF; ++u) {
         const int r = base + u;
         {
-          const bool rok = r >= 0 && r < a.H && r <= rl;
+          const bool rok = FAST || (r >= 0 && r < a.H && r <= rl);
           f32x2 dy[4][H2], av[4][H2], xr[2][H2];
 #pragma unroll
           for (int c = 0; c < 4; ++c)
@@ -455,7 +483,7 @@ __global__ __launch_bounds__(NTH) void dw3_bwd2_kernel(const Dw3BArgs a) {
               const f32x2 z = {(float)rz[u][c][2 * h], (float)rz[u][c][2 * h + 1]};
               const f32x2 yy = {(float)ry[u][c][2 * h], (float)ry[u][c][2 * h + 1]};
               av[c][h] = f32x2{(float)rx[u][c][2 * h], (float)rx[u][c][2 * h + 1]};
-              dy[c][h] = pk_fma(al2[h], z, pk_fma(be2[h], yy, ga2[h]));
+              dy[c][h] = pk_fma(alm[c][h], z, pk_fma(bem[c][h], yy, gam[c][h]));
             }
 #pragma unroll
           for (int c = 0; c < 4; ++c)
@@ -473,7 +501,7 @@ __global__ __launch_bounds__(NTH) void dw3_bwd2_kernel(const Dw3BArgs a) {
 #pragma unroll
             for (int c = 0; c < 4; ++c)
 #pragma unroll
-              for (int h = 0; h < H2; ++h) av[c][h] = pk_fma(av[c][h], sc2[h], sh2[h]);
+              for (int h = 0; h < H2; ++h) av[c][h] = pk_fma(av[c][h], scm[c][h], shm[c][h]);
             switch (ACT) {
               case T3D_ACT_RELU:
 #pragma unroll
@@ -501,30 +529,38 @@ __global__ __launch_bounds__(NTH) void dw3_bwd2_kernel(const Dw3BArgs a) {
               default: break;
             }
           }
-          const float rm = rok ? 1.f : 0.f;    // out-of-image row: everything it would contribute is zero
+          if (!affine) {                       // no prologue: the raw input itself is the operand and needs its column masks
 #pragma unroll
-          for (int c = 0; c < 4; ++c)
+            for (int c = 0; c < 4; ++c)
 #pragma unroll
-            for (int h = 0; h < H2; ++h) {
-              const f32x2 mm = {m[c] * rm, m[c] * rm};
-              dy[c][h] = dy[c][h] * mm;
-              av[c][h] = av[c][h] * mm;
-            }
+              for (int h = 0; h < H2; ++h) av[c][h] = av[c][h] * f32x2{m[c], m[c]};
+          }
+          if (!rok) {                          // out-of-image / padded row (at most 3 per item): contributes nothing
+            asm volatile("" ::: "memory");     // (a real wave-uniform branch: if-converted it is 16 selects per row)
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+#pragma unroll
+              for (int h = 0; h < H2; ++h) dy[c][h] = av[c][h] = f32x2{0.f, 0.f};
+          }
           f32x2* aA = accA[u % 3];
           f32x2* bA = accA[(u + 1) % 3];
           f32x2* cA = accA[(u + 2) % 3];
           f32x2* aB = accB[u % 3];
           f32x2* bB = accB[(u + 1) % 3];
           f32x2* cB = accB[(u + 2) % 3];
-          const bool own = r >= r0 && r < r1;
-          const float om = own ? 1.f : 0.f;
+          const bool own = FAST || (r >= r0 && r < r1);
           f32x2 dycA[H2], dycB[H2];
 #pragma unroll
           for (int h = 0; h < H2; ++h) {
-            dycA[h] = dy[1][h] * f32x2{om, om};
-            dycB[h] = dy[2][h] * f32x2{om, om};
+            dycA[h] = dy[1][h];
+            dycB[h] = dy[2][h];
           }
-          // stencil taps, one LDS read (4 channels) per tap
+          if (!own) {                          // the two halo rows of a chunk: their weight-gradient terms belong to the neighbour
+            asm volatile("" ::: "memory");
+#pragma unroll
+            for (int h = 0; h < H2; ++h) dycA[h] = dycB[h] = f32x2{0.f, 0.f};
+          }
+          // stencil taps
 #pragma unroll
           for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
@@ -534,8 +570,7 @@ __global__ __launch_bounds__(NTH) void dw3_bwd2_kernel(const Dw3BArgs a) {
                 const float4 wq = *reinterpret_cast<const float4*>(wl + (ky * 3 + kx) * Cb);
                 wv[0] = f32x2{wq.x, wq.y}; wv[1] = f32x2{wq.z, wq.w};
               } else {
-                const float2 wq = *reinterpret_cast<const float2*>(wl + (ky * 3 + kx) * Cb);
-                wv[0] = f32x2{wq.x, wq.y};
+                wv[0] = wreg[ky * 3 + kx];
               }
               // data gradient: dy row r reaches dx row r-1+ky; dy column (x + 1 - kx): local index 2-kx for A, 3-kx for B
               f32x2* dA = ky == 0 ? aA : (ky == 1 ? bA : cA);
@@ -559,10 +594,9 @@ __global__ __launch_bounds__(NTH) void dw3_bwd2_kernel(const Dw3BArgs a) {
           }
           // dx row r-1 complete
           const int iy = r - 1;
-          if (iy >= r0 && iy < r1) {
+          if (FAST || (iy >= r0 && iy < r1)) {
 #pragma unroll
             for (int col = 0; col < 2; ++col) {
-              if (col == 1 && !validB) break;
               const f32x2* acc = col == 0 ? aA : aB;
               float g[CH], xv[CH];
 #pragma unroll
@@ -580,21 +614,23 @@ __global__ __launch_bounds__(NTH) void dw3_bwd2_kernel(const Dw3BArgs a) {
                 act_grad_affine_vec<CH>(g, xv, scf, shf, ACT);
               }
               const size_t rowo = (imgrow + iy) * a.W * a.C;     // scalar
-              const unsigned lo = vst + (unsigned)(col * a.C) * (unsigned)sizeof(T);
+              const unsigned lo = col == 0 ? stA : stB;           // out-of-tile lanes / the missing odd column: dropped
               if (rb) {
-                const RV rr = *reinterpret_cast<const RV*>(reinterpret_cast<const char*>(rb + rowo) + lo);
+                const unsigned lr = vst + (unsigned)(col * a.C) * (unsigned)sizeof(T);
+                const RV rr = *reinterpret_cast<const RV*>(reinterpret_cast<const char*>(rb + rowo) + lr);
 #pragma unroll
                 for (int i = 0; i < CH; ++i) g[i] += (float)rr[i];
               }
+              const float mcol = col == 0 ? mA : mB;
               RV o;
 #pragma unroll
               for (int i = 0; i < CH; ++i) {
                 o[i] = (T)g[i];
-                const float v = (float)o[i];
+                const float v = (float)o[i] * mcol;               // a lane without this column adds nothing to the sums
                 psum[i] += v;
                 psq[i] = fmaf(v, xv[i], psq[i]);
               }
-              if (on) bufstore<RV>(o, rsd, lo, (unsigned)(rowo * sizeof(T)));
+              bufstore<RV>(o, rsd, lo, (unsigned)(rowo * sizeof(T)));
             }
           }
 #pragma unroll
@@ -609,7 +645,15 @@ __global__ __launch_bounds__(NTH) void dw3_bwd2_kernel(const Dw3BArgs a) {
           }
         }
       }
-    }
+    };
+    const int rend = rf + (rl - rf + PF) / PF * PF;
+    int base = rf;
+    group(std::false_type{}, base);                      // rows r0-1, r0, r0+1: halo row, nothing to store yet
+    base += PF;
+    // FAST groups: every row in [r0+2, r1-1] (owned, stored, inside the image), and the refill rows (r + PF) need no
+    // lower clamp
+    for (; base + PF - 1 <= r1 - 1 && base + PF < rend; base += PF) group(std::true_type{}, base);
+    for (; base < rend; base += PF) group(std::false_type{}, base);
   }  // item loop
 
   // ---- block-level reduction (the weights in LDS are dead now)

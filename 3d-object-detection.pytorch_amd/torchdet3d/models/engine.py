@@ -54,7 +54,7 @@ def _concurrent_stream(device, tries=8):
     with torch.cuda.device(device):
         probe = torch.zeros(1, device=device)
         for _ in range(tries):
-            st = torch.cuda.Stream(device=device)
+            st = torch.cuda.Stream(device=device, priority=int(os.environ.get('T3D_SIDE_PRIO', '0')))
             cands.append(st)
             e0, e_side, e_main = (torch.cuda.Event(enable_timing=True) for _ in range(3))
             torch.cuda.synchronize(device)
