@@ -422,13 +422,9 @@ template <int NT, int R>
 int launch_nt(GemmArgs& a, int KS, hipStream_t st) {
   if (a.a2) return launch_v<NT, R, true, false, true>(a, KS, st);   // y-free data gradient
   const bool gen = a.per_sample || a.ps_stats || a.e_se || (!a.dgrad && a.p2);
-  static const int ku_env = getenv("T3D_PW_KU") ? atoi(getenv("T3D_PW_KU")) : 0;   // 2: the shallow variant everywhere
-  const bool deep = KS >= 6 && !gen && ku_env != 2;
-  if (a.dgrad) {
-    if (deep) return launch_v<NT, R, true, false, false, (R == 1 ? 6 : 4)>(a, KS, st);    // two tensors per k-step in flight
-    return gen ? launch_v<NT, R, true, true>(a, KS, st) : launch_v<NT, R, true, false>(a, KS, st);
-  }
-  if (deep) return launch_v<NT, R, false, false, false, 6>(a, KS, st);
+  // (KU = 4 / 6 variants for the deep contractions of the 14x14 / 7x7 stages were measured: no difference -- those
+  // launches are bound by their fixed latency chain, not by the k-loop's load rounds)
+  if (a.dgrad) return gen ? launch_v<NT, R, true, true>(a, KS, st) : launch_v<NT, R, true, false>(a, KS, st);
   return gen ? launch_v<NT, R, false, true>(a, KS, st) : launch_v<NT, R, false, false>(a, KS, st);
 }
 

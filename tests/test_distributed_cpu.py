@@ -51,3 +51,14 @@ def test_gradsync_two_ranks_gloo():
         assert ok, f'rank {rank}: averaged gradient wrong'
         assert pvals == [5.0] * 7, 'parameters must come from rank 0'
         assert launched == [0, 1, 1, 2, 3], launched     # buckets of >= 3000 elements, tail first, remainder at 0
+
+
+def test_bench_refuses_a_rank_count_it_cannot_start():
+    """`bench.py --gpus N` run plainly starts its N ranks itself (child `torch.distributed.run`); here there is no GPU,
+    so every rank must stop with the explicit message and the parent must pass the failure on -- never a silent
+    single-GPU number."""
+    import subprocess
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '1', '--warmup', '1',
+                        '--no-cpu-baseline'], capture_output=True, text=True, timeout=600)
+    assert r.returncode != 0
+    assert 'GPU(s) visible' in (r.stdout + r.stderr)
