@@ -63,6 +63,24 @@ __global__ void bn_eval_affine_kernel(int C, const float* __restrict__ gamma, co
   shift[c] = (beta ? beta[c] : 0.f) - rm[c] * s;
 }
 
+// every BatchNorm of the model in one launch: desc[i] = {gamma, beta, running_mean, running_var, scale, shift, C} (int64)
+__global__ void bn_eval_affine_batched_kernel(const long long* __restrict__ desc, float eps) {
+  const long long* d = desc + (size_t)blockIdx.x * 7;
+  const float* gamma = reinterpret_cast<const float*>(d[0]);
+  const float* beta = reinterpret_cast<const float*>(d[1]);
+  const float* rm = reinterpret_cast<const float*>(d[2]);
+  const float* rv = reinterpret_cast<const float*>(d[3]);
+  float* scale = reinterpret_cast<float*>(d[4]);
+  float* shift = reinterpret_cast<float*>(d[5]);
+  const int C = (int)d[6];
+  for (int c = blockIdx.y * blockDim.x + threadIdx.x; c < C; c += gridDim.y * blockDim.x) {
+    const float invstd = 1.f / sqrtf(rv[c] + eps);
+    const float s = (gamma ? gamma[c] : 1.f) * invstd;
+    scale[c] = s;
+    shift[c] = (beta ? beta[c] : 0.f) - rm[c] * s;
+  }
+}
+
 __global__ void bn_bwd_finalize_kernel(const double* __restrict__ stats, int nrep, long long rstride, int C, double count,
                                        const float* __restrict__ gamma, const float* __restrict__ mean,
                                        const float* __restrict__ invstd, float* alpha, float* beta, float* gammac,
@@ -106,7 +124,14 @@ extern "C" int t3d_bn_eval_affine(int C, const float* gamma, const float* beta, 
   return T3D_OK;
 }
 
-extern "C" int t3d_version(void) { return 1; }
+extern "C" int t3d_bn_eval_affine_batched(const long long* desc, int n, float eps, void* stream) {
+  if (!desc || n <= 0) return T3D_ERR_ARG;
+  hipLaunchKernelGGL(bn_eval_affine_batched_kernel, dim3(n, 2), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), desc, eps);
+  T3D_CHECK_LAUNCH();
+  return T3D_OK;
+}
+
+extern "C" int t3d_version(void) { return 2; }
 
 extern "C" int t3d_bn_bwd_finalize(const double* stats, int C, double count, const float* gamma, const float* mean,
                                    const float* invstd, float* alpha, float* beta, float* gammac, float* dgamma,

@@ -46,6 +46,7 @@ SIGNATURES = {
     't3d_dwconv_fwd': [_I, _P, _PP, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
     't3d_bn_finalize': [_P, _I, _D, _P, _P, _P, _P, _P, _F, _F, _P, _P, _P, _P, _P],
     't3d_bn_eval_affine': [_I, _P, _P, _P, _P, _F, _P, _P, _P],
+    't3d_bn_eval_affine_batched': [_P, _I, _F, _P],
     't3d_pwconv_fwd': [_I, _P, _PP, _P, _P, _P, _P, _I, _I, _I, _I, _P],
     't3d_pwconv_dgrad': [_I, _P, _P, _BP, _P, _P, _PP, _P, _P, _P, _P, _I, _I, _I, _I, _P],
     't3d_pack_weight': [_I, _P, _P, _I, _I, _I, _P],

@@ -17,7 +17,8 @@ reference's).  Differences a caller can observe:
     a train-mode model called under `torch.no_grad()` evaluates with the running statistics and leaves them alone,
     where the reference would still use (and update) batch statistics.
 Config keys read: model.name, model.num_classes, model.pretrained (ignored: no network), model.load_weights,
-model.storage_dtype ('f32' default for parity | 'bf16' throughput mode), model.pooling_mode ('avg' | 'max' |
+model.storage_dtype ('f32' default for parity | 'bf16' throughput mode), model.eval_storage_dtype (optional: storage
+precision of eval-mode forwards, e.g. 'f32' validation of a model trained with 'bf16'), model.pooling_mode ('avg' | 'max' |
 'avg+max'; the reference fixes this at its default 'avg', model_builder.py:73-74)."""
 import torch
 from torch import nn
@@ -111,13 +112,16 @@ class _Sigmoid(nn.Module):
 
 
 class ModelWrapper(nn.Module):
-    def __init__(self, name, num_classes=9, export_mode=False, storage_dtype='f32', device='cpu', pooling_mode='avg'):
+    def __init__(self, name, num_classes=9, export_mode=False, storage_dtype='f32', device='cpu', pooling_mode='avg',
+                 eval_storage_dtype=None):
         super().__init__()
         assert name in AVAILABLE_MODELS, f'Wrong model name parameter. Expected one of {AVAILABLE_MODELS}'
         if pooling_mode not in ('avg', 'max', 'avg+max'):
             raise ValueError(f'Unknown pooling mode: {pooling_mode}')          # model_builder.py:105-106
         self.name, self.num_classes, self.export_mode, self.pooling_mode = name, num_classes, export_mode, pooling_mode
         self.storage_dtype = torch.bfloat16 if storage_dtype in ('bf16', torch.bfloat16) else torch.float32
+        self.eval_storage_dtype = (None if not eval_storage_dtype else
+                                   torch.bfloat16 if eval_storage_dtype in ('bf16', torch.bfloat16) else torch.float32)
         self.grad_sync = None          # optional torchdet3d.parallel.GradSync (one process per GPU)
         self._make(torch.device(device))
         # the reference's head attributes (model_builder.py:79-87) as views; kept out of `_modules` / `_parameters`
@@ -135,6 +139,11 @@ class ModelWrapper(nn.Module):
         self.net = Net(self.name, self.num_classes, device, self.storage_dtype, self.pooling_mode)
         if state is not None:
             self.net.load_state_dict(state)
+        # optional second engine over the SAME parameters / BatchNorm buffers for eval-mode forwards in another storage
+        # precision (fp32 validation of a bf16-trained model: the 3-D IoU then equals the fp32 path's)
+        self.net_eval = self.net
+        if self.eval_storage_dtype is not None and self.eval_storage_dtype != self.storage_dtype and device.type == 'cuda':
+            self.net_eval = Net(self.name, self.num_classes, device, self.eval_storage_dtype, self.pooling_mode, share=self.net)
         self.flat = nn.Parameter(self.net.flat)     # shares storage with the engine's master weights
         if self.grad_sync is not None:
             self.attach_grad_sync(self.grad_sync)
@@ -195,6 +204,10 @@ class ModelWrapper(nn.Module):
             raise RuntimeError('the HIP path needs the model and the crops on the GPU (no CPU fallback)')
         # train-mode BatchNorm / dropout only when a backward can follow (grad mode is off inside Function.forward)
         train = self.training and torch.is_grad_enabled()
+        if not train and self.net_eval is not self.net:
+            with torch.no_grad():
+                kp, logits = self.net_eval.forward(x.float(), cats, train=False)
+            return kp, (logits if self.num_classes > 1 else cats.unsqueeze(1))
         kp, logits = _Run.apply(self.flat, self, x.float(), cats, dropout_mask, train)
         targets = logits if self.num_classes > 1 else cats.unsqueeze(1)     # model_builder.py:141-144
         return kp, targets
@@ -205,7 +218,7 @@ class ModelWrapper(nn.Module):
         the backbone, then every regressor on every sample in one launch (`t3d_head_fwd_all`)."""
         if not x.is_cuda:
             raise RuntimeError('the HIP path needs the model and the crops on the GPU (no CPU fallback)')
-        kp, logits = self.net.forward(x.float(), None, train=False, all_heads=True)
+        kp, logits = self.net_eval.forward(x.float(), None, train=False, all_heads=True)
         return kp, (logits if self.num_classes > 1 else torch.zeros(x.shape[0], device=x.device))
 
 
@@ -213,7 +226,8 @@ def build_model(config, export_mode=False, weights_path=''):
     name = config.model.name
     assert name in AVAILABLE_MODELS, f'Wrong model name parameter. Expected one of {AVAILABLE_MODELS}'
     model = ModelWrapper(name, config.model.num_classes or 9, export_mode, config.model.storage_dtype or 'f32',
-                         pooling_mode=config.model.pooling_mode or 'avg')
+                         pooling_mode=config.model.pooling_mode or 'avg',
+                         eval_storage_dtype=config.model.eval_storage_dtype or None)
     weights = config.model.load_weights or weights_path
     if weights:
         load_pretrained_weights(model, weights)

@@ -82,7 +82,10 @@ class _Src:
 
 
 class Net:
-    def __init__(self, name, num_classes=9, device='cuda', dtype=torch.float32, pooling_mode='avg'):
+    def __init__(self, name, num_classes=9, device='cuda', dtype=torch.float32, pooling_mode='avg', share=None):
+        """share: another Net of the same architecture whose master weights / gradient buffer / BatchNorm buffers this
+        one aliases (a second storage precision over ONE set of parameters, e.g. fp32 validation of a bf16-trained
+        model: builders.model_builder `model.eval_storage_dtype`)."""
         if pooling_mode not in N.POOL:                 # model_builder.py:105-106
             raise ValueError(f'Unknown pooling mode: {pooling_mode}')
         self.pooling_mode, self.pool = pooling_mode, N.POOL[pooling_mode]
@@ -93,6 +96,7 @@ class Net:
         self.dtype = dtype
         self.dt = N.F32 if dtype == torch.float32 else N.BF16
         self.esz = 4 if dtype == torch.float32 else 2      # bytes per stored activation element
+        self._share = share
         self._layout()
         self._bufs = {}
         self._packed_dirty = True
@@ -131,8 +135,10 @@ class Net:
             self.offsets[f'regressors.{k}.0.bias'] = (self.offsets['__breg'][0] + k * 18, 18)
         self.nparams = off
         dev = self.device
-        self.flat = torch.zeros(off, device=dev)
-        self.gflat = torch.zeros(off, device=dev)
+        sh = self._share
+        assert sh is None or (sh.nparams == off and sh.name == self.name and sh.device == dev)
+        self.flat = sh.flat if sh is not None else torch.zeros(off, device=dev)
+        self.gflat = sh.gflat if sh is not None else torch.zeros(off, device=dev)
         self.p, self.g = {}, {}
         for k, (s, kind) in shapes.items():
             if kind == 'param':
@@ -147,8 +153,9 @@ class Net:
         self.bns = {}
         for k, (s, kind) in shapes.items():
             if kind == 'buffer':
-                self.buffers[k] = (torch.zeros(s, device=dev, dtype=torch.int64) if k.endswith('tracked')
-                                   else (torch.ones(s, device=dev) if k.endswith('var') else torch.zeros(s, device=dev)))
+                self.buffers[k] = sh.buffers[k] if sh is not None else (
+                    torch.zeros(s, device=dev, dtype=torch.int64) if k.endswith('tracked')
+                    else (torch.ones(s, device=dev) if k.endswith('var') else torch.zeros(s, device=dev)))
         nbn = [k[:-len('.running_mean')] for k in shapes if k.endswith('.running_mean')]
         tot = sum(shapes[k + '.weight'][0][0] for k in nbn)
         self._statbuf = torch.zeros(NREP, 4 * tot, device=dev, dtype=torch.float64)   # replicas x (fwd sums | bwd sums)
@@ -179,7 +186,8 @@ class Net:
             b.desc = {}
         # opt-in (T3D_FOLD=1): measured SLOWER than the standalone finalize launches on MI355X (findings)
         self._fold = bool(os.environ.get('T3D_FOLD'))
-        self.reset_parameters()
+        if sh is None:
+            self.reset_parameters()
 
     def _view(self, key, shape, n=None, g=False):
         o, m = self.offsets[key]
@@ -330,10 +338,15 @@ class Net:
                 N.call('t3d_bn_finalize', N.ptr(bn.stats), bn.C, float(count), N.ptr(bn.gamma), N.ptr(bn.beta),
                        N.ptr(bn.rm), N.ptr(bn.rv), N.ptr(bn.nbt), BN_MOM, BN_EPS, N.ptr(bn.scale), N.ptr(bn.shift),
                        N.ptr(bn.mean), N.ptr(bn.invstd), st)
-        else:
-            N.call('t3d_bn_eval_affine', bn.C, N.ptr(bn.gamma), N.ptr(bn.beta), N.ptr(bn.rm), N.ptr(bn.rv), BN_EPS,
-                   N.ptr(bn.scale), N.ptr(bn.shift), st)
+        # eval: every BatchNorm's affine was folded from the running estimates in one launch at the start of the forward
         return self._pro(bn, act)
+
+    def _eval_affines(self):
+        if getattr(self, '_evdesc', None) is None:
+            rows = [[N.ptr(b.gamma), N.ptr(b.beta), N.ptr(b.rm), N.ptr(b.rv), N.ptr(b.scale), N.ptr(b.shift), b.C]
+                    for b in self.bns.values()]
+            self._evdesc = torch.tensor(rows, dtype=torch.int64, device=self.device)
+        N.call('t3d_bn_eval_affine_batched', N.ptr(self._evdesc), self._evdesc.shape[0], BN_EPS, N.stream())
 
     def _const(self, n, v):
         key = f'const:{n}:{v}'
@@ -460,6 +473,8 @@ class Net:
         B, _, H, W = imgs.shape
         if train:
             self._statbuf.zero_()
+        else:
+            self._eval_affines()
         sv = dict(B=B, imgs=imgs, blocks=[])
 
         # ---- stem: patch gather + GEMM (mobilenetv3.py:110-115,178)

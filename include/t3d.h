@@ -70,6 +70,10 @@ int t3d_bn_finalize(const double* stats, int C, double count, const float* gamma
 int t3d_bn_eval_affine(int C, const float* gamma, const float* beta, const float* running_mean,
                        const float* running_var, float eps, float* scale, float* shift, void* stream);
 
+/* ... for every BatchNorm of a model in ONE launch (an inference forward otherwise issues ~50 of them): desc = n rows
+ * of int64 {gamma, beta, running_mean, running_var, scale, shift, C}, a DEVICE array. */
+int t3d_bn_eval_affine_batched(const long long* desc, int n, float eps, void* stream);
+
 /* BatchNorm backward as a per-channel affine of two tensors, applied by the consumer on load:
  *   dy = alpha*dz + beta*y + gamma      (dz: gradient at the BN output, y: raw BN input)
  * alpha/gamma are [C], or [B*C] when per_sample != 0 (a squeeze-excite gate sits between). */

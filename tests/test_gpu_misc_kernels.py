@@ -214,3 +214,41 @@ def test_reference_attributes_compose_like_model_wrapper_forward(golden_dir):
         lg2 = m.cls_fc[1](pooled)
     np.testing.assert_allclose(kp2.cpu().numpy(), kp.cpu().numpy(), atol=2e-6)
     np.testing.assert_allclose(lg2.cpu().numpy(), lg.cpu().numpy(), atol=1e-5)
+
+
+def test_eval_storage_dtype_runs_validation_in_fp32_over_the_bf16_trained_parameters():
+    """model.storage_dtype = 'bf16' + model.eval_storage_dtype = 'f32': train-mode forwards / backwards use the bf16
+    engine, eval-mode forwards a second fp32 engine over the SAME master weights and BatchNorm buffers."""
+    from oracle.weights import make_inputs, make_state_dict
+    from torchdet3d.builders import build_loss, build_model, build_optimizer
+    from torchdet3d.losses import LossManager
+    imgs, gt_kp, cats = make_inputs(8, 96, 96, 9)
+    im, gt, ca = imgs.cuda(), gt_kp.cuda(), cats.cuda()
+    cfg = _cfg('mobilenetv2')
+    cfg.model.storage_dtype, cfg.model.eval_storage_dtype = 'bf16', 'f32'
+    m = build_model(cfg).to('cuda')
+    m.load_state_dict(make_state_dict('mobilenetv2', 9))
+    assert m.net_eval is not m.net and m.net_eval.flat.data_ptr() == m.net.flat.data_ptr()
+    ref_cfg = _cfg('mobilenetv2')
+    ref = build_model(ref_cfg).to('cuda')                       # plain fp32 model
+    ref.load_state_dict(m.state_dict())
+    m.eval(), ref.eval()
+    with torch.no_grad():
+        kp, lg = m(im, ca)
+        kpr, lgr = ref(im, ca)
+    assert torch.equal(kp, kpr) and torch.equal(lg, lgr)         # same engine, same weights, same kernels
+    # one training step in bf16, then validation again: the fp32 eval engine must see the updated weights and buffers
+    opt = build_optimizer(cfg, m)
+    lm = LossManager(build_loss(cfg), cfg.loss.coeffs, cfg.loss.alwa)
+    m.train()
+    kpt, tg = m(im, ca)
+    loss = lm.parse_losses(kpt, gt, tg, ca, 0)
+    opt.zero_grad()
+    loss.backward()
+    opt.step()
+    m.eval()
+    ref.load_state_dict(m.state_dict())
+    with torch.no_grad():
+        kp2, _ = m(im, ca)
+        kpr2, _ = ref(im, ca)
+    assert torch.equal(kp2, kpr2) and not torch.equal(kp2, kp)
