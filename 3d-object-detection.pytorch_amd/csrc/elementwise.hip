@@ -13,25 +13,40 @@ namespace {
 // ------------------------------------------------------------------ stem im2col
 // One thread per output pixel: 27 scalar gathers (coalesced along x within a row: stride-2 reads,
 // each input byte is used by ~2.25 patches and served from L1/L2), 4 x 16-B stores.
-template <typename T>
-__global__ __launch_bounds__(256) void im2col_kernel(const float* __restrict__ x, T* __restrict__ col, int B,
+// U8: the crops are raw uint8 NHWC pixels, normalised here as (u/255 - mean[c]) * inv_std[c]; padding taps stay 0
+// (the reference pads the NORMALISED image, mobilenetv3.py:110-115 after dataloaders/objectron_main.py:84-96).
+template <typename T, bool U8>
+__global__ __launch_bounds__(256) void im2col_kernel(const void* __restrict__ xin, const float* __restrict__ mean,
+                                                     const float* __restrict__ istd, T* __restrict__ col, int B,
                                                      int H, int W, int Ho, int Wo) {
   const size_t npix = (size_t)B * Ho * Wo;
+  float mu[3] = {0.f, 0.f, 0.f}, is[3] = {1.f, 1.f, 1.f};
+  if constexpr (U8) {
+#pragma unroll
+    for (int c = 0; c < 3; ++c) mu[c] = mean[c], is[c] = istd[c];
+  }
   for (size_t p = blockIdx.x * (size_t)256 + threadIdx.x; p < npix; p += (size_t)gridDim.x * 256) {
     const int ox = (int)(p % Wo), oy = (int)((p / Wo) % Ho), b = (int)(p / ((size_t)Wo * Ho));
     float v[32];
 #pragma unroll
     for (int i = 27; i < 32; ++i) v[i] = 0.f;
 #pragma unroll
-    for (int ci = 0; ci < 3; ++ci)
+    for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
-      for (int ky = 0; ky < 3; ++ky)
+      for (int kx = 0; kx < 3; ++kx) {
+        const int iy = oy * 2 - 1 + ky, ix = ox * 2 - 1 + kx;
+        const bool ok = iy >= 0 && iy < H && ix >= 0 && ix < W;
 #pragma unroll
-        for (int kx = 0; kx < 3; ++kx) {
-          const int iy = oy * 2 - 1 + ky, ix = ox * 2 - 1 + kx;
-          const bool ok = iy >= 0 && iy < H && ix >= 0 && ix < W;
-          v[(ci * 3 + ky) * 3 + kx] = ok ? x[(((size_t)b * 3 + ci) * H + iy) * W + ix] : 0.f;
+        for (int ci = 0; ci < 3; ++ci) {
+          float t = 0.f;
+          if constexpr (U8) {
+            if (ok) t = ((float)((const unsigned char*)xin)[(((size_t)b * H + iy) * W + ix) * 3 + ci] * (1.0f / 255.0f) - mu[ci]) * is[ci];
+          } else {
+            if (ok) t = ((const float*)xin)[(((size_t)b * 3 + ci) * H + iy) * W + ix];
+          }
+          v[(ci * 3 + ky) * 3 + kx] = t;
         }
+      }
 #pragma unroll
     for (int q = 0; q < 4; ++q) Vec8<T>::store(col + p * 32 + q * 8, v + q * 8);
   }
@@ -358,20 +373,34 @@ inline int ew_grid(size_t nvec) {
 
 }  // namespace
 
-extern "C" int t3d_stem_im2col(int dtype, const float* x, void* col, int B, int H, int W, void* stream) {
-  if (!x || !col || B <= 0 || H <= 0 || W <= 0) return T3D_ERR_ARG;
+static int im2col_launch(int dtype, const void* x, bool u8, const float* mean, const float* istd, void* col, int B,
+                         int H, int W, void* stream) {
+  if (!x || !col || B <= 0 || H <= 0 || W <= 0 || (u8 && (!mean || !istd))) return T3D_ERR_ARG;
   const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
   const size_t npix = (size_t)B * Ho * Wo;
   const int grid = (int)((npix + 255) / 256 > 8192 ? 8192 : (npix + 255) / 256);
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-  if (dtype == T3D_F32)
-    hipLaunchKernelGGL(im2col_kernel<float>, dim3(grid), dim3(256), 0, st, x, (float*)col, B, H, W, Ho, Wo);
-  else if (dtype == T3D_BF16)
-    hipLaunchKernelGGL(im2col_kernel<bf16_t>, dim3(grid), dim3(256), 0, st, x, (bf16_t*)col, B, H, W, Ho, Wo);
-  else
+#define T3D_IM2COL(T, U) \
+  hipLaunchKernelGGL((im2col_kernel<T, U>), dim3(grid), dim3(256), 0, st, x, mean, istd, (T*)col, B, H, W, Ho, Wo)
+  if (dtype == T3D_F32) {
+    if (u8) T3D_IM2COL(float, true); else T3D_IM2COL(float, false);
+  } else if (dtype == T3D_BF16) {
+    if (u8) T3D_IM2COL(bf16_t, true); else T3D_IM2COL(bf16_t, false);
+  } else {
     return T3D_ERR_ARG;
+  }
+#undef T3D_IM2COL
   T3D_CHECK_LAUNCH();
   return T3D_OK;
+}
+
+extern "C" int t3d_stem_im2col(int dtype, const float* x, void* col, int B, int H, int W, void* stream) {
+  return im2col_launch(dtype, x, false, nullptr, nullptr, col, B, H, W, stream);
+}
+
+extern "C" int t3d_stem_im2col_u8(int dtype, const unsigned char* x, const float* mean, const float* inv_std, void* col,
+                                  int B, int H, int W, void* stream) {
+  return im2col_launch(dtype, x, true, mean, inv_std, col, B, H, W, stream);
 }
 
 extern "C" int t3d_bn_apply(int dtype, const void* y, const t3d_prologue* pro, const void* residual, void* z,

@@ -29,7 +29,7 @@ namespace {
 // coefficients present (MobileNetV3 only) -- compiled out of the common variants to keep registers down.
 // YF (with DG): y-free data gradient -- the main loop is the plain forward loop over two raw tensors ([dz | x], no
 // transform), the epilogue is the data gradient's (activation derivative, residual, BatchNorm-backward sums).
-template <int NT, int R, bool DG, bool GEN, bool YF = false, int KU = 2>
+template <int NT, int R, bool DG, bool GEN, bool YF = false, int KU = 2, bool STEM = false>
 __global__ __launch_bounds__(512, 2) void pw_stream_kernel(const GemmArgs a, const int nchunks, const int KS, const int nrep, const long long rstride) {
   constexpr int BN = NT * 16;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -170,8 +170,12 @@ __global__ __launch_bounds__(512, 2) void pw_stream_kernel(const GemmArgs a, con
           const int k = min(ks * 32 + lg * 8, a.row0 - 8);
 #pragma unroll
           for (int r = 0; r < R; ++r) {
-            fa[u][r] = *reinterpret_cast<const bf16x8*>(A0 + (size_t)mld[r] * a.row0 + k);
-            if (DGL) fb[u][r] = *reinterpret_cast<const bf16x8*>(A1 + (size_t)mld[r] * a.row0 + k);
+            if constexpr (STEM) {
+              fa[u][r] = stem_patch(a.stem, mld[r], lg * 8);
+            } else {
+              fa[u][r] = *reinterpret_cast<const bf16x8*>(A0 + (size_t)mld[r] * a.row0 + k);
+              if (DGL) fb[u][r] = *reinterpret_cast<const bf16x8*>(A1 + (size_t)mld[r] * a.row0 + k);
+            }
           }
         }
       }
@@ -382,7 +386,7 @@ __global__ __launch_bounds__(512, 2) void pw_stream_kernel(const GemmArgs a, con
   t3d_fold_tail(a.fold, nrep, rstride);
 }
 
-template <int NT, int R, bool DG, bool GEN, bool YF = false, int KU = 2>
+template <int NT, int R, bool DG, bool GEN, bool YF = false, int KU = 2, bool STEM = false>
 int launch_v(GemmArgs& a, int KS, hipStream_t st) {
   constexpr int BN = NT * 16;
   const int kpad = KS * 32;
@@ -393,7 +397,7 @@ int launch_v(GemmArgs& a, int KS, hipStream_t st) {
   // small weight chunks: 4-wave blocks, as many per CU as registers / LDS admit (each wave hides its own
   // load latency, so resident waves per CU are what matters); big chunks: one 8-wave block shares the copy
   const int threads = lds <= 48 * 1024 ? 256 : 512;
-  const void* fn = (const void*)pw_stream_kernel<NT, R, DG, GEN, YF, KU>;
+  const void* fn = (const void*)pw_stream_kernel<NT, R, DG, GEN, YF, KU, STEM>;
   if (lds > 64 * 1024) (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   static int occ_cache[2] = {0, 0};   // per instantiation (function-local static of the template), per block size
   int& occ = occ_cache[threads == 512];
@@ -412,7 +416,7 @@ int launch_v(GemmArgs& a, int KS, hipStream_t st) {
   if (nxb < 1) nxb = 1;
   // a pending BatchNorm-finalize fold belongs to this launch when it produces that BatchNorm's sums
   a.fold = t3d_take_fold(a.stats);
-  hipLaunchKernelGGL((pw_stream_kernel<NT, R, DG, GEN, YF, KU>), dim3(nxb * nchunks), dim3(threads), lds, st, a, nchunks, KS,
+  hipLaunchKernelGGL((pw_stream_kernel<NT, R, DG, GEN, YF, KU, STEM>), dim3(nxb * nchunks), dim3(threads), lds, st, a, nchunks, KS,
                      g_t3d_reduce.nrep, g_t3d_reduce.stats_stride);
   T3D_CHECK_LAUNCH();
   return T3D_OK;
@@ -432,6 +436,10 @@ int launch_nt(GemmArgs& a, int KS, hipStream_t st) {
 
 int stream_launch(GemmArgs& a, hipStream_t st) {
   if (!a.row0) a.row0 = a.Kin;
+  if (a.stem.img) {     // direct stem: K = 32 gathered patch taps, N = stem channels (16 / 32): one narrow instantiation
+    if (a.Kin != 32 || a.Nout > 32 || a.dgrad || a.p0 || a.p2) return T3D_ERR_UNSUPPORTED;
+    return launch_v<2, 2, false, false, false, 2, true>(a, 1, st);
+  }
 
   const int KS = cdiv(a.Kin, 32);
   // widest chunk whose weights fit ~120 KB of LDS, at most 10 tiles (register budget: 8*NT stat + 4*NT*R acc)

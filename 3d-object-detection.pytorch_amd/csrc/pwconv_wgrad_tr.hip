@@ -20,7 +20,7 @@
 // Grid = (P tiles * Q tiles) x pixel splits; partial dW leave as fp32 atomics (few, large, spread over the
 // whole dW -- no contention problem here, unlike per-channel sums).
 #include <cstdlib>
-#include "common.h"
+#include "pwconv_common.h"
 
 namespace {
 
@@ -38,6 +38,7 @@ struct WgtArgs {
   int swap;          // 0: P = N (dy side), Q = K (a side); 1: P = K, Q = N
   int ptiles, qtiles, rows_per_split;
   float* ws;         // partial tiles [split][tile][PB][QB] (plain stores) or null (atomics into dw)
+  t3d_pw::StemSrc stem;   // stem.img != null: the a side (K = 32) is gathered from the crops (pwconv_common.h)
 };
 
 // one 16x16 tile row (transposed) fragment: pixels 8*lg .. 8*lg+7 of the step, channels ch0..ch0+15
@@ -54,7 +55,7 @@ __device__ __forceinline__ bf16x8 tr_frag(const bf16_t* tile, int rs, int ch0, i
 // NTPW: 16-row tiles per wave on the P side (block: 64*NTPW rows); NTQ: 16-column tiles on the Q side
 // G: independent 4-wave pipelines per block, taking alternate 32-pixel steps (own LDS buffers, own accumulators);
 // they are summed through LDS before the block's single flush -- twice the per-block throughput for one flush.
-template <int NTPW, int NTQ, bool SWAP, int G, int D, bool GEN, bool YF>
+template <int NTPW, int NTQ, bool SWAP, int G, int D, bool GEN, bool YF, bool STEM = false>
 __global__ __launch_bounds__(256 * G) void pw_wgrad_tr_kernel(const WgtArgs a) {
   constexpr int PB = 64 * NTPW, QB = 16 * NTQ;
   constexpr int RSP = PB + 8, RSQ = QB + 8;            // LDS row strides (elements): +16 B against bank conflicts
@@ -124,7 +125,8 @@ __global__ __launch_bounds__(256 * G) void pw_wgrad_tr_kernel(const WgtArgs a) {
     for (int i = 0; i < VA; ++i) {
       const int v = min(tid + 256 * i, nav - 1);
       const int row = v / aV, k = min(a0c + (v % aV) * 8, a.K - 8), m = min(m0 + row, a.M - 1);
-      R.rx[i] = *reinterpret_cast<const bf16x8*>(xx + (size_t)m * a.K + k);
+      if constexpr (STEM) R.rx[i] = t3d_pw::stem_patch(a.stem, m, k);
+      else R.rx[i] = *reinterpret_cast<const bf16x8*>(xx + (size_t)m * a.K + k);
     }
   };
   auto ld8 = [](const float* p, float* o) {     // 8 consecutive LDS floats as two 16-B reads
@@ -327,7 +329,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
   if (i0 < i1) unsafeAtomicAdd(dw + (size_t)n * K + k, s);
 }
 
-template <int NTPW, int NTQ, bool SWAP, int D, bool GEN, bool YF = false>
+template <int NTPW, int NTQ, bool SWAP, int D, bool GEN, bool YF = false, bool STEM = false>
 int launch_d(WgtArgs& a, hipStream_t st) {
   constexpr int G = 2;
   constexpr int PB = 64 * NTPW, QB = 16 * NTQ;
@@ -357,8 +359,8 @@ int launch_d(WgtArgs& a, hipStream_t st) {
   S = cdiv(a.M, a.rows_per_split);
   a.ws = use_ws ? reinterpret_cast<float*>(g_t3d_ws.ptr) : nullptr;
   if (lds > 64 * 1024)
-    (void)hipFuncSetAttribute((const void*)pw_wgrad_tr_kernel<NTPW, NTQ, SWAP, G, D, GEN, YF>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  hipLaunchKernelGGL((pw_wgrad_tr_kernel<NTPW, NTQ, SWAP, G, D, GEN, YF>), dim3(tiles, S), dim3(256 * G), lds, st, a);
+    (void)hipFuncSetAttribute((const void*)pw_wgrad_tr_kernel<NTPW, NTQ, SWAP, G, D, GEN, YF, STEM>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipLaunchKernelGGL((pw_wgrad_tr_kernel<NTPW, NTQ, SWAP, G, D, GEN, YF, STEM>), dim3(tiles, S), dim3(256 * G), lds, st, a);
   if (use_ws)
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(cdiv((a.swap ? a.K : a.N) * a.qtiles * QB, 256), S >= 64 ? 16 : (S >= 8 ? 4 : 1)), dim3(256), 0, st, a.ws, a.dw, a.N, a.K, (int)SWAP, PB, QB,
                        a.qtiles, tiles, S);
@@ -422,6 +424,19 @@ int t3d_pw_wgrad_tr_entry(const void* dz, const void* y, const t3d_bnbwd* bb, co
   if (pro) { a.scale = pro->scale; a.shift = pro->shift; a.se = pro->se; a.act = pro->act; a.se_after = pro->se_after_act; }
   a.dw = dw; a.M = M; a.HW = HW; a.K = K; a.N = N;
   return choose_and_launch(a, st);
+}
+
+// stem weight gradient: dW32 [C][32] += dy^T * patches, the patches gathered from the crops (no saved patch matrix)
+int t3d_pw_wgrad_tr_stem(const void* dz, const void* y, const t3d_bnbwd* bb, const t3d_pw::StemSrc& src, float* dw, int M,
+                         int HW, int N, hipStream_t st) {
+  WgtArgs a{};
+  a.dz = dz; a.y = y; a.x = dz;
+  a.alpha = bb->alpha; a.beta = bb->beta; a.gamma = bb->gamma; a.per_sample = bb->per_sample;
+  a.dw = dw; a.M = M; a.HW = HW; a.K = 32; a.N = N;
+  a.stem = src;
+  if (N == 32) { a.swap = 0; return launch_d<1, 2, false, 2, false, false, true>(a, st); }     // P = N = 32, Q = K = 32
+  if (N == 16) { a.swap = 1; return launch_d<1, 1, true, 2, false, false, true>(a, st); }      // P = K = 32, Q = N = 16
+  return T3D_ERR_UNSUPPORTED;
 }
 
 // y-free weight-gradient products (pwconv_yfree.hip):  tmp[(N + K + 8)][K] += [dz | x | 1]^T x   -- rows 0..N-1 = dz^T x,

@@ -123,6 +123,7 @@ class ModelWrapper(nn.Module):
         self.eval_storage_dtype = (None if not eval_storage_dtype else
                                    torch.bfloat16 if eval_storage_dtype in ('bf16', torch.bfloat16) else torch.float32)
         self.grad_sync = None          # optional torchdet3d.parallel.GradSync (one process per GPU)
+        self.input_normalization = ([0.5931, 0.4690, 0.4229], [0.2471, 0.2214, 0.2157])   # configs/default_config.py:9-10
         self._make(torch.device(device))
         # the reference's head attributes (model_builder.py:79-87) as views; kept out of `_modules` / `_parameters`
         # so that parameters() stays the single flat tensor
@@ -144,9 +145,17 @@ class ModelWrapper(nn.Module):
         self.net_eval = self.net
         if self.eval_storage_dtype is not None and self.eval_storage_dtype != self.storage_dtype and device.type == 'cuda':
             self.net_eval = Net(self.name, self.num_classes, device, self.eval_storage_dtype, self.pooling_mode, share=self.net)
+        self.set_input_normalization(*self.input_normalization)
         self.flat = nn.Parameter(self.net.flat)     # shares storage with the engine's master weights
         if self.grad_sync is not None:
             self.attach_grad_sync(self.grad_sync)
+
+    def set_input_normalization(self, mean, std):
+        """Mean / std applied to uint8 NHWC crops inside the stem's patch gather (configs/default_config.py:9-10; fp32 crops
+        arrive normalised, as in the reference, and are not touched)."""
+        self.input_normalization = (list(mean), list(std))
+        for net in {id(self.net): self.net, id(self.net_eval): self.net_eval}.values():
+            net.set_input_normalization(mean, std)
 
     @torch.no_grad()
     def extract_features(self, x):
@@ -204,11 +213,13 @@ class ModelWrapper(nn.Module):
             raise RuntimeError('the HIP path needs the model and the crops on the GPU (no CPU fallback)')
         # train-mode BatchNorm / dropout only when a backward can follow (grad mode is off inside Function.forward)
         train = self.training and torch.is_grad_enabled()
+        # uint8 NHWC crops go to the stem kernel as they are (normalised there, bf16 storage); anything else as fp32 NCHW
+        x = x if x.dtype == torch.uint8 else x.float()
         if not train and self.net_eval is not self.net:
             with torch.no_grad():
-                kp, logits = self.net_eval.forward(x.float(), cats, train=False)
+                kp, logits = self.net_eval.forward(x, cats, train=False)
             return kp, (logits if self.num_classes > 1 else cats.unsqueeze(1))
-        kp, logits = _Run.apply(self.flat, self, x.float(), cats, dropout_mask, train)
+        kp, logits = _Run.apply(self.flat, self, x, cats, dropout_mask, train)
         targets = logits if self.num_classes > 1 else cats.unsqueeze(1)     # model_builder.py:141-144
         return kp, targets
 
@@ -231,4 +242,7 @@ def build_model(config, export_mode=False, weights_path=''):
     weights = config.model.load_weights or weights_path
     if weights:
         load_pretrained_weights(model, weights)
+    norm = getattr(getattr(config, 'data', None), 'normalization', None)
+    if norm:
+        model.set_input_normalization(norm.mean, norm.std)
     return model

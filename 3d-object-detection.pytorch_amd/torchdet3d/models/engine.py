@@ -111,6 +111,14 @@ class Net:
         if self.device.type == 'cuda' and not os.environ.get('T3D_NO_SIDE_STREAM'):
             self._side = _concurrent_stream(self.device)
         self._side_busy = False
+        # uint8 input path (include/t3d.h: t3d_stem_fwd, fmt 1): normalisation of configs/default_config.py:9-10
+        self.set_input_normalization([0.5931, 0.4690, 0.4229], [0.2471, 0.2214, 0.2157])
+        self._direct_stem = bool(os.environ.get('T3D_STEM_DIRECT'))
+
+    def set_input_normalization(self, mean, std):
+        """Per-channel mean / std applied to uint8 crops inside the stem kernel ((u/255 - mean) / std)."""
+        self.in_mean = torch.tensor(mean, dtype=torch.float32, device=self.device)
+        self.in_istd = 1.0 / torch.tensor(std, dtype=torch.float32, device=self.device)
 
     # ------------------------------------------------------------------ parameters
     def _layout(self):
@@ -466,27 +474,43 @@ class Net:
         """Stem + inverted-residual blocks + last 1x1 conv (`extract_features`): fills and returns the saved-state
         dict with the RAW last feature map `yl` and its BatchNorm/activation prologue `prol`."""
         a, st, dt = self.arch, N.stream(), self.dt
-        assert imgs.is_cuda and imgs.dtype == torch.float32 and imgs.dim() == 4 and imgs.shape[1] == 3
+        # crops: fp32 NCHW, normalised (the reference's input contract) -- or uint8 NHWC raw pixels, normalised inside the
+        # patch gather with set_input_normalization()'s mean / std
+        u8 = imgs.dtype == torch.uint8
+        assert imgs.is_cuda and imgs.dim() == 4 and ((u8 and imgs.shape[3] == 3) or (imgs.dtype == torch.float32 and imgs.shape[1] == 3))
         imgs = imgs.contiguous()
         self.training = bool(train)
         self._pack()
-        B, _, H, W = imgs.shape
+        if u8:
+            B, H, W, _ = imgs.shape
+        else:
+            B, _, H, W = imgs.shape
         if train:
             self._statbuf.zero_()
         else:
             self._eval_affines()
         sv = dict(B=B, imgs=imgs, blocks=[])
 
-        # ---- stem: patch gather + GEMM (mobilenetv3.py:110-115,178)
+        # ---- stem (mobilenetv3.py:110-115,178): patch gather + GEMM.  T3D_STEM_DIRECT=1 (bf16 storage) gathers the patches
+        # inside the GEMM kernels instead (no patch matrix; measured slower, DESIGN.md finding 13)
         Ho, Wo = (H + 2 - 3) // 2 + 1, (W + 2 - 3) // 2 + 1
         M = B * Ho * Wo
-        col = self._buf('col', (M, 32))
-        N.call('t3d_stem_im2col', dt, N.ptr(imgs), N.ptr(col), B, H, W, st)
         bn0 = self.bns['features.0.1']
         y0 = self._buf('y:stem', (M, a.stem_c))
+        direct = self._direct_stem and dt == N.BF16
         self._fold_fwd(bn0, M)
-        N.call('t3d_pwconv_fwd', dt, N.ptr(col), None, N.ptr(self.w['stem']), None, N.ptr(y0), self._st(bn0),
-               M, Ho * Wo, 32, a.stem_c, st, nbytes=M * (32 + a.stem_c) * self.esz)
+        if direct:
+            col = None
+            N.call('t3d_stem_fwd', dt, N.ptr(imgs), int(u8), N.ptr(self.in_mean), N.ptr(self.in_istd), N.ptr(self.w['stem']),
+                   N.ptr(y0), self._st(bn0), B, H, W, a.stem_c, st, nbytes=imgs.numel() * imgs.element_size() + M * a.stem_c * 2)
+        else:
+            col = self._buf('col', (M, 32))
+            if u8:
+                N.call('t3d_stem_im2col_u8', dt, N.ptr(imgs), N.ptr(self.in_mean), N.ptr(self.in_istd), N.ptr(col), B, H, W, st)
+            else:
+                N.call('t3d_stem_im2col', dt, N.ptr(imgs), N.ptr(col), B, H, W, st)
+            N.call('t3d_pwconv_fwd', dt, N.ptr(col), None, N.ptr(self.w['stem']), None, N.ptr(y0), self._st(bn0),
+                   M, Ho * Wo, 32, a.stem_c, st, nbytes=M * (32 + a.stem_c) * self.esz)
         pro0 = self._bn_fwd(bn0, M, a.stem_act)
         cur = _Src(y0, pro0, B, Ho, Wo, a.stem_c, raw=y0, bn=bn0, gpro=pro0)
         sv['col'], sv['stem'] = col, cur
@@ -693,8 +717,16 @@ class Net:
         bn0 = s0.bn
         bb = self._bn_bwd(bn0)
         M = s0.B * s0.H * s0.W
-        self._wgrad(dt, N.ptr(dz), N.ptr(s0.raw), bb, N.ptr(sv['col']), None, N.ptr(dw32),
-                    M, s0.H * s0.W, 32, a.stem_c, nbytes=M * (32 + a.stem_c) * self.esz)
+        if sv['col'] is None:       # direct stem: the patches are gathered from the crops again
+            im = sv['imgs']
+            u8 = im.dtype == torch.uint8
+            H, W = (im.shape[1], im.shape[2]) if u8 else (im.shape[2], im.shape[3])
+            self._wgrad(dt, N.ptr(dz), N.ptr(s0.raw), bb, N.ptr(im), int(u8), N.ptr(self.in_mean), N.ptr(self.in_istd),
+                        N.ptr(dw32), s0.B, H, W, a.stem_c, entry='t3d_stem_wgrad',
+                        nbytes=im.numel() * im.element_size() + M * a.stem_c * 2)
+        else:
+            self._wgrad(dt, N.ptr(dz), N.ptr(s0.raw), bb, N.ptr(sv['col']), None, N.ptr(dw32),
+                        M, s0.H * s0.W, 32, a.stem_c, nbytes=M * (32 + a.stem_c) * self.esz)
         self._flush_dw()
         self._join_side()
         N.call('t3d_copy_cols', N.ptr(dw32), N.ptr(self.g['features.0.0.weight']), a.stem_c, 32, 27, st)

@@ -160,6 +160,25 @@ int t3d_bn_bwd_finalize(const double* stats, int C, double count, const float* g
  * patches of nn.Conv2d(3,C,3,2,1) (mobilenetv3.py:110-115) in (ci,ky,kx) order, columns 27..31 zero.
  * The stem conv itself then runs as t3d_pwconv_{fwd,wgrad} with K = 32. */
 int t3d_stem_im2col(int dtype, const float* x, void* col, int B, int H, int W, void* stream);
+/* The same gather from raw uint8 NHWC crops [B,H,W,3], normalised on the way: (u/255 - mean[c]) * inv_std[c]
+ * (configs/default_config.py:9-10; padding taps are zeros of the NORMALISED image, as the reference's conv sees them).
+ * The crops can then stay uint8 from the decoder to the GPU: 4x less PCIe / HBM than the fp32 tensor. */
+int t3d_stem_im2col_u8(int dtype, const unsigned char* x, const float* mean, const float* inv_std, void* col, int B, int H,
+                       int W, void* stream);
+
+/* Direct stem (bf16 storage, opt-in: T3D_STEM_DIRECT=1): the same convolution WITHOUT the patch matrix -- the 3x3 /
+ * stride-2 taps are gathered from the crops inside the GEMM kernels (forward and weight gradient), so t3d_stem_im2col, its
+ * 205 MB matrix (B = 256 @224^2) and the passes over it disappear.  Measured SLOWER than the patch matrix on MI355X (the
+ * per-lane gathers run at the GEMM kernel's occupancy: step 9.4 vs 8.66 ms), hence not the default; DESIGN.md finding 13.  imgs: fmt 0 = fp32 NCHW [B,3,H,W], normalised (the reference's input contract);
+ * fmt 1 = uint8 NHWC [B,H,W,3] raw pixels, normalised in the kernel as (u/255 - mean[c]) * inv_std[c]
+ * (configs/default_config.py:9-10: the crops can then stay uint8 from the decoder to the GPU, 4x less PCIe / HBM).
+ * w32 [C,32] storage dtype (t3d_copy_cols + t3d_pack_weight of the [C,3,3,3] weight), y [B*Ho*Wo, C] raw output,
+ * stats as t3d_pwconv_fwd; _wgrad: dz, y, bb as t3d_pwconv_wgrad, dw32 [C,32] fp32 += (caller zeroes).
+ * fp32 storage returns T3D_ERR_UNSUPPORTED (parity mode keeps the patch matrix). */
+int t3d_stem_fwd(int dtype, const void* imgs, int fmt, const float* mean, const float* inv_std, const void* w32, void* y,
+                 double* stats, int B, int H, int W, int C, void* stream);
+int t3d_stem_wgrad(int dtype, const void* dz, const void* y, const t3d_bnbwd* bb, const void* imgs, int fmt,
+                   const float* mean, const float* inv_std, float* dw32, int B, int H, int W, int C, void* stream);
 
 /* Materialise a block output:  z = act(scale*y + shift) + residual   (residual may be NULL; scale NULL = identity).
  * Replaces the BatchNorm normalise pass + `x + self.conv(x)` (mobilenetv3.py:159,162-164). y,z,residual [M,C]. */
