@@ -15,7 +15,8 @@ INC = os.path.join(os.path.dirname(HERE), 'include')
 OBJ = os.path.join(HERE, 'build')
 LIB = os.path.join(HERE, 'libt3d_hip.so')
 HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
-FLAGS = ['--offload-arch=gfx950', '-O3', '-fPIC', '-std=c++17', '-ffp-contract=off', '-Wno-unused-result']
+FLAGS = ['--offload-arch=gfx950', '-O3', '-fPIC', '-std=c++17', '-ffp-contract=off', '-Wno-unused-result',
+         *os.environ.get('HIPCC_EXTRA', '').split()]      # e.g. -DT3D_PW_TRACE for tools/pw_trace.sh (debug builds only)
 
 
 def _newer(a, b):

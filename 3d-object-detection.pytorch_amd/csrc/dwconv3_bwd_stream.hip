@@ -385,6 +385,7 @@ __global__ __launch_bounds__(NTH) void dw3_bwd2_kernel(const Dw3BArgs a) {
   const __amdgpu_buffer_rsrc_t rsy = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(yb), 0, (int)tbytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rsx = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(xb), 0, (int)tbytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rsd = __builtin_amdgcn_make_buffer_rsrc(dxb, 0, (int)tbytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsr = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(rb ? rb : zb), 0, (int)tbytes, 0x00020000);
   for (int q = q0; q < a.nitems; q += qstride) {
     int xp, rest;
     if (!a.slab) { xp = xp_fixed; rest = q; } else { xp = q % Wp; rest = q / Wp; }
@@ -616,8 +617,9 @@ __global__ __launch_bounds__(NTH) void dw3_bwd2_kernel(const Dw3BArgs a) {
               const size_t rowo = (imgrow + iy) * a.W * a.C;     // scalar
               const unsigned lo = col == 0 ? stA : stB;           // out-of-tile lanes / the missing odd column: dropped
               if (rb) {
-                const unsigned lr = vst + (unsigned)(col * a.C) * (unsigned)sizeof(T);
-                const RV rr = *reinterpret_cast<const RV*>(reinterpret_cast<const char*>(rb + rowo) + lr);
+                // same dropped-lane offset as the store: the missing odd column of the last row would otherwise be read
+                // one pixel past the end of the tensor
+                const RV rr = bufload<RV>(rsr, lo, (unsigned)(rowo * sizeof(T)));
 #pragma unroll
                 for (int i = 0; i < CH; ++i) g[i] += (float)rr[i];
               }

@@ -19,6 +19,7 @@
 // Latency is hidden by wave-level parallelism (8-16 resident waves per CU, each with its own loads in
 // flight), not by a block-wide pipeline.
 #include <cstdlib>
+#include <type_traits>
 #include "pwconv_common.h"
 
 namespace t3d_pw {
@@ -29,8 +30,20 @@ namespace {
 // coefficients present (MobileNetV3 only) -- compiled out of the common variants to keep registers down.
 // YF (with DG): y-free data gradient -- the main loop is the plain forward loop over two raw tensors ([dz | x], no
 // transform), the epilogue is the data gradient's (activation derivative, residual, BatchNorm-backward sums).
+#ifdef T3D_PW_TRACE
+// debug build only (tools/pw_trace.sh): wall-clock stamps (10 ns units) of the first and the last block's wave 0
+__device__ unsigned long long g_pw_trace[16];
+#define PW_STAMP(i)                                                                                       \
+  do {                                                                                                    \
+    if (threadIdx.x == 0 && (blockIdx.x == 0 || blockIdx.x == gridDim.x - 1))                            \
+      g_pw_trace[(blockIdx.x == 0 ? 0 : 8) + (i)] = wall_clock64();                                       \
+  } while (0)
+#else
+#define PW_STAMP(i)
+#endif
+
 template <int NT, int R, bool DG, bool GEN, bool YF = false, int KU = 2, bool STEM = false>
-__global__ __launch_bounds__(512, 2) void pw_stream_kernel(const GemmArgs a, const int nchunks, const int KS, const int nrep, const long long rstride) {
+__global__ __launch_bounds__(512, KU > 2 ? 1 : 2) void pw_stream_kernel(const GemmArgs a, const int nchunks, const int KS, const int nrep, const long long rstride) {
   constexpr int BN = NT * 16;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   bf16x8* Wf = reinterpret_cast<bf16x8*>(smem);                                   // [NT][KS][64]
@@ -41,7 +54,21 @@ __global__ __launch_bounds__(512, 2) void pw_stream_kernel(const GemmArgs a, con
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int lg = lane >> 4, lc = lane & 15;
-  const int chunk = blockIdx.x % nchunks, xb = blockIdx.x / nchunks, nxb = gridDim.x / nchunks;
+  // block -> (pixel-block lane xb, output chunk).  The chunks of one lane read the SAME activation rows, and consecutive
+  // workgroup ids go round-robin over the 8 XCDs (each with its own L2): with chunk = id % nchunks the nchunks readers of a
+  // row sat on different XCDs and every one of them fetched it from HBM (K = 960 -> 160 in three chunks: 72 MB read for a
+  // 24 MB tensor, the whole launch).  When the grid is a multiple of 8 the lanes are dealt out per XCD instead, so the
+  // chunk blocks of a lane share an L2.
+  const int nxb = gridDim.x / nchunks;
+  int chunk, xb;
+  if (nchunks > 1 && (nxb & 7) == 0) {
+    const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+    chunk = j % nchunks;
+    xb = (j / nchunks) * 8 + xcd;
+  } else {
+    chunk = blockIdx.x % nchunks;
+    xb = blockIdx.x / nchunks;
+  }
   const int n0 = chunk * BN;
   const bf16_t* __restrict__ A0 = reinterpret_cast<const bf16_t*>(a.a0);
   const bf16_t* __restrict__ A1 = reinterpret_cast<const bf16_t*>(a.a1);
@@ -49,6 +76,7 @@ __global__ __launch_bounds__(512, 2) void pw_stream_kernel(const GemmArgs a, con
   const int ks1 = A2 ? a.ks1 : (1 << 30);   // k-steps >= ks1 read the second segment
   const bf16_t* __restrict__ Wg = reinterpret_cast<const bf16_t*>(a.w);
   bf16_t* __restrict__ out = reinterpret_cast<bf16_t*>(a.out);
+  PW_STAMP(0);
 
   // ---- stage the weight chunk in fragment order: MFMA row lc of tile t <-> n_local = (t>>1)*32 + (lc>>2)*8 + (t&1)*4 + (lc&3)
   const int nthr = blockDim.x, WAVES = nthr >> 6;
@@ -100,6 +128,7 @@ __global__ __launch_bounds__(512, 2) void pw_stream_kernel(const GemmArgs a, con
     }
   }
   __syncthreads();
+  PW_STAMP(1);
 
   const bool plainA = YF || (!DG && !a.p0 && !a.p2 && a.act == T3D_ACT_NONE);
   const bool keep_stats = a.stats != nullptr;
@@ -155,14 +184,19 @@ __global__ __launch_bounds__(512, 2) void pw_stream_kernel(const GemmArgs a, con
       mld[r] = min(mrow[r], a.M - 1);     // rows past the end re-read the last row; they are never stored or summed
     }
 
-    for (int ks0 = 0; ks0 < KS; ks0 += KU) {
-      bf16x8 fa[KU][R], fb[KU][R];
+    // one round = KUr k-steps: all their loads, then their multiplies.  GUARD: the round may run past KS (tail rounds);
+    // the unguarded full rounds of the deep variants are straight-line code -- with the wave-uniform guards the compiler
+    // places s_waitcnt inside the load sequence at every CFG join and the round's loads no longer overlap
+    auto k_round = [&](auto ku_tag, auto guard_tag, const int ks0) {
+      constexpr int KUr = decltype(ku_tag)::value;
+      constexpr bool GUARD = decltype(guard_tag)::value;
+      bf16x8 fa[KUr][R], fb[KUr][R];
       // branch-free loads: k-steps / channels past Kin read a clamped (valid) address -- their weights are zero
 #pragma unroll
-      for (int u = 0; u < KU; ++u) {
+      for (int u = 0; u < KUr; ++u) {
         const int ks = ks0 + u;
-        if (ks >= KS) continue;          // wave-uniform (K <= 32: one k-step, no second load)
-        if (!DGL && ks >= ks1) {         // wave-uniform: second segment (y-free data gradient)
+        if (GUARD && ks >= KS) continue;          // wave-uniform (K <= 32: one k-step, no second load)
+        if (YF && ks >= ks1) {         // wave-uniform: second segment (y-free data gradient)
           const int k = min((ks - ks1) * 32 + lg * 8, a.Kin2 - 8);
 #pragma unroll
           for (int r = 0; r < R; ++r) fa[u][r] = *reinterpret_cast<const bf16x8*>(A2 + (size_t)mld[r] * a.Kin2 + k);
@@ -180,9 +214,9 @@ __global__ __launch_bounds__(512, 2) void pw_stream_kernel(const GemmArgs a, con
         }
       }
 #pragma unroll
-      for (int u = 0; u < KU; ++u) {
+      for (int u = 0; u < KUr; ++u) {
         const int ks = ks0 + u;
-        if (ks < KS) {
+        if (!GUARD || ks < KS) {
           const int k = ks * 32 + lg * 8;
           bf16x8 b[R];
           if (plainA) {
@@ -243,8 +277,14 @@ __global__ __launch_bounds__(512, 2) void pw_stream_kernel(const GemmArgs a, con
           }
         }
       }
-    }
+    };
+    int ks0 = 0;
+    if constexpr (KU > 2)
+      for (; ks0 + KU <= KS; ks0 += KU) k_round(std::integral_constant<int, KU>{}, std::false_type{}, ks0);
+    for (; ks0 < KS; ks0 += 2) k_round(std::integral_constant<int, 2>{}, std::true_type{}, ks0);
 
+
+    if (g == g_begin) PW_STAMP(2);
     // ---------------- epilogue: lane holds channels nb .. nb+4*NT-1 of pixel mrow[r] ----------
 #pragma unroll
     for (int r = 0; r < R; ++r) {
@@ -363,6 +403,7 @@ __global__ __launch_bounds__(512, 2) void pw_stream_kernel(const GemmArgs a, con
     }
   }
   if (ps_mode && cur_b >= 0) ps_flush(cur_b);
+  PW_STAMP(3);
 
   if (keep_stats) {
 #pragma unroll
@@ -384,6 +425,7 @@ __global__ __launch_bounds__(512, 2) void pw_stream_kernel(const GemmArgs a, con
     }
   }
   t3d_fold_tail(a.fold, nrep, rstride);
+  PW_STAMP(4);
 }
 
 template <int NT, int R, bool DG, bool GEN, bool YF = false, int KU = 2, bool STEM = false>
@@ -414,6 +456,10 @@ int launch_v(GemmArgs& a, int KS, hipStream_t st) {
   const int need = cdiv(ngroups, threads / 64);
   if (nxb > need) nxb = need;
   if (nxb < 1) nxb = 1;
+  if (nchunks > 1 && nxb >= 8) {              // whole lanes per XCD (see the kernel's block mapping)
+    const int up = (nxb + 7) & ~7;            // round up while the launch still fits the chip in one wave of blocks
+    nxb = (up * nchunks <= 256 * per_cu) ? up : (nxb & ~7);
+  }
   // a pending BatchNorm-finalize fold belongs to this launch when it produces that BatchNorm's sums
   a.fold = t3d_take_fold(a.stats);
   hipLaunchKernelGGL((pw_stream_kernel<NT, R, DG, GEN, YF, KU, STEM>), dim3(nxb * nchunks), dim3(threads), lds, st, a, nchunks, KS,
@@ -426,13 +472,22 @@ template <int NT, int R>
 int launch_nt(GemmArgs& a, int KS, hipStream_t st) {
   if (a.a2) return launch_v<NT, R, true, false, true>(a, KS, st);   // y-free data gradient
   const bool gen = a.per_sample || a.ps_stats || a.e_se || (!a.dgrad && a.p2);
-  // (KU = 4 / 6 variants for the deep contractions of the 14x14 / 7x7 stages were measured: no difference -- those
-  // launches are bound by their fixed latency chain, not by the k-loop's load rounds)
+  // (KU = 4 / 6 / 8 variants for the deep contractions of the 14x14 / 7x7 stages were measured, the last with straight-line
+  // rounds (16 loads in flight, vmcnt counting down): K = 960 -> 160 k-loop 21 -> 18 us of a 33 us launch.  The in-kernel
+  // timeline (tools/pw_trace.sh) shows why: per round the operand transform (unpack, BatchNorm affine, activation, pack: ~4.5
+  // VALU ops per element, redone per output chunk) costs as much as the load latency, and with 2 waves per SIMD the two do
+  // not overlap; staging 120 KB of weights (5.7 us) and the statistics tail (3 us) are the rest.)
   if (a.dgrad) return gen ? launch_v<NT, R, true, true>(a, KS, st) : launch_v<NT, R, true, false>(a, KS, st);
   return gen ? launch_v<NT, R, false, true>(a, KS, st) : launch_v<NT, R, false, false>(a, KS, st);
 }
 
 }  // namespace
+
+#ifdef T3D_PW_TRACE
+extern "C" int t3d_debug_pw_trace(unsigned long long* out) {
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_pw_trace), sizeof(unsigned long long) * 16) == hipSuccess ? 0 : -1;
+}
+#endif
 
 int stream_launch(GemmArgs& a, hipStream_t st) {
   if (!a.row0) a.row0 = a.Kin;

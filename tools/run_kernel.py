@@ -83,3 +83,15 @@ for _ in range(reps):
 e1.record(); torch.cuda.synchronize()
 us = e0.elapsed_time(e1) * 1e3 / reps
 print(f'{kind} {dims}: {us:.1f} us  {nbytes / us / 1e6:.2f} TB/s algorithmic')
+if os.environ.get('T3D_TRACE'):      # library built with -DT3D_PW_TRACE (tools/pw_trace.sh): in-kernel wall-clock stamps
+    import ctypes
+    lib = ctypes.CDLL(N.LIB_PATH)
+    e0.record(); fn(); e1.record(); torch.cuda.synchronize()
+    buf = (ctypes.c_ulonglong * 16)()
+    assert lib.t3d_debug_pw_trace(buf) == 0
+    t = [v * 0.01 for v in buf]      # 100 MHz -> us
+    base = min(t[0], t[8])
+    print(f'  single launch {e0.elapsed_time(e1) * 1e3:.1f} us (events); stamps in us from the earlier block start:')
+    for nm, o in (('first block', 0), ('last block', 8)):
+        print(f'  {nm}: start {t[o] - base:.2f} | weights staged {t[o + 1] - base:.2f} | first k-loop done {t[o + 2] - base:.2f} | '
+              f'groups done {t[o + 3] - base:.2f} | stats done {t[o + 4] - base:.2f}')
