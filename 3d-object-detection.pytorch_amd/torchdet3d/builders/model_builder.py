@@ -229,7 +229,8 @@ class ModelWrapper(nn.Module):
         the backbone, then every regressor on every sample in one launch (`t3d_head_fwd_all`)."""
         if not x.is_cuda:
             raise RuntimeError('the HIP path needs the model and the crops on the GPU (no CPU fallback)')
-        kp, logits = self.net_eval.forward(x.float(), None, train=False, all_heads=True)
+        # uint8 NHWC crops (the two-stage path, utils/ie_wrappers.py) are normalised inside the stem's patch gather
+        kp, logits = self.net_eval.forward(x if x.dtype == torch.uint8 else x.float(), None, train=False, all_heads=True)
         return kp, (logits if self.num_classes > 1 else torch.zeros(x.shape[0], device=x.device))
 
 

@@ -1,0 +1,112 @@
+"""Second stage of the two-stage pipeline on the HIP path: batched keypoint regression over the detections of a frame.
+
+Mirrors the reference's `torchdet3d/utils/ie_wrappers.py` API for the regression stage (`Regressor`, :123-158) so that
+`scripts/demo.py:48-90` keeps its call sites -- `regressor.get_detections(prev_frame, detections)`, `regressor.transform_kp`
+-- but instead of one OpenVINO inference per detection (crop on the host, `cv.resize`, `net.forward`, :128-133) the frame
+goes to the GPU once and ALL its detections are cropped + resized by one kernel (`t3d_crop_resize_u8`), normalised inside the
+stem's patch gather, and regressed in one batched forward with every head (`forward_to_onnx` semantics, builders/
+model_builder.py:112-124); the head of the arg-max class is selected on the device (:135-139).
+
+The detector stage (`Detector`, :70-120) runs an SSD trained in an external mmdetection fork and deployed as an OpenVINO IR
+(configs/detection/mnv2_ssd_300_2_heads.py, README.md:56-57): there is no reference source for its arithmetic, so it is not
+rebuilt here -- any detector that yields `(left, top, right, bottom, confidence, label)` tuples plugs in.
+"""
+import numpy as np
+import torch
+
+from .. import _native as N
+
+__all__ = ['Regressor', 'Detector']
+
+
+class Regressor:
+    """HIP replacement of ie_wrappers.Regressor.  `model`: a `build_model(...)` result on the GPU (its eval-mode engine is
+    used; `model.set_input_normalization` / cfg.data.normalization give the mean / std the exported IR carried as
+    mean_values / scale_values, scripts/export.py:67-68).  `input_size` = (w, h) of the crops (cfg.data.resize)."""
+
+    def __init__(self, model, input_size=(224, 224), max_detections=64):
+        if not next(model.parameters()).is_cuda:
+            raise RuntimeError('the HIP path needs the model on the GPU (no CPU fallback)')
+        self.model = model
+        self.device = next(model.parameters()).device
+        self.w, self.h = int(input_size[0]), int(input_size[1])
+        self._rects = torch.empty(max_detections, 4, dtype=torch.int32, device=self.device)
+        self._rects_host = torch.empty(max_detections, 4, dtype=torch.int32).pin_memory()
+        self._crops = torch.empty(max_detections, self.h, self.w, 3, dtype=torch.uint8, device=self.device)
+
+    # ---- device-side API: no host synchronisation ------------------------------------------------------------------
+    def crop_resize(self, frame, rects):
+        """frame [H,W,3] uint8 (device), rects [n,4] int32 (device, x0,y0,x1,y1) -> crops [n,h,w,3] uint8 (a view into
+        the wrapper's buffer, valid until the next call)."""
+        n = int(rects.shape[0])
+        assert frame.is_cuda and frame.dtype == torch.uint8 and frame.dim() == 3 and frame.shape[2] == 3 and frame.is_contiguous()
+        assert rects.is_cuda and rects.dtype == torch.int32 and rects.is_contiguous()
+        if n > self._crops.shape[0]:
+            self._crops = torch.empty(n, self.h, self.w, 3, dtype=torch.uint8, device=self.device)
+        N.call('t3d_crop_resize_u8', N.ptr(frame), N.ptr(rects), N.ptr(self._crops), n, int(frame.shape[0]), int(frame.shape[1]),
+               self.h, self.w, N.stream())
+        return self._crops[:n]
+
+    @torch.no_grad()
+    def regress(self, frame, rects):
+        """-> (kp [n,9,2] fp32 of the arg-max class's head, in crop-normalised coordinates; labels [n] int64) on the device."""
+        crops = self.crop_resize(frame, rects)
+        was_training = self.model.training
+        self.model.eval()
+        try:
+            kp_all, logits = self.model.forward_to_onnx(crops)          # [9,n,9,2], [n,C]
+        finally:
+            self.model.train(was_training)
+        n = crops.shape[0]
+        if self.model.num_classes > 1:
+            labels = logits.argmax(1)
+        else:
+            labels = torch.zeros(n, dtype=torch.int64, device=self.device)
+        kp = kp_all[labels, torch.arange(n, device=self.device)]
+        return kp, labels
+
+    # ---- the reference's host API ------------------------------------------------------------------------------------
+    def get_detections(self, frame, detections):
+        """Returns [(kp ndarray [1,9,2], label)] for all detections on `frame` (ndarray [H,W,3] uint8 or a device tensor),
+        like ie_wrappers.py:128-142; detections with an empty crop are regressed on a black crop (the reference's
+        cv.resize would raise on them)."""
+        if len(detections) == 0:
+            return []
+        n = len(detections)
+        if n > self._rects.shape[0]:
+            self._rects = torch.empty(n, 4, dtype=torch.int32, device=self.device)
+            self._rects_host = torch.empty(n, 4, dtype=torch.int32).pin_memory()
+        self._rects_host[:n] = torch.as_tensor([[int(v) for v in d[:4]] for d in detections], dtype=torch.int32)
+        self._rects[:n].copy_(self._rects_host[:n], non_blocking=True)
+        if not torch.is_tensor(frame):
+            frame = torch.from_numpy(np.ascontiguousarray(frame))
+        frame = frame.to(self.device, non_blocking=True).contiguous()
+        kp, labels = self.regress(frame, self._rects[:n])
+        kp, labels = kp.cpu().numpy(), labels.cpu().numpy()
+        return [(kp[i][None], int(labels[i])) for i in range(n)]
+
+    @staticmethod
+    def transform_kp(kp: np.array, crop_cords: tuple):
+        """ie_wrappers.py:144-152: crop-normalised keypoints -> frame pixels (in place)."""
+        x0, y0, x1, y1 = crop_cords
+        crop_shape = (x1 - x0, y1 - y0)
+        kp[:, 0] = kp[:, 0] * crop_shape[0]
+        kp[:, 1] = kp[:, 1] * crop_shape[1]
+        kp[:, 0] += x0
+        kp[:, 1] += y0
+        return kp
+
+    @staticmethod
+    def crop(frame, rect):
+        """ie_wrappers.py:154-158 (host view; the batched path crops on the device)."""
+        x0, y0, x1, y1 = rect
+        return frame[y0:y1, x0:x1]
+
+
+class Detector:
+    """Not rebuilt: the reference's detector is an OpenVINO IR of an SSD trained in an external mmdetection fork
+    (ie_wrappers.py:70-120, configs/detection/mnv2_ssd_300_2_heads.py) -- no source for its arithmetic exists in the
+    reference.  Feed `Regressor.get_detections` from any detector producing (left, top, right, bottom, confidence, label)."""
+
+    def __init__(self, *args, **kwargs):
+        raise NotImplementedError(self.__doc__)

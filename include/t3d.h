@@ -166,6 +166,15 @@ int t3d_stem_im2col(int dtype, const float* x, void* col, int B, int H, int W, v
 int t3d_stem_im2col_u8(int dtype, const unsigned char* x, const float* mean, const float* inv_std, void* col, int B, int H,
                        int W, void* stream);
 
+/* Two-stage inference, input side: crop every detection out of ONE full frame and resize it to the regressor's input
+ * size, in one launch.  frame [H,W,3] uint8 (device), rects [n,4] int32 (x0,y0,x1,y1), device) -> out [n,oh,ow,3] uint8
+ * NHWC.  Replaces the host loop `frame[y0:y1, x0:x1]` + `cv.resize(crop, (w, h))` per detection (utils/ie_wrappers.py:
+ * 18-21,128-133,154-158; same crop as dataloaders/objectron_main.py:98-127): numpy slice semantics (bounds clamped to
+ * the frame; an empty crop gives zeros) and cv::resize INTER_LINEAR's 8-bit arithmetic (half-pixel centres, replicated
+ * border, 11-bit fixed-point weights) as restated in csrc/crop.hip -- bit-exact against oracle/crop_resize.py. */
+int t3d_crop_resize_u8(const unsigned char* frame, const int* rects, unsigned char* out, int n, int H, int W, int oh, int ow,
+                       void* stream);
+
 /* Direct stem (bf16 storage, opt-in: T3D_STEM_DIRECT=1): the same convolution WITHOUT the patch matrix -- the 3x3 /
  * stride-2 taps are gathered from the crops inside the GEMM kernels (forward and weight gradient), so t3d_stem_im2col, its
  * 205 MB matrix (B = 256 @224^2) and the passes over it disappear.  Measured SLOWER than the patch matrix on MI355X (the

@@ -1,0 +1,75 @@
+"""GPU: the two-stage pipeline's regression stage.  `t3d_crop_resize_u8` bit-exact against the oracle's crop + 8-bit bilinear
+resize on random and edge-case detections out of a 1080x1920 frame; `Regressor.get_detections` against the reference's
+per-detection loop (ie_wrappers.py:128-142) through the oracle model."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _rects(rng, n, H, W):
+    x0 = rng.integers(0, W - 8, n); y0 = rng.integers(0, H - 8, n)
+    x1 = np.minimum(x0 + rng.integers(2, 700, n), W + 40); y1 = np.minimum(y0 + rng.integers(2, 700, n), H + 40)
+    return np.stack([x0, y0, x1, y1], 1).astype(np.int32)
+
+
+@pytest.mark.parametrize('H,W,size', [(1080, 1920, (224, 224)), (97, 131, (224, 224)), (480, 640, (96, 128))])
+def test_crop_resize_kernel_is_bit_exact_against_the_oracle(H, W, size):
+    from oracle.crop_resize import crop, resize_linear_u8
+    from torchdet3d import _native as N
+    rng = np.random.default_rng(H)
+    frame = rng.integers(0, 256, (H, W, 3), dtype=np.uint8)
+    edge = np.array([[0, 0, W, H], [0, 0, 1, 1], [W - 1, H - 1, W, H], [5, 7, 6, 300 if H > 300 else H], [3, 3, 3 + size[0], 3 + size[1]],
+                     [0, 0, 2 * size[0], 2 * size[1]], [W - 9, 2, W + 50, 40], [10, 10, 10, 30], [-5, -7, 40, 50]], np.int32)
+    rects = np.concatenate([edge, _rects(rng, 40, H, W)])
+    fd, rd = torch.from_numpy(frame).cuda(), torch.from_numpy(rects).cuda()
+    out = torch.full((len(rects), size[1], size[0], 3), 77, dtype=torch.uint8, device='cuda')
+    N.call('t3d_crop_resize_u8', N.ptr(fd), N.ptr(rd), N.ptr(out), len(rects), H, W, size[1], size[0], N.stream())
+    got = out.cpu().numpy()
+    for i, r in enumerate(rects):
+        c = crop(frame, r)
+        ref = resize_linear_u8(c, size) if c.size else np.zeros((size[1], size[0], 3), np.uint8)
+        assert np.array_equal(got[i], ref), (i, r, np.abs(got[i].astype(int) - ref.astype(int)).max())
+
+
+def test_regressor_matches_the_reference_per_detection_loop():
+    from oracle import model as om
+    from oracle.crop_resize import regress_detections
+    from oracle.weights import make_state_dict
+    from test_host_logic import _cfg
+    from torchdet3d.builders import build_model
+    from torchdet3d.utils import Regressor
+    name = 'mobilenetv3_large'
+    cfg = _cfg(name)
+    cfg.model.storage_dtype = 'f32'
+    model = build_model(cfg, export_mode=True).to('cuda')
+    sd = make_state_dict(name, 9)
+    model.load_state_dict(sd)
+    model.eval()
+    rng = np.random.default_rng(3)
+    H, W = 540, 960
+    # smooth frame (random images are all high frequency: every crop would look alike to the network)
+    yy, xx = np.mgrid[0:H, 0:W]
+    frame = np.stack([(127 + 120 * np.sin(xx / 37.0 + c) * np.cos(yy / 53.0 - c)) for c in range(3)], -1)
+    frame = np.clip(frame + rng.normal(0, 6, frame.shape), 0, 255).astype(np.uint8)
+    dets = [(int(r[0]), int(r[1]), int(r[2]), int(r[3]), 0.9, 1) for r in _rects(rng, 12, H, W)]
+    reg = Regressor(model, (224, 224), max_detections=4)                      # grows its buffers
+    got = reg.get_detections(frame, dets)
+    mean, std = [0.5931, 0.4690, 0.4229], [0.2471, 0.2214, 0.2157]          # configs/default_config.py:9-10 (the model's default)
+    sdt = {k: v.double() if v.is_floating_point() else v for k, v in sd.items()}
+
+    def fwd(x):
+        kp, lg = om.forward_to_onnx(sdt, name, torch.from_numpy(x).double(), 9)
+        return kp.numpy(), lg.numpy()
+    ref = regress_detections(fwd, frame, dets, (224, 224), mean, std)
+    assert len(got) == len(ref) == 12
+    for (kpg, lg), (kpr, lr) in zip(got, ref):
+        assert lg == lr                                                        # arg-max head: bit-exact
+        assert kpg.shape == (1, 9, 2)
+        np.testing.assert_allclose(kpg, kpr, atol=1e-4, rtol=0)
+    assert reg.get_detections(frame, []) == []
+    # transform_kp: crop-normalised -> frame pixels, like ie_wrappers.py:144-152
+    kp = Regressor.transform_kp(got[0][0][0].copy(), dets[0][:4])
+    x0, y0, x1, y1 = dets[0][:4]
+    np.testing.assert_allclose(kp[:, 0], got[0][0][0][:, 0] * (x1 - x0) + x0, rtol=1e-6)

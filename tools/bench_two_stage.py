@@ -1,0 +1,63 @@
+"""Regression stage of the two-stage pipeline (BASELINE config 5's second stage): detections of a 1080x1920 uint8 frame ->
+crop + resize (t3d_crop_resize_u8) -> batched all-heads regression -> arg-max head, per frame.
+usage: python tools/bench_two_stage.py [--model mobilenetv2] [--dets 16] [--frames 200] [--dtype bf16]
+Prints one JSON line: frames/s and crops/s with the frame resident in HBM, the same with the 6.2 MB H2D copy of every frame
+inside the timed region, and the oracle's host crop+resize loop (numpy, 1 core) for the same detections."""
+import argparse, json, os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, '3d-object-detection.pytorch_amd')]
+import numpy as np
+import torch
+
+ap = argparse.ArgumentParser()
+ap.add_argument('--model', default='mobilenetv2')
+ap.add_argument('--dets', type=int, default=16)
+ap.add_argument('--frames', type=int, default=200)
+ap.add_argument('--dtype', default='bf16')
+args = ap.parse_args()
+
+from torchdet3d.builders import build_model
+from torchdet3d.utils import AttrDict, Regressor
+
+cfg = AttrDict(dict(model=dict(name=args.model, num_classes=9, pretrained=False, storage_dtype=args.dtype)))
+model = build_model(cfg, export_mode=True).to('cuda')
+model.eval()
+H, W, n = 1080, 1920, args.dets
+rng = np.random.default_rng(0)
+frame = rng.integers(0, 256, (H, W, 3), dtype=np.uint8)
+x0 = rng.integers(0, W - 400, n); y0 = rng.integers(0, H - 400, n)
+rects = np.stack([x0, y0, x0 + rng.integers(60, 400, n), y0 + rng.integers(60, 400, n)], 1).astype(np.int32)
+reg = Regressor(model, (224, 224), max_detections=n)
+fd, rd = torch.from_numpy(frame).cuda(), torch.from_numpy(rects).cuda()
+fh = torch.from_numpy(frame).pin_memory()
+
+
+def run(frames, upload):
+    torch.cuda.synchronize()
+    t = time.perf_counter()
+    for _ in range(frames):
+        f = fd
+        if upload:
+            fd.copy_(fh, non_blocking=True)
+        kp, labels = reg.regress(f, rd)
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t) / frames
+
+
+run(20, False)
+t_res, t_up = run(args.frames, False), run(args.frames, True)
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+e0.record()
+for _ in range(50):
+    reg.crop_resize(fd, rd)
+e1.record(); torch.cuda.synchronize()
+t_crop = e0.elapsed_time(e1) / 50 * 1e-3
+from oracle.crop_resize import crop, resize_linear_u8      # cpu_baseline leg only
+t = time.perf_counter()
+for r in rects:
+    resize_linear_u8(crop(frame, r), (224, 224))
+t_cpu = time.perf_counter() - t
+print(json.dumps({'metric': f'two-stage regression stage, {n} detections per 1080x1920 frame, {args.model}', 'frames_per_s': round(1 / t_res, 1),
+                  'crops_per_s': round(n / t_res, 1), 'ms_per_frame': round(t_res * 1e3, 3), 'frames_per_s_with_h2d': round(1 / t_up, 1),
+                  'crop_resize_us': round(t_crop * 1e6, 1), 'dtype': args.dtype,
+                  'cpu_baseline': {'what': 'oracle crop + 8-bit bilinear resize loop (numpy), 1 core', 'ms_per_frame': round(t_cpu * 1e3, 2)}}))
