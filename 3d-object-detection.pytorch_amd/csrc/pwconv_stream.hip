@@ -184,6 +184,20 @@ __global__ __launch_bounds__(512, KU > 2 ? 1 : 2) void pw_stream_kernel(const Ge
       mld[r] = min(mrow[r], a.M - 1);     // rows past the end re-read the last row; they are never stored or summed
     }
 
+    // HOIST (the deep-round data-gradient variants, KU > 2): the epilogue's activation-input tensor is loaded here, ahead
+    // of the k rounds -- those launches walk several pixel groups per wave with two resident waves per SIMD, and every
+    // dependent load round (operands | epilogue tensor) was ~1.5 us of exposed latency per group.  Dispatch guarantees
+    // e_y != nullptr and e_res == nullptr for them.
+    constexpr bool HOIST = DG && !YF && !GEN && KU > 2;
+    bf16x8 eyh[R][NT / 2];
+    if constexpr (HOIST) {
+#pragma unroll
+      for (int r = 0; r < R; ++r)
+#pragma unroll
+        for (int q = 0; q < NT / 2; ++q)
+          eyh[r][q] = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const bf16_t*>(a.e_y) + (size_t)mld[r] * a.Nout +
+                                                       min(nb + 32 * q, a.Nout - 8));
+    }
     // one round = KUr k-steps: all their loads, then their multiplies.  GUARD: the round may run past KS (tail rounds);
     // the unguarded full rounds of the deep variants are straight-line code -- with the wave-uniform guards the compiler
     // places s_waitcnt inside the load sequence at every CFG join and the round's loads no longer overlap
@@ -306,7 +320,10 @@ __global__ __launch_bounds__(512, KU > 2 ? 1 : 2) void pw_stream_kernel(const Ge
       // all epilogue loads of the row first: the stores below then issue back to back and the 16-B pieces of a line
       // meet in L2 (interleaved with load waits they were written back separately: 1.84x HBM write traffic, PMC)
       bf16x8 eyr[NT / 2], err[NT / 2];
-      if (DG) {
+      if constexpr (HOIST) {
+#pragma unroll
+        for (int q = 0; q < NT / 2; ++q) eyr[q] = eyh[r][q];
+      } else if (DG) {
         if (a.e_y) {
 #pragma unroll
           for (int q = 0; q < NT / 2; ++q)
@@ -469,7 +486,7 @@ int launch_v(GemmArgs& a, int KS, hipStream_t st) {
 }
 
 template <int NT, int R>
-int launch_nt(GemmArgs& a, int KS, hipStream_t st) {
+int launch_nt(GemmArgs& a, int KS, hipStream_t st, int deep_ku = 0) {
   if (a.a2) return launch_v<NT, R, true, false, true>(a, KS, st);   // y-free data gradient
   const bool gen = a.per_sample || a.ps_stats || a.e_se || (!a.dgrad && a.p2);
   // (KU = 4 / 6 / 8 variants for the deep contractions of the 14x14 / 7x7 stages were measured, the last with straight-line
@@ -477,6 +494,8 @@ int launch_nt(GemmArgs& a, int KS, hipStream_t st) {
   // timeline (tools/pw_trace.sh) shows why: per round the operand transform (unpack, BatchNorm affine, activation, pack: ~4.5
   // VALU ops per element, redone per output chunk) costs as much as the load latency, and with 2 waves per SIMD the two do
   // not overlap; staging 120 KB of weights (5.7 us) and the statistics tail (3 us) are the rest.)
+  if (a.dgrad && !gen && deep_ku == 3) return launch_v<NT, R, true, false, false, 3>(a, KS, st);
+  if (a.dgrad && !gen && deep_ku == 5) return launch_v<NT, R, true, false, false, 5>(a, KS, st);
   if (a.dgrad) return gen ? launch_v<NT, R, true, true>(a, KS, st) : launch_v<NT, R, true, false>(a, KS, st);
   return gen ? launch_v<NT, R, false, true>(a, KS, st) : launch_v<NT, R, false, false>(a, KS, st);
 }
@@ -507,6 +526,18 @@ int stream_launch(GemmArgs& a, hipStream_t st) {
   // squeeze-excite data gradient (per-sample sums / gates in registers): wider tiles spill (NT = 8: 216 B, 10: 412 B)
   static const int gen_cap = getenv("T3D_PW_GEN_NTCAP") ? atoi(getenv("T3D_PW_GEN_NTCAP")) : 6;
   if (a.dgrad && (a.per_sample || a.ps_stats || a.e_se) && nt_cap > gen_cap) nt_cap = gen_cap;
+  // small-stage data gradients of the projection convs (contraction over 96 / 160 / 320 bottleneck channels, <= 28x28
+  // pixels): all k-steps of a round in flight + hoisted epilogue loads (kernel: HOIST), at a tile width that leaves the
+  // registers for it.  OPT-IN (T3D_PW_DEEP_DG=1): the launches themselves get 3-8 % faster alone (576 <- 96 @14x14: 46.2 ->
+  // 45.0 us, 960 <- 160 @7x7: 31.7 -> 29.1), but the STEP gets slower (8.46 -> 8.54 ms, three A/B pairs): it is bound by the
+  // two streams' combined HBM traffic, and what these launches stop waiting for, the depthwise backward beside them loses
+  static const int deep_dg = getenv("T3D_PW_DEEP_DG") ? atoi(getenv("T3D_PW_DEEP_DG")) : 0;
+  int deep_ku = 0;
+  if (deep_dg && a.dgrad && !a.a2 && !(a.per_sample || a.ps_stats || a.e_se) && a.e_y && !a.e_res && a.M <= 256 * 28 * 28 &&
+      (KS == 3 || KS % 5 == 0) && a.Nout >= 96) {
+    deep_ku = KS == 3 ? 3 : 5;
+    if (nt_cap > 6) nt_cap = 6;
+  }
   nt_cap &= ~1;
   if (nt_cap < 2) return T3D_ERR_UNSUPPORTED;
   int NT = 2;
@@ -519,11 +550,11 @@ int stream_launch(GemmArgs& a, hipStream_t st) {
     }
   }
   switch (NT) {
-    case 2: return launch_nt<2, 2>(a, KS, st);
-    case 4: return launch_nt<4, 2>(a, KS, st);
-    case 6: return launch_nt<6, 1>(a, KS, st);
-    case 8: return launch_nt<8, 1>(a, KS, st);
-    default: return launch_nt<10, 1>(a, KS, st);
+    case 2: return launch_nt<2, 2>(a, KS, st, deep_ku);
+    case 4: return launch_nt<4, 2>(a, KS, st, deep_ku);
+    case 6: return launch_nt<6, 1>(a, KS, st, deep_ku);
+    case 8: return launch_nt<8, 1>(a, KS, st, deep_ku);
+    default: return launch_nt<10, 1>(a, KS, st, deep_ku);
   }
 }
 

@@ -83,7 +83,12 @@ def test_pwconv_fwd(B, HW, K, N, dt, mode):
     np.testing.assert_allclose(st[1].numpy(), (got.double() ** 2).sum(0).numpy(), rtol=1e-5, atol=1e-4)
 
 
-@pytest.mark.parametrize('B,HW,K,N', SHAPES)
+# projection-conv data gradients of the 14x14 / 7x7 stages: contraction over 96 / 160 / 320 channels -> the deep-round
+# variants with hoisted epilogue loads (pwconv_stream.hip: HOIST), incl. ragged widths
+DEEP_DG = [(16, 196, 576, 96), (8, 49, 960, 160), (3, 49, 960, 320), (5, 100, 384, 96), (7, 33, 200, 88), (2, 49, 104, 152)]
+
+
+@pytest.mark.parametrize('B,HW,K,N', SHAPES + DEEP_DG)
 @pytest.mark.parametrize('dt', ['f32', 'bf16'])
 @pytest.mark.parametrize('mode', ['input', 'input_res', 'bnact', 'se_pre', 'persample'])
 def test_pwconv_dgrad(B, HW, K, N, dt, mode):
