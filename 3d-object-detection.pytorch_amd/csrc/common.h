@@ -31,6 +31,7 @@ extern T3dReduceCfg g_t3d_reduce;
 // weight gradient) are written there with plain stores and summed by a second small kernel instead of leaving as atomics.
 struct T3dWorkspace { void* ptr; long long bytes; };
 extern T3dWorkspace g_t3d_ws;
+extern T3dWorkspace g_t3d_ws_main;   // scratch of the launches on the caller's MAIN stream (t3d_set_main_workspace)
 
 // BatchNorm finalize folded into the LAST workgroup of the kernel that produced the sums (t3d_fold_request, misc.hip;
 // descriptor: t3d_bn_fold in include/t3d.h, in DEVICE memory -- the kernels take one pointer, not the ~130 bytes: the

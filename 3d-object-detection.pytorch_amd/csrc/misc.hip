@@ -273,6 +273,14 @@ extern "C" int t3d_fold_pending(void) {
 }
 
 T3dWorkspace g_t3d_ws = {nullptr, 0};
+T3dWorkspace g_t3d_ws_main = {nullptr, 0};
+
+extern "C" int t3d_set_main_workspace(void* ptr, long long bytes) {
+  if ((ptr == nullptr) != (bytes <= 0)) return T3D_ERR_ARG;
+  g_t3d_ws_main.ptr = ptr;
+  g_t3d_ws_main.bytes = ptr ? bytes : 0;
+  return T3D_OK;
+}
 
 extern "C" int t3d_set_workspace(void* ptr, long long bytes) {
   if ((ptr == nullptr) != (bytes <= 0)) return T3D_ERR_ARG;

@@ -137,12 +137,17 @@ __global__ __launch_bounds__(256, 2) void pw_gemm_kernel(const GemmArgs a) {
       }
     };
 
-    gload(0);
-    for (int kc = 0; kc < nk; ++kc) {
+    // split contraction (a.kz > 1: few-pixel, deep layers -- the classifier's data gradient is 256 x 1280 -> 960 on 16
+    // workgroups, 40 serial chunk rounds): blockIdx.z owns chunks [kc0, kc1) and writes its partial product to the
+    // workspace (atomics into the output were no faster than the unsplit launch: device-scope float atomics from 8 XCDs)
+    const int kc0 = a.kz > 1 ? (int)((long long)blockIdx.z * nk / a.kz) : 0;
+    const int kc1 = a.kz > 1 ? (int)((long long)(blockIdx.z + 1) * nk / a.kz) : nk;
+    gload(kc0);
+    for (int kc = kc0; kc < kc1; ++kc) {
       __syncthreads();  // previous chunk consumed (and coef/lstat init visible)
       lstore(kc);
       __syncthreads();
-      if (kc + 1 < nk) gload(kc + 1);
+      if (kc + 1 < kc1) gload(kc + 1);
       const T* ap = As + (wave * 32 + lc) * LDK;
       // weight row owned by MFMA row lc of tile t:  n_local = (lc>>2)*4*NT + 4*t + (lc&3)
       const T* wp = Ws + ((lc >> 2) * 4 * NT + (lc & 3)) * LDK;
@@ -198,6 +203,12 @@ __global__ __launch_bounds__(256, 2) void pw_gemm_kernel(const GemmArgs a) {
         float v[8], yv[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) v[j] = acc[r][2 * q + (j >> 2)][j & 3];
+        if constexpr (std::is_same<T, float>::value) {
+          if (a.kz > 1) {      // plain product only (launcher): this split's partial tile; splitk_reduce_kernel finishes
+            if (mok) Vec8<float>::store(a.part + ((size_t)blockIdx.z * a.M + m) * a.Nout + n, v);
+            continue;
+          }
+        }
         if (a.bias) {
 #pragma unroll
           for (int j = 0; j < 8; ++j) v[j] += a.bias[n + j];
@@ -269,6 +280,35 @@ __global__ __launch_bounds__(256, 2) void pw_gemm_kernel(const GemmArgs a) {
   }
 }
 
+// out[m][n] = sum_z part[z][m][n] (+ bias[n]);  stats [2][N] fp64 += column sums of out, out^2.  Block = 64 columns x 64 rows.
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ part, const float* __restrict__ bias,
+                                                            float* __restrict__ out, double* __restrict__ stats, int kz, int M,
+                                                            int N) {
+  __shared__ float red[2][4][64];
+  const int n = blockIdx.x * 64 + (threadIdx.x & 63), rq = threadIdx.x >> 6;
+  float s1 = 0.f, s2 = 0.f;
+  if (n < N) {
+    const float b = bias ? bias[n] : 0.f;
+    for (int m = blockIdx.y * 64 + rq; m < min(M, (int)blockIdx.y * 64 + 64); m += 4) {
+      float v = 0.f;
+      for (int z = 0; z < kz; ++z) v += part[((size_t)z * M + m) * N + n];
+      v += b;
+      out[(size_t)m * N + n] = v;
+      s1 += v;
+      s2 += v * v;
+    }
+  }
+  if (!stats) return;
+  red[0][rq][threadIdx.x & 63] = s1;
+  red[1][rq][threadIdx.x & 63] = s2;
+  __syncthreads();
+  if (rq == 0 && n < N) {
+    const int l = threadIdx.x;
+    atomicAdd(stats + n, (double)(red[0][0][l] + red[0][1][l] + red[0][2][l] + red[0][3][l]));
+    atomicAdd(stats + N + n, (double)(red[1][0][l] + red[1][1][l] + red[1][2][l] + red[1][3][l]));
+  }
+}
+
 template <typename T, int NT>
 int launch_nt(GemmArgs& a, hipStream_t st) {
   constexpr int BN = NT * 16;
@@ -280,7 +320,20 @@ int launch_nt(GemmArgs& a, hipStream_t st) {
   if (gx < 1) gx = 1;
   if (lds > 64 * 1024)
     (void)hipFuncSetAttribute((const void*)pw_gemm_kernel<T, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  hipLaunchKernelGGL((pw_gemm_kernel<T, NT>), dim3(gx, ny), dim3(256), lds, st, a);
+  a.kz = 1;
+  const int nk = kpad / MM<T>::BK;
+  if (std::is_same<T, float>::value && gx * ny <= 64 && nk >= 16 && !a.e_y && !a.e_res && !a.ps_stats) {
+    int kz = nk / 4 < 8 ? nk / 4 : 8;
+    const size_t need = (size_t)kz * a.M * a.Nout * sizeof(float);
+    if (g_t3d_ws_main.ptr && (size_t)g_t3d_ws_main.bytes >= need) {
+      a.kz = kz;
+      a.part = reinterpret_cast<float*>(g_t3d_ws_main.ptr);
+    }
+  }
+  hipLaunchKernelGGL((pw_gemm_kernel<T, NT>), dim3(gx, ny, a.kz), dim3(256), lds, st, a);
+  if (a.kz > 1)
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(cdiv(a.Nout, 64), cdiv(a.M, 64)), dim3(256), 0, st, a.part, a.bias,
+                       reinterpret_cast<float*>(a.out), a.stats, a.kz, a.M, a.Nout);
   T3D_CHECK_LAUNCH();
   return T3D_OK;
 }

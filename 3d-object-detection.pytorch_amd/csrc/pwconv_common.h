@@ -55,6 +55,8 @@ struct GemmArgs {
   double* stats;      // [2][Nout]
   float* ps_stats;    // [B][Nout][2] per-sample sums (SE case)
   int M, HW, Kin, Nout, mtiles;
+  int kz;             // generic kernel: contraction split over blockIdx.z (fp32 plain products of few-pixel layers),
+  float* part;        // ... partial tiles [kz][M][Nout] in the workspace
   // second activation segment (y-free data gradient, streaming kernel only): k-steps >= ks1 read a2 [M][Kin2];
   // `Kin` is then the padded total (ks1*32 + round_up(Kin2, 32)) and indexes the weight rows directly
   const void* a2;

@@ -78,6 +78,7 @@ SIGNATURES = {
     't3d_se_after_apply': [_I, _P, _P, _PP, _P, _P, _P, _P, _I, _I, _I, _P],
     't3d_set_reduction_replicas': [_I, _L],
     't3d_set_workspace': [_P, _L],
+    't3d_set_main_workspace': [_P, _L],
     't3d_fold_request': [_P, _P],
     't3d_fold_pending': [],
     't3d_pack_weights_batched': [_I, _P, _I, _P],

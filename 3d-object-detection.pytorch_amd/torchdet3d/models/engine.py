@@ -32,6 +32,7 @@ from .arch import Arch
 BN_EPS, BN_MOM = 1e-5, 0.1      # PyTorch defaults the reference relies on
 NREP = 16                       # reduction replicas (include/t3d.h: t3d_set_reduction_replicas)
 WORKSPACE_BYTES = 64 << 20      # partial weight-gradient tiles (include/t3d.h: t3d_set_workspace)
+MAIN_WORKSPACE_BYTES = 16 << 20
 # y-free expand-layer backward (csrc/pwconv_yfree.hip): minimum M*N elements of the expanded tensor; 0 disables
 YFREE_MIN_ELEMS = int(os.environ.get('T3D_YFREE_MIN', 8 << 20))
 HOOK_MIN = 1 << 20              # gradient-exchange granularity (elements): parallel.GradSync's bucket size
@@ -389,12 +390,22 @@ class Net:
         return N.ptr(bn.stats) if self.training else None
 
     # ------------------------------------------------------------------ forward
+    def _main_scratch(self, on):
+        # split-contraction scratch of the fp32 classifier products (main stream; include/t3d.h: t3d_set_main_workspace)
+        if on and self.arch.classifier:
+            ws = self._buf('workspace_main', (MAIN_WORKSPACE_BYTES,), torch.uint8)
+            N.call('t3d_set_main_workspace', N.ptr(ws), MAIN_WORKSPACE_BYTES)
+        else:
+            N.call('t3d_set_main_workspace', None, 0)
+
     def forward(self, imgs, cats, train=False, dropout_mask=None, all_heads=False):
         N.call('t3d_set_reduction_replicas', NREP, self._stat_stride)
+        self._main_scratch(True)
         try:
             return self._forward(imgs, cats, train, dropout_mask, all_heads)
         finally:
             N.call('t3d_set_reduction_replicas', 1, 0)
+            self._main_scratch(False)
 
     def _forward(self, imgs, cats, train=False, dropout_mask=None, all_heads=False):
         """imgs [B,3,H,W] fp32 NCHW (the reference's input contract), cats int64 [B] ->
@@ -643,11 +654,13 @@ class Net:
         ws = self._buf('workspace', (WORKSPACE_BYTES,), torch.uint8)
         N.call('t3d_set_reduction_replicas', NREP, self._stat_stride)
         N.call('t3d_set_workspace', N.ptr(ws), WORKSPACE_BYTES)
+        self._main_scratch(True)
         try:
             return self._backward(dkp, dlogits)
         finally:
             N.call('t3d_set_reduction_replicas', 1, 0)
             N.call('t3d_set_workspace', None, 0)
+            self._main_scratch(False)
 
     def _backward(self, dkp, dlogits=None):
         """Gradient of the last train-mode forward w.r.t. every parameter -> `gflat` (overwritten).

@@ -342,6 +342,10 @@ int t3d_fold_pending(void);
  * second, deterministic pass; without one the partials leave as fp32 atomics.  64 MB covers every layer shape of
  * the supported models at batch 256. */
 int t3d_set_workspace(void* ptr, long long bytes);
+/* Scratch for launches on the caller's MAIN stream (the workspace above belongs to the weight-gradient launches, which the
+ * host side issues on a second stream): the fp32 pointwise kernel splits the contraction of few-pixel, deep layers over it
+ * (classifier Linear(960, 1280) on 256 samples: 16 workgroups x 40 serial rounds otherwise).  NULL / 0 = unsplit. */
+int t3d_set_main_workspace(void* ptr, long long bytes);
 
 /* All weight matrices of a model in ONE launch: desc is a DEVICE array of n records of 5 int64
  * {src fp32 [rows,cols], out [rows,cols] or 0, out_t [cols,rows] or 0, rows, cols} (outputs in `dtype`). */
