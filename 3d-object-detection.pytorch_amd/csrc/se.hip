@@ -227,6 +227,173 @@ __global__ __launch_bounds__(256) void se_bias_kernel(const SeArgs a) {
   }
 }
 
+
+// ------------------------------------------------------------------ one workgroup per group of samples
+// The tiled kernels above cost 4 launches forward and 8 backward per gate, each a short serial chain of chunk rounds:
+// 70 us + 96 us per gate on the step's critical stream for ~0.1 GFLOP (rocprofv3: 16 % of MobileNetV3-large's kernel
+// time together with their memsets).  Here ONE launch does a direction: a workgroup of 1024 threads owns SPG samples and
+// walks both products for them back to back, thread = output, the contraction split over the thread groups that the
+// output width leaves free; weights are read coalesced along the output axis ([I][O] layouts: the backward's natural
+// ones, transposed copies for the forward), inputs broadcast from LDS.  Every workgroup streams both weight matrices
+// (<= 1.8 MB fp32) out of L2.
+constexpr int SPG = 8;          // samples per workgroup
+constexpr int SE_T = 1024;
+
+// out[s][o] = sum_i in[i][s] * Wt[i*O + o]   for s < SPG;  in: LDS [I][SPG];  partials through `red` [SE_T][SPG].
+// Returns the finished sums in acc[] for threads with grp == 0 && o < O (other threads: garbage).  O <= SE_T.
+__device__ __forceinline__ void se_product(const float* __restrict__ Wt, int I, int O, const float* in, float* red,
+                                           float acc[SPG], int& o_out, bool& owner) {
+  const int t = threadIdx.x;
+  const int OP = (O + 63) & ~63;                 // whole waves per group
+  const int ngrp = SE_T / OP, grp = t / OP, o = t - grp * OP;
+  const bool live = grp < ngrp && o < O;
+  const int per = (I + ngrp - 1) / ngrp;
+  const int i0 = min(grp * per, I), i1 = min(i0 + per, I);
+#pragma unroll
+  for (int s = 0; s < SPG; ++s) acc[s] = 0.f;
+  if (live) {
+    int i = i0;
+    for (; i + 4 <= i1; i += 4) {                // four independent weight loads in flight
+      float w[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) w[u] = Wt[(size_t)(i + u) * O + o];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const float4 x0 = *reinterpret_cast<const float4*>(in + (i + u) * SPG);
+        const float4 x1 = *reinterpret_cast<const float4*>(in + (i + u) * SPG + 4);
+        acc[0] = fmaf(x0.x, w[u], acc[0]); acc[1] = fmaf(x0.y, w[u], acc[1]);
+        acc[2] = fmaf(x0.z, w[u], acc[2]); acc[3] = fmaf(x0.w, w[u], acc[3]);
+        acc[4] = fmaf(x1.x, w[u], acc[4]); acc[5] = fmaf(x1.y, w[u], acc[5]);
+        acc[6] = fmaf(x1.z, w[u], acc[6]); acc[7] = fmaf(x1.w, w[u], acc[7]);
+      }
+    }
+    for (; i < i1; ++i) {
+      const float w = Wt[(size_t)i * O + o];
+#pragma unroll
+      for (int s = 0; s < SPG; ++s) acc[s] = fmaf(in[i * SPG + s], w, acc[s]);
+    }
+  }
+  owner = live && grp == 0;
+  o_out = o;
+  if (ngrp > 1) {
+    __syncthreads();                             // `red` may still be read from the previous product
+    if (live && grp > 0) {
+#pragma unroll
+      for (int s = 0; s < SPG; ++s) red[(size_t)t * SPG + s] = acc[s];
+    }
+    __syncthreads();
+    if (owner) {
+      for (int g = 1; g < ngrp; ++g) {
+#pragma unroll
+        for (int s = 0; s < SPG; ++s) acc[s] += red[(size_t)(g * OP + o) * SPG + s];
+      }
+    }
+  }
+}
+
+// LDS: in0 [C][SPG] | in1 [R][SPG] | red [SE_T][SPG]
+__global__ __launch_bounds__(SE_T) void se_fwd_group_kernel(const SeArgs a, const float* __restrict__ w1t,
+                                                            const float* __restrict__ w2t) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* ms = lds;
+  float* hs = ms + (size_t)a.C * SPG;
+  float* red = hs + (size_t)a.R * SPG;
+  const int b0 = blockIdx.x * SPG, t = threadIdx.x;
+  const float inv = 1.f / (float)a.HW;
+  for (int i = t; i < a.C * SPG; i += SE_T) {
+    const int c = i / SPG, s = i % SPG, b = b0 + s;
+    float v = 0.f;
+    if (b < a.B) {
+      v = a.scale[c] * (a.gap[(size_t)b * a.C + c] * inv) + a.shift[c];
+      a.m[(size_t)b * a.C + c] = v;
+    }
+    ms[i] = v;
+  }
+  __syncthreads();
+  float acc[SPG];
+  int o;
+  bool own;
+  se_product(w1t, a.C, a.R, ms, red, acc, o, own);           // h = relu(W1 m + b1)
+  if (own) {
+    const float b1 = a.b1[o];
+#pragma unroll
+    for (int s = 0; s < SPG; ++s) {
+      const float h = fmaxf(acc[s] + b1, 0.f);
+      hs[o * SPG + s] = h;
+      if (b0 + s < a.B) a.h[(size_t)(b0 + s) * a.R + o] = h;
+    }
+  }
+  __syncthreads();
+  se_product(w2t, a.R, a.C, hs, red, acc, o, own);           // q = W2 h + b2, s = h_sigmoid(q)
+  if (own) {
+    const float b2 = a.b2[o];
+#pragma unroll
+    for (int s = 0; s < SPG; ++s) {
+      if (b0 + s < a.B) {
+        const float q = acc[s] + b2;
+        a.q[(size_t)(b0 + s) * a.C + o] = q;
+        a.s[(size_t)(b0 + s) * a.C + o] = hsigmoid(q);
+      }
+    }
+  }
+}
+
+// data part of the backward: dq, dp (kept for the weight gradients), g and the BatchNorm-backward sums
+__global__ __launch_bounds__(SE_T) void se_bwd_group_kernel(const SeArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* dqs = lds;
+  float* dps = dqs + (size_t)a.C * SPG;
+  float* red = dps + (size_t)a.R * SPG;
+  const int b0 = blockIdx.x * SPG, t = threadIdx.x;
+  for (int i = t; i < a.C * SPG; i += SE_T) {
+    const int c = i / SPG, s = i % SPG, b = b0 + s;
+    float v = 0.f;
+    if (b < a.B) {
+      const size_t k = (size_t)b * a.C + c;
+      const float ds = a.scale[c] * a.ps[2 * k + 1] + a.shift[c] * a.ps[2 * k];
+      const float q = a.q[k];
+      v = (q > -3.f && q < 3.f) ? ds * (1.f / 6.f) : 0.f;     // relu6 passes strictly inside
+      a.dq[k] = v;
+    }
+    dqs[i] = v;
+  }
+  __syncthreads();
+  float acc[SPG];
+  int o;
+  bool own;
+  se_product(a.w2, a.C, a.R, dqs, red, acc, o, own);          // dp = relu'(h) * (dq W2);  W2 is [C][R] = [I][O]
+  if (own) {
+#pragma unroll
+    for (int s = 0; s < SPG; ++s) {
+      float v = 0.f;
+      if (b0 + s < a.B) {
+        v = a.h[(size_t)(b0 + s) * a.R + o] > 0.f ? acc[s] : 0.f;
+        a.dp[(size_t)(b0 + s) * a.R + o] = v;
+      }
+      dps[o * SPG + s] = v;
+    }
+  }
+  __syncthreads();
+  se_product(a.w1, a.R, a.C, dps, red, acc, o, own);          // g = (dp W1) / HW;  W1 is [R][C] = [I][O]
+  if (own) {
+    const float inv = 1.f / (float)a.HW;
+    float v1 = 0.f, v2 = 0.f;
+#pragma unroll
+    for (int s = 0; s < SPG; ++s) {
+      if (b0 + s < a.B) {
+        const size_t k = (size_t)(b0 + s) * a.C + o;
+        const float gu = acc[s] * inv;                          // every pixel of u receives dL/dm / HW
+        a.g[k] = gu;
+        const float sg = a.s[k], p1 = a.ps[2 * k], p2 = a.ps[2 * k + 1];
+        v1 += sg * p1 + (float)a.HW * gu;
+        v2 += sg * p2 + gu * a.gap[k];
+      }
+    }
+    atomicAdd(a.stats + o, (double)v1);
+    atomicAdd(a.stats + a.C + o, (double)v2);
+  }
+}
+
 }  // namespace
 
 extern "C" int t3d_se_fwd(const float* gap_sum, const float* scale, const float* shift, const float* w1,
@@ -265,6 +432,69 @@ extern "C" int t3d_se_bwd(const float* ps_stats, const float* gap_sum, const flo
   hipLaunchKernelGGL(se_dh_kernel, dim3(cdiv(R, OT), cdiv(B, 64), KSPLIT), dim3(256), 0, st, a);
   hipLaunchKernelGGL(se_relu_mask_kernel, dim3(cdiv(B * R, 256)), dim3(256), 0, st, a);
   hipLaunchKernelGGL(se_dm_kernel, dim3(cdiv(C, OT), cdiv(B, 64)), dim3(256), 0, st, a);
+  hipLaunchKernelGGL(se_wgrad_tile_kernel, dim3(cdiv(R, OT), cdiv(C, 64)), dim3(256), 0, st, a, 0);
+  hipLaunchKernelGGL(se_wgrad_tile_kernel, dim3(cdiv(C, OT), cdiv(R, 64)), dim3(256), 0, st, a, 1);
+  hipLaunchKernelGGL(se_bias_kernel, dim3(cdiv(C + R, 64)), dim3(256), 0, st, a);
+  T3D_CHECK_LAUNCH();
+  return T3D_OK;
+}
+
+static size_t se_group_lds(int C, int R) { return ((size_t)(C + R) * SPG + (size_t)SE_T * SPG) * sizeof(float); }
+
+// One launch per direction (kernels above).  w1t [C][R], w2t [R][C]: transposed fp32 copies of fc.0 / fc.2 (the caller
+// keeps them current, e.g. t3d_pack_weights_batched).  C, R <= 1024.
+extern "C" int t3d_se_fwd_fused(const float* gap_sum, const float* scale, const float* shift, const float* w1t,
+                                const float* b1, const float* w2t, const float* b2, float* m, float* h, float* q, float* s,
+                                int B, int C, int R, int HW, void* stream) {
+  if (!gap_sum || !scale || !shift || !w1t || !b1 || !w2t || !b2 || !m || !h || !q || !s || B <= 0 || C <= 0 || R <= 0 ||
+      HW <= 0)
+    return T3D_ERR_ARG;
+  if (C > SE_T || R > SE_T) return T3D_ERR_UNSUPPORTED;
+  SeArgs a{};
+  a.gap = gap_sum; a.scale = scale; a.shift = shift; a.b1 = b1; a.b2 = b2;
+  a.m = m; a.h = h; a.q = q; a.s = s; a.B = B; a.C = C; a.R = R; a.HW = HW;
+  const size_t lds = se_group_lds(C, R);
+  static bool attr = false;
+  if (!attr) {
+    (void)hipFuncSetAttribute((const void*)se_fwd_group_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+    (void)hipFuncSetAttribute((const void*)se_bwd_group_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+    attr = true;
+  }
+  hipLaunchKernelGGL(se_fwd_group_kernel, dim3(cdiv(B, SPG)), dim3(SE_T), lds, reinterpret_cast<hipStream_t>(stream), a, w1t, w2t);
+  T3D_CHECK_LAUNCH();
+  return T3D_OK;
+}
+
+extern "C" int t3d_se_bwd_data(const float* ps_stats, const float* gap_sum, const float* scale, const float* shift,
+                               const float* w1, const float* w2, const float* h, const float* q, const float* s, float* g,
+                               float* dq, float* dp, double* stats, int B, int C, int R, int HW, void* stream) {
+  if (!ps_stats || !gap_sum || !scale || !shift || !w1 || !w2 || !h || !q || !s || !g || !dq || !dp || !stats || B <= 0 ||
+      C <= 0 || R <= 0 || HW <= 0)
+    return T3D_ERR_ARG;
+  if (C > SE_T || R > SE_T) return T3D_ERR_UNSUPPORTED;
+  SeArgs a{};
+  a.ps = ps_stats; a.gap = gap_sum; a.scale = scale; a.shift = shift; a.w1 = w1; a.w2 = w2;
+  a.h = const_cast<float*>(h); a.q = const_cast<float*>(q); a.s = const_cast<float*>(s);
+  a.g = g; a.dq = dq; a.dp = dp; a.stats = stats; a.B = B; a.C = C; a.R = R; a.HW = HW;
+  static bool attr = false;
+  if (!attr) {
+    (void)hipFuncSetAttribute((const void*)se_bwd_group_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+    attr = true;
+  }
+  hipLaunchKernelGGL(se_bwd_group_kernel, dim3(cdiv(B, SPG)), dim3(SE_T), se_group_lds(C, R), reinterpret_cast<hipStream_t>(stream), a);
+  T3D_CHECK_LAUNCH();
+  return T3D_OK;
+}
+
+// weight / bias gradients of the two FCs from the dq, dp that t3d_se_bwd_data left (leaves of the backward graph: the
+// host side issues them on its weight-gradient stream)
+extern "C" int t3d_se_bwd_weights(const float* m, const float* h, const float* dq, const float* dp, float* dw1, float* db1,
+                                  float* dw2, float* db2, int B, int C, int R, void* stream) {
+  if (!m || !h || !dq || !dp || !dw1 || !db1 || !dw2 || !db2 || B <= 0 || C <= 0 || R <= 0) return T3D_ERR_ARG;
+  SeArgs a{};
+  a.m = const_cast<float*>(m); a.h = const_cast<float*>(h); a.dq = const_cast<float*>(dq); a.dp = const_cast<float*>(dp);
+  a.dw1 = dw1; a.db1 = db1; a.dw2 = dw2; a.db2 = db2; a.B = B; a.C = C; a.R = R; a.HW = 1;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   hipLaunchKernelGGL(se_wgrad_tile_kernel, dim3(cdiv(R, OT), cdiv(C, 64)), dim3(256), 0, st, a, 0);
   hipLaunchKernelGGL(se_wgrad_tile_kernel, dim3(cdiv(C, OT), cdiv(R, 64)), dim3(256), 0, st, a, 1);
   hipLaunchKernelGGL(se_bias_kernel, dim3(cdiv(C + R, 64)), dim3(256), 0, st, a);

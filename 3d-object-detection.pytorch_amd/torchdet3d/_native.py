@@ -74,6 +74,9 @@ SIGNATURES = {
     't3d_head_bwd': [_P, _PP, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P],
     't3d_se_fwd': [_P] * 11 + [_I, _I, _I, _I, _P],
     't3d_se_bwd': [_P] * 18 + [_I, _I, _I, _I, _P],
+    't3d_se_fwd_fused': [_P] * 11 + [_I] * 4 + [_P],
+    't3d_se_bwd_data': [_P] * 13 + [_I] * 4 + [_P],
+    't3d_se_bwd_weights': [_P] * 8 + [_I] * 3 + [_P],
     't3d_se_after_sums': [_I, _P, _P, _PP, _P, _I, _I, _I, _P],
     't3d_se_after_apply': [_I, _P, _P, _PP, _P, _P, _P, _P, _I, _I, _I, _P],
     't3d_set_reduction_replicas': [_I, _L],

@@ -286,6 +286,16 @@ class Net:
                 rows.append([src.data_ptr(), out, self.wt[k].data_ptr(), n, kk])
             self._pack_desc = torch.tensor(rows, dtype=torch.int64, device=self.device)
         N.call('t3d_pack_weights_batched', self.dt, N.ptr(self._pack_desc), self._pack_desc.shape[0], st)
+        # squeeze-excite FCs (nn.Linear, fp32): transposed copies for the one-launch forward (t3d_se_fwd_fused)
+        if getattr(self, '_se_pack_desc', None) is None:
+            rows = []
+            for k, (s, kind) in self.shapes.items():
+                if kind == 'param' and len(s) == 2 and ('.fc.0.weight' in k or '.fc.2.weight' in k):
+                    self.wt[k] = self._buf('wt:' + k, (s[1], s[0]), torch.float32)
+                    rows.append([self.p[k].data_ptr(), 0, self.wt[k].data_ptr(), s[0], s[1]])
+            self._se_pack_desc = torch.tensor(rows, dtype=torch.int64, device=self.device) if rows else False
+        if self._se_pack_desc is not False:
+            N.call('t3d_pack_weights_batched', N.F32, N.ptr(self._se_pack_desc), self._se_pack_desc.shape[0], st)
         # stem: [C,3,3,3] -> [C,32] patch-row weights (columns 27..31 zero)
         c0 = self.arch.stem_c
         w32 = self._buf('stem32', (c0, 32), torch.float32)
@@ -593,8 +603,8 @@ class Net:
                       h=self._buf(f'se_h:{i}', (B, R), torch.float32), q=self._buf(f'se_q:{i}', (B, C), torch.float32),
                       s=self._buf(f'se_s:{i}', (B, C), torch.float32), name=sen, HW=Ho * Wo, after=True, pro2n=pro2)
             ones, zeros = self._const(C, 1.0), self._const(C, 0.0)
-            N.call('t3d_se_fwd', N.ptr(pooled), N.ptr(ones), N.ptr(zeros), N.ptr(self.p[sen + '.fc.0.weight']),
-                   N.ptr(self.p[sen + '.fc.0.bias']), N.ptr(self.p[sen + '.fc.2.weight']),
+            N.call('t3d_se_fwd_fused', N.ptr(pooled), N.ptr(ones), N.ptr(zeros), N.ptr(self.wt[sen + '.fc.0.weight']),
+                   N.ptr(self.p[sen + '.fc.0.bias']), N.ptr(self.wt[sen + '.fc.2.weight']),
                    N.ptr(self.p[sen + '.fc.2.bias']), N.ptr(se['m']), N.ptr(se['h']), N.ptr(se['q']), N.ptr(se['s']),
                    B, C, R, 1, st)
             pro2 = self._pro(bn2, blk.act, se['s'], True)
@@ -604,8 +614,8 @@ class Net:
             se = dict(gap=gap, m=self._buf(f'se_m:{i}', (B, C), torch.float32),
                       h=self._buf(f'se_h:{i}', (B, R), torch.float32), q=self._buf(f'se_q:{i}', (B, C), torch.float32),
                       s=self._buf(f'se_s:{i}', (B, C), torch.float32), name=sen, HW=Ho * Wo)
-            N.call('t3d_se_fwd', N.ptr(gap), N.ptr(bn2.scale), N.ptr(bn2.shift), N.ptr(self.p[sen + '.fc.0.weight']),
-                   N.ptr(self.p[sen + '.fc.0.bias']), N.ptr(self.p[sen + '.fc.2.weight']),
+            N.call('t3d_se_fwd_fused', N.ptr(gap), N.ptr(bn2.scale), N.ptr(bn2.shift), N.ptr(self.wt[sen + '.fc.0.weight']),
+                   N.ptr(self.p[sen + '.fc.0.bias']), N.ptr(self.wt[sen + '.fc.2.weight']),
                    N.ptr(self.p[sen + '.fc.2.bias']), N.ptr(se['m']), N.ptr(se['h']), N.ptr(se['q']), N.ptr(se['s']),
                    B, C, R, Ho * Wo, st)
             pro2 = self._pro(bn2, blk.act, se['s'], False)                # SE before the activation (:155-156)
@@ -644,6 +654,12 @@ class Net:
             with torch.cuda.stream(self._side):                    # timed launches: events on the launch stream
                 N.call(entry, *args, N.stream(), **kw)
         self._side_busy = True
+
+    def _se_wgrad(self, se, sen, dq, dp, B, C, R):
+        # FC weight / bias gradients of a squeeze-excite gate: off the data-gradient chain, on the weight-gradient stream
+        self._wgrad(N.ptr(se['m']), N.ptr(se['h']), N.ptr(dq), N.ptr(dp), N.ptr(self.g[sen + '.fc.0.weight']),
+                    N.ptr(self.g[sen + '.fc.0.bias']), N.ptr(self.g[sen + '.fc.2.weight']), N.ptr(self.g[sen + '.fc.2.bias']),
+                    B, C, R, entry='t3d_se_bwd_weights')
 
     def _join_side(self):
         if self._side is not None and self._side_busy:
@@ -873,11 +889,11 @@ class Net:
             dp = self._buf(f'se_dp:{i}', (B, R), torch.float32)
             scratch = self._buf(f'se_scr:{i}', (2 * C,), torch.float64)      # t3d_se_bwd's before-activation sums: unused
             ones, zeros = self._const(C, 1.0), self._const(C, 0.0)
-            N.call('t3d_se_bwd', N.ptr(ps), N.ptr(se['gap']), N.ptr(zeros), N.ptr(ones),
-                   N.ptr(self.p[sen + '.fc.0.weight']), N.ptr(self.p[sen + '.fc.2.weight']), N.ptr(se['m']),
+            N.call('t3d_se_bwd_data', N.ptr(ps), N.ptr(se['gap']), N.ptr(zeros), N.ptr(ones),
+                   N.ptr(self.p[sen + '.fc.0.weight']), N.ptr(self.p[sen + '.fc.2.weight']),
                    N.ptr(se['h']), N.ptr(se['q']), N.ptr(se['s']), N.ptr(g), N.ptr(dq), N.ptr(dp), N.ptr(scratch),
-                   N.ptr(self.g[sen + '.fc.0.weight']), N.ptr(self.g[sen + '.fc.0.bias']),
-                   N.ptr(self.g[sen + '.fc.2.weight']), N.ptr(self.g[sen + '.fc.2.bias']), B, C, R, se['HW'], st)
+                   B, C, R, se['HW'], st)
+            self._se_wgrad(se, sen, dq, dp, B, C, R)
             dv2 = self._buf(f'dv2:{i}', (M2, C))
             N.call('t3d_se_after_apply', dt, N.ptr(dv), N.ptr(s2.raw), se['pro2n'], N.ptr(se['s']), N.ptr(g), N.ptr(dv2),
                    N.ptr(bn2.bstats), B, HW2, C, st)
@@ -894,11 +910,11 @@ class Net:
             dq = self._buf(f'se_dq:{i}', (B, C), torch.float32)
             dp = self._buf(f'se_dp:{i}', (B, R), torch.float32)
             bn2 = s2.bn
-            N.call('t3d_se_bwd', N.ptr(ps), N.ptr(se['gap']), N.ptr(bn2.scale), N.ptr(bn2.shift),
-                   N.ptr(self.p[sen + '.fc.0.weight']), N.ptr(self.p[sen + '.fc.2.weight']), N.ptr(se['m']),
+            N.call('t3d_se_bwd_data', N.ptr(ps), N.ptr(se['gap']), N.ptr(bn2.scale), N.ptr(bn2.shift),
+                   N.ptr(self.p[sen + '.fc.0.weight']), N.ptr(self.p[sen + '.fc.2.weight']),
                    N.ptr(se['h']), N.ptr(se['q']), N.ptr(se['s']), N.ptr(g), N.ptr(dq), N.ptr(dp), N.ptr(bn2.bstats),
-                   N.ptr(self.g[sen + '.fc.0.weight']), N.ptr(self.g[sen + '.fc.0.bias']),
-                   N.ptr(self.g[sen + '.fc.2.weight']), N.ptr(self.g[sen + '.fc.2.bias']), B, C, R, se['HW'], st)
+                   B, C, R, se['HW'], st)
+            self._se_wgrad(se, sen, dq, dp, B, C, R)
             self._bn_bwd(bn2)
             aps = self._buf(f'se_aps:{i}', (B, C), torch.float32)
             gps = self._buf(f'se_gps:{i}', (B, C), torch.float32)

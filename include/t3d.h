@@ -303,6 +303,20 @@ int t3d_se_bwd(const float* ps_stats, const float* gap_sum, const float* scale, 
                float* dp, double* stats, float* dw1, float* db1, float* dw2, float* db2, int B, int C, int R, int HW,
                void* stream);
 
+/* The same gate with ONE launch per direction (a workgroup per 8 samples walks both FCs; csrc/se.hip): what the host side
+ * uses.  _fwd_fused takes TRANSPOSED fp32 copies of the FC weights (w1t [C][R] = fc.0.weight^T, w2t [R][C] = fc.2.weight^T;
+ * e.g. kept current by t3d_pack_weights_batched(T3D_F32, ...)) and otherwise t3d_se_fwd's arguments.  _bwd_data is
+ * t3d_se_bwd without the weight gradients (dq, dp stay behind for them); _bwd_weights computes dw1, db1, dw2, db2 from
+ * m, h, dq, dp -- leaves of the backward graph, issued on the weight-gradient stream.  C, R <= 1024. */
+int t3d_se_fwd_fused(const float* gap_sum, const float* scale, const float* shift, const float* w1t, const float* b1,
+                     const float* w2t, const float* b2, float* m, float* h, float* q, float* s, int B, int C, int R, int HW,
+                     void* stream);
+int t3d_se_bwd_data(const float* ps_stats, const float* gap_sum, const float* scale, const float* shift, const float* w1,
+                    const float* w2, const float* h, const float* q, const float* s, float* g, float* dq, float* dp,
+                    double* stats, int B, int C, int R, int HW, void* stream);
+int t3d_se_bwd_weights(const float* m, const float* h, const float* dq, const float* dp, float* dw1, float* db1, float* dw2,
+                       float* db2, int B, int C, int R, void* stream);
+
 /* Reduction replicas.  Every `+=` reduction output of the kernels (the fp64 BatchNorm sums `stats`, the depthwise
  * weight gradient `dw`) is hit by one atomic per channel per workgroup; with hundreds of workgroups on a few KB of
  * addresses those atomics serialise.  With nrep > 1 the streaming kernels add into replica (workgroup % nrep):

@@ -130,9 +130,12 @@ def test_head_fwd_bwd(B, F, nc, with_pro):
         np.testing.assert_allclose(stats[F:].cpu().numpy(), (u.grad.double() * f.double()).sum(0).numpy(), atol=1e-5)
 
 
-@pytest.mark.parametrize('B,C,R,HW', [(256, 960, 240, 49), (5, 72, 24, 196), (70, 16, 8, 3136)])
-def test_se_gate_fwd_bwd(B, C, R, HW):
-    """t3d_se_fwd / t3d_se_bwd (SELayer, mobilenetv3.py:92-107) against torch autograd of the same two FCs."""
+@pytest.mark.parametrize('fused', [False, True])
+@pytest.mark.parametrize('B,C,R,HW', [(256, 960, 240, 49), (5, 72, 24, 196), (70, 16, 8, 3136), (33, 672, 168, 196),
+                                      (9, 1000, 1024, 1)])
+def test_se_gate_fwd_bwd(B, C, R, HW, fused):
+    """t3d_se_fwd / t3d_se_bwd (SELayer, mobilenetv3.py:92-107) and their one-launch forms (t3d_se_fwd_fused,
+    t3d_se_bwd_data + t3d_se_bwd_weights: what the engine runs) against torch autograd of the same two FCs."""
     import torch.nn.functional as F
     from torchdet3d import _native as N
     g = torch.Generator().manual_seed(B + C)
@@ -150,14 +153,25 @@ def test_se_gate_fwd_bwd(B, C, R, HW):
     d = lambda t: t.contiguous().cuda()
     gd, scd, shd, w1d, b1d, w2d, b2d, psd = map(d, (gap, scale, shift, w1, b1, w2, b2, ps))
     mo, ho, qo, so = (torch.empty(B, n, device='cuda') for n in (C, R, C, C))
-    N.call('t3d_se_fwd', N.ptr(gd), N.ptr(scd), N.ptr(shd), N.ptr(w1d), N.ptr(b1d), N.ptr(w2d), N.ptr(b2d), N.ptr(mo),
-           N.ptr(ho), N.ptr(qo), N.ptr(so), B, C, R, HW, N.stream())
+    if fused:
+        w1t, w2t = w1d.t().contiguous(), w2d.t().contiguous()
+        N.call('t3d_se_fwd_fused', N.ptr(gd), N.ptr(scd), N.ptr(shd), N.ptr(w1t), N.ptr(b1d), N.ptr(w2t), N.ptr(b2d), N.ptr(mo),
+               N.ptr(ho), N.ptr(qo), N.ptr(so), B, C, R, HW, N.stream())
+    else:
+        N.call('t3d_se_fwd', N.ptr(gd), N.ptr(scd), N.ptr(shd), N.ptr(w1d), N.ptr(b1d), N.ptr(w2d), N.ptr(b2d), N.ptr(mo),
+               N.ptr(ho), N.ptr(qo), N.ptr(so), B, C, R, HW, N.stream())
     go, dq, dp = torch.empty(B, C, device='cuda'), torch.empty(B, C, device='cuda'), torch.empty(B, R, device='cuda')
     stats = torch.zeros(2 * C, device='cuda', dtype=torch.float64)
     dw1, db1, dw2, db2 = (torch.empty_like(t) for t in (w1d, b1d, w2d, b2d))
-    N.call('t3d_se_bwd', N.ptr(psd), N.ptr(gd), N.ptr(scd), N.ptr(shd), N.ptr(w1d), N.ptr(w2d), N.ptr(mo), N.ptr(ho),
-           N.ptr(qo), N.ptr(so), N.ptr(go), N.ptr(dq), N.ptr(dp), N.ptr(stats), N.ptr(dw1), N.ptr(db1), N.ptr(dw2),
-           N.ptr(db2), B, C, R, HW, N.stream())
+    if fused:
+        N.call('t3d_se_bwd_data', N.ptr(psd), N.ptr(gd), N.ptr(scd), N.ptr(shd), N.ptr(w1d), N.ptr(w2d), N.ptr(ho),
+               N.ptr(qo), N.ptr(so), N.ptr(go), N.ptr(dq), N.ptr(dp), N.ptr(stats), B, C, R, HW, N.stream())
+        N.call('t3d_se_bwd_weights', N.ptr(mo), N.ptr(ho), N.ptr(dq), N.ptr(dp), N.ptr(dw1), N.ptr(db1), N.ptr(dw2),
+               N.ptr(db2), B, C, R, N.stream())
+    else:
+        N.call('t3d_se_bwd', N.ptr(psd), N.ptr(gd), N.ptr(scd), N.ptr(shd), N.ptr(w1d), N.ptr(w2d), N.ptr(mo), N.ptr(ho),
+               N.ptr(qo), N.ptr(so), N.ptr(go), N.ptr(dq), N.ptr(dp), N.ptr(stats), N.ptr(dw1), N.ptr(db1), N.ptr(dw2),
+               N.ptr(db2), B, C, R, HW, N.stream())
     torch.cuda.synchronize()
     close = lambda a, b, tol=2e-5: np.testing.assert_allclose(a.cpu().numpy(), b.detach().numpy(), rtol=1e-4,
                                                               atol=tol * max(1., b.detach().abs().max().item()))

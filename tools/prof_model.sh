@@ -8,7 +8,7 @@ import sys,glob,csv
 f=glob.glob(sys.argv[1]+'/**/*kernel_stats.csv',recursive=True)[0]
 rows=list(csv.DictReader(open(f)))
 steps=15
-for r in rows[:26]:
+for r in rows[:45]:
     print('%-92s %5.1f/step %7.3f ms avg %7.1f us'%(r['Name'][:92], int(r['Calls'])/steps, float(r['TotalDurationNs'])/1e6/steps, float(r['AverageNs'])/1e3))
 print('sum', sum(float(r['TotalDurationNs']) for r in rows)/1e6/steps)
 PY
