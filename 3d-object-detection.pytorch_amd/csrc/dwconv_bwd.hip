@@ -333,7 +333,7 @@ extern "C" int t3d_dwconv_bwd(int dtype, const void* dz, const void* y, const t3
                                       reinterpret_cast<hipStream_t>(stream));
     if (rc != T3D_ERR_UNSUPPORTED) return rc;
   }
-  if (k == 5 && stride == 2 && !getenv("T3D_DW_TILED")) {   // 5x5 stride 2: streaming kernel (dwconv5_bwd_stream.hip)
+  if (k == 5 && !getenv("T3D_DW_TILED")) {   // 5x5: streaming kernels (dwconv5_bwd_stream.hip)
     const int rc = t3d_dw5_bwd_stream(dtype, dz, y, bb, w, x, pro, residual, dx, stats, dw, B, H, W, C, stride,
                                       reinterpret_cast<hipStream_t>(stream));
     if (rc != T3D_ERR_UNSUPPORTED) return rc;

@@ -253,12 +253,12 @@ __device__ __forceinline__ void se_product(const float* __restrict__ Wt, int I, 
   for (int s = 0; s < SPG; ++s) acc[s] = 0.f;
   if (live) {
     int i = i0;
-    for (; i + 4 <= i1; i += 4) {                // four independent weight loads in flight
-      float w[4];
+    for (; i + 8 <= i1; i += 8) {                // eight independent weight loads in flight (the walk is latency-bound)
+      float w[8];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) w[u] = Wt[(size_t)(i + u) * O + o];
+      for (int u = 0; u < 8; ++u) w[u] = Wt[(size_t)(i + u) * O + o];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
+      for (int u = 0; u < 8; ++u) {
         const float4 x0 = *reinterpret_cast<const float4*>(in + (i + u) * SPG);
         const float4 x1 = *reinterpret_cast<const float4*>(in + (i + u) * SPG + 4);
         acc[0] = fmaf(x0.x, w[u], acc[0]); acc[1] = fmaf(x0.y, w[u], acc[1]);
