@@ -145,31 +145,19 @@ __global__ __launch_bounds__(512, KU > 2 ? 1 : 2) void pw_stream_kernel(const Ge
   // launches have fewer pixel groups than the chip has wave slots, so a wave's own serial load -> wait -> multiply
   // rounds ARE the kernel's duration (K = 960: 15 rounds of ~1.5 us with KU = 2).
 
-  // per-sample sums (squeeze-excite blocks): a wave walks a CONTIGUOUS range of pixel groups, so consecutive groups
-  // mostly belong to one sample and its sums stay in st1/st2 until the sample changes (cur_b)
+  // per-sample sums (squeeze-excite blocks): the WORKGROUP owns whole samples (its waves share a sample's pixel groups),
+  // so a sample's sums are complete inside the block: reduced through `lstat` and written with plain stores.  (A wave per
+  // contiguous group range + float atomics per sample change was 25-60 us of a 60-170 us launch: up to 1.5 M device-scope
+  // atomics.)
   const bool ps_mode = GEN && a.ps_stats != nullptr;
-  int cur_b = -1;
-  auto ps_flush = [&](int b) {
-#pragma unroll
-    for (int q = 0; q < NT / 2; ++q) {
-      const int n = nb + 32 * q;
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const float s1 = row16_sum(st1[q][j]), s2 = row16_sum(st2[q][j]);
-        st1[q][j] = st2[q][j] = 0.f;
-        if (lc == 0 && n < a.Nout) {
-          unsafeAtomicAdd(a.ps_stats + ((size_t)b * a.Nout + n + j) * 2, s1);
-          unsafeAtomicAdd(a.ps_stats + ((size_t)b * a.Nout + n + j) * 2 + 1, s2);
-        }
-      }
-    }
-  };
   const int wv = xb * WAVES + wave, nwv = nxb * WAVES;
-  const int per_w = (ngroups + nwv - 1) / nwv;
-  const int g_begin = ps_mode ? wv * per_w : wv, g_end = ps_mode ? min(ngroups, (wv + 1) * per_w) : ngroups;
-  const int g_step = ps_mode ? 1 : nwv;
+  const int gps = (a.HW + 16 * R - 1) / (16 * R);          // pixel groups per sample
+  const int s_end = ps_mode ? a.M / a.HW : 1, s_step = ps_mode ? nxb : 1;
+  for (int sb = ps_mode ? xb : 0; sb < s_end; sb += s_step) {
+  const int g_begin = ps_mode ? wave : wv, g_end = ps_mode ? gps : ngroups, g_step = ps_mode ? WAVES : nwv;
+  const int mbase = ps_mode ? sb * a.HW : 0, mlim = ps_mode ? min(a.M, (sb + 1) * a.HW) : a.M;
   for (int g = g_begin; g < g_end; g += g_step) {
-    const int m0 = g * 16 * R;
+    const int m0 = mbase + g * 16 * R;
     f32x4 acc[R][NT];
 #pragma unroll
     for (int r = 0; r < R; ++r)
@@ -180,8 +168,8 @@ __global__ __launch_bounds__(512, KU > 2 ? 1 : 2) void pw_stream_kernel(const Ge
 #pragma unroll
     for (int r = 0; r < R; ++r) {
       mrow[r] = m0 + r * 16 + lc;
-      mok[r] = mrow[r] < a.M;
-      mld[r] = min(mrow[r], a.M - 1);     // rows past the end re-read the last row; they are never stored or summed
+      mok[r] = mrow[r] < mlim;            // (ps_mode: rows of the next sample belong to another group)
+      mld[r] = min(mrow[r], a.M - 1);     // rows past the end re-read a valid row; they are never stored or summed
     }
 
     // HOIST (the deep-round data-gradient variants, KU > 2): the epilogue's activation-input tensor is loaded here, ahead
@@ -306,17 +294,6 @@ __global__ __launch_bounds__(512, KU > 2 ? 1 : 2) void pw_stream_kernel(const Ge
       const bool ok = mok[r];
       const int mrow0 = m0 + r * 16, mlast = mrow0 + 15;
       const int bidx = ok ? m / a.HW : 0;
-      const int b_first = min(mrow0, a.M - 1) / a.HW, b_last = min(mlast, a.M - 1) / a.HW;
-      const bool two = (b_last - b_first) <= 1;
-      if (ps_mode && two) {
-        if (cur_b != b_first) {
-          if (cur_b >= 0) ps_flush(cur_b);
-          cur_b = b_first;
-        }
-      } else if (ps_mode && cur_b >= 0) {
-        ps_flush(cur_b);
-        cur_b = -1;
-      }
       // all epilogue loads of the row first: the stores below then issue back to back and the 16-B pieces of a line
       // meet in L2 (interleaved with load waits they were written back separately: 1.84x HBM write traffic, PMC)
       bf16x8 eyr[NT / 2], err[NT / 2];
@@ -390,36 +367,38 @@ __global__ __launch_bounds__(512, KU > 2 ? 1 : 2) void pw_stream_kernel(const Ge
             st2[q][j] = fmaf(v[j], (DG && a.e_y) ? yv[j] : v[j], st2[q][j]);
           }
         } else if (GEN && a.ps_stats) {
-          // rows of the group's FIRST sample go to the running registers; the rows of a second sample (straddling group)
-          // take one masked 16-lane reduction + atomic pair; more than two samples (HW < 16): one atomic pair per lane
 #pragma unroll
-          for (int j = 0; j < 8; ++j) {
-            const float s1 = v[j], s2 = v[j] * yv[j];      // v is 0 for rows past M
-            if (two) {
-              const bool in0 = bidx == b_first;
-              st1[q][j] += in0 ? s1 : 0.f;
-              st2[q][j] += in0 ? s2 : 0.f;
-              if (b_last != b_first) {                     // wave-uniform
-                const float c1 = row16_sum(in0 ? 0.f : s1), c2 = row16_sum(in0 ? 0.f : s2);
-                if (lc == 0) {
-                  unsafeAtomicAdd(a.ps_stats + ((size_t)b_last * a.Nout + n + j) * 2, c1);
-                  unsafeAtomicAdd(a.ps_stats + ((size_t)b_last * a.Nout + n + j) * 2 + 1, c2);
-                }
-              }
-            } else if (ok) {
-              unsafeAtomicAdd(a.ps_stats + ((size_t)bidx * a.Nout + n + j) * 2, s1);
-              unsafeAtomicAdd(a.ps_stats + ((size_t)bidx * a.Nout + n + j) * 2 + 1, s2);
-            }
+          for (int j = 0; j < 8; ++j) {                    // v is 0 for rows outside the sample
+            st1[q][j] += v[j];
+            st2[q][j] = fmaf(v[j], yv[j], st2[q][j]);
           }
         }
       }
-      if (ps_mode && two && b_last != b_first) {   // the first sample ended inside this group
-        ps_flush(b_first);
-        cur_b = -1;
-      }
     }
   }
-  if (ps_mode && cur_b >= 0) ps_flush(cur_b);
+  if (ps_mode) {      // sample sb is complete in this block
+#pragma unroll
+    for (int q = 0; q < NT / 2; ++q) {
+      const int n = nb + 32 * q;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float s1 = row16_sum(st1[q][j]), s2 = row16_sum(st2[q][j]);
+        st1[q][j] = st2[q][j] = 0.f;
+        if (lc == 0 && n < a.Nout && g_begin < g_end) {
+          atomicAdd(lstat + (n - n0 + j) * 2, s1);
+          atomicAdd(lstat + (n - n0 + j) * 2 + 1, s2);
+        }
+      }
+    }
+    __syncthreads();
+    for (int i = tid; i < BN * 2; i += nthr) {
+      const int n = n0 + (i >> 1);
+      if (n < a.Nout) a.ps_stats[((size_t)sb * a.Nout + n) * 2 + (i & 1)] = lstat[i];
+      lstat[i] = 0.f;
+    }
+    __syncthreads();
+  }
+  }   // sample loop (one pass when there are no per-sample sums)
   PW_STAMP(3);
 
   if (keep_stats) {
@@ -455,7 +434,9 @@ int launch_v(GemmArgs& a, int KS, hipStream_t st) {
   const int ngroups = cdiv(a.M, 16 * R);
   // small weight chunks: 4-wave blocks, as many per CU as registers / LDS admit (each wave hides its own
   // load latency, so resident waves per CU are what matters); big chunks: one 8-wave block shares the copy
-  const int threads = lds <= 48 * 1024 ? 256 : 512;
+  const bool ps = GEN && a.ps_stats != nullptr;          // per-sample sums: a block owns whole samples (kernel)
+  const int gps = cdiv(a.HW, 16 * R);
+  const int threads = (lds <= 48 * 1024 || (ps && gps <= 4)) ? 256 : 512;
   const void* fn = (const void*)pw_stream_kernel<NT, R, DG, GEN, YF, KU, STEM>;
   if (lds > 64 * 1024) (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   static int occ_cache[2] = {0, 0};   // per instantiation (function-local static of the template), per block size
@@ -470,7 +451,7 @@ int launch_v(GemmArgs& a, int KS, hipStream_t st) {
   if (per_cu > by_lds) per_cu = by_lds;
   if (per_cu < 1) per_cu = 1;
   int nxb = (256 * per_cu) / nchunks;
-  const int need = cdiv(ngroups, threads / 64);
+  const int need = ps ? a.M / a.HW : cdiv(ngroups, threads / 64);
   if (nxb > need) nxb = need;
   if (nxb < 1) nxb = 1;
   if (nchunks > 1 && nxb >= 8) {              // whole lanes per XCD (see the kernel's block mapping)
@@ -515,6 +496,7 @@ int stream_launch(GemmArgs& a, hipStream_t st) {
     return launch_v<2, 2, false, false, false, 2, true>(a, 1, st);
   }
 
+  if (a.ps_stats && (a.stats || a.M % a.HW)) return T3D_ERR_UNSUPPORTED;   // the block-level per-sample reduction uses the statistics scratch
   const int KS = cdiv(a.Kin, 32);
   // widest chunk whose weights fit ~120 KB of LDS, at most 10 tiles (register budget: 8*NT stat + 4*NT*R acc)
   int nt_cap = (120 * 1024 / 1024) / KS;
