@@ -231,63 +231,65 @@ __global__ __launch_bounds__(256) void se_bias_kernel(const SeArgs a) {
 // ------------------------------------------------------------------ one workgroup per group of samples
 // The tiled kernels above cost 4 launches forward and 8 backward per gate, each a short serial chain of chunk rounds:
 // 70 us + 96 us per gate on the step's critical stream for ~0.1 GFLOP (rocprofv3: 16 % of MobileNetV3-large's kernel
-// time together with their memsets).  Here ONE launch does a direction: a workgroup of 1024 threads owns SPG samples and
-// walks both products for them back to back, thread = output, the contraction split over the thread groups that the
-// output width leaves free; weights are read coalesced along the output axis ([I][O] layouts: the backward's natural
+// time together with their memsets).  Here ONE launch does a direction: a workgroup owns SPG samples and walks both
+// products for them back to back, thread = output, the contraction split over the thread groups that the output width
+// leaves free; weights are read coalesced along the output axis ([I][O] layouts: the backward's natural
 // ones, transposed copies for the forward), inputs broadcast from LDS.  Every workgroup streams both weight matrices
 // (<= 1.8 MB fp32) out of L2.
-constexpr int SPG = 8;          // samples per workgroup
-constexpr int SE_T = 1024;
+constexpr int SPG = 4;          // samples per workgroup
+constexpr int SE_T = 512;       // (1024-thread blocks of 8 samples ran 37 us alone but 114 us inside the step: a block that
+                                // needs a whole CU's wave slots waits for the weight-gradient stream's blocks to drain)
 
 // out[s][o] = sum_i in[i][s] * Wt[i*O + o]   for s < SPG;  in: LDS [I][SPG];  partials through `red` [SE_T][SPG].
-// Returns the finished sums in acc[] for threads with grp == 0 && o < O (other threads: garbage).  O <= SE_T.
-__device__ __forceinline__ void se_product(const float* __restrict__ Wt, int I, int O, const float* in, float* red,
-                                           float acc[SPG], int& o_out, bool& owner) {
+// fin(o, acc) runs once per output o with the finished sums.  Outputs are walked in blocks of OP <= SE_T; within a block
+// the contraction is split over the SE_T / OP thread groups.
+template <typename Fin>
+__device__ __forceinline__ void se_product(const float* __restrict__ Wt, int I, int O, const float* in, float* red, Fin fin) {
   const int t = threadIdx.x;
-  const int OP = (O + 63) & ~63;                 // whole waves per group
-  const int ngrp = SE_T / OP, grp = t / OP, o = t - grp * OP;
-  const bool live = grp < ngrp && o < O;
+  const int OP = min((O + 63) & ~63, SE_T);      // whole waves per group
+  const int ngrp = SE_T / OP, grp = t / OP, ol = t - grp * OP;
   const int per = (I + ngrp - 1) / ngrp;
   const int i0 = min(grp * per, I), i1 = min(i0 + per, I);
+  for (int ob = 0; ob < O; ob += OP) {
+    const int o = ob + ol;
+    const bool live = grp < ngrp && o < O;
+    float acc[SPG];
 #pragma unroll
-  for (int s = 0; s < SPG; ++s) acc[s] = 0.f;
-  if (live) {
-    int i = i0;
-    for (; i + 8 <= i1; i += 8) {                // eight independent weight loads in flight (the walk is latency-bound)
-      float w[8];
+    for (int s = 0; s < SPG; ++s) acc[s] = 0.f;
+    if (live) {
+      int i = i0;
+      for (; i + 16 <= i1; i += 16) {            // sixteen independent weight loads in flight (the walk is latency-bound)
+        float w[16];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) w[u] = Wt[(size_t)(i + u) * O + o];
+        for (int u = 0; u < 16; ++u) w[u] = Wt[(size_t)(i + u) * O + o];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        const float4 x0 = *reinterpret_cast<const float4*>(in + (i + u) * SPG);
-        const float4 x1 = *reinterpret_cast<const float4*>(in + (i + u) * SPG + 4);
-        acc[0] = fmaf(x0.x, w[u], acc[0]); acc[1] = fmaf(x0.y, w[u], acc[1]);
-        acc[2] = fmaf(x0.z, w[u], acc[2]); acc[3] = fmaf(x0.w, w[u], acc[3]);
-        acc[4] = fmaf(x1.x, w[u], acc[4]); acc[5] = fmaf(x1.y, w[u], acc[5]);
-        acc[6] = fmaf(x1.z, w[u], acc[6]); acc[7] = fmaf(x1.w, w[u], acc[7]);
+        for (int u = 0; u < 16; ++u) {
+          const float4 x0 = *reinterpret_cast<const float4*>(in + (i + u) * SPG);
+          acc[0] = fmaf(x0.x, w[u], acc[0]); acc[1] = fmaf(x0.y, w[u], acc[1]);
+          acc[2] = fmaf(x0.z, w[u], acc[2]); acc[3] = fmaf(x0.w, w[u], acc[3]);
+        }
+      }
+      for (; i < i1; ++i) {
+        const float w = Wt[(size_t)i * O + o];
+#pragma unroll
+        for (int s = 0; s < SPG; ++s) acc[s] = fmaf(in[i * SPG + s], w, acc[s]);
       }
     }
-    for (; i < i1; ++i) {
-      const float w = Wt[(size_t)i * O + o];
+    if (ngrp > 1) {
+      __syncthreads();                             // `red` may still be read from the previous block / product
+      if (live && grp > 0) {
 #pragma unroll
-      for (int s = 0; s < SPG; ++s) acc[s] = fmaf(in[i * SPG + s], w, acc[s]);
-    }
-  }
-  owner = live && grp == 0;
-  o_out = o;
-  if (ngrp > 1) {
-    __syncthreads();                             // `red` may still be read from the previous product
-    if (live && grp > 0) {
+        for (int s = 0; s < SPG; ++s) red[(size_t)t * SPG + s] = acc[s];
+      }
+      __syncthreads();
+      if (live && grp == 0) {
+        for (int g = 1; g < ngrp; ++g) {
 #pragma unroll
-      for (int s = 0; s < SPG; ++s) red[(size_t)t * SPG + s] = acc[s];
-    }
-    __syncthreads();
-    if (owner) {
-      for (int g = 1; g < ngrp; ++g) {
-#pragma unroll
-        for (int s = 0; s < SPG; ++s) acc[s] += red[(size_t)(g * OP + o) * SPG + s];
+          for (int s = 0; s < SPG; ++s) acc[s] += red[(size_t)(g * OP + ol) * SPG + s];
+        }
       }
     }
+    if (live && grp == 0) fin(o, acc);
   }
 }
 
@@ -310,11 +312,7 @@ __global__ __launch_bounds__(SE_T) void se_fwd_group_kernel(const SeArgs a, cons
     ms[i] = v;
   }
   __syncthreads();
-  float acc[SPG];
-  int o;
-  bool own;
-  se_product(w1t, a.C, a.R, ms, red, acc, o, own);           // h = relu(W1 m + b1)
-  if (own) {
+  se_product(w1t, a.C, a.R, ms, red, [&](int o, const float* acc) {          // h = relu(W1 m + b1)
     const float b1 = a.b1[o];
 #pragma unroll
     for (int s = 0; s < SPG; ++s) {
@@ -322,10 +320,9 @@ __global__ __launch_bounds__(SE_T) void se_fwd_group_kernel(const SeArgs a, cons
       hs[o * SPG + s] = h;
       if (b0 + s < a.B) a.h[(size_t)(b0 + s) * a.R + o] = h;
     }
-  }
+  });
   __syncthreads();
-  se_product(w2t, a.R, a.C, hs, red, acc, o, own);           // q = W2 h + b2, s = h_sigmoid(q)
-  if (own) {
+  se_product(w2t, a.R, a.C, hs, red, [&](int o, const float* acc) {          // q = W2 h + b2, s = h_sigmoid(q)
     const float b2 = a.b2[o];
 #pragma unroll
     for (int s = 0; s < SPG; ++s) {
@@ -335,11 +332,11 @@ __global__ __launch_bounds__(SE_T) void se_fwd_group_kernel(const SeArgs a, cons
         a.s[(size_t)(b0 + s) * a.C + o] = hsigmoid(q);
       }
     }
-  }
+  });
 }
 
 // data part of the backward: dq, dp (kept for the weight gradients), g and the BatchNorm-backward sums
-__global__ __launch_bounds__(SE_T) void se_bwd_group_kernel(const SeArgs a) {
+__global__ __launch_bounds__(SE_T) void se_bwd_group_kernel(const SeArgs a, const int nrep, const long long rstride) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* dqs = lds;
   float* dps = dqs + (size_t)a.C * SPG;
@@ -358,11 +355,7 @@ __global__ __launch_bounds__(SE_T) void se_bwd_group_kernel(const SeArgs a) {
     dqs[i] = v;
   }
   __syncthreads();
-  float acc[SPG];
-  int o;
-  bool own;
-  se_product(a.w2, a.C, a.R, dqs, red, acc, o, own);          // dp = relu'(h) * (dq W2);  W2 is [C][R] = [I][O]
-  if (own) {
+  se_product(a.w2, a.C, a.R, dqs, red, [&](int o, const float* acc) {        // dp = relu'(h) * (dq W2);  W2 is [C][R] = [I][O]
 #pragma unroll
     for (int s = 0; s < SPG; ++s) {
       float v = 0.f;
@@ -372,11 +365,10 @@ __global__ __launch_bounds__(SE_T) void se_bwd_group_kernel(const SeArgs a) {
       }
       dps[o * SPG + s] = v;
     }
-  }
+  });
   __syncthreads();
-  se_product(a.w1, a.R, a.C, dps, red, acc, o, own);          // g = (dp W1) / HW;  W1 is [R][C] = [I][O]
-  if (own) {
-    const float inv = 1.f / (float)a.HW;
+  const float inv = 1.f / (float)a.HW;
+  se_product(a.w1, a.R, a.C, dps, red, [&](int o, const float* acc) {        // g = (dp W1) / HW;  W1 is [R][C] = [I][O]
     float v1 = 0.f, v2 = 0.f;
 #pragma unroll
     for (int s = 0; s < SPG; ++s) {
@@ -389,9 +381,14 @@ __global__ __launch_bounds__(SE_T) void se_bwd_group_kernel(const SeArgs a) {
         v2 += sg * p2 + gu * a.gap[k];
       }
     }
-    atomicAdd(a.stats + o, (double)v1);
-    atomicAdd(a.stats + a.C + o, (double)v2);
-  }
+    // one add per (workgroup, channel): spread over the reduction replicas (64 blocks on one address made this launch 3x
+    // longer inside the step than alone)
+    if (a.stats) {
+      double* st = a.stats + (size_t)(blockIdx.x % nrep) * rstride;
+      atomicAdd(st + o, (double)v1);
+      atomicAdd(st + a.C + o, (double)v2);
+    }
+  });
 }
 
 }  // namespace
@@ -449,7 +446,6 @@ extern "C" int t3d_se_fwd_fused(const float* gap_sum, const float* scale, const 
   if (!gap_sum || !scale || !shift || !w1t || !b1 || !w2t || !b2 || !m || !h || !q || !s || B <= 0 || C <= 0 || R <= 0 ||
       HW <= 0)
     return T3D_ERR_ARG;
-  if (C > SE_T || R > SE_T) return T3D_ERR_UNSUPPORTED;
   SeArgs a{};
   a.gap = gap_sum; a.scale = scale; a.shift = shift; a.b1 = b1; a.b2 = b2;
   a.m = m; a.h = h; a.q = q; a.s = s; a.B = B; a.C = C; a.R = R; a.HW = HW;
@@ -468,10 +464,9 @@ extern "C" int t3d_se_fwd_fused(const float* gap_sum, const float* scale, const 
 extern "C" int t3d_se_bwd_data(const float* ps_stats, const float* gap_sum, const float* scale, const float* shift,
                                const float* w1, const float* w2, const float* h, const float* q, const float* s, float* g,
                                float* dq, float* dp, double* stats, int B, int C, int R, int HW, void* stream) {
-  if (!ps_stats || !gap_sum || !scale || !shift || !w1 || !w2 || !h || !q || !s || !g || !dq || !dp || !stats || B <= 0 ||
-      C <= 0 || R <= 0 || HW <= 0)
+  if (!ps_stats || !gap_sum || !scale || !shift || !w1 || !w2 || !h || !q || !s || !g || !dq || !dp || B <= 0 || C <= 0 ||
+      R <= 0 || HW <= 0)
     return T3D_ERR_ARG;
-  if (C > SE_T || R > SE_T) return T3D_ERR_UNSUPPORTED;
   SeArgs a{};
   a.ps = ps_stats; a.gap = gap_sum; a.scale = scale; a.shift = shift; a.w1 = w1; a.w2 = w2;
   a.h = const_cast<float*>(h); a.q = const_cast<float*>(q); a.s = const_cast<float*>(s);
@@ -481,7 +476,8 @@ extern "C" int t3d_se_bwd_data(const float* ps_stats, const float* gap_sum, cons
     (void)hipFuncSetAttribute((const void*)se_bwd_group_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
     attr = true;
   }
-  hipLaunchKernelGGL(se_bwd_group_kernel, dim3(cdiv(B, SPG)), dim3(SE_T), se_group_lds(C, R), reinterpret_cast<hipStream_t>(stream), a);
+  hipLaunchKernelGGL(se_bwd_group_kernel, dim3(cdiv(B, SPG)), dim3(SE_T), se_group_lds(C, R), reinterpret_cast<hipStream_t>(stream), a,
+                     g_t3d_reduce.nrep, g_t3d_reduce.stats_stride);
   T3D_CHECK_LAUNCH();
   return T3D_OK;
 }

@@ -887,12 +887,11 @@ class Net:
             g = self._buf(f'se_g:{i}', (B, C), torch.float32)
             dq = self._buf(f'se_dq:{i}', (B, C), torch.float32)
             dp = self._buf(f'se_dp:{i}', (B, R), torch.float32)
-            scratch = self._buf(f'se_scr:{i}', (2 * C,), torch.float64)      # t3d_se_bwd's before-activation sums: unused
             ones, zeros = self._const(C, 1.0), self._const(C, 0.0)
             N.call('t3d_se_bwd_data', N.ptr(ps), N.ptr(se['gap']), N.ptr(zeros), N.ptr(ones),
                    N.ptr(self.p[sen + '.fc.0.weight']), N.ptr(self.p[sen + '.fc.2.weight']),
-                   N.ptr(se['h']), N.ptr(se['q']), N.ptr(se['s']), N.ptr(g), N.ptr(dq), N.ptr(dp), N.ptr(scratch),
-                   B, C, R, se['HW'], st)
+                   N.ptr(se['h']), N.ptr(se['q']), N.ptr(se['s']), N.ptr(g), N.ptr(dq), N.ptr(dp), None,
+                   B, C, R, se['HW'], st)            # (the before-activation sums are not needed here)
             self._se_wgrad(se, sen, dq, dp, B, C, R)
             dv2 = self._buf(f'dv2:{i}', (M2, C))
             N.call('t3d_se_after_apply', dt, N.ptr(dv), N.ptr(s2.raw), se['pro2n'], N.ptr(se['s']), N.ptr(g), N.ptr(dv2),

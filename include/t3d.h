@@ -306,8 +306,9 @@ int t3d_se_bwd(const float* ps_stats, const float* gap_sum, const float* scale, 
 /* The same gate with ONE launch per direction (a workgroup per 8 samples walks both FCs; csrc/se.hip): what the host side
  * uses.  _fwd_fused takes TRANSPOSED fp32 copies of the FC weights (w1t [C][R] = fc.0.weight^T, w2t [R][C] = fc.2.weight^T;
  * e.g. kept current by t3d_pack_weights_batched(T3D_F32, ...)) and otherwise t3d_se_fwd's arguments.  _bwd_data is
- * t3d_se_bwd without the weight gradients (dq, dp stay behind for them); _bwd_weights computes dw1, db1, dw2, db2 from
- * m, h, dq, dp -- leaves of the backward graph, issued on the weight-gradient stream.  C, R <= 1024. */
+ * t3d_se_bwd without the weight gradients (dq, dp stay behind for them; stats may be NULL, and is spread over the
+ * reduction replicas of t3d_set_reduction_replicas like the conv kernels' sums); _bwd_weights computes dw1, db1, dw2, db2 from
+ * m, h, dq, dp -- leaves of the backward graph, issued on the weight-gradient stream. */
 int t3d_se_fwd_fused(const float* gap_sum, const float* scale, const float* shift, const float* w1t, const float* b1,
                      const float* w2t, const float* b2, float* m, float* h, float* q, float* s, int B, int C, int R, int HW,
                      void* stream);
