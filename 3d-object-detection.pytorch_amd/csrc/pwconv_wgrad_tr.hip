@@ -36,7 +36,7 @@ struct WgtArgs {
   int M, HW, K, N;
   int yfree, Nz;     // y-free mode: dy side = [dz (Nz channels) | x (K channels) | 1, 0 x 7], N = Nz + K + 8 virtual channels
   int swap;          // 0: P = N (dy side), Q = K (a side); 1: P = K, Q = N
-  int ptiles, qtiles, rows_per_split;
+  int ptiles, qtiles, rows_per_split, nsplit;
   float* ws;         // partial tiles [split][tile][PB][QB] (plain stores) or null (atomics into dw)
   t3d_pw::StemSrc stem;   // stem.img != null: the a side (K = 32) is gathered from the crops (pwconv_common.h)
 };
@@ -68,9 +68,27 @@ __global__ __launch_bounds__(256 * G) void pw_wgrad_tr_kernel(const WgtArgs a) {
 
   const int tid = threadIdx.x & 255, lane = tid & 63, wave = tid >> 6;
   const int P = SWAP ? a.K : a.N, Q = SWAP ? a.N : a.K;
-  const int tile = blockIdx.x, pt = tile / a.qtiles, qt = tile % a.qtiles;
+  // block -> (output tile, pixel split).  All tiles of one split read the same pixel rows (dy and a columns of their own
+  // tile only), and consecutive workgroup ids go round-robin over the 8 XCDs: with tile = id % ntiles every tile of a split
+  // fetched those rows into a different L2.  Splits are dealt out per XCD instead (whole groups of 8 splits; the rest
+  // keeps the plain order), so a split's tiles share an L2.
+  const int ntiles = a.ptiles * a.qtiles, s8 = a.nsplit & ~7;
+  int tile, split;
+  {
+    const int L = blockIdx.x;
+    if (ntiles > 1 && L < ntiles * s8) {
+      const int j = L >> 3;
+      tile = j % ntiles;
+      split = (j / ntiles) * 8 + (L & 7);
+    } else {
+      const int Lr = ntiles > 1 ? L - ntiles * s8 : L;
+      tile = Lr % ntiles;
+      split = (ntiles > 1 ? s8 : 0) + Lr / ntiles;
+    }
+  }
+  const int pt = tile / a.qtiles, qt = tile % a.qtiles;
   const int p0 = pt * PB, q0 = qt * QB;
-  const int mbeg = blockIdx.y * a.rows_per_split, mend = min(a.M, mbeg + a.rows_per_split);
+  const int mbeg = split * a.rows_per_split, mend = min(a.M, mbeg + a.rows_per_split);
   // which side carries dy (N channels) / a (K channels)
   constexpr int dyB = SWAP ? QB : PB, aB = SWAP ? PB : QB;
   const int dy0 = SWAP ? q0 : p0, a0c = SWAP ? p0 : q0;
@@ -282,7 +300,7 @@ __global__ __launch_bounds__(256 * G) void pw_wgrad_tr_kernel(const WgtArgs a) {
   // D[row = 4*(lane>>4) + reg -> p][col = lane&15 -> q]
   const int lg = lane >> 4, lc = lane & 15;
   if (a.ws) {
-    float* wsb = a.ws + ((size_t)blockIdx.y * gridDim.x + tile) * (PB * QB);
+    float* wsb = a.ws + ((size_t)split * ntiles + tile) * (PB * QB);
 #pragma unroll
     for (int i = 0; i < NTPW; ++i)
 #pragma unroll
@@ -360,7 +378,8 @@ int launch_d(WgtArgs& a, hipStream_t st) {
   a.ws = use_ws ? reinterpret_cast<float*>(g_t3d_ws.ptr) : nullptr;
   if (lds > 64 * 1024)
     (void)hipFuncSetAttribute((const void*)pw_wgrad_tr_kernel<NTPW, NTQ, SWAP, G, D, GEN, YF, STEM>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  hipLaunchKernelGGL((pw_wgrad_tr_kernel<NTPW, NTQ, SWAP, G, D, GEN, YF, STEM>), dim3(tiles, S), dim3(256 * G), lds, st, a);
+  a.nsplit = S;
+  hipLaunchKernelGGL((pw_wgrad_tr_kernel<NTPW, NTQ, SWAP, G, D, GEN, YF, STEM>), dim3(tiles * S), dim3(256 * G), lds, st, a);
   if (use_ws)
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(cdiv((a.swap ? a.K : a.N) * a.qtiles * QB, 256), S >= 64 ? 16 : (S >= 8 ? 4 : 1)), dim3(256), 0, st, a.ws, a.dw, a.N, a.K, (int)SWAP, PB, QB,
                        a.qtiles, tiles, S);
