@@ -4,7 +4,10 @@ f = sys.argv[1]
 rows = [(int(r['Start_Timestamp']), int(r['End_Timestamp']), r['Kernel_Name'], r.get('Queue_Id', '0')) for r in csv.DictReader(open(f))]
 rows.sort()
 loss = [i for i, r in enumerate(rows) if 'loss_kernel' in r[2]]
-i0, i1 = loss[-3], loss[-2]          # one full step: loss -> backward -> optimizer -> next forward -> loss
+# one full step: loss -> backward -> optimizer -> next forward -> loss; the shortest of the last ones (the bench's
+# host-issue probe steps at the end contain synchronisation gaps)
+k = min(range(max(1, len(loss) - 8), len(loss)), key=lambda j: rows[loss[j]][0] - rows[loss[j - 1]][0])
+i0, i1 = loss[k - 1], loss[k]
 seg = rows[i0:i1]
 t0 = seg[0][0]
 qs = collections.defaultdict(list)
