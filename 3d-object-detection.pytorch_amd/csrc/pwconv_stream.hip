@@ -193,6 +193,10 @@ __global__ __launch_bounds__(512, KU > 2 ? 1 : 2) void pw_stream_kernel(const Ge
       constexpr int KUr = decltype(ku_tag)::value;
       constexpr bool GUARD = decltype(guard_tag)::value;
       bf16x8 fa[KUr][R], fb[KUr][R];
+      // squeeze-excite gates of the forward operand (per sample x input channel, fp32): fetched WITH the operand -- loaded
+      // inside the transform they were one more dependent global round trip per k-step
+      float4 gs[GEN && !DGL ? KUr : 1][R][2];
+      const bool gated = GEN && !DGL && a.p2 != nullptr;
       // branch-free loads: k-steps / channels past Kin read a clamped (valid) address -- their weights are zero
 #pragma unroll
       for (int u = 0; u < KUr; ++u) {
@@ -211,6 +215,13 @@ __global__ __launch_bounds__(512, KU > 2 ? 1 : 2) void pw_stream_kernel(const Ge
             } else {
               fa[u][r] = *reinterpret_cast<const bf16x8*>(A0 + (size_t)mld[r] * a.row0 + k);
               if (DGL) fb[u][r] = *reinterpret_cast<const bf16x8*>(A1 + (size_t)mld[r] * a.row0 + k);
+              if constexpr (GEN && !DGL) {
+                if (gated) {
+                  const float* gp = a.p2 + (size_t)(mld[r] / a.HW) * a.Kin + min(ks * 32 + lg * 8, a.Kin - 8);
+                  gs[u][r][0] = *reinterpret_cast<const float4*>(gp);
+                  gs[u][r][1] = *reinterpret_cast<const float4*>(gp + 4);
+                }
+              }
             }
           }
         }
@@ -238,15 +249,22 @@ __global__ __launch_bounds__(512, KU > 2 ? 1 : 2) void pw_stream_kernel(const Ge
 #pragma unroll
                 for (int j = 0; j < 8; ++j) x[j] = (float)fa[u][r][j];
                 if (GEN && a.p2) {
-                  const float* se = ok ? a.p2 + (size_t)(mrow[r] / a.HW) * a.Kin + k : nullptr;
+                  const float4 g0 = gs[GEN && !DGL ? u : 0][r][0], g1 = gs[GEN && !DGL ? u : 0][r][1];
+                  const float sg[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
+                  float sv[8];
 #pragma unroll
-                  for (int j = 0; j < 8; ++j) {
-                    float t = x[j] * c0[j] + c1[j];
-                    const float sv = se ? se[j] : 1.f;
-                    if (!a.se_after) t *= sv;
-                    t = act_apply(t, a.act);
-                    if (a.se_after) t *= sv;
-                    x[j] = t;
+                  for (int j = 0; j < 8; ++j) sv[j] = ok ? sg[j] : 1.f;
+                  // one activation switch per 8 elements (act_affine_vec), not one per element: gate before the
+                  // activation = act(sv * (c0 x + c1)) folds into the affine, gate after it multiplies the result
+                  if (!a.se_after) {
+                    float c0s[8], c1s[8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) { c0s[j] = c0[j] * sv[j]; c1s[j] = c1[j] * sv[j]; }
+                    act_affine_vec<8>(x, c0s, c1s, a.act);
+                  } else {
+                    act_affine_vec<8>(x, c0, c1, a.act);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) x[j] *= sv[j];
                   }
                 } else {
                   act_affine_vec<8>(x, c0, c1, a.act);

@@ -95,7 +95,9 @@ def test_bf16_mnv3_large_b32_224_metrics_vs_reference_golden(golden_dir):
     N.call('t3d_loss_fwd_bwd', _loss_cfg(['l1', 'add_loss', 'cross_entropy'], ([1., .1], [.2])), N.ptr(kpt), N.ptr(gtd),
            N.ptr(lgt), N.ptr(cd), N.ptr(out), N.ptr(dkp), N.ptr(dlg), B, nc, N.stream())
     print(f'   train loss bf16 {out[0].item():.6f} reference {g["loss"][0]:.6f}')
-    assert abs(out[0].item() - g['loss'][0]) < 2e-3
+    # train mode: the float atomics of the squeeze-excite pooled sums make the bf16 forward itself vary run to run, and
+    # ~50 train-mode BatchNorm layers amplify that (five runs: 1.1321 .. 1.1349 against the reference's 1.1343)
+    assert abs(out[0].item() - g['loss'][0]) < 5e-3
 
 
 def test_bf16_mnv2_b256_224_eval_metrics_vs_cpu_oracle():
