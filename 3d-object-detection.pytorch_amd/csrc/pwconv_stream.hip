@@ -315,6 +315,17 @@ __global__ __launch_bounds__(512, KU > 2 ? 1 : 2) void pw_stream_kernel(const Ge
       // all epilogue loads of the row first: the stores below then issue back to back and the 16-B pieces of a line
       // meet in L2 (interleaved with load waits they were written back separately: 1.84x HBM write traffic, PMC)
       bf16x8 eyr[NT / 2], err[NT / 2];
+      float4 esg[GEN ? NT / 2 : 1][2];       // squeeze-excite gates of the epilogue tensor (per sample x channel)
+      if constexpr (GEN && DG) {
+        if (a.e_se) {
+#pragma unroll
+          for (int q = 0; q < NT / 2; ++q) {
+            const float* gp = a.e_se + (size_t)(mld[r] / a.HW) * a.Nout + min(nb + 32 * q, a.Nout - 8);
+            esg[q][0] = *reinterpret_cast<const float4*>(gp);
+            esg[q][1] = *reinterpret_cast<const float4*>(gp + 4);
+          }
+        }
+      }
       if constexpr (HOIST) {
 #pragma unroll
         for (int q = 0; q < NT / 2; ++q) eyr[q] = eyh[r][q];
@@ -347,13 +358,23 @@ __global__ __launch_bounds__(512, KU > 2 ? 1 : 2) void pw_stream_kernel(const Ge
 #pragma unroll
           for (int j = 0; j < 8; ++j) yv[j] = (float)eyr[q][j];
           if (GEN && a.e_se) {
-            const float* se = ok ? a.e_se + (size_t)bidx * a.Nout + n : nullptr;
+            const float4 s0 = *reinterpret_cast<const float4*>(ecoef + (n - n0)), s1 = *reinterpret_cast<const float4*>(ecoef + (n - n0) + 4);
+            const float4 h0 = *reinterpret_cast<const float4*>(ecoef + BN + (n - n0)),
+                         h1 = *reinterpret_cast<const float4*>(ecoef + BN + (n - n0) + 4);
+            float es[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
+            float eh[8] = {h0.x, h0.y, h0.z, h0.w, h1.x, h1.y, h1.z, h1.w};
+            const float4 g0 = esg[GEN ? q : 0][0], g1 = esg[GEN ? q : 0][1];
+            const float sv[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
+            // one derivative switch per 8 elements: gate before the activation folds into the affine (act'(sv (es y + eh))),
+            // gate after it scales the result
+            if (!a.e_se_after) {
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-              const float u = yv[j] * ecoef[n - n0 + j] + ecoef[BN + n - n0 + j];
-              const float sv = se ? se[j] : 1.f;
-              if (!a.e_se_after) v[j] *= act_grad(u * sv, a.e_act);
-              else v[j] *= sv * act_grad(u, a.e_act);
+              for (int j = 0; j < 8; ++j) { es[j] *= sv[j]; eh[j] *= sv[j]; }
+              act_grad_affine_vec<8>(v, yv, es, eh, a.e_act);
+            } else {
+              act_grad_affine_vec<8>(v, yv, es, eh, a.e_act);
+#pragma unroll
+              for (int j = 0; j < 8; ++j) v[j] *= sv[j];
             }
           } else if (a.e_act != T3D_ACT_NONE) {
             const float4 s0 = *reinterpret_cast<const float4*>(ecoef + (n - n0)), s1 = *reinterpret_cast<const float4*>(ecoef + (n - n0) + 4);
