@@ -115,6 +115,7 @@ class Net:
         # uint8 input path (include/t3d.h: t3d_stem_fwd, fmt 1): normalisation of configs/default_config.py:9-10
         self.set_input_normalization([0.5931, 0.4690, 0.4229], [0.2471, 0.2214, 0.2157])
         self._direct_stem = bool(os.environ.get('T3D_STEM_DIRECT'))
+        self._fused_eval = not os.environ.get('T3D_NO_FUSED_EVAL')   # 14x14 / 7x7 blocks as one launch in inference mode
 
     def set_input_normalization(self, mean, std):
         """Per-channel mean / std applied to uint8 crops inside the stem kernel ((u/255 - mean) / std)."""
@@ -559,10 +560,36 @@ class Net:
         N.call('t3d_bn_apply', self.dt, N.ptr(src.t), src.pro, None, N.ptr(z), M, src.C, N.stream())
         return _Src(z, None, src.B, src.H, src.W, src.C, raw=src.raw, bn=src.bn, gpro=src.gpro, finished_act=True)
 
+    def _fused_eval_ok(self, blk, x):
+        """Inference mode, bf16: may this block run as ONE launch (csrc/block_eval.hip: expanded tensors stay in LDS)?"""
+        # one workgroup per image: below ~100 images the launch-per-layer path fills the chip better
+        if self.training or not self._fused_eval or self.dt != N.BF16 or x.pro is not None or x.B < 96:
+            return False
+        if not blk.expand or blk.se or blk.s != 1 or blk.k != 3 or blk.cin % 32 or blk.cexp % 64 or blk.cout % 16:
+            return False
+        P = x.H * x.W
+        mt = (P + 15) // 16
+        nt2, mtw = blk.cout // 16, (mt + 7) // 8
+        # (built but not used: 7x7 160 -> 960 -> 320, 102 us fused against 97 us layer by layer)
+        if not ((mtw == 1 and nt2 == 10) or (mtw == 2 and nt2 in (4, 6))):
+            return False
+        lds = mt * 16 * (blk.cin + 8) * 2 + P * 68 * 4 + mt * 16 * 72 * 2 + 64 * (blk.cin + 8) * 2 + blk.cout * 72 * 2 + 64 * 9 * 4 + 4 * 64 * 4
+        return lds <= 160 * 1024
+
     def _block_fwd(self, i, blk, x, sv):
         st, dt = N.stream(), self.dt
         p = f'features.{i + 1}.conv'
         B, H, W = x.B, x.H, x.W
+        if self._fused_eval_ok(blk, x):
+            bn1, bn2, bn3 = self.bns[p + '.1'], self.bns[p + '.4'], self.bns[p + '.8']
+            z = self._buf(f'z:{i}', (B * H * W, blk.cout))
+            act = N.ACT[blk.act] if isinstance(blk.act, str) else blk.act
+            N.call('t3d_ir_block_eval', N.ptr(x.t), N.ptr(self.w[p + '.0.weight']), N.ptr(bn1.scale), N.ptr(bn1.shift),
+                   act, N.ptr(self.p[p + '.3.weight']), N.ptr(bn2.scale), N.ptr(bn2.shift), act,
+                   N.ptr(self.w[p + '.7.weight']), N.ptr(bn3.scale), N.ptr(bn3.shift), int(bool(blk.res)), N.ptr(z),
+                   B, H, W, blk.cin, blk.cexp, blk.cout, st,
+                   nbytes=B * H * W * (2 * blk.cin + 4 * blk.cexp + 2 * blk.cout) * self.esz)
+            return _Src(z, None, B, H, W, blk.cout, raw=None, bn=bn3, gpro=None)
         if blk.res and x.pro is not None:
             x = self._finish(x, f'z:in{i}')
         rec = dict(x=x)

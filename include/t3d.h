@@ -166,6 +166,16 @@ int t3d_stem_im2col(int dtype, const float* x, void* col, int B, int H, int W, v
 int t3d_stem_im2col_u8(int dtype, const unsigned char* x, const float* mean, const float* inv_std, void* col, int B, int H,
                        int W, void* stream);
 
+/* A whole inverted-residual block in inference mode (running statistics: every BatchNorm is a per-channel affine), bf16,
+ * for the 14x14 / 7x7 stages: z = BN3(W2 * act2(BN2(dw3x3(act1(BN1(W1 * x)))))) [+ x], models/mobilenetv3.py:146-164 in
+ * eval().  One workgroup per image keeps the expanded tensors in LDS (csrc/block_eval.hip); replaces
+ * t3d_pwconv_fwd + t3d_dwconv_fwd + t3d_pwconv_fwd + t3d_bn_apply of that block with the same rounding points.
+ * x [B,H,W,Cin] finished input, w1 [Ce,Cin], w2 [Cout,Ce] bf16, wdw [Ce,9] fp32, scale/shift fp32 per channel (eval affines),
+ * z [B,H,W,Cout].  Stride 1, 3x3, no squeeze-excite; shapes outside the built set return T3D_ERR_UNSUPPORTED. */
+int t3d_ir_block_eval(const void* x, const void* w1, const float* scale1, const float* shift1, int act1, const float* wdw,
+                      const float* scale2, const float* shift2, int act2, const void* w2, const float* scale3,
+                      const float* shift3, int residual, void* z, int B, int H, int W, int Cin, int Ce, int Cout, void* stream);
+
 /* Two-stage inference, input side: crop every detection out of ONE full frame and resize it to the regressor's input
  * size, in one launch.  frame [H,W,3] uint8 (device), rects [n,4] int32 (x0,y0,x1,y1), device) -> out [n,oh,ow,3] uint8
  * NHWC.  Replaces the host loop `frame[y0:y1, x0:x1]` + `cv.resize(crop, (w, h))` per detection (utils/ie_wrappers.py:
