@@ -249,3 +249,32 @@ def test_pw_yfree_backward(M, HW, K, N, res):
     ew, ew2 = (dw.double().cpu() - dw_ref).abs().max().item() / sw, (dw2.double().cpu() - dw_ref).abs().max().item() / sw
     assert ex < 1.5e-2 and ex < 2 * ex2 + 4e-3, (ex, ex2)          # bf16 output rounding dominates both
     assert ew < 1e-2 and ew < 2 * ew2 + 4e-3, (ew, ew2)
+
+
+@pytest.mark.parametrize('dt', ['f32', 'bf16'])
+@pytest.mark.parametrize('ratio', [3.0, 30.0])
+def test_batch_variance_from_the_one_pass_sums_when_the_mean_dominates(dt, ratio):
+    """The conv epilogues emit sum(y), sum(y^2) in one pass (fp32 per-lane partials, fp64 across lanes / blocks) and
+    t3d_bn_finalize forms var = E[y^2] - E[y]^2 in fp64; PyTorch's BatchNorm is two-pass.  What that costs when
+    |mean| >> std (a bias of `ratio` standard deviations on every output channel, production pixel count): the relative
+    error of the variance stays below (1 + ratio^2) x the 1e-6 relative error of the sums."""
+    from torchdet3d import _native as Nt
+    dtype = _dt(dt)
+    g = torch.Generator().manual_seed(17)
+    M, HW, K, N = 256 * 196, 196, 64, 96
+    x = torch.randn(M, K, generator=g)
+    w = torch.randn(N, K, generator=g) / K ** 0.5
+    bias = torch.full((N,), ratio) * (torch.rand(N, generator=g) + 0.5)
+    xd, wd, bd = x.to('cuda', dtype), _pack(w, dtype), bias.cuda()
+    y = torch.empty(M, N, device='cuda', dtype=dtype)
+    stats = torch.zeros(2 * N, device='cuda', dtype=torch.float64)
+    Nt.call('t3d_pwconv_fwd', Nt.dtype_code(xd), Nt.ptr(xd), None, Nt.ptr(wd), Nt.ptr(bd), Nt.ptr(y), Nt.ptr(stats),
+            M, HW, K, N, Nt.stream())
+    torch.cuda.synchronize()
+    yd = y.double()
+    st = stats.view(2, N)
+    var = (st[1] / M - (st[0] / M) ** 2).cpu()
+    ref = yd.var(0, unbiased=False).cpu()          # two-pass, fp64, of the stored outputs
+    rel = ((var - ref).abs() / ref).max().item()
+    assert rel < 2e-6 * (1 + (1.5 * ratio) ** 2), rel
+    print(f'   {dt} |mean| ~ {ratio} std: worst relative variance error {rel:.1e}')
