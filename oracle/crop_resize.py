@@ -84,3 +84,19 @@ def regress_detections(forward_all_heads, frame, detections, size, mean, std):
         label = int(np.argmax(logits[0]))
         out.append((kp[label], label))
     return out
+
+
+def objectron_crop(image, keypoints):
+    """Objectron.crop (dataloaders/objectron_main.py:98-137): -> (keypoints shifted into the crop, crop, (x0, y0, x1, y1))."""
+    real_h, real_w, _ = image.shape
+    clamp = lambda x, lo, hi: min(max(x, lo), hi)
+    kp = np.asarray(keypoints)
+    clipped = np.empty_like(kp)
+    clipped[:, 0] = [clamp(x, 3, real_w - 3) for x in kp[:, 0]]
+    clipped[:, 1] = [clamp(y, 3, real_h - 3) for y in kp[:, 1]]
+    x0 = clamp(min(clipped[:, 0]) - 10, 0, real_w)
+    y0 = clamp(min(clipped[:, 1]) - 10, 0, real_h)
+    x1 = clamp(max(clipped[:, 0]) + 10, 0, real_w)
+    y1 = clamp(max(clipped[:, 1]) + 10, 0, real_h)
+    x0, y0, x1, y1 = int(x0), int(y0), int(x1), int(y1)
+    return clipped - np.asarray([x0, y0], clipped.dtype), image[y0:y1, x0:x1], (x0, y0, x1, y1)

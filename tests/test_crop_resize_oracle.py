@@ -34,3 +34,17 @@ def test_crop_is_the_numpy_slice():
     assert np.array_equal(crop(frame, (3, 4, 10, 9)), frame[4:9, 3:10])
     assert crop(frame, (25, 15, 60, 40)).shape == (5, 5, 3)         # clamped at the frame like numpy
     assert crop(frame, (10, 10, 10, 12)).size == 0
+
+
+def test_crop_box_from_keypoints_matches_the_oracle_restatement():
+    from oracle.crop_resize import objectron_crop
+    from torchdet3d.dataloaders import crop_cords_from_keypoints
+    rng = np.random.default_rng(1)
+    frame = rng.integers(0, 256, (480, 640, 3), dtype=np.uint8)
+    for _ in range(50):
+        kp = rng.integers(-40, 700, (9, 2)).astype(np.int64)            # some points outside the frame
+        clipped, box = crop_cords_from_keypoints(kp, 640, 480)
+        skp, crop, obox = objectron_crop(frame, kp)
+        assert tuple(int(v) for v in box) == obox
+        assert np.array_equal(clipped - np.asarray(obox[:2]), skp)
+        assert crop.shape[0] == obox[3] - obox[1] and crop.shape[1] == obox[2] - obox[0]

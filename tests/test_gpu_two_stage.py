@@ -73,3 +73,27 @@ def test_regressor_matches_the_reference_per_detection_loop():
     kp = Regressor.transform_kp(got[0][0][0].copy(), dets[0][:4])
     x0, y0, x1, y1 = dets[0][:4]
     np.testing.assert_allclose(kp[:, 0], got[0][0][0][:, 0] * (x1 - x0) + x0, rtol=1e-6)
+
+
+def test_frame_cropper_feeds_the_trainer_tuple():
+    """FrameCropper: crops == oracle Objectron.crop + 8-bit bilinear resize, keypoints == (kp - origin) / crop size
+    (A.Crop + Resize + ToTensor's normalisation, objectron_main.py:98-126, utils/transforms.py:112-114)."""
+    from oracle.crop_resize import objectron_crop, resize_linear_u8
+    from torchdet3d.dataloaders import FrameCropper
+    rng = np.random.default_rng(9)
+    H, W = 720, 1280
+    frame = rng.integers(0, 256, (H, W, 3), dtype=np.uint8)
+    objs = []
+    for _ in range(7):
+        c = rng.integers(100, [W - 100, H - 100])
+        objs.append((c + rng.integers(-90, 90, (9, 2))).astype(np.int64))
+    objs.append(rng.integers(-50, 1400, (9, 2)).astype(np.int64))        # partly outside the frame
+    crops, kps, boxes = FrameCropper((224, 224))(frame, objs)
+    assert crops.shape == (8, 224, 224, 3) and crops.dtype == torch.uint8 and kps.shape == (8, 9, 2)
+    for i, kp in enumerate(objs):
+        skp, crop, box = objectron_crop(frame, kp)
+        assert boxes[i] == box
+        assert np.array_equal(crops[i].cpu().numpy(), resize_linear_u8(crop, (224, 224)))
+        ref = skp.astype(np.float32) / np.float32([box[2] - box[0], box[3] - box[1]])
+        np.testing.assert_allclose(kps[i].cpu().numpy(), ref, rtol=1e-6, atol=1e-7)
+        assert kps[i].min().item() >= 0 and kps[i].max().item() <= 1
