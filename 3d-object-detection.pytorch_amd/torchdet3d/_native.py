@@ -73,6 +73,7 @@ SIGNATURES = {
     't3d_linear_fwd': [_P, _P, _P, _P, _I, _I, _I, _P],
     't3d_head_fwd_all': [_P, _PP, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P],
     't3d_head_bwd': [_P, _PP, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P],
+    't3d_head_bwd_weights': [_P, _PP] + [_P] * 8 + [_I, _I, _I, _P],
     't3d_se_fwd': [_P] * 11 + [_I, _I, _I, _I, _P],
     't3d_se_bwd': [_P] * 18 + [_I, _I, _I, _I, _P],
     't3d_se_fwd_fused': [_P] * 11 + [_I] * 4 + [_P],

@@ -734,14 +734,17 @@ class Net:
         bnc = self.bns['classifier.1'] if a.classifier else None
         N.call('t3d_head_bwd', N.ptr(sv['f']), sv['fpro'], N.ptr(sv['cats']), N.ptr(self.wreg),
                N.ptr(self.p['cls_fc.1.weight']), N.ptr(sv['mask']), N.ptr(sv['kp']), N.ptr(dkp), N.ptr(dlogits),
-               N.ptr(dpre), N.ptr(df), N.ptr(bnc.bstats) if bnc else None, N.ptr(self.dwreg), N.ptr(self.dbreg),
-               N.ptr(self.g['cls_fc.1.weight']), N.ptr(self.g['cls_fc.1.bias']), B, F, ncls, st)
+               N.ptr(dpre), N.ptr(df), N.ptr(bnc.bstats) if bnc else None, None, None, None, None, B, F, ncls, st)
+        # the heads' weight gradients are leaves: second stream (idle at this point of the step)
+        self._wgrad(N.ptr(sv['f']), sv['fpro'], N.ptr(sv['cats']), N.ptr(sv['mask']), N.ptr(dpre), N.ptr(dlogits),
+                    N.ptr(self.dwreg), N.ptr(self.dbreg), N.ptr(self.g['cls_fc.1.weight']), N.ptr(self.g['cls_fc.1.bias']),
+                    B, F, ncls, entry='t3d_head_bwd_weights')
         dpooled = df
         if a.classifier:
             bb = self._bn_bwd(bnc)
             yc, pooled = sv['f'], sv['pooled']
-            N.call('t3d_pwconv_wgrad', N.F32, N.ptr(df), N.ptr(yc), bb, N.ptr(pooled), None,
-                   N.ptr(self.g['classifier.0.weight']), B, 1, a.last_c, a.classifier, st)
+            self._wgrad(N.F32, N.ptr(df), N.ptr(yc), bb, N.ptr(pooled), None,
+                        N.ptr(self.g['classifier.0.weight']), B, 1, a.last_c, a.classifier)
             # bias gradient = sum_b dy = alpha*sum(dz) + beta*sum(y) + B*gamma (exactly 0 in exact arithmetic)
             N.call('t3d_bn_bias_grad', N.ptr(bnc.stats), N.ptr(bnc.bstats), a.classifier, float(B), N.ptr(bnc.alpha),
                    N.ptr(bnc.bbeta), N.ptr(bnc.gammac), N.ptr(self.g['classifier.0.bias']), st)

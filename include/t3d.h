@@ -257,6 +257,11 @@ int t3d_head_bwd(const float* f, const t3d_prologue* pro, const int64_t* cats, c
                  const float* wcls, const float* mask, const float* kp, const float* dkp, const float* dlogits,
                  float* dpre, float* df, double* stats, float* dwreg, float* dbreg, float* dwcls, float* dbcls,
                  int B, int F, int ncls, void* stream);
+/* The weight / bias gradients of t3d_head_bwd on their own: pass dwreg = NULL there (data gradient only, dpre is left
+ * behind) and issue this on the weight-gradient stream -- 44 us off the start of the backward's critical chain. */
+int t3d_head_bwd_weights(const float* f, const t3d_prologue* pro, const int64_t* cats, const float* mask, const float* dpre,
+                         const float* dlogits, float* dwreg, float* dbreg, float* dwcls, float* dbcls, int B, int F, int ncls,
+                         void* stream);
 
 /* Keypoint / class losses of torchdet3d/losses/regression_losses.py + builders/loss_builder.py:7-28,
  * combined as LossManager.parse_losses does (:79-95), value AND gradient in one launch, plus the
