@@ -302,7 +302,7 @@ __global__ __launch_bounds__(256) void gap_fwd_kernel(const EwArgs a) {
 
 // dz[b][hw][c] = dpooled[b][c]/HW * act'(scale*y+shift); stats.  grid (nb, ceil(CG/32)): block loops over samples
 template <typename T>
-__global__ __launch_bounds__(256) void gap_bwd_kernel(const EwArgs a, int B) {
+__global__ __launch_bounds__(256) void gap_bwd_kernel(const EwArgs a, int B, const int g_nrep, const long long g_rstride) {
   __shared__ float red[2][8][32 * 8];
   const int CG = a.C / 8;
   const int cgl = threadIdx.x & 31, slot = threadIdx.x >> 5;
@@ -331,9 +331,11 @@ __global__ __launch_bounds__(256) void gap_bwd_kernel(const EwArgs a, int B) {
         float v[8], d[8];
         Vec8<T>::load(y + off, v);
 #pragma unroll
+        for (int j = 0; j < 8; ++j) d[j] = dp[j] + (hw == am[j] ? dm[j] : 0.f);
+        act_grad_affine_vec<8>(d, v, sc, sh, a.act);          // one activation switch per 8 elements
+#pragma unroll
         for (int j = 0; j < 8; ++j) {
-          const float gin = dp[j] + (hw == am[j] ? dm[j] : 0.f);
-          d[j] = Vec8<T>::round(gin * act_grad(v[j] * sc[j] + sh[j], a.act));
+          d[j] = Vec8<T>::round(d[j]);
           s1[j] += d[j];
           s2[j] = fmaf(d[j], v[j], s2[j]);
         }
@@ -356,8 +358,10 @@ __global__ __launch_bounds__(256) void gap_bwd_kernel(const EwArgs a, int B) {
         u1 += (double)red[0][q][t];
         u2 += (double)red[1][q][t];
       }
-      atomicAdd(a.stats + c, u1);
-      atomicAdd(a.stats + a.C + c, u2);
+      // one add per (block, channel), 256 sample blocks per channel: spread over the reduction replicas
+      double* st = a.stats + (size_t)(blockIdx.x % g_nrep) * g_rstride;
+      atomicAdd(st + c, u1);
+      atomicAdd(st + a.C + c, u2);
     }
   }
   t3d_fold_tail(a.fold, 1, 0);
@@ -510,8 +514,8 @@ extern "C" int t3d_pool_bwd(int dtype, const float* dpooled, const void* y, cons
   fill_pro(a, pro);
   dim3 grid(B < 256 ? B : 256, cdiv(C / 8, 32));
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-  if (dtype == T3D_F32) hipLaunchKernelGGL(gap_bwd_kernel<float>, grid, dim3(256), 0, st, a, B);
-  else if (dtype == T3D_BF16) hipLaunchKernelGGL(gap_bwd_kernel<bf16_t>, grid, dim3(256), 0, st, a, B);
+  if (dtype == T3D_F32) hipLaunchKernelGGL(gap_bwd_kernel<float>, grid, dim3(256), 0, st, a, B, g_t3d_reduce.nrep, g_t3d_reduce.stats_stride);
+  else if (dtype == T3D_BF16) hipLaunchKernelGGL(gap_bwd_kernel<bf16_t>, grid, dim3(256), 0, st, a, B, g_t3d_reduce.nrep, g_t3d_reduce.stats_stride);
   else return T3D_ERR_ARG;
   T3D_CHECK_LAUNCH();
   return T3D_OK;
