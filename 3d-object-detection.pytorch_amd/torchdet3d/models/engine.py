@@ -66,9 +66,14 @@ def _concurrent_stream(device, tries=8):
                 probe.add_(1.0)
                 e_side.record(st)
             torch.cuda.synchronize(device)
-            if e0.elapsed_time(e_side) < 0.5 * e0.elapsed_time(e_main):
+            ratio = e0.elapsed_time(e_side) / max(e0.elapsed_time(e_main), 1e-6)
+            _concurrent_stream.log.append(round(ratio, 3))
+            if ratio < 0.5:
                 return st
     return cands[0]
+
+
+_concurrent_stream.log = []
 
 
 class _Src:

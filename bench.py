@@ -216,6 +216,15 @@ def main():
     # for the main stream's persistent kernels to free registers, not just the kernel)
     fam = {}
     side = net._side
+    # untimed pre-warm ahead of the W warm-up steps: the first process on a fresh box sometimes ran its whole timed region
+    # 12-15 % slow (9.5-10.2 instead of 8.4-8.5 ms/step; never a later process) -- clock / power state still ramping.  About two
+    # seconds of steps first; the W warm-up steps and the K timed steps follow unchanged.
+    # (a fixed count, not a time budget: with several ranks every step holds an all-reduce, so all ranks must run the same
+    # number of them)
+    prewarm_steps = 0 if os.environ.get('T3D_NO_PREWARM') else 200
+    for i in range(prewarm_steps):
+        step(i)
+    torch.cuda.synchronize()
     for i in range(args.warmup):
         if args.profile_all and i == max(1, args.warmup // 2):
             N.timer = N.KernelTimer(None)
@@ -276,7 +285,7 @@ def main():
                                       f'train step (fwd + l1/add/CE losses + bwd + AdamW{" + RCCL grad all-reduce" if world > 1 else ""})')
                                    + f', {S}x{S} crops, per-GPU batch {B}', 'global_batch': B * world, 'parallelism': f'dp{world}',
                        'final_loss': round(loss, 5), 'host_issue_ms_per_step': round(t_issue * 1e3, 3),
-                       'rccl_ranks': world if dist.is_initialized() else 0},
+                       'prewarm_steps': prewarm_steps, 'side_stream_probe': list(__import__('torchdet3d.models.engine', fromlist=['x'])._concurrent_stream.log), 'rccl_ranks': world if dist.is_initialized() else 0},
         }
         # per depthwise family: (entry, k, stride) from the launch's integer arguments (..., B, H, W, C, k, stride)
         groups = {}
