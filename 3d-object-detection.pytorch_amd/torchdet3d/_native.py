@@ -146,8 +146,15 @@ class KernelTimer:
     """Optional per-launch device timing (HIP events on the launch stream), used by bench.py.
     `only`: set of entry-point names to time (None = all).  Events are resolved after a sync."""
 
-    def __init__(self, only=None):
+    def __init__(self, only=None, prealloc=0):
         self.only, self.rec, self.sig = only, [], []
+        # events created (and recorded once, which is when torch really creates them) ahead of the timed region
+        self.pool = [torch.cuda.Event(enable_timing=True) for _ in range(prealloc)]
+        for e in self.pool:
+            e.record()
+
+    def event(self):
+        return self.pool.pop() if self.pool else torch.cuda.Event(enable_timing=True)
 
     def per_launch(self):
         """[(name, int-args signature, ms, algorithmic bytes)] in launch order."""
@@ -174,7 +181,7 @@ def call(name, *args, nbytes=None):
     fn = getattr(lib(), name)
     t = timer
     if t is not None and (t.only is None or name in t.only):
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0, e1 = t.event(), t.event()
         e0.record()
         rc = fn(*args)
         e1.record()

@@ -257,13 +257,23 @@ def main():
         N.timer = None
 
     # ---- timed region: exactly K steps; the depthwise launches (main stream) carry HIP-event pairs
-    N.timer = N.KernelTimer(set(DW_ENTRIES))
+    N.timer = N.KernelTimer(set(DW_ENTRIES), prealloc=2 * 40 * args.steps)
+    # no cyclic-GC pass inside the timed region: one in three fresh processes had a single 36-44 ms step in it
+    # (config.step_ms_min_med_max), i.e. +12 % on the 30-step average, from a collection over the freshly imported heap
+    import gc
+    gc.collect()
+    gc.disable()
     barrier()
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]   # step boundaries on the main stream
     t0 = time.perf_counter()
+    marks[0].record()
     for i in range(args.steps):
         step(i)
+        marks[i + 1].record()
     barrier()
     dt = time.perf_counter() - t0
+    gc.enable()
+    per_step = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps))
     launches = N.timer.per_launch() if N.timer else []
     N.timer = None
     if world > 1:
@@ -285,7 +295,7 @@ def main():
                                       f'train step (fwd + l1/add/CE losses + bwd + AdamW{" + RCCL grad all-reduce" if world > 1 else ""})')
                                    + f', {S}x{S} crops, per-GPU batch {B}', 'global_batch': B * world, 'parallelism': f'dp{world}',
                        'final_loss': round(loss, 5), 'host_issue_ms_per_step': round(t_issue * 1e3, 3),
-                       'prewarm_steps': prewarm_steps, 'side_stream_probe': list(__import__('torchdet3d.models.engine', fromlist=['x'])._concurrent_stream.log), 'rccl_ranks': world if dist.is_initialized() else 0},
+                       'prewarm_steps': prewarm_steps, 'step_ms_min_med_max': [round(per_step[0], 3), round(per_step[len(per_step) // 2], 3), round(per_step[-1], 3)], 'side_stream_probe': list(__import__('torchdet3d.models.engine', fromlist=['x'])._concurrent_stream.log), 'rccl_ranks': world if dist.is_initialized() else 0},
         }
         # per depthwise family: (entry, k, stride) from the launch's integer arguments (..., B, H, W, C, k, stride)
         groups = {}
