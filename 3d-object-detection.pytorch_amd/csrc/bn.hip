@@ -100,7 +100,24 @@ __global__ void bn_bwd_finalize_kernel(const double* __restrict__ stats, int nre
   if (dbeta) dbeta[c] = (float)s1;
 }
 
+// a requested finalize whose consumer has no derive prologue: the same arithmetic as a launch of its own, driven by the
+// device-resident descriptor (the host does not know its contents); 64 channels per workgroup, C <= 64 * gridDim.x
+__global__ __launch_bounds__(256) void bn_fold_kernel(const T3dFold* __restrict__ fp) {
+  __shared__ float sink[3 * 64];
+  const int C = fp->C, cbase = blockIdx.x * 64;
+  if (cbase >= C) return;
+  t3d_fold_block(fp, cbase, min(64, C - cbase), sink, 64, true);
+}
+
 }  // namespace
+
+int t3d_fold_fallback(const void* key, hipStream_t st) {
+  const T3dFold* d = t3d_take_fold(key);
+  if (!d) return T3D_OK;
+  hipLaunchKernelGGL(bn_fold_kernel, dim3(32), dim3(256), 0, st, d);      // up to 2048 channels
+  T3D_CHECK_LAUNCH();
+  return T3D_OK;
+}
 
 extern "C" int t3d_bn_finalize(const double* stats, int C, double count, const float* gamma, const float* beta,
                                float* running_mean, float* running_var, int64_t* num_batches_tracked,

@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 #include "../../include/t3d.h"
 
 typedef __bf16 bf16_t;
@@ -33,82 +34,60 @@ struct T3dWorkspace { void* ptr; long long bytes; };
 extern T3dWorkspace g_t3d_ws;
 extern T3dWorkspace g_t3d_ws_main;   // scratch of the launches on the caller's MAIN stream (t3d_set_main_workspace)
 
-// BatchNorm finalize folded into the LAST workgroup of the kernel that produced the sums (t3d_fold_request, misc.hip;
-// descriptor: t3d_bn_fold in include/t3d.h, in DEVICE memory -- the kernels take one pointer, not the ~130 bytes: the
-// streaming kernels sit at the SGPR limit and the by-value form spilled scalars into their row loops, -40 %).
-// Every workgroup ends with: its stat atomics -> wait for them -> barrier -> one ticket from a device counter; the
-// workgroup that draws the last ticket knows all sums are complete, acquires, and does what t3d_bn_finalize /
-// t3d_bn_bwd_finalize would have done in a launch of their own (~5 us each, ~100 of them per training step, all on the
-// critical stream).
+// BatchNorm finalize DERIVED BY THE CONSUMER (t3d_fold_request, misc.hip; descriptor: t3d_bn_fold in include/t3d.h, in
+// DEVICE memory -- the kernels take one pointer, not the ~130 bytes: the streaming kernels sit at the SGPR limit and a
+// by-value descriptor spilled scalars into their row loops, -40 %).  t3d_bn_finalize / t3d_bn_bwd_finalize are ~5-us
+// launches between every convolution and its consumer, ~100 per training step on the critical stream: with the launch
+// gaps 0.64 ms of an 8.4-ms step (skip-the-launch ablation, tools/ablate.sh).  Folding them into the PRODUCER's last
+// workgroup needs a device-wide "all sums have arrived" and was slower than the launches (round 2: the release fence
+// writes back the XCD's dirty L2 lines; without it every wave waits for its output stores before it may exit).  The
+// CONSUMER needs no such thing -- the kernel boundary already orders the sums before it -- so the first kernel that
+// reads a BatchNorm's coefficients derives them itself: every workgroup computes the channels it is going to use from
+// the replica sums (same arithmetic as bn.hip, all loads L2 hits), and one designated workgroup per channel also
+// PUBLISHES what the standalone finalize would have written (scale / shift / mean / invstd + running statistics, or
+// alpha / beta / gamma + dgamma / dbeta) for every later reader (the backward, the weight-gradient stream).
 typedef t3d_bn_fold T3dFold;
-struct T3dFoldReq { const T3dFold* desc; const double* stats; };
+struct T3dFoldReq { const T3dFold* desc; const void* key; };
 extern T3dFoldReq g_t3d_fold;
-// host side: the pending request if it is for the sums this launch accumulates (consumes it), else null
-inline const T3dFold* t3d_take_fold(const double* stats) {
-  if (!stats || !g_t3d_fold.desc || g_t3d_fold.stats != stats) return nullptr;
+// host side: the pending request if it names the coefficient array this launch reads (consumes it), else null
+inline const T3dFold* t3d_take_fold(const void* key) {
+  if (!key || !g_t3d_fold.desc || g_t3d_fold.key != key) return nullptr;
   const T3dFold* d = g_t3d_fold.desc;
   g_t3d_fold.desc = nullptr;
   return d;
 }
 
-// called by ALL threads of every workgroup, after the workgroup's stat atomics have been issued
-__device__ __forceinline__ void t3d_fold_tail(const T3dFold* __restrict__ fp, int nrep, long long rstride) {
-  if (fp == nullptr) return;
-  // 16 bytes, 16-aligned: the kernels' dynamic LDS starts behind this static block, and an odd 4-byte shift of that
-  // base turned their 8- / 16-byte LDS reads (stencil weights) into misaligned ones: the depthwise backward lost 40 %
-  __shared__ __attribute__((aligned(16))) int s_lastv[4];
-  int& s_last = s_lastv[0];
-  // The sums leave as device-scope atomics, which are performed at the memory side: waiting for them (vmcnt) orders
-  // them before the ticket.  NOT __threadfence(): its release half writes back the XCD's dirty L2 lines -- after a
-  // kernel that has just stored hundreds of MB that made every workgroup's exit cost more than the finalize launch
-  // it replaces (measured: step 9.4 -> 15.9 ms).
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    const unsigned nblk = gridDim.x * gridDim.y * gridDim.z;
-    s_last = atomicAdd(fp->counter, 1u) == nblk - 1;
-  }
-  __syncthreads();
-  if (!s_last) return;
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+// host side, for the launch paths WITHOUT a derive prologue (fp32 parity kernels, tiled fallbacks): if a request for `key`
+// is pending, run the finalize as a launch of its own on `st` (bn.hip) and consume the request
+int t3d_fold_fallback(const void* key, hipStream_t st);
+
+// Whole workgroup: channels [cbase, cbase + Cb) -> dst[0 .. Cb) = o0, dst[ld .. ld + Cb) = o1, dst[2 ld ..) = o2 (kind 2);
+// ends with a barrier.  One thread per channel (consecutive threads = consecutive channels: coalesced 8-B loads), U
+// channels per thread at once when the replica count leaves registers for it; every replica load is issued before the
+// first add (the sums were written by device-scope atomics and live at the memory side, ~2 us away: a loop with a
+// data-dependent trip count would make one round trip per iteration).  `between` runs once per thread between the issue
+// of the first batch of loads and their use -- work that does not need the coefficients (weight staging) hides the round
+// trip.  `publish`: this workgroup is the one that writes the channels' finalize outputs.
+struct T3dNoop { __device__ __forceinline__ void operator()() const {} };
+template <class Between = T3dNoop>
+__device__ __forceinline__ void t3d_fold_block(const T3dFold* __restrict__ fp, int cbase, int Cb, float* dst, int ld,
+                                               bool publish, Between between = Between()) {
   const T3dFold f = *fp;
-  if (threadIdx.x == 0) {
-    *f.counter = 0;
-    if (f.kind == 1 && f.nbt) *f.nbt += 1;
-  }
-  // 16 replica lanes per channel (all replica loads of a channel in flight at once), 4 channel groups unrolled
-  const int rl = threadIdx.x & 15, cl = threadIdx.x >> 4, cpp = blockDim.x >> 4;     // channels per pass
-  for (int c0 = 0; c0 < f.C; c0 += 4 * cpp) {
-    double s1[4], s2[4];
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int c = c0 + u * cpp + cl;
-      s1[u] = s2[u] = 0.0;
-      if (c < f.C) {
-        for (int r = rl; r < nrep; r += 16) {
-          s1[u] += f.stats[r * rstride + c];
-          s2[u] += f.stats[r * rstride + f.C + c];
-        }
-      }
-    }
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-#pragma unroll
-      for (int o = 8; o > 0; o >>= 1) {
-        s1[u] += __shfl_xor(s1[u], o, 16);
-        s2[u] += __shfl_xor(s2[u], o, 16);
-      }
-      const int c = c0 + u * cpp + cl;
-      if (c >= f.C || rl != 0) continue;
-      if (f.kind == 1) {
-        const double mean = s1[u] / f.count;
-        double var = s2[u] / f.count - mean * mean;  // biased
-        if (var < 0.0) var = 0.0;
-        const float invstd = (float)(1.0 / sqrt(var + (double)f.eps));
-        const float g = f.gamma ? f.gamma[c] : 1.f, b = f.beta ? f.beta[c] : 0.f;
-        const float sc = g * invstd;
+  const int nthr = blockDim.x;
+  auto finish = [&](int i, double s1, double s2) {
+    const int c = cbase + i;
+    if (f.kind == 1) {
+      const double mean = s1 / f.count;
+      double var = s2 / f.count - mean * mean;  // biased
+      if (var < 0.0) var = 0.0;
+      const float invstd = (float)(1.0 / sqrt(var + (double)f.eps));
+      const float g = f.gamma ? f.gamma[c] : 1.f, b = f.beta ? f.beta[c] : 0.f;
+      const float sc = g * invstd, sh = b - (float)mean * sc;
+      dst[i] = sc;
+      dst[ld + i] = sh;
+      if (publish) {
         f.o0[c] = sc;
-        f.o1[c] = b - (float)mean * sc;
+        f.o1[c] = sh;
         if (f.o2) f.o2[c] = (float)mean;
         if (f.o3) f.o3[c] = invstd;
         if (f.rm) f.rm[c] = (1.f - f.momentum) * f.rm[c] + f.momentum * (float)mean;
@@ -116,19 +95,63 @@ __device__ __forceinline__ void t3d_fold_tail(const T3dFold* __restrict__ fp, in
           const double unbiased = f.count > 1.0 ? var * f.count / (f.count - 1.0) : var;
           f.rv[c] = (1.f - f.momentum) * f.rv[c] + f.momentum * (float)unbiased;
         }
-      } else {
-        const double mu = (double)f.mean[c], is = (double)f.invstd[c];
-        const double dg = is * (s2[u] - mu * s1[u]);
-        const double al = (double)(f.gamma ? f.gamma[c] : 1.f) * is;
-        const double be = -al * is * dg / f.count;
+        if (c == 0 && f.nbt) *f.nbt += 1;
+      }
+    } else {
+      const double mu = (double)f.mean[c], is = (double)f.invstd[c];
+      const double dg = is * (s2 - mu * s1);
+      const double al = (double)(f.gamma ? f.gamma[c] : 1.f) * is;
+      const double be = -al * is * dg / f.count;
+      const float ga = (float)(-al * s1 / f.count - be * mu);
+      dst[i] = (float)al;
+      dst[ld + i] = (float)be;
+      dst[2 * ld + i] = ga;
+      if (publish) {
         f.o0[c] = (float)al;
         f.o1[c] = (float)be;
-        f.o2[c] = (float)(-al * s1[u] / f.count - be * mu);
+        f.o2[c] = ga;
         if (f.o3) f.o3[c] = (float)dg;
-        if (f.o4) f.o4[c] = (float)s1[u];
+        if (f.o4) f.o4[c] = (float)s1;
       }
     }
-  }
+  };
+  auto pass = [&](auto nr_tag, auto u_tag) {
+    constexpr int NR = decltype(nr_tag)::value, U = decltype(u_tag)::value;
+    bool first = true;
+    for (int i0 = threadIdx.x; i0 < Cb || first; i0 += U * nthr) {      // (every thread runs the first round: `between`)
+      double v1[U][NR], v2[U][NR];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int i = min(i0 + u * nthr, Cb - 1);          // clamped: the surplus lanes' results are never used
+        const double* p = f.stats + cbase + i;
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+          const size_t o = (size_t)min(r, f.nrep - 1) * f.rstride;
+          v1[u][r] = p[o];
+          v2[u][r] = p[o + f.C];
+        }
+      }
+      if (first) {
+        between();
+        first = false;
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        double s1 = 0.0, s2 = 0.0;
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+          s1 += r < f.nrep ? v1[u][r] : 0.0;
+          s2 += r < f.nrep ? v2[u][r] : 0.0;
+        }
+        if (i0 + u * nthr < Cb) finish(i0 + u * nthr, s1, s2);
+      }
+    }
+  };
+  if (f.nrep <= 2) pass(std::integral_constant<int, 2>{}, std::integral_constant<int, 8>{});
+  else if (f.nrep <= 4) pass(std::integral_constant<int, 4>{}, std::integral_constant<int, 4>{});
+  else if (f.nrep <= 8) pass(std::integral_constant<int, 8>{}, std::integral_constant<int, 2>{});
+  else pass(std::integral_constant<int, 16>{}, std::integral_constant<int, 1>{});
+  __syncthreads();
 }
 
 // ---- 8-channel vector load/store, storage type T, math in fp32 ------------

@@ -37,7 +37,7 @@ struct Dw3BArgs {
   int nrep;
   long long rstride;
   int noflush;   // profiling ablation only (T3D_DEBUG_NOFLUSH): skip the end-of-block reduction
-  const T3dFold* fold;  // BatchNorm backward finalize folded into the last workgroup (common.h)
+  const T3dFold* fold;  // requested BatchNorm-backward finalize of (alpha, beta, gamma), derived in the prologue (common.h)
 };
 
 template <typename T, int CH> using rawvec = T __attribute__((ext_vector_type(CH)));
@@ -279,7 +279,6 @@ __global__ __launch_bounds__(256) void dw3_bwd_s1_kernel(const Dw3BArgs a) {
       }
     }
   }
-  t3d_fold_tail(a.fold, a.nrep, a.rstride);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -356,6 +355,10 @@ __global__ __launch_bounds__(NTH) void dw3_bwd2_kernel(const Dw3BArgs a) {
     __syncthreads();
   }
 
+  // requested BatchNorm-backward finalize of the gradient's coefficients (alpha, beta, gamma), derived here (common.h):
+  // the block's own channel range into the scratch behind the weights; one block per channel range publishes
+  float* fco = lred + 9 * Cb;           // [3][Cb]
+  if (a.fold) t3d_fold_block(a.fold, cbase, Cb, fco, Cb, a.slab ? blockIdx.x == 0 : (blockIdx.x == 0 && blockIdx.y == 0));
   f32x2 sc2[H2], sh2[H2], al2[H2], be2[H2], ga2[H2];
   f32x2 wacc[9][H2];
   float psum[CH], psq[CH];
@@ -364,14 +367,22 @@ __global__ __launch_bounds__(NTH) void dw3_bwd2_kernel(const Dw3BArgs a) {
     const int c = c0 + 2 * h;
     sc2[h] = f32x2{a.scale ? a.scale[c] : 1.f, a.scale ? a.scale[c + 1] : 1.f};
     sh2[h] = f32x2{a.scale ? a.shift[c] : 0.f, a.scale ? a.shift[c + 1] : 0.f};
-    be2[h] = f32x2{a.beta[c], a.beta[c + 1]};
-    al2[h] = a.per_sample ? f32x2{0.f, 0.f} : f32x2{a.alpha[c], a.alpha[c + 1]};
-    ga2[h] = a.per_sample ? f32x2{0.f, 0.f} : f32x2{a.gamma[c], a.gamma[c + 1]};
+    if (a.fold) {
+      const float* fc = fco + (c - cbase);
+      al2[h] = f32x2{fc[0], fc[1]};
+      be2[h] = f32x2{fc[Cb], fc[Cb + 1]};
+      ga2[h] = f32x2{fc[2 * Cb], fc[2 * Cb + 1]};
+    } else {
+      be2[h] = f32x2{a.beta[c], a.beta[c + 1]};
+      al2[h] = a.per_sample ? f32x2{0.f, 0.f} : f32x2{a.alpha[c], a.alpha[c + 1]};
+      ga2[h] = a.per_sample ? f32x2{0.f, 0.f} : f32x2{a.gamma[c], a.gamma[c + 1]};
+    }
 #pragma unroll
     for (int t = 0; t < 9; ++t) wacc[t][h] = f32x2{0.f, 0.f};
   }
 #pragma unroll
   for (int i = 0; i < CH; ++i) psum[i] = psq[i] = 0.f;
+  if (a.fold) __syncthreads();          // the scratch is cleared again for the end-of-kernel reduction
 
   // Addressing: every row base is wave-uniform (scalar registers / SALU), the lane part (column, channel group) is a
   // 32-bit element offset computed once per item -- no 64-bit vector address arithmetic in the row loop.
@@ -695,7 +706,6 @@ __global__ __launch_bounds__(NTH) void dw3_bwd2_kernel(const Dw3BArgs a) {
       }
     }
   }
-  t3d_fold_tail(a.fold, a.nrep, a.rstride);
 }
 
 template <typename T, int CH>
@@ -739,13 +749,19 @@ int launch_s1c(Dw3BArgs& a, hipStream_t st) {
     if (gx < 1) gx = 1;
     grid = dim3(gx, ns);
   }
-  const size_t lds = (size_t)11 * a.C * sizeof(float);
+  if (two_col && (size_t)a.B * a.H * a.W * a.C * sizeof(T) >= (1ull << 32)) return T3D_ERR_UNSUPPORTED;   // 32-bit buffer offsets
+  const size_t lds = (size_t)12 * a.C * sizeof(float);     // [11][C] reduction scratch; [9 .. 12)[Cb]: derived coefficients
   a.noflush = getenv("T3D_DEBUG_NOFLUSH") ? 1 : 0;
-  a.fold = t3d_take_fold(a.stats);
+  // a pending BatchNorm-backward finalize of this launch's gradient coefficients is derived in the two-column kernel
+  if (two_col && !a.per_sample) {
+    a.fold = t3d_take_fold(a.alpha);
+  } else {
+    if (const int rc = t3d_fold_fallback(a.alpha, st)) return rc;
+    a.fold = nullptr;
+  }
   // (forcing 3-4 waves/SIMD through launch bounds spills to scratch: 3-7x slower)
   // (a 6-row prefetch ring needs AGPR spill space -> 1 wave/SIMD: 40 % slower; PMC: VALU busy 46 %, memory unit stalled
   //  0.1 % -- the kernel is bound by the latency two resident waves per SIMD can hide)
-  if (two_col && (size_t)a.B * a.H * a.W * a.C * sizeof(T) >= (1ull << 32)) return T3D_ERR_UNSUPPORTED;   // 32-bit buffer offsets
   if (two_col) {
     switch (a.act) {
       case T3D_ACT_RELU: hipLaunchKernelGGL((dw3_bwd2_kernel<T, PF, 256, CH, T3D_ACT_RELU>), grid, dim3(256), lds, st, a); break;
@@ -803,6 +819,8 @@ __global__ __launch_bounds__(NTH) void dw3_bwd_s2_kernel(const Dw3BArgs a) {
   const bool affine = a.scale != nullptr || a.act != T3D_ACT_NONE;
   const int cbase = a.slab ? blockIdx.y * 64 * CH : 0;
   const int Cb = a.slab ? min(64 * CH, a.C - cbase) : a.C;
+  // requested BatchNorm-backward finalize of the gradient's coefficients, derived here (see dw3_bwd2_kernel)
+  if (a.fold) t3d_fold_block(a.fold, cbase, Cb, lred, Cb, a.slab ? blockIdx.x == 0 : (blockIdx.x == 0 && blockIdx.y == 0));
 
   f32x2 sc2[H2], sh2[H2], al2[H2], be2[H2], ga2[H2];
   f32x2 wt[9][H2], wacc[9][H2];
@@ -820,9 +838,16 @@ __global__ __launch_bounds__(NTH) void dw3_bwd_s2_kernel(const Dw3BArgs a) {
       const int c = c0 + 2 * h;
       sc2[h] = f32x2{a.scale ? a.scale[c] : 1.f, a.scale ? a.scale[c + 1] : 1.f};
       sh2[h] = f32x2{a.scale ? a.shift[c] : 0.f, a.scale ? a.shift[c + 1] : 0.f};
-      be2[h] = f32x2{a.beta[c], a.beta[c + 1]};
-      al2[h] = a.per_sample ? f32x2{0.f, 0.f} : f32x2{a.alpha[c], a.alpha[c + 1]};
-      ga2[h] = a.per_sample ? f32x2{0.f, 0.f} : f32x2{a.gamma[c], a.gamma[c + 1]};
+      if (a.fold) {
+        const float* fc = lred + (c - cbase);
+        al2[h] = f32x2{fc[0], fc[1]};
+        be2[h] = f32x2{fc[Cb], fc[Cb + 1]};
+        ga2[h] = f32x2{fc[2 * Cb], fc[2 * Cb + 1]};
+      } else {
+        be2[h] = f32x2{a.beta[c], a.beta[c + 1]};
+        al2[h] = a.per_sample ? f32x2{0.f, 0.f} : f32x2{a.alpha[c], a.alpha[c + 1]};
+        ga2[h] = a.per_sample ? f32x2{0.f, 0.f} : f32x2{a.gamma[c], a.gamma[c + 1]};
+      }
 #pragma unroll
       for (int t = 0; t < 9; ++t) {
         wt[t][h] = f32x2{wb[(2 * h) * 9 + t], wb[(2 * h + 1) * 9 + t]};
@@ -830,6 +855,7 @@ __global__ __launch_bounds__(NTH) void dw3_bwd_s2_kernel(const Dw3BArgs a) {
       }
     }
   }
+  if (a.fold) __syncthreads();          // the scratch is cleared again for the end-of-kernel reduction
 #pragma unroll
   for (int i = 0; i < CH; ++i) psum[i] = psq[i] = 0.f;
   float scf[CH] = {sc2[0][0], sc2[0][1], sc2[1][0], sc2[1][1]}, shf[CH] = {sh2[0][0], sh2[0][1], sh2[1][0], sh2[1][1]};
@@ -1041,7 +1067,6 @@ __global__ __launch_bounds__(NTH) void dw3_bwd_s2_kernel(const Dw3BArgs a) {
       }
     }
   }
-  t3d_fold_tail(a.fold, a.nrep, a.rstride);
 }
 
 template <typename T>
@@ -1081,7 +1106,12 @@ int launch_s2(Dw3BArgs& a, hipStream_t st) {
   }
   const size_t lds = (size_t)11 * (a.slab ? 64 * CH : a.C) * sizeof(float);
   a.noflush = getenv("T3D_DEBUG_NOFLUSH") ? 1 : 0;
-  a.fold = t3d_take_fold(a.stats);
+  if (!a.per_sample) {
+    a.fold = t3d_take_fold(a.alpha);
+  } else {
+    if (const int rc = t3d_fold_fallback(a.alpha, st)) return rc;
+    a.fold = nullptr;
+  }
   // (a compile-time activation, as in the stride-1 kernel, pushes this one over 256 VGPRs -> 1 wave/SIMD: slower)
   hipLaunchKernelGGL((dw3_bwd_s2_kernel<T, PF, 256>), grid, dim3(256), lds, st, a);
   T3D_CHECK_LAUNCH();

@@ -32,7 +32,7 @@ struct Dw3Args {
   int nitems;      // work items a thread walks: flattened: B*nchunks; slab: Wo*B*nchunks
   int nrep;        // reduction replicas (common.h)
   long long rstride;
-  const T3dFold* fold;    // BatchNorm finalize folded into the last workgroup (common.h)
+  const T3dFold* fold;    // requested BatchNorm finalize of the INPUT's coefficients, derived in the prologue (common.h)
 };
 
 template <typename T, int CH> using rawvec = T __attribute__((ext_vector_type(CH)));
@@ -89,6 +89,10 @@ __global__ __launch_bounds__(256) void dw3_fwd_kernel(const Dw3Args a) {
   }
   const int c0 = cg * CH;
   const bool affine = a.scale != nullptr || a.act != T3D_ACT_NONE;
+  // the producer's BatchNorm finalize, derived here when requested (common.h): the block's own channel range through
+  // the statistics scratch (free until the end of the kernel); one block per channel range publishes
+  const int fbase = a.slab ? blockIdx.y * 64 * CH : 0, fCb = a.slab ? min(64 * CH, a.C - fbase) : a.C;
+  if (a.fold) t3d_fold_block(a.fold, fbase, fCb, lstat, fCb, a.slab ? blockIdx.x == 0 : (blockIdx.x == 0 && blockIdx.y == 0));
 
   float wt[9][CH], sc[CH], sh[CH], psum[CH], psq[CH];
   {
@@ -102,13 +106,14 @@ __global__ __launch_bounds__(256) void dw3_fwd_kernel(const Dw3Args a) {
     }
 #pragma unroll
     for (int i = 0; i < CH; ++i) {
-      sc[i] = a.scale ? a.scale[c0 + i] : 1.f;
-      sh[i] = a.scale ? a.shift[c0 + i] : 0.f;
+      sc[i] = a.fold ? lstat[c0 - fbase + i] : (a.scale ? a.scale[c0 + i] : 1.f);
+      sh[i] = a.fold ? lstat[fCb + c0 - fbase + i] : (a.scale ? a.shift[c0 + i] : 0.f);
       psum[i] = psq[i] = 0.f;
 #pragma unroll
       for (int t = 0; t < 9; ++t) wt[t][i] = wb[i * 9 + t];
     }
   }
+  if (a.fold) __syncthreads();      // the scratch is zeroed again at the end of the kernel
   for (int q = q0; q < a.nitems && on; q += qstride) {
   int ox, rest;
   if (!a.slab) { ox = ox_fixed; rest = q; } else { ox = q % a.Wo; rest = q / a.Wo; }
@@ -238,7 +243,6 @@ __global__ __launch_bounds__(256) void dw3_fwd_kernel(const Dw3Args a) {
         atomicAdd(a.stats + (size_t)((blockIdx.x + blockIdx.y) % a.nrep) * a.rstride + (size_t)(i / Cb) * a.C + cbase + i % Cb,
                   (double)lstat[i]);
   }
-  t3d_fold_tail(a.fold, a.nrep, a.rstride);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -271,27 +275,39 @@ __global__ __launch_bounds__(256) void dw3_fwd2_kernel(const Dw3Args a) {
   }
   const int c0 = cg * CH;
   const bool affine = a.scale != nullptr || a.act != T3D_ACT_NONE;
-
+  // requested BatchNorm finalize of the producer: derived here (see dw3_fwd_kernel)
+  const int fbase = a.slab ? blockIdx.y * 64 * CH : 0, fCb = a.slab ? min(64 * CH, a.C - fbase) : a.C;
   f32x2 w2[9][H2], sc2[H2], sh2[H2];
   float psum[CH], psq[CH];
   {
     float wb[CH * 9];
-    const float4* wp = reinterpret_cast<const float4*>(a.w + (size_t)c0 * 9);
+    auto load_w = [&]() {
+      const float4* wp = reinterpret_cast<const float4*>(a.w + (size_t)c0 * 9);
 #pragma unroll
-    for (int i = 0; i < CH * 9 / 4; ++i) {
-      const float4 q = wp[i];
-      wb[4 * i] = q.x; wb[4 * i + 1] = q.y; wb[4 * i + 2] = q.z; wb[4 * i + 3] = q.w;
-    }
+      for (int i = 0; i < CH * 9 / 4; ++i) {
+        const float4 q = wp[i];
+        wb[4 * i] = q.x; wb[4 * i + 1] = q.y; wb[4 * i + 2] = q.z; wb[4 * i + 3] = q.w;
+      }
+    };
+    // (the stencil weights are fetched while the sums of a derived finalize are in flight)
+    if (a.fold) t3d_fold_block(a.fold, fbase, fCb, lstat, fCb, a.slab ? blockIdx.x == 0 : (blockIdx.x == 0 && blockIdx.y == 0), load_w);
+    else load_w();
 #pragma unroll
     for (int h = 0; h < H2; ++h) {
-      sc2[h] = f32x2{a.scale ? a.scale[c0 + 2 * h] : 1.f, a.scale ? a.scale[c0 + 2 * h + 1] : 1.f};
-      sh2[h] = f32x2{a.scale ? a.shift[c0 + 2 * h] : 0.f, a.scale ? a.shift[c0 + 2 * h + 1] : 0.f};
+      if (a.fold) {
+        sc2[h] = f32x2{lstat[c0 - fbase + 2 * h], lstat[c0 - fbase + 2 * h + 1]};
+        sh2[h] = f32x2{lstat[fCb + c0 - fbase + 2 * h], lstat[fCb + c0 - fbase + 2 * h + 1]};
+      } else {
+        sc2[h] = f32x2{a.scale ? a.scale[c0 + 2 * h] : 1.f, a.scale ? a.scale[c0 + 2 * h + 1] : 1.f};
+        sh2[h] = f32x2{a.scale ? a.shift[c0 + 2 * h] : 0.f, a.scale ? a.shift[c0 + 2 * h + 1] : 0.f};
+      }
 #pragma unroll
       for (int t = 0; t < 9; ++t) w2[t][h] = f32x2{wb[(2 * h) * 9 + t], wb[(2 * h + 1) * 9 + t]};
     }
 #pragma unroll
     for (int i = 0; i < CH; ++i) psum[i] = psq[i] = 0.f;
   }
+  if (a.fold) __syncthreads();      // the scratch is zeroed again at the end of the kernel
 
   for (int q = q0; q < a.nitems && on; q += qstride) {
     int xp, rest;
@@ -446,7 +462,6 @@ __global__ __launch_bounds__(256) void dw3_fwd2_kernel(const Dw3Args a) {
         atomicAdd(a.stats + (size_t)((blockIdx.x + blockIdx.y) % a.nrep) * a.rstride + (size_t)(i / Cb) * a.C + cbase + i % Cb,
                   (double)lstat[i]);
   }
-  t3d_fold_tail(a.fold, a.nrep, a.rstride);
 }
 
 template <typename T, int CH>
@@ -490,7 +505,7 @@ int launch_ch(Dw3Args& a, int s, hipStream_t st) {
     grid = dim3(gx, ns);
   }
   const size_t lds = (size_t)2 * a.C * sizeof(float);
-  a.fold = t3d_take_fold(a.stats);
+  a.fold = t3d_take_fold(a.scale);
   if (use2) hipLaunchKernelGGL((dw3_fwd2_kernel<T, PF>), grid, dim3(256), lds, st, a);
   else if (s == 1) hipLaunchKernelGGL((dw3_fwd_kernel<T, 1, CH, PF>), grid, dim3(256), lds, st, a);
   else hipLaunchKernelGGL((dw3_fwd_kernel<T, 2, CH, PF>), grid, dim3(256), lds, st, a);

@@ -521,6 +521,7 @@ int t3d_dw5_bwd_stream(int dtype, const void* dz, const void* y, const t3d_bnbwd
                        int W, int C, int stride, hipStream_t st) {
   if (stride != 1 && stride != 2) return T3D_ERR_UNSUPPORTED;
   if (C % 2) return T3D_ERR_UNSUPPORTED;
+  if (const int rc = t3d_fold_fallback(bb->alpha, st)) return rc;     // no derive prologue in the 5x5 kernels
   Dw5BArgs a{};
   a.dz = dz; a.y = y; a.x = x; a.res = residual; a.dx = dx; a.w = w;
   a.alpha = bb->alpha; a.beta = bb->beta; a.gamma = bb->gamma; a.per_sample = bb->per_sample;

@@ -338,6 +338,8 @@ extern "C" int t3d_dwconv_bwd(int dtype, const void* dz, const void* y, const t3
                                       reinterpret_cast<hipStream_t>(stream));
     if (rc != T3D_ERR_UNSUPPORTED) return rc;
   }
+  // the tiled kernel reads finished coefficients: a pending derive request for them becomes a launch of its own
+  if (const int rc = t3d_fold_fallback(bb->alpha, reinterpret_cast<hipStream_t>(stream))) return rc;
   DwBwdArgs a{};
   a.dz = dz; a.y = y; a.x = x; a.res = residual; a.dx = dx; a.w = w;
   a.alpha = bb->alpha; a.beta = bb->beta; a.gamma = bb->gamma; a.per_sample = bb->per_sample;

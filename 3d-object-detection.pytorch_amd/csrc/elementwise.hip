@@ -65,7 +65,7 @@ struct EwArgs {
   int act;
   int M, C, HW;
   float inv_hw;
-  const T3dFold* fold;        // BatchNorm backward finalize folded into the last workgroup (common.h)
+  const T3dFold* fold;        // requested BatchNorm finalize of (scale, shift), derived by the kernel (bn_apply only)
   int mode;            // global pool: T3D_POOL_AVG / _MAX / _AVGMAX
   int* argmax;         // [B,C] position (hw) of the per-sample maximum, written by the forward, read by the backward
 };
@@ -105,10 +105,17 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const EwArgs a) {
   // stride is a multiple of CG -> each thread keeps one channel group
   const size_t nthr = ((size_t)gridDim.x * 256 / CG) * CG;
   const size_t g = blockIdx.x * (size_t)256 + threadIdx.x;
+  extern __shared__ float fco[];     // [2][C], only with a requested finalize (common.h): derived here, block 0 publishes
+  if (a.fold) t3d_fold_block(a.fold, 0, a.C, fco, a.C, blockIdx.x == 0);
   if (g >= nthr) return;
   const int c0 = (int)(g % CG) * 8;
   float sc[8], sh[8];
-  load_affine(a, c0, sc, sh);
+  if (a.fold) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { sc[i] = fco[c0 + i]; sh[i] = fco[a.C + c0 + i]; }
+  } else {
+    load_affine(a, c0, sc, sh);
+  }
   for (size_t i = g; i < nvec; i += nthr) {
     float v[8];
     Vec8<T>::load(y + i * 8, v);
@@ -156,7 +163,6 @@ __global__ __launch_bounds__(256) void bn_act_bwd_kernel(const EwArgs a) {
     }
   }
   if (a.stats) flush_stats(lstat, a.C, c0, on, s1, s2, a.stats);
-  t3d_fold_tail(a.fold, 1, 0);
 }
 
 // Squeeze-excite AFTER the activation (no-expand layout, mobilenetv3.py:138-140; MobileNetV3-small features.1):
@@ -364,7 +370,6 @@ __global__ __launch_bounds__(256) void gap_bwd_kernel(const EwArgs a, int B, con
       atomicAdd(st + a.C + c, u2);
     }
   }
-  t3d_fold_tail(a.fold, 1, 0);
 }
 
 inline void fill_pro(EwArgs& a, const t3d_prologue* pro) {
@@ -417,8 +422,10 @@ extern "C" int t3d_bn_apply(int dtype, const void* y, const t3d_prologue* pro, c
   const int grid = ew_grid((size_t)M * (C / 8));
   if ((size_t)grid * 256 < (size_t)(C / 8)) return T3D_ERR_UNSUPPORTED;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-  if (dtype == T3D_F32) hipLaunchKernelGGL(bn_apply_kernel<float>, dim3(grid), dim3(256), 0, st, a);
-  else if (dtype == T3D_BF16) hipLaunchKernelGGL(bn_apply_kernel<bf16_t>, dim3(grid), dim3(256), 0, st, a);
+  a.fold = t3d_take_fold(a.scale);      // a requested finalize of this BatchNorm is derived inside the kernel
+  const size_t lds = a.fold ? (size_t)2 * C * sizeof(float) : 0;
+  if (dtype == T3D_F32) hipLaunchKernelGGL(bn_apply_kernel<float>, dim3(grid), dim3(256), lds, st, a);
+  else if (dtype == T3D_BF16) hipLaunchKernelGGL(bn_apply_kernel<bf16_t>, dim3(grid), dim3(256), lds, st, a);
   else return T3D_ERR_ARG;
   T3D_CHECK_LAUNCH();
   return T3D_OK;
@@ -431,7 +438,6 @@ extern "C" int t3d_bn_act_bwd(int dtype, const void* dz, const void* y, const t3
   EwArgs a{};
   a.a = dz; a.b = y; a.out = dzp; a.stats = stats; a.M = M; a.C = C;
   fill_pro(a, pro);
-  a.fold = t3d_take_fold(stats);
   int grid = ew_grid((size_t)M * (C / 8));
   if (grid > 1024) grid = 1024;
   if ((size_t)grid * 256 < (size_t)(C / 8)) return T3D_ERR_UNSUPPORTED;
@@ -453,6 +459,7 @@ extern "C" int t3d_se_after_sums(int dtype, const void* dv, const void* y, const
   fill_pro(a, pro);
   dim3 grid(B, cdiv(C / 8, 32));
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (const int rc = t3d_fold_fallback(a.scale, st)) return rc;      // no derive prologue here: finalize as its own launch
   if (dtype == T3D_F32) hipLaunchKernelGGL(se_after_sums_kernel<float>, grid, dim3(256), 0, st, a);
   else if (dtype == T3D_BF16) hipLaunchKernelGGL(se_after_sums_kernel<bf16_t>, grid, dim3(256), 0, st, a);
   else return T3D_ERR_ARG;
@@ -489,6 +496,7 @@ extern "C" int t3d_pool_fwd(int dtype, const void* y, const t3d_prologue* pro, i
   fill_pro(a, pro);
   dim3 grid(B, cdiv(C / 8, 32));
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (const int rc = t3d_fold_fallback(a.scale, st)) return rc;      // no derive prologue here: finalize as its own launch
   if (dtype == T3D_F32) hipLaunchKernelGGL(gap_fwd_kernel<float>, grid, dim3(256), 0, st, a);
   else if (dtype == T3D_BF16) hipLaunchKernelGGL(gap_fwd_kernel<bf16_t>, grid, dim3(256), 0, st, a);
   else return T3D_ERR_ARG;
@@ -510,7 +518,6 @@ extern "C" int t3d_pool_bwd(int dtype, const float* dpooled, const void* y, cons
   EwArgs a{};
   a.a = y; a.vec = dpooled; a.out = dz; a.stats = stats; a.C = C; a.HW = HW; a.inv_hw = 1.f / (float)HW;
   a.mode = mode; a.argmax = const_cast<int*>(argmax);
-  a.fold = t3d_take_fold(stats);
   fill_pro(a, pro);
   dim3 grid(B < 256 ? B : 256, cdiv(C / 8, 32));
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);

@@ -250,7 +250,7 @@ extern "C" int t3d_pack_weight(int dtype, const float* w, void* out, int rows, i
 T3dReduceCfg g_t3d_reduce = {1, 0};
 
 extern "C" int t3d_set_reduction_replicas(int nrep, long long stats_stride) {
-  if (nrep < 1 || nrep > 64 || (nrep > 1 && stats_stride <= 0)) return T3D_ERR_ARG;
+  if (nrep < 1 || nrep > 16 || (nrep > 1 && stats_stride <= 0)) return T3D_ERR_ARG;
   g_t3d_reduce.nrep = nrep;
   g_t3d_reduce.stats_stride = nrep > 1 ? stats_stride : 0;
   return T3D_OK;
@@ -258,14 +258,14 @@ extern "C" int t3d_set_reduction_replicas(int nrep, long long stats_stride) {
 
 T3dFoldReq g_t3d_fold = {nullptr, nullptr};
 
-extern "C" int t3d_fold_request(const t3d_bn_fold* desc_device, const double* stats) {
-  if (!desc_device || !stats) return T3D_ERR_ARG;
+extern "C" int t3d_fold_request(const t3d_bn_fold* desc_device, const void* key) {
+  if (!desc_device || !key) return T3D_ERR_ARG;
   g_t3d_fold.desc = desc_device;
-  g_t3d_fold.stats = stats;
+  g_t3d_fold.key = key;
   return T3D_OK;
 }
 
-/* 1: a fold request is still pending (the last launch did not implement the tail); clears it either way */
+/* 1: a fold request is still pending (the last launch did not derive the coefficients); clears it either way */
 extern "C" int t3d_fold_pending(void) {
   const int p = g_t3d_fold.desc != nullptr;
   g_t3d_fold.desc = nullptr;

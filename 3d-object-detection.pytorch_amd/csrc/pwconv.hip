@@ -348,12 +348,14 @@ int launch(GemmArgs& a, hipStream_t st) {
 int dispatch(int dtype, GemmArgs& a, void* stream) {
   if (a.M <= 0 || a.Kin <= 0 || a.Nout <= 0 || (a.Kin % 8) || (a.Nout % 8) || a.HW <= 0) return T3D_ERR_ARG;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-  if (dtype == T3D_F32) return launch<float>(a, st);
   if (dtype == T3D_BF16) {
     const int rc = stream_launch(a, st);
     if (rc != T3D_ERR_UNSUPPORTED) return rc;
-    return launch<bf16_t>(a, st);
   }
+  // the LDS-tiled kernel reads finished coefficients: a pending derive request for them becomes a launch of its own
+  if (const int rc = t3d_fold_fallback(a.p0, st)) return rc;
+  if (dtype == T3D_F32) return launch<float>(a, st);
+  if (dtype == T3D_BF16) return launch<bf16_t>(a, st);
   return T3D_ERR_ARG;
 }
 

@@ -62,7 +62,7 @@ struct GemmArgs {
   const void* a2;
   int Kin2, ks1;
   int row0;   // row stride (= channel count) of a0 / a1; equals Kin without a second segment
-  const T3dFold* fold;   // BatchNorm finalize folded into the last workgroup (streaming kernel only)
+  const T3dFold* fold;   // BatchNorm finalize of the operand's coefficients derived in the prologue (streaming kernel only)
   StemSrc stem;          // stem.img != null: a0 is not a tensor, the K = 32 operand is gathered from the crops
 };
 

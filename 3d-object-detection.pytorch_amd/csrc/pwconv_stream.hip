@@ -78,8 +78,9 @@ __global__ __launch_bounds__(512, KU > 2 ? 1 : 2) void pw_stream_kernel(const Ge
   bf16_t* __restrict__ out = reinterpret_cast<bf16_t*>(a.out);
   PW_STAMP(0);
 
-  // ---- stage the weight chunk in fragment order: MFMA row lc of tile t <-> n_local = (t>>1)*32 + (lc>>2)*8 + (t&1)*4 + (lc&3)
   const int nthr = blockDim.x, WAVES = nthr >> 6;
+  auto stage_weights = [&]() {
+  // ---- stage the weight chunk in fragment order: MFMA row lc of tile t <-> n_local = (t>>1)*32 + (lc>>2)*8 + (t&1)*4 + (lc&3)
   // (eight independent loads in flight per thread, branch-free: a block of the 7x7 stage stages up to 120 KB before it
   // can start, and with one dependent load -> store round per 8 KB that prologue WAS most of those launches)
   {
@@ -113,7 +114,18 @@ __global__ __launch_bounds__(512, KU > 2 ? 1 : 2) void pw_stream_kernel(const Ge
     ecoef[i] = v ? a.e_scale[n] : 1.f;
     ecoef[BN + i] = v ? a.e_shift[n] : 0.f;
   }
+  };
   constexpr bool DGL = DG && !YF;     // two-tensor main loop with the BatchNorm-backward affine
+  if (!YF && a.fold) {
+    // the BatchNorm finalize of the operand's coefficients happens HERE (common.h): scale / shift (forward) or alpha /
+    // beta / gamma (data gradient) of all Kin channels from the replica sums; workgroup 0 publishes them
+    for (int i = a.Kin + tid; i < kpad; i += nthr) {
+      coef[i] = DG ? 0.f : 1.f; coef[kpad + i] = 0.f; coef[2 * kpad + i] = 0.f;
+    }
+    // (the weight staging runs between the issue of the sums' loads and their use: one round trip instead of two)
+    t3d_fold_block(a.fold, 0, a.Kin, coef, kpad, blockIdx.x == 0, stage_weights);
+  } else {
+  stage_weights();
   for (int i = tid; i < kpad; i += nthr) {
     const bool v = i < a.Kin;
     if (YF) {
@@ -126,6 +138,7 @@ __global__ __launch_bounds__(512, KU > 2 ? 1 : 2) void pw_stream_kernel(const Ge
       coef[kpad + i] = v ? a.p1[i] : 0.f;
       coef[2 * kpad + i] = (v && !a.per_sample) ? a.p2[i] : 0.f;
     }
+  }
   }
   __syncthreads();
   PW_STAMP(1);
@@ -459,7 +472,6 @@ __global__ __launch_bounds__(512, KU > 2 ? 1 : 2) void pw_stream_kernel(const Ge
       if (n < a.Nout) atomicAdd(a.stats + (size_t)(xb % nrep) * rstride + (size_t)(i & 1) * a.Nout + n, (double)lstat[i]);
     }
   }
-  t3d_fold_tail(a.fold, nrep, rstride);
   PW_STAMP(4);
 }
 
@@ -497,8 +509,14 @@ int launch_v(GemmArgs& a, int KS, hipStream_t st) {
     const int up = (nxb + 7) & ~7;            // round up while the launch still fits the chip in one wave of blocks
     nxb = (up * nchunks <= 256 * per_cu) ? up : (nxb & ~7);
   }
-  // a pending BatchNorm-finalize fold belongs to this launch when it produces that BatchNorm's sums
-  a.fold = t3d_take_fold(a.stats);
+  // a pending BatchNorm-finalize request belongs to this launch when it names the coefficients of its operand
+  // (per-sample coefficients and the y-free / stem variants have none to derive)
+  if (YF || STEM || a.per_sample) {
+    if (const int rc = t3d_fold_fallback(a.p0, st)) return rc;
+    a.fold = nullptr;
+  } else {
+    a.fold = t3d_take_fold(a.p0);
+  }
   hipLaunchKernelGGL((pw_stream_kernel<NT, R, DG, GEN, YF, KU, STEM>), dim3(nxb * nchunks), dim3(threads), lds, st, a, nchunks, KS,
                      g_t3d_reduce.nrep, g_t3d_reduce.stats_stride);
   T3D_CHECK_LAUNCH();

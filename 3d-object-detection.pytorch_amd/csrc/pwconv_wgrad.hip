@@ -190,6 +190,8 @@ extern "C" int t3d_pwconv_wgrad(int dtype, const void* dz, const void* y, const 
   if (!dz || !y || !bb || !x || !dw || M <= 0 || K <= 0 || N <= 0 || (K % 8) || (N % 8) || HW <= 0) return T3D_ERR_ARG;
   if (dtype == T3D_BF16 && !getenv("T3D_WGRAD_TILED"))
     return t3d_pw_wgrad_tr_entry(dz, y, bb, x, pro, dw, M, HW, K, N, reinterpret_cast<hipStream_t>(stream));
+  // the tiled kernel reads finished coefficients: a pending derive request for them becomes a launch of its own
+  if (const int rc = t3d_fold_fallback(bb->alpha, reinterpret_cast<hipStream_t>(stream))) return rc;
   WgArgs a{};
   a.dz = dz; a.y = y; a.x = x;
   a.alpha = bb->alpha; a.beta = bb->beta; a.gamma = bb->gamma; a.per_sample = bb->per_sample;

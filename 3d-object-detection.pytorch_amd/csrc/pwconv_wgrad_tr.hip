@@ -39,6 +39,8 @@ struct WgtArgs {
   int ptiles, qtiles, rows_per_split, nsplit;
   float* ws;         // partial tiles [split][tile][PB][QB] (plain stores) or null (atomics into dw)
   t3d_pw::StemSrc stem;   // stem.img != null: the a side (K = 32) is gathered from the crops (pwconv_common.h)
+  const T3dFold* fold;    // requested BatchNorm-backward finalize: (alpha, beta, gamma) derived per block, NOT published
+                          // (the data-gradient kernel of the main stream publishes; common.h)
 };
 
 // one 16x16 tile row (transposed) fragment: pixels 8*lg .. 8*lg+7 of the step, channels ch0..ch0+15
@@ -94,12 +96,18 @@ __global__ __launch_bounds__(256 * G) void pw_wgrad_tr_kernel(const WgtArgs a) {
   const int dy0 = SWAP ? q0 : p0, a0c = SWAP ? p0 : q0;
   float* cdy = coef;                 // [3][dyB]
   float* ca = coef + 3 * dyB;        // [2][aB]
+  if (!YF && a.fold) {
+    const int nv = min(dyB, a.N - dy0);
+    for (int i = nv + threadIdx.x; i < dyB; i += 256 * G) cdy[i] = cdy[dyB + i] = cdy[2 * dyB + i] = 0.f;
+    t3d_fold_block(a.fold, dy0, nv, cdy, dyB, false);
+  } else {
   for (int i = threadIdx.x; i < dyB && !YF; i += 256 * G) {
     const int n = dy0 + i;
     const bool v = n < a.N;
     cdy[i] = (v && !a.per_sample) ? a.alpha[n] : 0.f;
     cdy[dyB + i] = v ? a.beta[n] : 0.f;
     cdy[2 * dyB + i] = (v && !a.per_sample) ? a.gamma[n] : 0.f;
+  }
   }
   for (int i = threadIdx.x; i < aB; i += 256 * G) {
     const int k = a0c + i;
@@ -442,6 +450,11 @@ int t3d_pw_wgrad_tr_entry(const void* dz, const void* y, const t3d_bnbwd* bb, co
   a.alpha = bb->alpha; a.beta = bb->beta; a.gamma = bb->gamma; a.per_sample = bb->per_sample;
   if (pro) { a.scale = pro->scale; a.shift = pro->shift; a.se = pro->se; a.act = pro->act; a.se_after = pro->se_after_act; }
   a.dw = dw; a.M = M; a.HW = HW; a.K = K; a.N = N;
+  if (a.per_sample) {
+    if (const int rc = t3d_fold_fallback(a.alpha, st)) return rc;
+  } else {
+    a.fold = t3d_take_fold(a.alpha);
+  }
   return choose_and_launch(a, st);
 }
 

@@ -88,6 +88,8 @@ extern "C" int t3d_pwconv_yfree_prep(const void* w, const t3d_bnbwd* bb, void* w
   if (!w || !bb || !bb->alpha || !bb->beta || !bb->gamma || !wcat || !cvec || K <= 0 || N <= 0 || (K % 8) || (N % 8))
     return T3D_ERR_ARG;
   if (bb->per_sample) return T3D_ERR_UNSUPPORTED;
+  // every workgroup reads all N coefficients: a requested finalize runs as a launch of its own ahead of this kernel
+  if (const int rc = t3d_fold_fallback(bb->alpha, reinterpret_cast<hipStream_t>(stream))) return rc;
   hipLaunchKernelGGL(yfree_prep_kernel, dim3(K, rup32(K) / 16), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
                      reinterpret_cast<const bf16_t*>(w), bb->alpha, bb->beta, bb->gamma, reinterpret_cast<bf16_t*>(wcat),
                      cvec, K, N, rup32(N), rup32(K));

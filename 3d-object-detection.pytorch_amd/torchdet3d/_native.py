@@ -31,7 +31,7 @@ class LossCfg(ctypes.Structure):
 
 
 class BnFold(ctypes.Structure):          # t3d_bn_fold (include/t3d.h); lives in device memory
-    _fields_ = [('kind', _I), ('C', _I), ('counter', _P), ('stats', _P), ('count', _D), ('gamma', _P), ('beta', _P),
+    _fields_ = [('kind', _I), ('C', _I), ('nrep', _I), ('rstride', _L), ('stats', _P), ('count', _D), ('gamma', _P), ('beta', _P),
                 ('rm', _P), ('rv', _P), ('nbt', _P), ('momentum', _F), ('eps', _F), ('o0', _P), ('o1', _P), ('o2', _P),
                 ('o3', _P), ('o4', _P), ('mean', _P), ('invstd', _P)]
 
@@ -173,11 +173,16 @@ class KernelTimer:
 
 
 timer = None    # set to a KernelTimer to time launches
+# measurement aid (tools/ablate.sh): entry points whose launches are SKIPPED -- the results are then garbage, only the
+# step time means something (an upper bound on what removing / fusing that family of launches can buy)
+_ABLATE = frozenset(x for x in os.environ.get('T3D_ABLATE', '').split(',') if x)
 
 
 def call(name, *args, nbytes=None):
     """Enqueue one C-ABI entry point on the current stream; `nbytes` = algorithmic HBM bytes of the launch
     (bookkeeping for the roofline report only)."""
+    if _ABLATE and name in _ABLATE:
+        return
     fn = getattr(lib(), name)
     t = timer
     if t is not None and (t.only is None or name in t.only):

@@ -40,13 +40,30 @@ class FusedAdamW(torch.optim.Optimizer):
                     st['step'] = 0
                     st['exp_avg'] = torch.zeros_like(p, memory_format=torch.preserve_format)
                     st['exp_avg_sq'] = torch.zeros_like(p, memory_format=torch.preserve_format)
-                st['step'] = int(st['step']) + 1          # a torch.optim.AdamW checkpoint stores a tensor here
+                st['step'] += 1                           # a host int (load_state_dict normalises a tensor step)
                 g = p.grad if p.grad.is_contiguous() else p.grad.contiguous()
                 N.call('t3d_adamw_step', N.ptr(p), N.ptr(g), N.ptr(st['exp_avg']), N.ptr(st['exp_avg_sq']), p.numel(),
                        float(group['lr']), float(b1), float(b2), float(group['eps']), float(group['weight_decay']),
                        st['step'], float(self.grad_scale), N.stream())
                 torch.autograd.graph.increment_version(p)     # written through a raw pointer: tell version-tracking users
         return loss
+
+
+    # `step` is a host int here; torch.optim.AdamW keeps a float tensor.  Checkpoints travel in torch's form, so that a
+    # snapshot written by either optimizer loads into the other (build_optimizer falls back to torch.optim.AdamW for
+    # parameters that are not on the GPU), and a loaded device tensor never costs a sync per step.
+    def state_dict(self):
+        sd = super().state_dict()
+        # (the packed state holds the optimizer's own per-parameter dicts: copy before rewriting `step`)
+        sd['state'] = {k: ({**st, 'step': torch.tensor(float(st['step']))} if 'step' in st and not torch.is_tensor(st['step'])
+                           else st) for k, st in sd['state'].items()}
+        return sd
+
+    def load_state_dict(self, state_dict):
+        super().load_state_dict(state_dict)
+        for st in self.state.values():
+            if 'step' in st:
+                st['step'] = int(st['step'].item()) if torch.is_tensor(st['step']) else int(st['step'])
 
 
 def build_optimizer(cfg, net):

@@ -41,7 +41,23 @@ class FrameCropper:
     def __init__(self, size=(224, 224), device='cuda', max_objects=256):
         self.w, self.h = int(size[0]), int(size[1])
         self.device = torch.device(device)
-        self._rects = torch.empty(max_objects, 4, dtype=torch.int32).pin_memory()
+        # Pinned staging for the crop boxes.  The upload is asynchronous, so a staging buffer may only be rewritten once the
+        # copy that read it has run: NBUF buffers in rotation, each guarded by the event recorded after its last upload
+        # (a single reused buffer let frame k be cropped with frame k+1's boxes whenever the stream was running behind).
+        self._max = int(max_objects)
+        self._slots = [[torch.empty(self._max, 4, dtype=torch.int32).pin_memory(), None] for _ in range(self.NBUF)]
+        self._turn = 0
+
+    NBUF = 3
+
+    def _staging(self, n):
+        slot = self._slots[self._turn]
+        self._turn = (self._turn + 1) % self.NBUF
+        if slot[1] is not None:
+            slot[1].synchronize()                 # the upload that last used this buffer has completed
+        if n > slot[0].shape[0]:
+            slot[0] = torch.empty(n, 4, dtype=torch.int32).pin_memory()
+        return slot
 
     def __call__(self, frame, keypoints_per_object):
         """frame: [H, W, 3] uint8 (ndarray or tensor, host or device); keypoints_per_object: list of [9,2] pixel keypoints."""
@@ -50,17 +66,20 @@ class FrameCropper:
         frame = frame.to(self.device, non_blocking=True).contiguous()
         H, W = int(frame.shape[0]), int(frame.shape[1])
         n = len(keypoints_per_object)
-        if n > self._rects.shape[0]:
-            self._rects = torch.empty(n, 4, dtype=torch.int32).pin_memory()
+        slot = self._staging(n)
+        host = slot[0]
         kps, boxes = [], []
         for i, kp in enumerate(keypoints_per_object):
             clipped, (x0, y0, x1, y1) = crop_cords_from_keypoints(kp, W, H)
             x0, y0, x1, y1 = int(x0), int(y0), int(x1), int(y1)                  # A.Crop takes integer pixel bounds
             boxes.append((x0, y0, x1, y1))
-            self._rects[i] = torch.tensor([x0, y0, x1, y1], dtype=torch.int32)
+            host[i, 0], host[i, 1], host[i, 2], host[i, 3] = x0, y0, x1, y1
             # A.Crop shifts the keypoints, Resize scales them, ToTensor divides by the final size: net (kp - origin) / crop size
             kps.append((np.asarray(clipped, np.float32) - np.float32([x0, y0])) / np.float32([max(x1 - x0, 1), max(y1 - y0, 1)]))
-        rects = self._rects[:n].to(self.device, non_blocking=True)
+        rects = host[:n].to(self.device, non_blocking=True)
+        if self.device.type == 'cuda':
+            slot[1] = torch.cuda.Event()
+            slot[1].record(torch.cuda.current_stream(self.device))
         crops = torch.empty(n, self.h, self.w, 3, dtype=torch.uint8, device=self.device)
         N.call('t3d_crop_resize_u8', N.ptr(frame), N.ptr(rects), N.ptr(crops), n, H, W, self.h, self.w, N.stream())
         return crops, torch.from_numpy(np.stack(kps)).to(self.device), boxes

@@ -281,7 +281,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = t.item()
     loss = out[0].item()
-    assert loss == loss, 'loss is NaN'
+    assert loss == loss or os.environ.get('T3D_ABLATE'), 'loss is NaN'
 
     if rank == 0:
         crops = B * world * args.steps / dt

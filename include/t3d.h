@@ -341,20 +341,24 @@ int t3d_se_bwd_weights(const float* m, const float* h, const float* dq, const fl
  * Process-wide setting (default 1 = plain behaviour); kernels that do not implement replicas use replica 0. */
 int t3d_set_reduction_replicas(int nrep, long long stats_stride);
 
-/* BatchNorm finalize folded into its producer.  t3d_bn_finalize / t3d_bn_bwd_finalize are 5-us launches that sit
- * between every convolution and its consumer (~100 per training step, all on the critical stream).  A fold request
- * names the sums (`stats`, replica 0) and a DEVICE-resident descriptor of everything the finalize would compute; the
- * NEXT launch that accumulates into exactly those sums consumes the request and lets its last workgroup (device ticket
- * counter, zero before and after) do the finalize.  Implemented by the bf16 streaming kernels (t3d_pwconv_fwd /
- * _dgrad / _dgrad_yfree, t3d_dwconv_fwd / _bwd with k = 3) and by t3d_bn_act_bwd / t3d_pool_bwd; other launches
- * leave the request pending: t3d_fold_pending() returns 1 (and clears it) and the caller runs the standalone
- * finalize.
+/* BatchNorm finalize derived by the CONSUMER.  t3d_bn_finalize / t3d_bn_bwd_finalize are 5-us launches that sit
+ * between every convolution and its consumer (~100 per training step, all on the critical stream: 0.64 ms of an
+ * 8.4-ms MobileNetV2 step with the launch gaps).  A fold request names a coefficient array (`key`: the `scale` pointer
+ * of a t3d_prologue, or the `alpha` pointer of a t3d_bnbwd) and a DEVICE-resident descriptor of everything the finalize
+ * would compute; the NEXT launch that takes exactly that array as its prologue / BatchNorm-backward coefficients
+ * consumes the request: its workgroups derive the coefficients of their own channels from the replica sums (the
+ * kernel boundary already orders the sums before them -- no device-wide barrier), and one workgroup per channel also
+ * writes the finalize's outputs for every later reader.  Implemented by the bf16 streaming kernels (t3d_pwconv_fwd /
+ * _dgrad, t3d_dwconv_fwd / _bwd with k = 3), t3d_pwconv_yfree_prep, t3d_bn_apply and t3d_pool_fwd; other launches
+ * leave the request pending: ask t3d_fold_supported() first, or check t3d_fold_pending() (returns 1 and clears it)
+ * right after the launch -- the launch then read unfinalized coefficients and must be treated as failed.
  *   kind 1 (forward, = t3d_bn_finalize):      stats = sum(y), sum(y^2); o0..o3 = scale, shift, mean, invstd
  *   kind 2 (backward, = t3d_bn_bwd_finalize): stats = sum(dz), sum(dz*y); o0..o4 = alpha, beta, gammac, dgamma, dbeta */
 typedef struct {
   int kind;
   int C;
-  unsigned* counter;
+  int nrep;                  /* reduction replicas behind `stats` ... */
+  long long rstride;         /* ... replica r at stats + r*rstride (doubles) */
   const double* stats;
   double count;
   const float *gamma, *beta;
@@ -364,7 +368,7 @@ typedef struct {
   float *o0, *o1, *o2, *o3, *o4;
   const float *mean, *invstd; /* kind 2: the forward's batch mean / invstd */
 } t3d_bn_fold;
-int t3d_fold_request(const t3d_bn_fold* desc_device, const double* stats);
+int t3d_fold_request(const t3d_bn_fold* desc_device, const void* key);
 int t3d_fold_pending(void);
 
 /* Optional device scratch (caller-owned, process-wide setting; NULL/0 clears it).  With a workspace the bf16

@@ -58,7 +58,10 @@ def test_bench_refuses_a_rank_count_it_cannot_start():
     so every rank must stop with the explicit message and the parent must pass the failure on -- never a silent
     single-GPU number."""
     import subprocess
+    # no device visible to the child whatever the host has: on a multi-GPU box the command would otherwise run a real
+    # 2-rank benchmark and exit 0
+    env = dict(os.environ, HIP_VISIBLE_DEVICES='', CUDA_VISIBLE_DEVICES='', ROCR_VISIBLE_DEVICES='')
     r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '1', '--warmup', '1',
-                        '--no-cpu-baseline'], capture_output=True, text=True, timeout=600)
+                        '--no-cpu-baseline'], capture_output=True, text=True, timeout=600, env=env)
     assert r.returncode != 0
     assert 'GPU(s) visible' in (r.stdout + r.stderr)

@@ -97,3 +97,28 @@ def test_frame_cropper_feeds_the_trainer_tuple():
         ref = skp.astype(np.float32) / np.float32([box[2] - box[0], box[3] - box[1]])
         np.testing.assert_allclose(kps[i].cpu().numpy(), ref, rtol=1e-6, atol=1e-7)
         assert kps[i].min().item() >= 0 and kps[i].max().item() <= 1
+
+
+def test_frame_cropper_on_a_busy_stream_keeps_each_frames_boxes():
+    """the crop boxes go up through pinned staging with an asynchronous copy.  With the stream running
+    behind, a second call used to overwrite the staging buffer before the first call's copy had run, so frame k was
+    cropped with frame k+1's boxes.  Queue ~50 ms of spinning, issue five frames back to back, compare each with the
+    oracle."""
+    from oracle.crop_resize import objectron_crop, resize_linear_u8
+    from torchdet3d.dataloaders import FrameCropper
+    rng = np.random.default_rng(21)
+    H, W = 360, 640
+    frame = rng.integers(0, 256, (H, W, 3), dtype=np.uint8)
+    dframe = torch.from_numpy(frame).cuda()
+    fc = FrameCropper((96, 96))
+    sets = [[(rng.integers(60, [W - 60, H - 60]) + rng.integers(-50, 50, (9, 2))).astype(np.int64) for _ in range(3)]
+            for _ in range(5)]
+    torch.cuda.synchronize()
+    torch.cuda._sleep(100_000_000)
+    outs = [fc(dframe, objs) for objs in sets]
+    torch.cuda.synchronize()
+    for objs, (crops, kps, boxes) in zip(sets, outs):
+        for i, kp in enumerate(objs):
+            _, crop, box = objectron_crop(frame, kp)
+            assert boxes[i] == box
+            assert np.array_equal(crops[i].cpu().numpy(), resize_linear_u8(crop, (96, 96)))
