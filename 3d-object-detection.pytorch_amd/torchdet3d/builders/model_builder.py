@@ -20,7 +20,10 @@ Config keys read: model.name, model.num_classes, model.pretrained (ignored: no n
 model.storage_dtype ('f32' default for parity | 'bf16' throughput mode), model.eval_storage_dtype (optional: storage
 precision of eval-mode forwards, e.g. 'f32' validation of a model trained with 'bf16'), model.pooling_mode ('avg' | 'max' |
 'avg+max'; the reference fixes this at its default 'avg', model_builder.py:73-74)."""
+import os
+
 import torch
+import torch.distributed as dist
 from torch import nn
 
 from ..models.arch import AVAILABLE_MODELS
@@ -147,7 +150,13 @@ class ModelWrapper(nn.Module):
             self.net_eval = Net(self.name, self.num_classes, device, self.eval_storage_dtype, self.pooling_mode, share=self.net)
         self.set_input_normalization(*self.input_normalization)
         self.flat = nn.Parameter(self.net.flat)     # shares storage with the engine's master weights
-        if self.grad_sync is not None:
+        # one process per GPU (launched by torch.distributed.run): the gradient exchange attaches itself as soon as the
+        # model sits on its GPU -- scripts/main.py needs no change (its nn.DataParallel branch, main.py:60-61, is what
+        # this replaces; `cfg.data_parallel.use_parallel` stays False)
+        if self.grad_sync is None and device.type == 'cuda' and dist.is_available() and dist.is_initialized() and \
+                (dist.get_world_size() > 1 or os.environ.get('T3D_FORCE_SYNC')):
+            self.grad_sync = True
+        if self.grad_sync is not None and device.type == 'cuda':
             self.attach_grad_sync(self.grad_sync)
 
     def set_input_normalization(self, mean, std):
@@ -187,6 +196,13 @@ class ModelWrapper(nn.Module):
         self.grad_sync.g = self.net.gflat
         self.net.grad_hook = self.grad_sync.ready
         self.grad_sync.broadcast([self.net.flat] + list(self.net.buffers.values()))
+
+    def _replicate_for_data_parallel(self):
+        # nn.DataParallel(net, ...) (scripts/main.py:60-61) copies per-layer parameters to several devices from ONE process;
+        # this model is a single flat parameter over one engine per process
+        raise RuntimeError('this model runs one process per GPU (python -m torch.distributed.run --nproc-per-node N '
+                           'scripts/main.py ...): set data_parallel.use_parallel = False; the RCCL gradient exchange '
+                           'attaches itself when WORLD_SIZE > 1')
 
     # ---- nn.Module surface -------------------------------------------------------------------------
     def _apply(self, fn, recurse=True):
@@ -234,7 +250,31 @@ class ModelWrapper(nn.Module):
         return kp, (logits if self.num_classes > 1 else torch.zeros(x.shape[0], device=x.device))
 
 
+def _init_distributed():
+    """Launched by torch.distributed.run with more than one rank (WORLD_SIZE > 1) and no process group yet: bind this
+    process to its GPU and join the RCCL group BEFORE anything else touches the device, so that an unchanged
+    scripts/main.py (`net.to('cuda')`) trains data-parallel.  Replaces main.py:60-61."""
+    if not dist.is_available() or dist.is_initialized():
+        return
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    if world <= 1 and not os.environ.get('T3D_FORCE_SYNC'):
+        return
+    if 'RANK' not in os.environ or 'MASTER_ADDR' not in os.environ:
+        return
+    local = int(os.environ.get('LOCAL_RANK', '0'))
+    if torch.cuda.device_count() > local:          # (device_count does not initialise the GPU)
+        torch.cuda.set_device(local)
+        dist.init_process_group('nccl', device_id=torch.device('cuda', local))
+    else:
+        dist.init_process_group('gloo')
+
+
 def build_model(config, export_mode=False, weights_path=''):
+    _init_distributed()
+    if config.data_parallel and config.data_parallel.use_parallel and \
+            (int(os.environ.get('WORLD_SIZE', '1')) > 1 or (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1)):
+        raise RuntimeError('data_parallel.use_parallel = True (nn.DataParallel, scripts/main.py:60-61) under a multi-process '
+                           'launch: set it to False -- every rank already owns one GPU and the gradients are exchanged over RCCL')
     name = config.model.name
     assert name in AVAILABLE_MODELS, f'Wrong model name parameter. Expected one of {AVAILABLE_MODELS}'
     model = ModelWrapper(name, config.model.num_classes or 9, export_mode, config.model.storage_dtype or 'f32',

@@ -24,12 +24,20 @@ class GradSync:
         self.force = bool(os.environ.get('T3D_FORCE_SYNC')) and dist.is_initialized()
         self.hi = flat_grad.numel()
         self.works = []
+        # backend 'gloo' with device tensors (two test ranks sharing one GPU -- RCCL refuses two ranks per device): the
+        # collectives run on host copies; 'nccl' (= RCCL) takes the device buffers as they are
+        self.staged = dist.is_initialized() and dist.get_backend(group) == 'gloo' and flat_grad.is_cuda
 
     def broadcast(self, tensors, src=0):
         """One-time parameter / buffer sync from rank `src` (DataParallel replicates from device 0)."""
         if self.world > 1 or self.force:
             for t in tensors:
-                dist.broadcast(t, src, group=self.group)
+                if self.staged and t.is_cuda:
+                    h = t.cpu()
+                    dist.broadcast(h, src, group=self.group)
+                    t.copy_(h)
+                else:
+                    dist.broadcast(t, src, group=self.group)
 
     def start(self):
         self.hi = self.g.numel()
@@ -40,7 +48,11 @@ class GradSync:
         if self.world == 1 and not self.force:
             return
         if lo == 0 or self.hi - lo >= self.min_bucket:
-            if self.hi > lo:
+            if self.hi > lo and self.staged:
+                h = self.g[lo:self.hi].cpu()           # (synchronises the stream: test configuration only)
+                dist.all_reduce(h, op=dist.ReduceOp.SUM, group=self.group)
+                self.g[lo:self.hi].copy_(h)
+            elif self.hi > lo:
                 self.works.append(dist.all_reduce(self.g[lo:self.hi], op=dist.ReduceOp.SUM, group=self.group,
                                                   async_op=True))
             self.hi = lo

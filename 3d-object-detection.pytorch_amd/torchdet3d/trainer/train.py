@@ -12,6 +12,62 @@ from ..evaluation.metrics import compute_accuracy, compute_average_distance
 from ..utils import AverageMeter, put_on_device, save_snap
 
 
+class _Pending(dict):
+    """Metrics of one iteration on their way to the host (asynchronous copy into a pinned slot + event); behaves like
+    the dict(loss, ADD, SADD, acc) of python floats once any entry is read."""
+    _FIELDS = (('loss', 0), ('ADD', 3), ('SADD', 4), ('acc', 5))
+
+    def __init__(self, dev_vec, slot):
+        super().__init__()
+        self._slot = slot
+        slot[0][:dev_vec.numel()].copy_(dev_vec, non_blocking=True)
+        slot[1].record()
+        slot[2] = self
+
+    def _resolve(self):
+        slot = self._slot
+        if slot is not None:
+            slot[1].synchronize()
+            o = slot[0].tolist()
+            for k, i in self._FIELDS:
+                dict.__setitem__(self, k, o[i])
+            slot[2] = None
+            self._slot = None
+        return self
+
+    def __getitem__(self, k):
+        return dict.__getitem__(self._resolve(), k)
+
+    def get(self, k, default=None):
+        return dict.get(self._resolve(), k, default)
+
+    def keys(self):
+        return dict.keys(self._resolve())
+
+    def items(self):
+        return dict.items(self._resolve())
+
+    def values(self):
+        return dict.values(self._resolve())
+
+    def __iter__(self):
+        return dict.__iter__(self._resolve())
+
+    def __len__(self):
+        return dict.__len__(self._resolve())
+
+    def __contains__(self, k):
+        return dict.__contains__(self._resolve(), k)
+
+    def __repr__(self):
+        return dict.__repr__(self._resolve())
+
+    def __eq__(self, other):
+        return dict.__eq__(self._resolve(), other)
+
+    __hash__ = None
+
+
 class Trainer:
     def __init__(self, model, train_loader, optimizer, scheduler, loss_manager, writer, max_epoch, log_path,
                  device='cuda', save_chkpt=True, debug=False, debug_steps=30, save_freq=10, print_freq=10,
@@ -22,7 +78,11 @@ class Trainer:
         self.save_freq, self.print_freq, self.global_step = save_freq, print_freq, train_step
 
     def train_step(self, imgs, gt_kp, gt_cats, it=0):
-        """One iteration (train.py:44-55) -> dict(loss, ADD, SADD, acc) of python floats."""
+        """One iteration (train.py:44-55) -> mapping with loss, ADD, SADD, acc (python floats).  The values come out of the
+        fused loss launch; they travel to the host through a pinned buffer with an asynchronous copy, and the returned
+        mapping waits for that copy only when a value is first READ -- so a caller that looks at the numbers every
+        `print_freq` iterations (as `train` does) never stalls the launch queue (the reference's loop has six `.item()`
+        syncs per iteration, train.py:57-62 + metrics.py:29,35)."""
         imgs, gt_kp, gt_cats = put_on_device([imgs, gt_kp, gt_cats], self.device)
         pred_kp, pred_cats = self.model(imgs, gt_cats)
         loss = self.loss_manager.parse_losses(pred_kp, gt_kp, pred_cats, gt_cats, it)
@@ -30,31 +90,58 @@ class Trainer:
         loss.backward()
         self.optimizer.step()
         last = getattr(self.loss_manager, 'last', None)
-        if last is not None:                 # the loss launch already reduced the metrics: one read-back
+        if last is not None and last.is_cuda:      # the loss launch already reduced the metrics: one read-back
+            return _Pending(last, self._slot())
+        if last is not None:
             o = last.tolist()
             return dict(loss=o[0], ADD=o[3], SADD=o[4], acc=o[5])
         ADD, SADD = compute_average_distance(pred_kp, gt_kp)
         return dict(loss=loss.item(), ADD=ADD, SADD=SADD, acc=compute_accuracy(pred_cats, gt_cats))
+
+    RING = 64      # read-back slots in rotation; a slot is reused RING iterations later (its mapping is resolved first)
+
+    def _slot(self):
+        ring = self.__dict__.setdefault('_ring', [])
+        turn = self.__dict__.get('_turn', 0)
+        self._turn = (turn + 1) % self.RING
+        if len(ring) < self.RING:
+            import torch
+            ring.append([torch.empty(16, dtype=torch.float32).pin_memory(), torch.cuda.Event(), None])
+            return ring[-1]
+        slot = ring[turn]
+        if slot[2] is not None:
+            slot[2]._resolve()                     # an unread mapping from RING iterations ago: take its values first
+        return slot
 
     def train(self, epoch, is_last_epoch):
         meters = {k: AverageMeter() for k in ('loss', 'ADD', 'SADD', 'acc', 'time')}
         self.model.train()
         self.num_iters = len(self.train_loader)
         start = time.time()
+        backlog = []        # (mapping, batch size, global step) of iterations whose numbers have not been looked at yet
+
+        def drain():
+            # meters and TensorBoard scalars in iteration order, with each iteration's own global step (train.py:57-65)
+            for r, n, gs in backlog:
+                for k in ('loss', 'ADD', 'SADD', 'acc'):
+                    meters[k].update(r[k], n)
+                if self.writer is not None:
+                    self.writer.add_scalar('Train/loss', r['loss'], global_step=gs)
+                    self.writer.add_scalar('Train/ADD', meters['ADD'].avg, global_step=gs)
+                    self.writer.add_scalar('Train/SADD', meters['SADD'].avg, global_step=gs)
+                    self.writer.add_scalar('Train/ACC', meters['acc'].avg, global_step=gs)
+            backlog.clear()
+
         for it, (imgs, gt_kp, gt_cats) in enumerate(self.train_loader):
             r = self.train_step(imgs, gt_kp, gt_cats, it)
-            n = imgs.size(0)
-            for k in ('loss', 'ADD', 'SADD', 'acc'):
-                meters[k].update(r[k], n)
-            if self.writer is not None:
-                self.writer.add_scalar('Train/loss', r['loss'], global_step=self.global_step)
-                self.writer.add_scalar('Train/ADD', meters['ADD'].avg, global_step=self.global_step)
-                self.writer.add_scalar('Train/SADD', meters['SADD'].avg, global_step=self.global_step)
-                self.writer.add_scalar('Train/ACC', meters['acc'].avg, global_step=self.global_step)
+            backlog.append((r, imgs.size(0), self.global_step))
             self.global_step += 1
-            meters['time'].update(time.time() - start)
             left = (self.num_iters - (it + 1)) + (self.max_epoch - (epoch + 1)) * self.num_iters
-            if it % self.print_freq == 0 or it == self.num_iters - 1:
+            show = it % self.print_freq == 0 or it == self.num_iters - 1
+            if show or len(backlog) >= self.RING // 2 or (self.debug and it == self.debug_steps):
+                drain()                            # the only host <-> device wait of the loop
+            meters['time'].update(time.time() - start)
+            if show:
                 print(f'epoch: [{epoch}/{self.max_epoch}][{it}/{self.num_iters}]\t'
                       f'time {meters["time"].val:.3f} ({meters["time"].avg:.3f})\t'
                       f'eta {datetime.timedelta(seconds=int(meters["time"].avg * left))}\t'
@@ -65,6 +152,7 @@ class Trainer:
             start = time.time()
             if self.debug and it == self.debug_steps:
                 break
+        drain()
         if self.save_chkpt and (epoch % self.save_freq == 0 or is_last_epoch) and not self.debug:
             save_snap(self.model, self.optimizer, self.scheduler, epoch, self.log_path)
         if self.scheduler is not None:

@@ -55,11 +55,54 @@ def spawn_ranks(args):
     sys.exit(subprocess.run(cmd, env=env).returncode)
 
 
+def device_warmup(dev, seconds=None):
+    """Keeps the GPU busy with device-to-device copies for ~`seconds` (clock / power-state ramp of a fresh box); returns
+    the seconds spent.  T3D_DEVICE_WARMUP_S overrides (0 disables)."""
+    seconds = float(os.environ.get('T3D_DEVICE_WARMUP_S', 2.0)) if seconds is None else seconds
+    if seconds <= 0:
+        return 0.0
+    a = torch.empty(64 << 20, dtype=torch.float32, device=dev)
+    b = torch.empty_like(a)
+    t0 = time.perf_counter()
+    while time.perf_counter() - t0 < seconds:
+        for _ in range(20):
+            b.copy_(a)
+            a.copy_(b)
+        torch.cuda.synchronize(dev)
+    return round(time.perf_counter() - t0, 2)
+
+
+def api_objects(args, dev):
+    """The step as scripts/main.py of the reference builds it (main.py:46-82): build_model -> build_optimizer ->
+    build_loss / LossManager -> Trainer; `Trainer.train_step` is the loop body of trainer/train.py:42-66.  Under a
+    multi-rank launch `build_model(...).to(dev)` attaches the RCCL gradient exchange by itself."""
+    from torchdet3d.builders import build_loss, build_model, build_optimizer
+    from torchdet3d.losses import LossManager
+    from torchdet3d.trainer import Trainer
+    from torchdet3d.utils.utils import AttrDict
+    cfg = AttrDict(dict(
+        model=dict(name=args.model, num_classes=9, pretrained=False, load_weights='', storage_dtype=args.dtype),
+        data=dict(normalization=dict(mean=[0.5931, 0.4690, 0.4229], std=[0.2471, 0.2214, 0.2157])),
+        data_parallel=dict(use_parallel=False),
+        optim=dict(name='adam', lr=1e-3, wd=1e-4, betas=(0.9, 0.999)),          # default_config.py:18
+        loss=dict(names=['l1', 'add_loss', 'cross_entropy'], coeffs=([1., .1], [.2]), smoothl1_beta=0.2, w=5.18, eps=1.,
+                  alwa=dict(use=False, lam_cls=1., lam_reg=1., C=100, compute_std=True))))      # default_config.py:22
+    model = build_model(cfg).to(dev)
+    model.net.reset_parameters(seed=5)
+    if model.grad_sync is not None:              # the seeded weights of rank 0 everywhere
+        model.grad_sync.broadcast([model.net.flat] + list(model.net.buffers.values()))
+    opt = build_optimizer(cfg, model)
+    lm = LossManager(build_loss(cfg), cfg.loss.coeffs, cfg.loss.alwa)
+    tr = Trainer(model, None, opt, None, lm, None, 1, '', device=dev, save_chkpt=False)
+    model.train()
+    return model, tr
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=30)
-    ap.add_argument('--warmup', type=int, default=10)
+    ap.add_argument('--steps', type=int, default=100)
+    ap.add_argument('--warmup', type=int, default=20)
     ap.add_argument('--batch', type=int, default=256)
     ap.add_argument('--size', type=int, default=224)
     ap.add_argument('--model', default='mobilenetv2')
@@ -70,6 +113,11 @@ def parse():
     ap.add_argument('--cpu-baseline-only', action='store_true', help=argparse.SUPPRESS)
     ap.add_argument('--eval', action='store_true', help='time the inference forward (Evaluator.val_step: running BatchNorm '
                     'statistics, values-only losses + metrics) instead of the train step')
+    ap.add_argument('--engine', action='store_true', help='drive models.engine.Net + the loss / optimizer kernels directly '
+                    'instead of going through the reference-shaped API (build_model / build_optimizer / LossManager / '
+                    'Trainer.train_step), which is what the headline number is measured through')
+    ap.add_argument('--roofline-every', type=int, default=4, help='the depthwise launches of every n-th timed step carry '
+                    'HIP-event pairs (an event pair per launch on all steps costs ~0.25 ms per step)')
     ap.add_argument('--per-launch', action='store_true', help='print every conv launch of one step (stderr)')
     ap.add_argument('--profile-all', action='store_true', help='time every kernel family, print a table to stderr')
     return ap.parse_args()
@@ -158,16 +206,22 @@ def main():
 
     B, S = args.batch, args.size
     dtype = torch.bfloat16 if args.dtype == 'bf16' else torch.float32
-    net = Net(args.model, 9, dev, dtype)
-    net.reset_parameters(seed=5)
-    sync = GradSync(net.gflat)
-    sync.broadcast([net.flat] + [b for b in net.buffers.values()])
-    if world > 1 or sync.force:
-        net.grad_hook = sync.ready
-    flat = torch.nn.Parameter(net.flat)          # one hand-written AdamW launch over the flat master weights
-    flat.grad = net.gflat
-    # default_config.py:18 (lr 1e-3, wd 1e-4); the 1/world of the gradient average rides on the optimizer's gradient load
-    opt = FusedAdamW([flat], lr=1e-3, weight_decay=1e-4, grad_scale=1.0 / world)
+    use_api = not args.eval and not args.engine
+    torch.manual_seed(5)
+    if use_api:
+        model, trainer = api_objects(args, dev)
+        net = model.net
+    else:
+        net = Net(args.model, 9, dev, dtype)
+        net.reset_parameters(seed=5)
+        sync = GradSync(net.gflat)
+        sync.broadcast([net.flat] + [b for b in net.buffers.values()])
+        if world > 1 or sync.force:
+            net.grad_hook = sync.ready
+        flat = torch.nn.Parameter(net.flat)          # one hand-written AdamW launch over the flat master weights
+        flat.grad = net.gflat
+        # default_config.py:18 (lr 1e-3, wd 1e-4); the 1/world of the gradient average rides on the optimizer's gradient load
+        opt = FusedAdamW([flat], lr=1e-3, weight_decay=1e-4, grad_scale=1.0 / world)
 
     g = torch.Generator(device=dev).manual_seed(5 + rank)
     nb = 2                                       # synthetic batches resident in HBM, cycled
@@ -186,10 +240,15 @@ def main():
         N.call('t3d_loss_fwd_bwd', cfg, N.ptr(kp), N.ptr(gts[j]), N.ptr(lg), N.ptr(cats[j]), N.ptr(out), None, None, B, 9,
                N.stream())
 
+    last = [None]
+
     def step(i):
         if args.eval:
             return eval_step(i)
         j = i % nb
+        if use_api:
+            last[0] = trainer.train_step(imgs[j], gts[j].view(B, 9, 2), cats[j], i)
+            return
         kp, lg = net.forward(imgs[j], cats[j], train=True)
         N.call('t3d_loss_fwd_bwd', cfg, N.ptr(kp), N.ptr(gts[j]), N.ptr(lg), N.ptr(cats[j]), N.ptr(out), N.ptr(dkp),
                N.ptr(dlg), B, 9, N.stream())
@@ -216,15 +275,11 @@ def main():
     # for the main stream's persistent kernels to free registers, not just the kernel)
     fam = {}
     side = net._side
-    # untimed pre-warm ahead of the W warm-up steps: the first process on a fresh box sometimes ran its whole timed region
+    # device warm-up ahead of the W warm-up steps: the first process on a fresh box sometimes ran its whole timed region
     # 12-15 % slow (9.5-10.2 instead of 8.4-8.5 ms/step; never a later process) -- clock / power state still ramping.  About two
-    # seconds of steps first; the W warm-up steps and the K timed steps follow unchanged.
-    # (a fixed count, not a time budget: with several ranks every step holds an all-reduce, so all ranks must run the same
-    # number of them)
-    prewarm_steps = 0 if os.environ.get('T3D_NO_PREWARM') else 200
-    for i in range(prewarm_steps):
-        step(i)
-    torch.cuda.synchronize()
+    # seconds of plain HBM copy kernels first (NOT steps of the workload: `warmup` below is the true number of untimed steps);
+    # the W warm-up steps and the K timed steps follow.
+    device_warmup_s = device_warmup(dev)
     for i in range(args.warmup):
         if args.profile_all and i == max(1, args.warmup // 2):
             N.timer = N.KernelTimer(None)
@@ -257,7 +312,9 @@ def main():
         N.timer = None
 
     # ---- timed region: exactly K steps; the depthwise launches (main stream) carry HIP-event pairs
-    N.timer = N.KernelTimer(set(DW_ENTRIES), prealloc=2 * 40 * args.steps)
+    every = max(1, args.roofline_every)
+    rtimer = N.KernelTimer(set(DW_ENTRIES), prealloc=2 * 40 * ((args.steps + every - 1) // every))
+    N.timer = None
     # no cyclic-GC pass inside the timed region: one in three fresh processes had a single 36-44 ms step in it
     # (config.step_ms_min_med_max), i.e. +12 % on the 30-step average, from a collection over the freshly imported heap
     import gc
@@ -268,19 +325,21 @@ def main():
     t0 = time.perf_counter()
     marks[0].record()
     for i in range(args.steps):
+        N.timer = rtimer if i % every == 0 else None
         step(i)
         marks[i + 1].record()
+    N.timer = None
     barrier()
     dt = time.perf_counter() - t0
     gc.enable()
     per_step = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps))
-    launches = N.timer.per_launch() if N.timer else []
-    N.timer = None
+    launches = rtimer.per_launch()
+    nsampled = (args.steps + every - 1) // every
     if world > 1:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = t.item()
-    loss = out[0].item()
+    loss = last[0]['loss'] if use_api else out[0].item()
     assert loss == loss or os.environ.get('T3D_ABLATE'), 'loss is NaN'
 
     if rank == 0:
@@ -295,7 +354,10 @@ def main():
                                       f'train step (fwd + l1/add/CE losses + bwd + AdamW{" + RCCL grad all-reduce" if world > 1 else ""})')
                                    + f', {S}x{S} crops, per-GPU batch {B}', 'global_batch': B * world, 'parallelism': f'dp{world}',
                        'final_loss': round(loss, 5), 'host_issue_ms_per_step': round(t_issue * 1e3, 3),
-                       'prewarm_steps': prewarm_steps, 'step_ms_min_med_max': [round(per_step[0], 3), round(per_step[len(per_step) // 2], 3), round(per_step[-1], 3)], 'side_stream_probe': list(__import__('torchdet3d.models.engine', fromlist=['x'])._concurrent_stream.log), 'rccl_ranks': world if dist.is_initialized() else 0},
+                       'driven_through': ('torchdet3d.builders.build_model / build_optimizer / LossManager / Trainer.train_step'
+                                          if use_api else 'models.engine.Net + loss / optimizer entry points'),
+                       'roofline_sampled_steps': nsampled,
+                       'device_warmup_s': device_warmup_s, 'step_ms_min_med_max': [round(per_step[0], 3), round(per_step[len(per_step) // 2], 3), round(per_step[-1], 3)], 'side_stream_probe': list(__import__('torchdet3d.models.engine', fromlist=['x'])._concurrent_stream.log), 'rccl_ranks': world if dist.is_initialized() else 0},
         }
         # per depthwise family: (entry, k, stride) from the launch's integer arguments (..., B, H, W, C, k, stride)
         groups = {}
@@ -310,10 +372,10 @@ def main():
             ach = d['bytes'] / (d['ms'] * 1e-3) / 1e9
             rows.append({'kernel': DW_KERNEL_NAMES.get(key, '?') if args.dtype == 'bf16' else f'{key[0]} k{key[1]} s{key[2]} (fp32)',
                          'entry': key[0], 'k': key[1], 'stride': key[2],
-                         'launches_per_step': d['launches'] // args.steps,
+                         'launches_per_step': d['launches'] // nsampled,
                          'avg_launch_us': round(1e3 * d['ms'] / d['launches'], 2),
-                         'ms_per_step': round(d['ms'] / args.steps, 4),
-                         'algorithmic_MB_per_step': round(d['bytes'] / args.steps / 1e6, 1),
+                         'ms_per_step': round(d['ms'] / nsampled, 4),
+                         'algorithmic_MB_per_step': round(d['bytes'] / nsampled / 1e6, 1),
                          'achieved': round(ach, 1), 'frac': round(ach * 1e9 / HBM_PEAK, 4)})
         if rows:
             top = rows[0]

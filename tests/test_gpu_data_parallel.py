@@ -1,0 +1,59 @@
+"""Data-parallel training through the API, without an 8-GPU box:
+  * two ranks sharing GPU 0 (gloo) run `Net` on their own shards: the exchanged gradient equals the oracle's
+    shard-averaged gradient and both ranks hold identical weights after FusedAdamW;
+  * scripts/main.py's flow under `torch.distributed.run` with ONE RCCL rank: `build_model` joins the group and attaches
+    the gradient exchange by itself -- main.py needs no change (its nn.DataParallel branch, main.py:60-61, is replaced).
+The ranks are CHILD processes; this process never touches the GPU before it starts them."""
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+
+
+def _launch(nproc, args, extra_env=None, timeout=900):
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'), **(extra_env or {}))
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={nproc}', '--master-addr', '127.0.0.1',
+           '--master-port', str(port), os.path.join(ROOT, 'tests', '_dp_worker.py')] + args
+    return subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=timeout)
+
+
+def test_two_ranks_on_one_gpu_exchange_the_oracles_shard_averaged_gradient():
+    r = _launch(2, ['engine2'])
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    assert 'DP2_OK' in r.stdout, r.stdout[-2000:]
+
+
+def test_main_py_flow_under_the_launcher_attaches_rccl_by_itself(tmp_path):
+    r = _launch(1, ['main1', str(tmp_path / 'log')], {'T3D_FORCE_SYNC': '1'})
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    assert 'MAIN1_OK' in r.stdout, r.stdout[-2000:]
+
+
+def test_data_parallel_wrap_is_refused_with_a_clear_message():
+    """`nn.DataParallel(net, device_ids=[0, 1])` (main.py:60-61 with use_parallel=True) cannot replicate the single
+    flat-parameter model: the error says what to do instead."""
+    import torch
+    from test_host_logic import _cfg
+    from torchdet3d.builders import build_model
+    m = build_model(_cfg('mobilenetv2')).to('cuda')
+    with pytest.raises(RuntimeError, match='one process per GPU'):
+        m._replicate_for_data_parallel()
+    cfg = _cfg('mobilenetv2')
+    from torchdet3d.utils.utils import AttrDict
+    cfg.data_parallel = AttrDict(dict(use_parallel=True))
+    os.environ['WORLD_SIZE'] = '2'
+    try:
+        with pytest.raises(RuntimeError, match='use_parallel'):
+            build_model(cfg)
+    finally:
+        del os.environ['WORLD_SIZE']
+    assert torch.cuda.is_available()
