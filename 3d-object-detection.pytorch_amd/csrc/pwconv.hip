@@ -363,12 +363,18 @@ int dispatch(int dtype, GemmArgs& a, void* stream) {
 
 extern "C" int t3d_pwconv_fwd(int dtype, const void* x, const t3d_prologue* pro, const void* w, const float* bias,
                               void* y, double* stats, int M, int HW, int K, int N, void* stream) {
-  if (!x || !w || !y) return T3D_ERR_ARG;
+  if (!x || !w || (!y && !stats)) return T3D_ERR_ARG;
   GemmArgs a{};
   a.a0 = x;
   if (pro) { a.p0 = pro->scale; a.p1 = pro->shift; a.p2 = pro->se; a.act = pro->act; a.se_after = pro->se_after_act; }
   a.w = w; a.bias = bias; a.out = y; a.stats = stats;
   a.M = M; a.HW = HW; a.Kin = K; a.Nout = N;
+  if (!y) {
+    // statistics-only pass (the BatchNorm sums of a conv whose output is never stored: t3d_expdw_fwd recomputes it in
+    // LDS): bf16 streaming kernel only
+    if (dtype != T3D_BF16 || (K % 8) || (N % 8) || M <= 0 || HW <= 0) return T3D_ERR_UNSUPPORTED;
+    return stream_launch(a, reinterpret_cast<hipStream_t>(stream));
+  }
   return dispatch(dtype, a, stream);
 }
 

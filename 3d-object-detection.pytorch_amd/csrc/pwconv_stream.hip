@@ -411,7 +411,7 @@ __global__ __launch_bounds__(512, KU > 2 ? 1 : 2) void pw_stream_kernel(const Ge
         }
 #pragma unroll
         for (int j = 0; j < 8; ++j) v[j] = ok ? Vec8<bf16_t>::round(v[j]) : 0.f;
-        if (ok) Vec8<bf16_t>::store(out + (size_t)m * a.Nout + n, v);
+        if (ok && out) Vec8<bf16_t>::store(out + (size_t)m * a.Nout + n, v);   // (out == null: statistics-only pass)
         if (keep_stats) {
 #pragma unroll
           for (int j = 0; j < 8; ++j) {

@@ -17,8 +17,9 @@ reference's).  Differences a caller can observe:
     a train-mode model called under `torch.no_grad()` evaluates with the running statistics and leaves them alone,
     where the reference would still use (and update) batch statistics.
 Config keys read: model.name, model.num_classes, model.pretrained (ignored: no network), model.load_weights,
-model.storage_dtype ('f32' default for parity | 'bf16' throughput mode), model.eval_storage_dtype (optional: storage
-precision of eval-mode forwards, e.g. 'f32' validation of a model trained with 'bf16'), model.pooling_mode ('avg' | 'max' |
+model.storage_dtype ('f32' default for parity | 'bf16' throughput mode), model.eval_storage_dtype (storage precision of
+eval-mode forwards; default 'f32' also for a 'bf16' model, so that inference outputs meet the parity bounds -- 'bf16' makes
+inference run in the throughput mode too), model.pooling_mode ('avg' | 'max' |
 'avg+max'; the reference fixes this at its default 'avg', model_builder.py:73-74)."""
 import os
 
@@ -123,6 +124,13 @@ class ModelWrapper(nn.Module):
             raise ValueError(f'Unknown pooling mode: {pooling_mode}')          # model_builder.py:105-106
         self.name, self.num_classes, self.export_mode, self.pooling_mode = name, num_classes, export_mode, pooling_mode
         self.storage_dtype = torch.bfloat16 if storage_dtype in ('bf16', torch.bfloat16) else torch.float32
+        # Inference precision.  The throughput mode ('bf16' storage) trains with bf16 activations; what the model RETURNS in
+        # eval mode -- the outputs the parity bounds are about (keypoints 1e-4, class arg-max exact, 3-D IoU 1e-3) -- comes
+        # from an fp32-storage engine over the same parameters unless the config asks for 'bf16' inference explicitly
+        # (MobileNetV2's bf16 inference keypoints are 3e-4 rms off, which moves the ill-conditioned 3-D IoU by 2e-3 .. 4e-3:
+        # tests/test_gpu_bf16_gate.py)
+        if not eval_storage_dtype:
+            eval_storage_dtype = 'f32' if self.storage_dtype == torch.bfloat16 else None
         self.eval_storage_dtype = (None if not eval_storage_dtype else
                                    torch.bfloat16 if eval_storage_dtype in ('bf16', torch.bfloat16) else torch.float32)
         self.grad_sync = None          # optional torchdet3d.parallel.GradSync (one process per GPU)

@@ -128,6 +128,11 @@ class Net:
         self.set_input_normalization([0.5931, 0.4690, 0.4229], [0.2471, 0.2214, 0.2157])
         self._direct_stem = bool(os.environ.get('T3D_STEM_DIRECT'))
         self._fused_eval = not os.environ.get('T3D_NO_FUSED_EVAL')   # 14x14 / 7x7 blocks as one launch in inference mode
+        # expand + depthwise as one launch in training mode (csrc/expdw_fwd.hip): OPT-IN (T3D_EXPDW=1).  First version, correct
+        # but latency-bound (112x112x16->96: 516 us against 400 for the two launches it replaces) and it needs a
+        # statistics-only pass of the 1x1 conv in front (94 us there) -- DESIGN.md section 7 has the measurements and what
+        # the fused forward + backward pair would remove (the expanded tensor's 6 HBM passes per block)
+        self._fuse_expdw = bool(os.environ.get('T3D_EXPDW'))
 
     def set_input_normalization(self, mean, std):
         """Per-channel mean / std applied to uint8 crops inside the stem kernel ((u/255 - mean) / std)."""
@@ -569,6 +574,7 @@ class Net:
         else:
             self._eval_affines()
         sv = dict(B=B, imgs=imgs, blocks=[])
+        self.saved_blocks = sv['blocks']
 
         # ---- stem (mobilenetv3.py:110-115,178): patch gather + GEMM.  T3D_STEM_DIRECT=1 (bf16 storage) gathers the patches
         # inside the GEMM kernels instead (no patch matrix; measured slower, DESIGN.md finding 13)
@@ -632,6 +638,46 @@ class Net:
         lds = mt * 16 * (blk.cin + 8) * 2 + P * 68 * 4 + mt * 16 * 72 * 2 + 64 * (blk.cin + 8) * 2 + blk.cout * 72 * 2 + 64 * 9 * 4 + 4 * 64 * 4
         return lds <= 160 * 1024
 
+    def _fuse_expdw_ok(self, blk, x):
+        """Training, bf16: expand 1x1 + BatchNorm + activation + depthwise 3x3 as ONE launch (csrc/expdw_fwd.hip) -- the
+        expanded tensor is consumed out of LDS instead of being read back from HBM."""
+        return (self.training and self._fuse_expdw and self.dt == N.BF16 and blk.expand and blk.k == 3 and not blk.se
+                and blk.act in ('relu', 'relu6') and x.pro is None and blk.cin % 8 == 0 and blk.cin <= 160)
+
+    def _block_fwd_fused(self, i, blk, x, rec):
+        st, dt = N.stream(), self.dt
+        p = f'features.{i + 1}.conv'
+        B, H, W = x.B, x.H, x.W
+        bn1, bn2, bn3 = self.bns[p + '.1'], self.bns[p + '.4'], self.bns[p + '.8']
+        dwn, pwn = p + '.3.weight', p + '.7.weight'
+        M = B * H * W
+        # the expansion's batch statistics: the 1x1 conv as a statistics-only pass over the narrow input (nothing stored)
+        N.call('t3d_pwconv_fwd', dt, N.ptr(x.t), None, N.ptr(self.w[p + '.0.weight']), None, None, self._st(bn1),
+               M, H * W, blk.cin, blk.cexp, st, nbytes=M * blk.cin * self.esz)
+        pro1 = self._bn_fwd(bn1, M, blk.act)
+        self._settle_f(bn1)
+        Ho, Wo = (H + 2 - 3) // blk.s + 1, (W + 2 - 3) // blk.s + 1
+        M2 = B * Ho * Wo
+        y1 = self._buf(f'y1:{i}', (M, blk.cexp))
+        y2 = self._buf(f'y2:{i}', (M2, blk.cexp))
+        N.call('t3d_expdw_fwd', N.ptr(x.t), N.ptr(self.w[p + '.0.weight']), N.ptr(bn1.scale), N.ptr(bn1.shift),
+               N.ACT[blk.act], N.ptr(self.p[dwn]), N.ptr(y1), N.ptr(y2), self._st(bn2), B, H, W, blk.cin, blk.cexp, blk.s, st,
+               nbytes=(M * (blk.cin + 2 * blk.cexp) + M2 * blk.cexp) * self.esz)
+        src = _Src(y1, pro1, B, H, W, blk.cexp, raw=y1, bn=bn1, gpro=pro1)
+        rec['s1'] = src
+        pro2 = self._bn_fwd(bn2, M2, blk.act)
+        s2 = _Src(y2, pro2, B, Ho, Wo, blk.cexp, raw=y2, bn=bn2, gpro=pro2)
+        y3 = self._buf(f'y3:{i}', (M2, blk.cout))
+        self._c('t3d_pwconv_fwd', dt, N.ptr(y2), pro2, N.ptr(self.w[pwn]), None, N.ptr(y3), self._st(bn3),
+                M2, Ho * Wo, blk.cexp, blk.cout, st, nbytes=M2 * (blk.cexp + blk.cout) * self.esz, fwd=bn2)
+        pro3 = self._bn_fwd(bn3, M2, 'none')
+        z = self._buf(f'z:{i}', (M2, blk.cout))
+        self._c('t3d_bn_apply', dt, N.ptr(y3), pro3, N.ptr(x.t) if blk.res else None, N.ptr(z), M2, blk.cout, st, fwd=bn3)
+        out = _Src(z, None, B, Ho, Wo, blk.cout, raw=y3, bn=bn3, gpro=None)
+        rec.update(src=src, s2=s2, y3=y3, bn3=bn3, out=out, names=(dwn, pwn), blk=blk, idx=i)
+        self.saved_blocks.append(rec)
+        return out
+
     def _block_fwd(self, i, blk, x, sv):
         st, dt = N.stream(), self.dt
         p = f'features.{i + 1}.conv'
@@ -650,6 +696,8 @@ class Net:
             x = self._finish(x, f'z:in{i}')
         rec = dict(x=x)
         src = x
+        if self._fuse_expdw_ok(blk, x):
+            return self._block_fwd_fused(i, blk, x, rec)
         if blk.expand:                                                    # mobilenetv3.py:146-150
             bn1 = self.bns[p + '.1']
             M = B * H * W

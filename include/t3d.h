@@ -333,6 +333,19 @@ int t3d_se_bwd_data(const float* ps_stats, const float* gap_sum, const float* sc
 int t3d_se_bwd_weights(const float* m, const float* h, const float* dq, const float* dp, float* dw1, float* db1, float* dw2,
                        float* db2, int B, int C, int R, void* stream);
 
+/* Fused expand 1x1 conv + BatchNorm + activation + depthwise 3x3 conv forward of an inverted-residual block, training
+ * mode, bf16 storage (models/mobilenetv3.py:146-153: nn.Conv2d(K, C, 1) -> BatchNorm2d -> act -> nn.Conv2d(C, C, 3, s, 1,
+ * groups=C) + the statistics pass of the BatchNorm that follows).  The expanded tensor is recomputed per tile on the
+ * matrix cores and consumed out of LDS, so it costs no HBM read (and, with y1 == NULL, no write).
+ *   z [B,H,W,K] finished block input, w1 [C,K] bf16, scale1 / shift1 [C]: the FINALIZED affine of the expansion's
+ *   BatchNorm (its batch sums come from a statistics-only pass: t3d_pwconv_fwd with y = NULL), act: T3D_ACT_*,
+ *   wdw [C,9] fp32, y1 [B,H,W,C] raw expansion or NULL (stored for a backward that reads it; the stored, rounded value is
+ *   then the one that is normalised, exactly as layer by layer), y2 [B,Ho,Wo,C] raw depthwise output,
+ *   stats2 [2*C] fp64 or NULL: += sum(y2), sum(y2^2) (replicas as in t3d_set_reduction_replicas).
+ * K <= 160, K % 8 == 0, C % 8 == 0, stride 1 or 2; T3D_ERR_UNSUPPORTED otherwise. */
+int t3d_expdw_fwd(const void* z, const void* w1, const float* scale1, const float* shift1, int act, const float* wdw,
+                  void* y1, void* y2, double* stats2, int B, int H, int W, int K, int C, int stride, void* stream);
+
 /* Reduction replicas.  Every `+=` reduction output of the kernels (the fp64 BatchNorm sums `stats`, the depthwise
  * weight gradient `dw`) is hit by one atomic per channel per workgroup; with hundreds of workgroups on a few KB of
  * addresses those atomics serialise.  With nrep > 1 the streaming kernels add into replica (workgroup % nrep):
@@ -349,9 +362,11 @@ int t3d_set_reduction_replicas(int nrep, long long stats_stride);
  * consumes the request: its workgroups derive the coefficients of their own channels from the replica sums (the
  * kernel boundary already orders the sums before them -- no device-wide barrier), and one workgroup per channel also
  * writes the finalize's outputs for every later reader.  Implemented by the bf16 streaming kernels (t3d_pwconv_fwd /
- * _dgrad, t3d_dwconv_fwd / _bwd with k = 3), t3d_pwconv_yfree_prep, t3d_bn_apply and t3d_pool_fwd; other launches
- * leave the request pending: ask t3d_fold_supported() first, or check t3d_fold_pending() (returns 1 and clears it)
- * right after the launch -- the launch then read unfinalized coefficients and must be treated as failed.
+ * _dgrad / _wgrad (the weight gradient derives without publishing), t3d_dwconv_fwd / _bwd with k = 3) and
+ * t3d_bn_apply; other launches
+ * leave the request pending: check t3d_fold_pending() (returns 1 and clears it) right after the launch -- the launch
+ * then read unfinalized coefficients and must be treated as failed (the entry points listed above fall back to a
+ * finalize launch of their own on code paths without the derive prologue, e.g. fp32 storage).
  *   kind 1 (forward, = t3d_bn_finalize):      stats = sum(y), sum(y^2); o0..o3 = scale, shift, mean, invstd
  *   kind 2 (backward, = t3d_bn_bwd_finalize): stats = sum(dz), sum(dz*y); o0..o4 = alpha, beta, gammac, dgamma, dbeta */
 typedef struct {

@@ -19,7 +19,8 @@ args = ap.parse_args()
 from torchdet3d.builders import build_model
 from torchdet3d.utils import AttrDict, Regressor
 
-cfg = AttrDict(dict(model=dict(name=args.model, num_classes=9, pretrained=False, storage_dtype=args.dtype)))
+cfg = AttrDict(dict(model=dict(name=args.model, num_classes=9, pretrained=False, storage_dtype=args.dtype,
+                               eval_storage_dtype=args.dtype)))      # inference in the SAME storage precision (opt-in for bf16)
 model = build_model(cfg, export_mode=True).to('cuda')
 model.eval()
 H, W, n = 1080, 1920, args.dets
