@@ -63,6 +63,10 @@ struct GemmArgs {
   int Kin2, ks1;
   int row0;   // row stride (= channel count) of a0 / a1; equals Kin without a second segment
   const T3dFold* fold;   // BatchNorm finalize of the operand's coefficients derived in the prologue (streaming kernel only)
+  // materialising forward (t3d_pwconv_fwd_mat, streaming kernel only): the operand is z = bf16(p0*a0 + p1 + z_res), i.e.
+  // the finished block output that t3d_bn_apply would have written; the blocks of output chunk 0 also STORE it to z_out
+  const void* z_res;
+  void* z_out;
   StemSrc stem;          // stem.img != null: a0 is not a tensor, the K = 32 operand is gathered from the crops
 };
 

@@ -42,7 +42,9 @@ __device__ unsigned long long g_pw_trace[16];
 #define PW_STAMP(i)
 #endif
 
-template <int NT, int R, bool DG, bool GEN, bool YF = false, int KU = 2, bool STEM = false>
+// ZM (forward only): materialising operand -- z = bf16(affine(a0) + residual) is formed on load, used as the operand and
+// written out once (what a t3d_bn_apply launch in front of this kernel would have done: one launch and one pass less)
+template <int NT, int R, bool DG, bool GEN, bool YF = false, int KU = 2, bool STEM = false, bool ZM = false>
 __global__ __launch_bounds__(512, KU > 2 ? 1 : 2) void pw_stream_kernel(const GemmArgs a, const int nchunks, const int KS, const int nrep, const long long rstride) {
   constexpr int BN = NT * 16;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -143,7 +145,7 @@ __global__ __launch_bounds__(512, KU > 2 ? 1 : 2) void pw_stream_kernel(const Ge
   __syncthreads();
   PW_STAMP(1);
 
-  const bool plainA = YF || (!DG && !a.p0 && !a.p2 && a.act == T3D_ACT_NONE);
+  const bool plainA = !ZM && (YF || (!DG && !a.p0 && !a.p2 && a.act == T3D_ACT_NONE));
   const bool keep_stats = a.stats != nullptr;
   float st1[NT / 2][8], st2[NT / 2][8];
 #pragma unroll
@@ -206,6 +208,7 @@ __global__ __launch_bounds__(512, KU > 2 ? 1 : 2) void pw_stream_kernel(const Ge
       constexpr int KUr = decltype(ku_tag)::value;
       constexpr bool GUARD = decltype(guard_tag)::value;
       bf16x8 fa[KUr][R], fb[KUr][R];
+      bf16x8 fz[ZM ? KUr : 1][R];      // ZM: residual fragments, fetched with the operand
       // squeeze-excite gates of the forward operand (per sample x input channel, fp32): fetched WITH the operand -- loaded
       // inside the transform they were one more dependent global round trip per k-step
       float4 gs[GEN && !DGL ? KUr : 1][R][2];
@@ -228,6 +231,10 @@ __global__ __launch_bounds__(512, KU > 2 ? 1 : 2) void pw_stream_kernel(const Ge
             } else {
               fa[u][r] = *reinterpret_cast<const bf16x8*>(A0 + (size_t)mld[r] * a.row0 + k);
               if (DGL) fb[u][r] = *reinterpret_cast<const bf16x8*>(A1 + (size_t)mld[r] * a.row0 + k);
+              if constexpr (ZM) {
+                if (a.z_res)
+                  fz[u][r] = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const bf16_t*>(a.z_res) + (size_t)mld[r] * a.row0 + k);
+              }
               if constexpr (GEN && !DGL) {
                 if (gated) {
                   const float* gp = a.p2 + (size_t)(mld[r] / a.HW) * a.Kin + min(ks * 32 + lg * 8, a.Kin - 8);
@@ -282,8 +289,18 @@ __global__ __launch_bounds__(512, KU > 2 ? 1 : 2) void pw_stream_kernel(const Ge
                 } else {
                   act_affine_vec<8>(x, c0, c1, a.act);
                 }
+                if constexpr (ZM) {
+                  if (a.z_res) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) x[j] += (float)fz[u][r][j];
+                  }
+                }
 #pragma unroll
                 for (int j = 0; j < 8; ++j) b[r][j] = (bf16_t)x[j];
+                if constexpr (ZM) {
+                  if (chunk == 0 && ok)
+                    *reinterpret_cast<bf16x8*>(reinterpret_cast<bf16_t*>(a.z_out) + (size_t)mrow[r] * a.row0 + k) = b[r];
+                }
               }
             } else {
               const float4 c2a = *reinterpret_cast<const float4*>(coef + 2 * kpad + k),
@@ -475,7 +492,7 @@ __global__ __launch_bounds__(512, KU > 2 ? 1 : 2) void pw_stream_kernel(const Ge
   PW_STAMP(4);
 }
 
-template <int NT, int R, bool DG, bool GEN, bool YF = false, int KU = 2, bool STEM = false>
+template <int NT, int R, bool DG, bool GEN, bool YF = false, int KU = 2, bool STEM = false, bool ZM = false>
 int launch_v(GemmArgs& a, int KS, hipStream_t st) {
   constexpr int BN = NT * 16;
   const int kpad = KS * 32;
@@ -488,7 +505,7 @@ int launch_v(GemmArgs& a, int KS, hipStream_t st) {
   const bool ps = GEN && a.ps_stats != nullptr;          // per-sample sums: a block owns whole samples (kernel)
   const int gps = cdiv(a.HW, 16 * R);
   const int threads = (lds <= 48 * 1024 || (ps && gps <= 4)) ? 256 : 512;
-  const void* fn = (const void*)pw_stream_kernel<NT, R, DG, GEN, YF, KU, STEM>;
+  const void* fn = (const void*)pw_stream_kernel<NT, R, DG, GEN, YF, KU, STEM, ZM>;
   if (lds > 64 * 1024) (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   static int occ_cache[2] = {0, 0};   // per instantiation (function-local static of the template), per block size
   int& occ = occ_cache[threads == 512];
@@ -517,7 +534,7 @@ int launch_v(GemmArgs& a, int KS, hipStream_t st) {
   } else {
     a.fold = t3d_take_fold(a.p0);
   }
-  hipLaunchKernelGGL((pw_stream_kernel<NT, R, DG, GEN, YF, KU, STEM>), dim3(nxb * nchunks), dim3(threads), lds, st, a, nchunks, KS,
+  hipLaunchKernelGGL((pw_stream_kernel<NT, R, DG, GEN, YF, KU, STEM, ZM>), dim3(nxb * nchunks), dim3(threads), lds, st, a, nchunks, KS,
                      g_t3d_reduce.nrep, g_t3d_reduce.stats_stride);
   T3D_CHECK_LAUNCH();
   return T3D_OK;
@@ -535,6 +552,7 @@ int launch_nt(GemmArgs& a, int KS, hipStream_t st, int deep_ku = 0) {
   if (a.dgrad && !gen && deep_ku == 3) return launch_v<NT, R, true, false, false, 3>(a, KS, st);
   if (a.dgrad && !gen && deep_ku == 5) return launch_v<NT, R, true, false, false, 5>(a, KS, st);
   if (a.dgrad) return gen ? launch_v<NT, R, true, true>(a, KS, st) : launch_v<NT, R, true, false>(a, KS, st);
+  if (a.z_out) return gen ? T3D_ERR_UNSUPPORTED : launch_v<NT, R, false, false, false, 2, false, true>(a, KS, st);
   return gen ? launch_v<NT, R, false, true>(a, KS, st) : launch_v<NT, R, false, false>(a, KS, st);
 }
 

@@ -86,12 +86,15 @@ _concurrent_stream.log = []
 class _Src:
     """A tensor as a consumer sees it: `t` [M,C] + how to read it (`pro`), and, for the backward,
     the raw producer tensor / BatchNorm its gradient must be reported against."""
-    __slots__ = ('t', 'pro', 'B', 'H', 'W', 'C', 'raw', 'bn', 'gpro', 'finished_act', 'dz')
+    __slots__ = ('t', 'pro', 'B', 'H', 'W', 'C', 'raw', 'bn', 'gpro', 'finished_act', 'dz', 'zres', 'zbuf')
 
     def __init__(self, t, pro, B, H, W, C, raw=None, bn=None, gpro=None, finished_act=False):
         self.t, self.pro, self.B, self.H, self.W, self.C = t, pro, B, H, W, C
         self.raw, self.bn, self.gpro, self.finished_act = raw, bn, gpro, finished_act
         self.dz = None
+        # a block output that has not been materialised yet: t = raw projection output, pro = its BatchNorm affine,
+        # zres = the skip connection's tensor (or None), zbuf = where z = BN(t) + zres goes (Net._resolve / _pw_from)
+        self.zres = self.zbuf = None
 
 
 class Net:
@@ -214,6 +217,7 @@ class Net:
         self._cur_nrep = None
         # T3D_NO_LAZY_BN=1: every BatchNorm finalize as a launch of its own (the round-2 behaviour)
         self._lazy = not os.environ.get('T3D_NO_LAZY_BN')
+        self._zfuse = not os.environ.get('T3D_NO_ZFUSE')        # block outputs materialised by the consuming 1x1 conv
         if os.environ.get('T3D_LAZY_SKIP'):     # measurement aid: entry points that get the standalone finalize instead
             self.DERIVING = self.DERIVING - frozenset(os.environ['T3D_LAZY_SKIP'].split(','))
         if sh is None:
@@ -362,7 +366,7 @@ class Net:
     # or is preceded by the standalone finalize (`_settle_f` / `_settle_b`: every other reader).
     # (the depthwise kernels implement the derive prologue too -- T3D_LAZY_DW=1 -- but every one of their 500-700 persistent
     # workgroups then starts with the ~3-us round trip to the sums: same step time, depthwise launches 3-4 us longer)
-    DERIVING = frozenset(('t3d_pwconv_fwd', 't3d_bn_apply', 't3d_pool_fwd', 't3d_pwconv_dgrad', 't3d_pwconv_yfree_prep')
+    DERIVING = frozenset(('t3d_pwconv_fwd', 't3d_pwconv_fwd_mat', 't3d_bn_apply', 't3d_pool_fwd', 't3d_pwconv_dgrad', 't3d_pwconv_yfree_prep')
                          + (('t3d_dwconv_fwd', 't3d_dwconv_bwd') if os.environ.get('T3D_LAZY_DW') else ()))
 
     def _c(self, entry, *args, fwd=None, bwd=None, **kw):
@@ -607,13 +611,32 @@ class Net:
         bnl = self.bns[ln + '.1']
         M = cur.B * cur.H * cur.W
         yl = self._buf('y:last', (M, a.last_c))
-        self._c('t3d_pwconv_fwd', dt, N.ptr(cur.t), cur.pro, N.ptr(self.w[ln + '.0.weight']), None, N.ptr(yl),
-                self._st(bnl), M, cur.H * cur.W, cur.C, a.last_c, st, nbytes=M * (cur.C + a.last_c) * self.esz,
-                fwd=cur.bn if cur.pro is not None else None)
+        self._pw_from(cur, self.w[ln + '.0.weight'], yl, bnl, M, cur.H * cur.W, cur.C, a.last_c)
         prol = self._bn_fwd(bnl, M, a.last_act)
         pooled = self._buf('pooled', (B, a.last_c), torch.float32)
         sv.update(last_in=cur, yl=yl, prol=prol, pooled=pooled, HWl=cur.H * cur.W, bnl=bnl)
         return sv
+
+    def _resolve(self, src):
+        """Materialise a pending block output (z = BN(y3) + skip) as a launch of its own -- for the consumers that are not
+        a 1x1 conv (a 1x1 conv forms z while it loads its operand: `_pw_from`)."""
+        if src.zbuf is not None:
+            M = src.B * src.H * src.W
+            self._c('t3d_bn_apply', self.dt, N.ptr(src.t), src.pro, N.ptr(src.zres), N.ptr(src.zbuf), M, src.C, N.stream(),
+                    fwd=src.bn)
+            src.t, src.pro, src.zres, src.zbuf = src.zbuf, None, None, None
+        return src
+
+    def _pw_from(self, x, w, y, bn_out, M, HW, K, Nn):
+        """1x1 conv forward reading `x`; a pending block output is materialised by the conv itself (t3d_pwconv_fwd_mat)."""
+        st, nb = N.stream(), M * (K + Nn) * self.esz
+        if x.zbuf is not None:
+            self._c('t3d_pwconv_fwd_mat', self.dt, N.ptr(x.t), x.pro, N.ptr(x.zres), N.ptr(x.zbuf), N.ptr(w), N.ptr(y),
+                    self._st(bn_out), M, HW, K, Nn, st, nbytes=nb, fwd=x.bn)
+            x.t, x.pro, x.zres, x.zbuf = x.zbuf, None, None, None
+        else:
+            self._c('t3d_pwconv_fwd', self.dt, N.ptr(x.t), x.pro, N.ptr(w), None, N.ptr(y), self._st(bn_out), M, HW, K, Nn,
+                    st, nbytes=nb, fwd=x.bn if x.pro is not None else None)
 
     def _finish(self, src, tag):
         """Materialise act(BN(y)) (needed when a deferred tensor also feeds a skip connection)."""
@@ -692,7 +715,11 @@ class Net:
                    B, H, W, blk.cin, blk.cexp, blk.cout, st,
                    nbytes=B * H * W * (2 * blk.cin + 4 * blk.cexp + 2 * blk.cout) * self.esz)
             return _Src(z, None, B, H, W, blk.cout, raw=None, bn=bn3, gpro=None)
-        if blk.res and x.pro is not None:
+        if x.zbuf is not None and not blk.expand:
+            self._resolve(x)                   # (the depthwise conv of a no-expand block reads the finished tensor)
+        if x.zbuf is not None and self._fuse_expdw:
+            self._resolve(x)
+        if blk.res and x.pro is not None and x.zbuf is None:
             x = self._finish(x, f'z:in{i}')
         rec = dict(x=x)
         src = x
@@ -702,9 +729,7 @@ class Net:
             bn1 = self.bns[p + '.1']
             M = B * H * W
             y1 = self._buf(f'y1:{i}', (M, blk.cexp))
-            self._c('t3d_pwconv_fwd', dt, N.ptr(x.t), x.pro, N.ptr(self.w[p + '.0.weight']), None, N.ptr(y1),
-                    self._st(bn1), M, H * W, blk.cin, blk.cexp, st, nbytes=M * (blk.cin + blk.cexp) * self.esz,
-                    fwd=x.bn if x.pro is not None else None)
+            self._pw_from(x, self.w[p + '.0.weight'], y1, bn1, M, H * W, blk.cin, blk.cexp)
             pro1 = self._bn_fwd(bn1, M, blk.act)
             src = _Src(y1, pro1, B, H, W, blk.cexp, raw=y1, bn=bn1, gpro=pro1)
             rec['s1'] = src
@@ -761,8 +786,12 @@ class Net:
                 M2, Ho * Wo, blk.cexp, blk.cout, st, nbytes=M2 * (blk.cexp + blk.cout) * self.esz, fwd=bn2)
         pro3 = self._bn_fwd(bn3, M2, 'none')
         z = self._buf(f'z:{i}', (M2, blk.cout))
-        self._c('t3d_bn_apply', dt, N.ptr(y3), pro3, N.ptr(x.t) if blk.res else None, N.ptr(z), M2, blk.cout, st, fwd=bn3)
-        out = _Src(z, None, B, Ho, Wo, blk.cout, raw=y3, bn=bn3, gpro=None)
+        # the block output z = BN(y3) (+ x) stays PENDING: the next 1x1 conv forms it on load and writes it out
+        # (t3d_pwconv_fwd_mat) -- one launch and one pass over the narrow tensor less per block
+        out = _Src(y3, pro3, B, Ho, Wo, blk.cout, raw=y3, bn=bn3, gpro=None)
+        out.zres, out.zbuf = (x.t if blk.res else None), z
+        if not (self.training and self._zfuse):
+            self._resolve(out)
         rec.update(src=src, s2=s2, y3=y3, bn3=bn3, out=out, names=(dwn, pwn), blk=blk, idx=i)
         sv['blocks'].append(rec)
         return out

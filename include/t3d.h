@@ -333,6 +333,16 @@ int t3d_se_bwd_data(const float* ps_stats, const float* gap_sum, const float* sc
 int t3d_se_bwd_weights(const float* m, const float* h, const float* dq, const float* dp, float* dw1, float* db1, float* dw2,
                        float* db2, int B, int C, int R, void* stream);
 
+/* t3d_bn_apply + t3d_pwconv_fwd in one launch: the 1x1 conv whose input is the previous block's OUTPUT, still in its raw
+ * form (models/mobilenetv3.py:158-166: `x + conv(x)` feeding the next block's expansion).  The operand
+ *   z = round_to_storage(act(scale*y_in + shift) + residual)
+ * is formed on load exactly as t3d_bn_apply would have stored it, used for the contraction, and written to z_out once
+ * (the skip connection and the backward need it).  bf16 streaming kernel; other cases run the two launches.
+ *   y_in [M,K] raw, pro_in: its BatchNorm affine (+ activation), residual [M,K] or NULL, z_out [M,K],
+ *   w [N,K], y [M,N] raw output, stats as in t3d_pwconv_fwd. */
+int t3d_pwconv_fwd_mat(int dtype, const void* y_in, const t3d_prologue* pro_in, const void* residual, void* z_out,
+                       const void* w, void* y, double* stats, int M, int HW, int K, int N, void* stream);
+
 /* Fused expand 1x1 conv + BatchNorm + activation + depthwise 3x3 conv forward of an inverted-residual block, training
  * mode, bf16 storage (models/mobilenetv3.py:146-153: nn.Conv2d(K, C, 1) -> BatchNorm2d -> act -> nn.Conv2d(C, C, 3, s, 1,
  * groups=C) + the statistics pass of the BatchNorm that follows).  The expanded tensor is recomputed per tile on the
