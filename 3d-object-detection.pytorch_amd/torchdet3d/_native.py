@@ -61,6 +61,7 @@ SIGNATURES = {
     't3d_stem_im2col_u8': [_I, _P, _P, _P, _P, _I, _I, _I, _P],
     't3d_crop_resize_u8': [_P, _P, _P, _I, _I, _I, _I, _I, _P],
     't3d_pwconv_fwd_mat': [_I, _P, _PP, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
+    't3d_ssd_decode_nms': [_I, _I, _P, _P, _P, _P, _P, _P, _P, _I, _I, _F, _F, _I, _F, _F, _P, _P, _P, _P],
     't3d_expdw_fwd': [_P, _P, _P, _P, _I, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
     't3d_ir_block_eval': [_P, _P, _P, _P, _I, _P, _P, _P, _I, _P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _I, _P],
     't3d_stem_fwd': [_I, _P, _I, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P],

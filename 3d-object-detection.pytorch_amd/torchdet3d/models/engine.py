@@ -541,6 +541,21 @@ class Net:
         self.saved = sv if train else None
         return kp.view(B, 9, 2), logits
 
+    def forward_taps(self, imgs, tap_blocks):
+        """Inference pass over the backbone up to the last requested block: -> {k: (tensor [B*H*W, C] in the storage dtype,
+        B, H, W, C)} with the finished (BatchNorm + skip applied) outputs of `features.k` -- the feature maps an SSD head
+        taps (configs/detection/mnv2_ssd_300_2_heads.py:7-18: the 96- and 320-channel maps of mobilenetv2)."""
+        self._cur_nrep = None
+        self._replicas(NREP)
+        self._want_taps = set(tap_blocks)
+        try:
+            sv = self._features(imgs, False)
+        finally:
+            self._want_taps = None
+            N.call('t3d_set_reduction_replicas', 1, 0)
+            self._cur_nrep = None
+        return {k: (s.t, s.B, s.H, s.W, s.C) for k, s in sv['taps'].items()}
+
     def extract_features(self, imgs):
         """`MobileNetV3.extract_features` (mobilenetv3.py:199-203) as a caller sees it: the activated last feature map,
         fp32 NCHW [B, C, H/32, W/32].  Inference only (running BatchNorm statistics); the layout conversion from the
@@ -603,8 +618,11 @@ class Net:
         cur = _Src(y0, pro0, B, Ho, Wo, a.stem_c, raw=y0, bn=bn0, gpro=pro0)
         sv['col'], sv['stem'] = col, cur
 
+        taps = getattr(self, '_want_taps', None)
         for i, blk in enumerate(a.blocks):
             cur = self._block_fwd(i, blk, cur, sv)
+            if taps and (i + 1) in taps:        # finished output of features.{i+1} (the detector's feature maps)
+                sv.setdefault('taps', {})[i + 1] = self._resolve(cur)
 
         # ---- last 1x1 conv (mobilenetv3.py:118-123,188) + global average pool (model_builder.py:96-110)
         ln = a.last_name

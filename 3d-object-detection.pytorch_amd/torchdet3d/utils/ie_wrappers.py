@@ -8,8 +8,9 @@ stem's patch gather, and regressed in one batched forward with every head (`forw
 model_builder.py:112-124); the head of the arg-max class is selected on the device (:135-139).
 
 The detector stage (`Detector`, :70-120) runs an SSD trained in an external mmdetection fork and deployed as an OpenVINO IR
-(configs/detection/mnv2_ssd_300_2_heads.py, README.md:56-57): there is no reference source for its arithmetic, so it is not
-rebuilt here -- any detector that yields `(left, top, right, bottom, confidence, label)` tuples plugs in.
+(configs/detection/mnv2_ssd_300_2_heads.py, README.md:56-57): there is no reference source for its arithmetic; `Detector`
+here runs the same architecture built from that config on the product's kernels (models/ssd.py, parity unpinned) -- any other
+detector that yields `(left, top, right, bottom, confidence, label)` tuples plugs into `Regressor` as well.
 """
 import numpy as np
 import torch
@@ -104,9 +105,59 @@ class Regressor:
 
 
 class Detector:
-    """Not rebuilt: the reference's detector is an OpenVINO IR of an SSD trained in an external mmdetection fork
-    (ie_wrappers.py:70-120, configs/detection/mnv2_ssd_300_2_heads.py) -- no source for its arithmetic exists in the
-    reference.  Feed `Regressor.get_detections` from any detector producing (left, top, right, bottom, confidence, label)."""
+    """HIP replacement of ie_wrappers.Detector (:70-120): the SSD300-MobileNetV2 of configs/detection/mnv2_ssd_300_2_heads.py
+    (models/ssd.py -- arithmetic per the published mmdet definitions, parity with the reference's externally trained
+    detector unpinned).  Same call surface: `get_detections(frame)`, `run_async(frame)` / `wait_and_grab()`, `confidence`,
+    `expand_ratio`; detections are `(left, top, right, bottom, confidence, label)` in frame pixels.  The frame is resized to
+    300x300 on the GPU (`t3d_crop_resize_u8`, cv.resize's 8-bit bilinear arithmetic) and normalised inside the stem."""
 
-    def __init__(self, *args, **kwargs):
-        raise NotImplementedError(self.__doc__)
+    def __init__(self, model, conf=.6):
+        self.model = model
+        self.device = model.device
+        self.confidence = conf
+        self.expand_ratio = (1., 1.)
+        self._pending = None
+
+    def _enqueue(self, frame):
+        from ..models.ssd import INPUT_SIZE
+        if not torch.is_tensor(frame):
+            frame = torch.from_numpy(np.ascontiguousarray(frame))
+        frame = frame.to(self.device, non_blocking=True).contiguous()
+        H, W = int(frame.shape[0]), int(frame.shape[1])
+        rect = torch.tensor([[0, 0, W, H]], dtype=torch.int32, device=self.device)
+        img = torch.empty(1, INPUT_SIZE, INPUT_SIZE, 3, dtype=torch.uint8, device=self.device)
+        N.call('t3d_crop_resize_u8', N.ptr(frame), N.ptr(rect), N.ptr(img), 1, H, W, INPUT_SIZE, INPUT_SIZE, N.stream())
+        return img, (H, W)
+
+    def run_async(self, frame):
+        self._pending = self._enqueue(frame)
+        self.frame_shape = tuple(frame.shape)
+
+    def wait_and_grab(self):
+        img, shape = self._pending
+        self._pending = None
+        return self._decode_detections(self.model.detect(img)[0], shape)
+
+    def get_detections(self, frame):
+        """Returns all detections on frame"""
+        img, shape = self._enqueue(frame)
+        return self._decode_detections(self.model.detect(img)[0], shape)
+
+    def _decode_detections(self, rows, frame_shape):
+        """ie_wrappers.py:94-120 on rows (x1, y1, x2, y2 normalised, confidence, label)."""
+        detections = []
+        for x1, y1, x2, y2, confidence, label in rows:
+            if confidence > self.confidence:
+                left = int(max(x1, 0) * frame_shape[1])
+                top = int(max(y1, 0) * frame_shape[0])
+                right = int(max(x2, 0) * frame_shape[1])
+                bottom = int(max(y2, 0) * frame_shape[0])
+                if self.expand_ratio != (1., 1.):
+                    w, h = (right - left), (bottom - top)
+                    dw, dh = w * (self.expand_ratio[0] - 1.) / 2, h * (self.expand_ratio[1] - 1.) / 2
+                    left, right = max(int(left - dw), 0), int(right + dw)
+                    top, bottom = max(int(top - dh), 0), int(bottom + dh)
+                detections.append((left, top, right, bottom, float(confidence), int(label)))
+        if len(detections) > 1:
+            detections.sort(key=lambda x: x[1], reverse=True)          # (the reference sorts on element 1, :118-119)
+        return detections

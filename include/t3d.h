@@ -356,6 +356,20 @@ int t3d_pwconv_fwd_mat(int dtype, const void* y_in, const t3d_prologue* pro_in, 
 int t3d_expdw_fwd(const void* z, const void* w1, const float* scale1, const float* shift1, int act, const float* wdw,
                   void* y1, void* y2, double* stats2, int B, int H, int W, int K, int C, int stride, void* stream);
 
+/* SSD detector post-processing (configs/detection/mnv2_ssd_300_2_heads.py:15-39,65-69: SSDHead outputs of <= 2 feature
+ * maps -> DeltaXYWH decode -> softmax -> per-class greedy NMS), one launch per frame batch.  The implementing mmdetection
+ * fork is external to the reference (README.md:56-57): arithmetic per the published mmdet definitions, parity unpinned.
+ *   cls[l] [B*hw[l]][cls_stride[l]]: logits, channel = anchor*(num_classes+1) + class, background LAST;
+ *   reg[l] [B*hw[l]][reg_stride[l]]: deltas, channel = anchor*4 + (dx, dy, dw, dh); storage dtype;
+ *   anchors [sum hw*nanchors][4] fp32 (x1, y1, x2, y2 in input pixels), level-major, then pixel, then anchor;
+ *   stds [4]; boxes are clipped to (img_w, img_h).
+ *   out [B][num_classes][max_per_class][6] = x1, y1, x2, y2, score, label in NMS order; counts [B][num_classes].
+ * cls / reg / hw / nanchors / *_stride are HOST arrays of length nlevels. */
+int t3d_ssd_decode_nms(int dtype, int nlevels, const void* const* cls, const void* const* reg, const int* hw,
+                       const int* nanchors, const int* cls_stride, const int* reg_stride, const float* anchors, int B,
+                       int num_classes, float score_thr, float iou_thr, int max_per_class, float img_w, float img_h,
+                       const float* stds, float* out, int* counts, void* stream);
+
 /* Reduction replicas.  Every `+=` reduction output of the kernels (the fp64 BatchNorm sums `stats`, the depthwise
  * weight gradient `dw`) is hit by one atomic per channel per workgroup; with hundreds of workgroups on a few KB of
  * addresses those atomics serialise.  With nrep > 1 the streaming kernels add into replica (workgroup % nrep):

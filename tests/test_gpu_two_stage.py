@@ -122,3 +122,94 @@ def test_frame_cropper_on_a_busy_stream_keeps_each_frames_boxes():
             _, crop, box = objectron_crop(frame, kp)
             assert boxes[i] == box
             assert np.array_equal(crops[i].cpu().numpy(), resize_linear_u8(crop, (96, 96)))
+
+
+def _ssd_pair(dtype, seed=4):
+    from oracle.ssd import detect as odetect
+    from torchdet3d.models.ssd import SSD300, make_anchors
+    m = SSD300('cuda', dtype, seed=seed)
+    g = torch.Generator().manual_seed(seed)
+    sd = m.state_dict()
+    for k in sd:                      # trained-looking BatchNorm buffers and class biases: the scores must discriminate
+        if k.startswith('bbox_head') and k.endswith('running_mean'):
+            sd[k] = torch.randn(sd[k].shape, generator=g) * 0.1
+        elif k.startswith('bbox_head') and k.endswith('running_var'):
+            sd[k] = torch.rand(sd[k].shape, generator=g) + 0.5
+        elif k.startswith('bbox_head.cls_convs') and k.endswith('.3.bias'):
+            sd[k] = torch.randn(sd[k].shape, generator=g) * 2.0
+        elif k.startswith('bbox_head.reg_convs') and k.endswith('.3.bias'):
+            sd[k] = torch.randn(sd[k].shape, generator=g) * 0.5
+    m.load_state_dict(sd)
+    return m, {k: v.cpu() for k, v in sd.items()}, odetect, make_anchors()
+
+
+def test_ssd_detector_forward_decode_nms_matches_the_oracle():
+    """BASELINE config 5, detector stage: SSD300-MobileNetV2 (fp32 storage) -- head outputs within 1e-4 of the oracle,
+    then boxes / scores / labels after decode + softmax + per-class NMS + top-200 (parity with the reference's externally
+    trained detector is unpinned; this pins the product to its own restatement of the config)."""
+    from oracle.ssd import head_outputs as ohead
+    m, sd, odetect, anchors = _ssd_pair(torch.float32)
+    g = torch.Generator().manual_seed(1)
+    imgs = torch.randn(2, 3, 300, 300, generator=g)
+    outs = m.head_outputs(imgs.cuda())
+    ref = ohead(sd, imgs)
+    for (c, r, hw), (oc, orr) in zip(outs, ref):
+        oc2, or2 = oc.reshape(2 * hw, -1), orr.reshape(2 * hw, -1)
+        np.testing.assert_allclose(c.cpu().numpy()[:, :oc2.shape[1]], oc2.numpy(), atol=2e-4)
+        np.testing.assert_allclose(r.cpu().numpy()[:, :or2.shape[1]], or2.numpy(), atol=2e-4)
+        assert (c.cpu().numpy()[:, oc2.shape[1]:] == 0).all()                # padded output channels
+    # decode + softmax + NMS + top-200 on RANDOM head outputs (no ties; the synthetic network's feature maps are nearly
+    # constant, and among equal scores an ulp between expf and np.exp decides the order): the post-processing kernel against
+    # the oracle's on identical inputs ...
+    from oracle.ssd import postprocess
+    g2 = torch.Generator().manual_seed(7)
+    rnd = [(torch.randn(2, hw, c.shape[1], generator=g2) * 3, torch.randn(2, hw, r.shape[1], generator=g2)) for c, r, hw in outs]
+    ro = [(cc[:, :, :len(W_) * 10].reshape(2, hw, len(W_), 10).numpy(), rr[:, :, :len(W_) * 4].reshape(2, hw, len(W_), 4).numpy())
+          for (cc, rr), (_, _, hw), W_ in zip(rnd, outs, __import__('torchdet3d.models.ssd', fromlist=['WIDTHS']).WIDTHS)]
+    want = postprocess(ro, anchors)
+    real_heads = m.head_outputs
+    m.head_outputs = lambda _: [(cc.reshape(2 * hw, -1).cuda().contiguous(), rr.reshape(2 * hw, -1).cuda().contiguous(), hw)
+                                for (cc, rr), (_, _, hw) in zip(rnd, outs)]
+    got = m.detect(imgs.cuda())
+    m.head_outputs = real_heads
+    for a, b in zip(got, want):
+        assert a.shape == b.shape and a.shape[0] == 200
+        assert (a[:, 5] == b[:, 5]).all()
+        np.testing.assert_allclose(a[:, :5], b[:, :5], atol=1e-4)
+    want = odetect(sd, imgs, anchors)
+    # ... and end to end the product's own detections are the oracle's up to those flips: every oracle detection above 0.3
+    # has a product detection of the same class within 2e-3
+    for a, b in zip(m.detect(imgs.cuda()), want):
+        hit = 0
+        strong = b[b[:, 4] > 0.3]
+        for row in strong:
+            cand = a[a[:, 5] == row[5]]
+            hit += bool(len(cand)) and np.abs(cand[:, :5] - row[:5]).max(1).min() < 2e-3
+        assert len(strong) == 0 or hit >= 0.8 * len(strong), (hit, len(strong))     # (ties at the top-200 cut, see above)
+
+
+def test_detector_then_regressor_is_the_whole_two_stage_pipeline():
+    """scripts/demo.py:48-90's flow on one 1080x1920 frame: Detector.get_detections -> Regressor.get_detections ->
+    transform_kp, everything on the GPU (bf16 storage, the throughput mode)."""
+    from test_host_logic import _cfg
+    from torchdet3d.builders import build_model
+    from torchdet3d.utils import Detector, Regressor
+    m, _, _, _ = _ssd_pair(torch.bfloat16)
+    det = Detector(m, conf=0.3)
+    rng = np.random.default_rng(5)
+    frame = rng.integers(0, 256, (1080, 1920, 3), dtype=np.uint8)
+    dets = det.get_detections(frame)
+    det.run_async(frame)
+    assert det.wait_and_grab() == dets
+    assert len(dets) > 0
+    for left, top, right, bottom, conf, label in dets:
+        assert 0 <= left <= right <= 1920 and 0 <= top <= bottom <= 1080 and 0.3 < conf <= 1 and 0 <= label < 9
+    cfg = _cfg('mobilenetv2')
+    cfg.model.storage_dtype = 'bf16'
+    reg = Regressor(build_model(cfg, export_mode=True).to('cuda'))
+    res = reg.get_detections(frame, dets[:16])
+    assert len(res) == min(len(dets), 16)
+    for (kp, label), d in zip(res, dets):
+        assert kp.shape == (1, 9, 2) and 0 <= label < 9
+        pix = Regressor.transform_kp(kp[0].copy(), d[:4])
+        assert np.isfinite(pix).all()
