@@ -30,6 +30,7 @@ struct Dw3Args {
   int rows_per_chunk, nchunks;
   int slab;        // 0: flattened (column, channel-group) mapping; 1: 64-group channel slabs (wide layers)
   int nitems;      // work items a thread walks: flattened: B*nchunks; slab: Wo*B*nchunks
+  T3dQuant quant;  // BatchNorm sums snapped onto a fixed grid: order-independent (common.h)
   int nrep;        // reduction replicas (common.h)
   long long rstride;
   const T3dFold* fold;    // requested BatchNorm finalize of the INPUT's coefficients, derived in the prologue (common.h)
@@ -63,7 +64,7 @@ __device__ __forceinline__ void store_round(T* p, const float* acc, float* psum,
 // CH channels per thread (8 -> 16-B bf16 vectors, 4 -> 8-B: more resident waves), PF input rows in flight
 template <typename T, int S, int CH, int PF>
 __global__ __launch_bounds__(256) void dw3_fwd_kernel(const Dw3Args a) {
-  extern __shared__ float lstat[];  // [2][C]
+  extern __shared__ __attribute__((aligned(16))) float lstat[];  // [2][C] doubles at the end of the kernel (sums); floats for a derived finalize
   using RV = rawvec<T, CH>;
   const int CG = a.C / CH;
   // A thread keeps ONE channel group for its whole life (weights + BatchNorm partial sums stay in registers)
@@ -228,20 +229,21 @@ __global__ __launch_bounds__(256) void dw3_fwd_kernel(const Dw3Args a) {
     // only the block's own channel range (whole tensor, or one 64-group slab) goes through LDS and out
     const int cbase = a.slab ? blockIdx.y * 64 * CH : 0;
     const int Cb = a.slab ? min(64 * CH, a.C - cbase) : a.C;
-    for (int i = threadIdx.x; i < 2 * Cb; i += 256) lstat[i] = 0.f;
+    double* dstat = reinterpret_cast<double*>(lstat);     // [2][Cb], exact adds of snapped partial sums (common.h)
+    for (int i = threadIdx.x; i < 2 * Cb; i += 256) dstat[i] = 0.0;
     __syncthreads();
     if (on) {
 #pragma unroll
       for (int i = 0; i < CH; ++i) {
-        atomicAdd(lstat + c0 - cbase + i, psum[i]);
-        atomicAdd(lstat + Cb + c0 - cbase + i, psq[i]);
+        atomicAdd(dstat + c0 - cbase + i, t3d_snap(psum[i], a.quant, false));
+        atomicAdd(dstat + Cb + c0 - cbase + i, t3d_snap(psq[i], a.quant, true));
       }
     }
     __syncthreads();
     for (int i = threadIdx.x; i < 2 * Cb; i += 256)
-      if (lstat[i] != 0.f)
+      if (dstat[i] != 0.0)
         atomicAdd(a.stats + (size_t)((blockIdx.x + blockIdx.y) % a.nrep) * a.rstride + (size_t)(i / Cb) * a.C + cbase + i % Cb,
-                  (double)lstat[i]);
+                  dstat[i]);
   }
 }
 
@@ -254,7 +256,7 @@ __global__ __launch_bounds__(256) void dw3_fwd_kernel(const Dw3Args a) {
 template <typename T, int PF>
 __global__ __launch_bounds__(256) void dw3_fwd2_kernel(const Dw3Args a) {
   constexpr int CH = 4, H2 = CH / 2;
-  extern __shared__ float lstat[];  // [2][C]
+  extern __shared__ __attribute__((aligned(16))) float lstat[];  // [2][C] doubles at the end of the kernel (sums); floats for a derived finalize
   using RV = rawvec<T, CH>;
   const int CG = a.C / CH, Wp = (a.Wo + 1) / 2;
   int cg, xp_fixed = 0, q0, qstride;
@@ -447,20 +449,21 @@ __global__ __launch_bounds__(256) void dw3_fwd2_kernel(const Dw3Args a) {
     // only the block's own channel range (whole tensor, or one 64-group slab) goes through LDS and out
     const int cbase = a.slab ? blockIdx.y * 64 * CH : 0;
     const int Cb = a.slab ? min(64 * CH, a.C - cbase) : a.C;
-    for (int i = threadIdx.x; i < 2 * Cb; i += 256) lstat[i] = 0.f;
+    double* dstat = reinterpret_cast<double*>(lstat);     // [2][Cb], exact adds of snapped partial sums (common.h)
+    for (int i = threadIdx.x; i < 2 * Cb; i += 256) dstat[i] = 0.0;
     __syncthreads();
     if (on) {
 #pragma unroll
       for (int i = 0; i < CH; ++i) {
-        atomicAdd(lstat + c0 - cbase + i, psum[i]);
-        atomicAdd(lstat + Cb + c0 - cbase + i, psq[i]);
+        atomicAdd(dstat + c0 - cbase + i, t3d_snap(psum[i], a.quant, false));
+        atomicAdd(dstat + Cb + c0 - cbase + i, t3d_snap(psq[i], a.quant, true));
       }
     }
     __syncthreads();
     for (int i = threadIdx.x; i < 2 * Cb; i += 256)
-      if (lstat[i] != 0.f)
+      if (dstat[i] != 0.0)
         atomicAdd(a.stats + (size_t)((blockIdx.x + blockIdx.y) % a.nrep) * a.rstride + (size_t)(i / Cb) * a.C + cbase + i % Cb,
-                  (double)lstat[i]);
+                  dstat[i]);
   }
 }
 
@@ -504,8 +507,12 @@ int launch_ch(Dw3Args& a, int s, hipStream_t st) {
     if (gx < 1) gx = 1;
     grid = dim3(gx, ns);
   }
-  const size_t lds = (size_t)2 * a.C * sizeof(float);
+  const size_t lds = (size_t)2 * a.C * sizeof(double);
   a.fold = t3d_take_fold(a.scale);
+  // (throughput mode only: in fp32 storage the sums' order noise stays at 1e-6 of the outputs and the grid would be one more
+  // perturbation between the parity mode and the reference)
+  a.quant = (a.stats && std::is_same<T, bf16_t>::value && !getenv("T3D_NO_SNAP")) ? t3d_quant_for((long long)a.B * a.Ho * a.Wo)
+                                                                                  : T3dQuant{0.0, 0.0};
   if (use2) hipLaunchKernelGGL((dw3_fwd2_kernel<T, PF>), grid, dim3(256), lds, st, a);
   else if (s == 1) hipLaunchKernelGGL((dw3_fwd_kernel<T, 1, CH, PF>), grid, dim3(256), lds, st, a);
   else hipLaunchKernelGGL((dw3_fwd_kernel<T, 2, CH, PF>), grid, dim3(256), lds, st, a);

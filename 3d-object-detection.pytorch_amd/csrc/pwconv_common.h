@@ -67,6 +67,7 @@ struct GemmArgs {
   // the finished block output that t3d_bn_apply would have written; the blocks of output chunk 0 also STORE it to z_out
   const void* z_res;
   void* z_out;
+  T3dQuant quant;        // forward BatchNorm sums snapped onto a fixed grid (order-independent, common.h); q == 0: off
   StemSrc stem;          // stem.img != null: a0 is not a tensor, the K = 32 operand is gathered from the crops
 };
 

@@ -53,6 +53,7 @@ __global__ __launch_bounds__(512, KU > 2 ? 1 : 2) void pw_stream_kernel(const Ge
   float* coef = reinterpret_cast<float*>(smem + (size_t)NT * KS * 1024);          // [3][kpad]
   float* lstat = coef + 3 * kpad;                                                 // [BN][2]
   float* ecoef = lstat + BN * 2;                                                  // [2][BN] epilogue scale / shift
+  double* dstat = reinterpret_cast<double*>(ecoef + 2 * BN);                      // [BN][2] block sums, exact adds (common.h)
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int lg = lane >> 4, lc = lane & 15;
@@ -109,7 +110,7 @@ __global__ __launch_bounds__(512, KU > 2 ? 1 : 2) void pw_stream_kernel(const Ge
       }
     }
   }
-  for (int i = tid; i < BN * 2; i += nthr) lstat[i] = 0.f;
+  for (int i = tid; i < BN * 2; i += nthr) { lstat[i] = 0.f; dstat[i] = 0.0; }
   for (int i = tid; i < BN; i += nthr) {
     const int n = n0 + i;
     const bool v = DG && a.e_scale && n < a.Nout;
@@ -478,15 +479,15 @@ __global__ __launch_bounds__(512, KU > 2 ? 1 : 2) void pw_stream_kernel(const Ge
       for (int j = 0; j < 8; ++j) {
         const float s1 = row16_sum(st1[q][j]), s2 = row16_sum(st2[q][j]);
         if (lc == 0 && n < a.Nout) {
-          atomicAdd(lstat + (n - n0 + j) * 2, s1);
-          atomicAdd(lstat + (n - n0 + j) * 2 + 1, s2);
+          atomicAdd(dstat + (n - n0 + j) * 2, t3d_snap(s1, a.quant, false));
+          atomicAdd(dstat + (n - n0 + j) * 2 + 1, t3d_snap(s2, a.quant, !DG));
         }
       }
     }
     __syncthreads();
     for (int i = tid; i < BN * 2; i += nthr) {
       const int n = n0 + (i >> 1);
-      if (n < a.Nout) atomicAdd(a.stats + (size_t)(xb % nrep) * rstride + (size_t)(i & 1) * a.Nout + n, (double)lstat[i]);
+      if (n < a.Nout) atomicAdd(a.stats + (size_t)(xb % nrep) * rstride + (size_t)(i & 1) * a.Nout + n, dstat[i]);
     }
   }
   PW_STAMP(4);
@@ -496,7 +497,7 @@ template <int NT, int R, bool DG, bool GEN, bool YF = false, int KU = 2, bool ST
 int launch_v(GemmArgs& a, int KS, hipStream_t st) {
   constexpr int BN = NT * 16;
   const int kpad = KS * 32;
-  const size_t lds = (size_t)NT * KS * 1024 + (size_t)3 * kpad * 4 + BN * 4 * 4;
+  const size_t lds = (size_t)NT * KS * 1024 + (size_t)3 * kpad * 4 + BN * 4 * 4 + BN * 2 * 8;
   if (lds > 150 * 1024) return T3D_ERR_UNSUPPORTED;
   const int nchunks = cdiv(a.Nout, BN);
   const int ngroups = cdiv(a.M, 16 * R);
@@ -528,6 +529,7 @@ int launch_v(GemmArgs& a, int KS, hipStream_t st) {
   }
   // a pending BatchNorm-finalize request belongs to this launch when it names the coefficients of its operand
   // (per-sample coefficients and the y-free / stem variants have none to derive)
+  a.quant = (!DG && a.stats && !getenv("T3D_NO_SNAP")) ? t3d_quant_for(a.M) : T3dQuant{0.0, 0.0};
   if (YF || STEM || a.per_sample) {
     if (const int rc = t3d_fold_fallback(a.p0, st)) return rc;
     a.fold = nullptr;

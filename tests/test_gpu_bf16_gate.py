@@ -280,7 +280,9 @@ def test_bf16_backward_vs_fp32_backward_on_the_same_forward_224(name, B):
 
 def test_bf16_mnv2_b64_224_train_loss_vs_fp32_engine():
     """Two independent train steps (bf16 vs fp32 storage) at production resolution: the loss (what the optimizer follows)
-    within 5e-3; gradient-level agreement is the subject of the same-forward test above."""
+    within 2e-3 (the bf16 forward is bit-reproducible since the BatchNorm sums are order-independent -- 1.2e-3 measured, run
+    after run; the bound was 5e-3 while the sums were added in arrival order); gradient-level agreement is the subject of
+    the same-forward test above."""
     from oracle.weights import make_inputs, make_state_dict
     from test_gpu_engine import _loss_cfg
     from torchdet3d import _native as N
@@ -301,4 +303,4 @@ def test_bf16_mnv2_b64_224_train_loss_vs_fp32_engine():
         losses[dt] = out[0].item()
         del net
     print(f'mnv2 b64@224 train loss fp32 {losses[torch.float32]:.6f} bf16 {losses[torch.bfloat16]:.6f}')
-    assert abs(losses[torch.float32] - losses[torch.bfloat16]) < 5e-3
+    assert abs(losses[torch.float32] - losses[torch.bfloat16]) < 2e-3

@@ -232,3 +232,28 @@ def test_yfree_expand_backward_matches_regular_path(monkeypatch):
     assert worst(yf, ref)[0] < 6e-2, (worst(yf, ref), worst(ref2, ref))
     # and the y-free path really ran: the expand weight gradients differ in the last bits
     assert any((yf[k] != ref[k]).any() for k in ref if k.endswith('conv.0.weight'))
+
+
+@pytest.mark.parametrize('name,B,HW', [('mobilenetv2', 64, 224), ('mobilenetv2', 8, 96)])
+def test_bf16_train_forward_is_bit_reproducible(name, B, HW):
+    """the BatchNorm batch sums used to be added in arrival order (fp64 atomics), a last-bit difference of
+    a sum flipped a bf16 rounding a few layers on, and two forwards of the same batch ended 2.5e-3 apart in the loss.  The
+    partial sums are snapped onto a fixed grid now (csrc/common.h: every add exact, hence order-independent): repeated
+    train-mode forwards of MobileNetV2 in bf16 storage return identical bits, BatchNorm running statistics included."""
+    from oracle.weights import make_inputs, make_state_dict
+    from torchdet3d.models.engine import Net
+    imgs, _, cats = make_inputs(B, HW, HW, 9)
+    sd = make_state_dict(name, 9)
+    mask = torch.full((B, 1280), 2.0, device='cuda')
+    outs = []
+    for rep in range(4):
+        net = Net(name, 9, 'cuda', torch.bfloat16)
+        net.load_state_dict(sd)
+        kp, lg = net.forward(imgs.cuda(), cats.cuda(), train=True, dropout_mask=mask)
+        torch.cuda.synchronize()
+        outs.append((kp.clone(), lg.clone(), net.buffers['features.9.conv.4.running_var'].clone(),
+                     net.buffers['conv.1.running_mean'].clone()))
+        del net
+    for o in outs[1:]:
+        for a, b in zip(outs[0], o):
+            assert torch.equal(a, b)

@@ -14,6 +14,8 @@ ap.add_argument('--model', default='mobilenetv2')
 ap.add_argument('--dets', type=int, default=16)
 ap.add_argument('--frames', type=int, default=200)
 ap.add_argument('--dtype', default='bf16')
+ap.add_argument('--detector', action='store_true', help='time the whole pipeline: SSD300-MobileNetV2 detector (models/ssd.py) '
+                'on the frame, then the regression stage on its detections (scripts/demo.py:48-90)')
 args = ap.parse_args()
 
 from torchdet3d.builders import build_model
@@ -58,7 +60,43 @@ t = time.perf_counter()
 for r in rects:
     resize_linear_u8(crop(frame, r), (224, 224))
 t_cpu = time.perf_counter() - t
-print(json.dumps({'metric': f'two-stage regression stage, {n} detections per 1080x1920 frame, {args.model}', 'frames_per_s': round(1 / t_res, 1),
+extra = {}
+if args.detector:
+    from torchdet3d.models.ssd import SSD300
+    from torchdet3d.utils import Detector
+    det = Detector(SSD300('cuda', torch.bfloat16 if args.dtype == 'bf16' else torch.float32), conf=0.3)
+    gd = torch.Generator().manual_seed(0)
+    sd = det.model.state_dict()
+    for k in sd:
+        if k.startswith('bbox_head.cls_convs') and k.endswith('.3.bias'):
+            sd[k] = torch.randn(sd[k].shape, generator=gd) * 2.0
+    det.model.load_state_dict(sd)
+
+    def pipeline(frames):
+        torch.cuda.synchronize()
+        t = time.perf_counter()
+        nd = 0
+        for _ in range(frames):
+            dets = det.get_detections(fd)[:n]
+            nd += len(dets)
+            if dets:
+                reg.get_detections(fd, dets)
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t) / frames, nd / frames
+
+    def detector_only(frames):
+        torch.cuda.synchronize()
+        t = time.perf_counter()
+        for _ in range(frames):
+            det.get_detections(fd)
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t) / frames
+    pipeline(5)
+    tp, nd = pipeline(max(20, args.frames // 4))
+    td = detector_only(max(20, args.frames // 4))
+    extra = {'pipeline_ms_per_frame': round(tp * 1e3, 3), 'pipeline_frames_per_s': round(1 / tp, 1), 'detections_regressed_per_frame': round(nd, 1),
+             'detector_ms_per_frame': round(td * 1e3, 3), 'detector': 'SSD300-MobileNetV2 (random weights), one frame per launch chain, host read-back of the detections'}
+print(json.dumps({**extra, 'metric': f'two-stage regression stage, {n} detections per 1080x1920 frame, {args.model}', 'frames_per_s': round(1 / t_res, 1),
                   'crops_per_s': round(n / t_res, 1), 'ms_per_frame': round(t_res * 1e3, 3), 'frames_per_s_with_h2d': round(1 / t_up, 1),
                   'crop_resize_us': round(t_crop * 1e6, 1), 'dtype': args.dtype,
                   'cpu_baseline': {'what': 'oracle crop + 8-bit bilinear resize loop (numpy), 1 core', 'ms_per_frame': round(t_cpu * 1e3, 2)}}))
