@@ -22,6 +22,7 @@ CASES = [('mnv3_large_b4_96', 'mobilenetv3_large', 4, 96, 9, ['l1', 'add_loss', 
          # flip no longer moves the gradients visibly -> the gradient bound for this case is 1e-2 (typically ~1e-4)
          ('mnv3_large_b32_224', 'mobilenetv3_large', 32, 224, 9, ['l1', 'add_loss', 'cross_entropy'], ([1., .1], [.2]))]
 GRAD_TOL = {'mnv3_large_b32_224': 1e-2}
+GRAD_L2_TOL = {'mnv3_large_b32_224': 5e-3}       # per tensor, relative L2 against the reference's gradient (typically 3e-4)
 
 
 @pytest.mark.parametrize('tag,name,B,HW,nc,lnames,coeffs', CASES)
@@ -67,7 +68,8 @@ def test_hip_path_matches_reference_golden(golden_dir, tag, name, B, HW, nc, lna
     np.testing.assert_allclose(dkp.cpu().numpy().reshape(B, 9, 2), g['dkp'], atol=5e-5, rtol=2e-2)
     net.backward(dkp, dlg)
     torch.cuda.synchronize()
-    bad = []
+    bad, l2s = [], []
+    gmax = max(float(np.abs(g[f]).max()) for f in g.files if f.startswith('grad:'))
     for k in [f for f in g.files if f.startswith('grad:') or f.startswith('gradrows:')]:
         name_ = k.split(':', 1)[1]
         ref = g[k]
@@ -78,11 +80,20 @@ def test_hip_path_matches_reference_golden(golden_dir, tag, name, B, HW, nc, lna
         err = np.abs(got - ref).max() / scale
         if not err < GRAD_TOL.get(tag, 5e-2):
             bad.append((name_, err))
+        # ... and in the L2 sense, which one flipped activation kink barely moves (the max-norm bound above has to leave room
+        # for it): a systematic backward error of a per cent would show here
+        # (tensors whose true gradient is a cancelling sum -- a bias in front of a mean-subtracting BatchNorm -- are judged
+        # against the fixture's overall gradient scale, not against their own round-off-level norm)
+        l2 = np.linalg.norm((got - ref).ravel()) / max(np.linalg.norm(ref.ravel()), 1e-3 * gmax * ref.size ** 0.5)
+        l2s.append((float(l2), name_))
+        if tag in GRAD_L2_TOL and not l2 < GRAD_L2_TOL[tag]:
+            bad.append((name_, 'relative L2', l2))
     for k in [f for f in g.files if f.startswith('gsum:')]:
         ref = g[k][1]
         got = net.g[k[5:]].double().abs().sum().item()
         if abs(got - ref) > GRAD_TOL.get(tag, 5e-2) * max(ref, 1e-2):
             bad.append((k, got, ref))
+    print(f'   {tag}: gradient relative-L2 errors, worst three: {[(round(a, 5), b) for a, b in sorted(l2s, reverse=True)[:3]]}')
     assert not bad, bad[:10]
     for k in [f for f in g.files if f.startswith('rm:')]:
         bn = k[3:]
