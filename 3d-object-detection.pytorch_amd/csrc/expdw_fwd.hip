@@ -39,6 +39,18 @@ struct EdArgs {
 
 constexpr int KSMAX = 5;     // K <= 160
 
+#ifdef T3D_ED_TRACE
+// debug build only (tools/time_expdw.py --trace): accumulated wall-clock ticks (10 ns) per phase of workgroup 0, wave 0
+__device__ unsigned long long g_ed_trace[8];
+#define ED_T0() unsigned long long t_prev = wall_clock64(), t_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}
+#define ED_PH(i) do { const unsigned long long t_now = wall_clock64(); t_acc[i] += t_now - t_prev; t_prev = t_now; } while (0)
+#define ED_OUT() do { if (blockIdx.x == 0 && threadIdx.x == 0) for (int i_ = 0; i_ < 8; ++i_) g_ed_trace[i_] = t_acc[i_]; } while (0)
+#else
+#define ED_T0()
+#define ED_PH(i)
+#define ED_OUT()
+#endif
+
 template <int CS, int NTH>
 __global__ __launch_bounds__(NTH) void expdw_fwd_kernel(const EdArgs a) {
   constexpr int CT = CS / 16;          // 16-channel MFMA tiles per slab
@@ -55,6 +67,7 @@ __global__ __launch_bounds__(NTH) void expdw_fwd_kernel(const EdArgs a) {
   for (int i = tid; i < 2 * a.C; i += NTH) lstat[i] = 0.f;
   __syncthreads();
 
+  ED_T0();
   for (int item = blockIdx.x; item < a.nitems; item += gridDim.x) {
     const int slab = item % a.nslab, tile = item / a.nslab;
     const int b = tile / a.tiles_per_img, tr = tile - b * a.tiles_per_img;
@@ -91,6 +104,7 @@ __global__ __launch_bounds__(NTH) void expdw_fwd_kernel(const EdArgs a) {
         sh[ct][i] = c < a.C ? a.sh1[c] : 0.f;
       }
     }
+    ED_PH(0);      // padding columns, weight / coefficient fragments
     const int npx = nrows * a.W, ngroups = (npx + 15) >> 4;
     for (int g = wave; g < ngroups; g += NW) {
       const int p = g * 16 + lp;
@@ -133,7 +147,9 @@ __global__ __launch_bounds__(NTH) void expdw_fwd_kernel(const EdArgs a) {
         if (pv) *reinterpret_cast<bf16x4*>(act + ((size_t)r * Wp + x + 1) * PS + cl) = av;
       }
     }
+    ED_PH(1);      // expansion loop
     __syncthreads();
+    ED_PH(2);      // barrier
 
     // ---- phase 2: depthwise 3x3 out of LDS
     {
@@ -145,6 +161,7 @@ __global__ __launch_bounds__(NTH) void expdw_fwd_kernel(const EdArgs a) {
         for (int i = 0; i < 4; ++i)
 #pragma unroll
           for (int t = 0; t < 9; ++t) wk[t][i] = a.wdw[(size_t)(cc + i) * 9 + t];
+        ED_PH(3);  // depthwise weights
         float ps[4] = {0.f, 0.f, 0.f, 0.f}, pq[4] = {0.f, 0.f, 0.f, 0.f};
         for (int ox = slot; ox < a.Wo; ox += NSLOT) {
           const bf16_t* col = act + (size_t)(ox * a.S) * PS + 4 * cg;
@@ -171,6 +188,7 @@ __global__ __launch_bounds__(NTH) void expdw_fwd_kernel(const EdArgs a) {
             *reinterpret_cast<bf16x4*>(a.y2 + (((size_t)b * a.Ho + oy0 + t) * a.Wo + ox) * a.C + cc) = ov;
           }
         }
+        ED_PH(4);  // stencil + stores
         if (a.stats) {
 #pragma unroll
           for (int i = 0; i < 4; ++i) {
@@ -180,8 +198,11 @@ __global__ __launch_bounds__(NTH) void expdw_fwd_kernel(const EdArgs a) {
         }
       }
     }
+    ED_PH(5);              // statistics into LDS
     __syncthreads();       // the tile is rewritten by the next item
+    ED_PH(6);
   }
+  ED_OUT();
   if (a.stats) {
     for (int i = tid; i < 2 * a.C; i += NTH) {
       const float v = lstat[i];
@@ -244,3 +265,9 @@ extern "C" int t3d_expdw_fwd(const void* z, const void* w1, const float* scale1,
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   return cs == 64 ? launch<64>(a, st) : launch<32>(a, st);
 }
+
+#ifdef T3D_ED_TRACE
+extern "C" int t3d_debug_ed_trace(unsigned long long* out) {
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_ed_trace), sizeof(unsigned long long) * 8) == hipSuccess ? 0 : -1;
+}
+#endif

@@ -43,3 +43,23 @@ for H, K, C, s in SHAPES:
     t_f0 = timeit(lambda: N.call('t3d_expdw_fwd', N.ptr(z), N.ptr(w1), N.ptr(sc), N.ptr(sh), 2, N.ptr(wdw), None, N.ptr(y2), (stats.data_ptr() + 16 * C), B, H, H, K, C, s, N.stream()))
     N.call('t3d_set_reduction_replicas', 1, 0)
     print(f'{H:4d}^2 {K:4d}->{C:4d} s{s}: pw {t_pw:7.1f}  dw {t_dw:7.1f}  (sum {t_pw + t_dw:7.1f}) | stats-only {t_st:6.1f}  fused+y1 {t_f1:7.1f}  fused {t_f0:7.1f} us')
+
+# in-kernel phase timeline (needs the -DT3D_ED_TRACE build: HIPCC_EXTRA=-DT3D_ED_TRACE python 3d-object-detection.pytorch_amd/build.py --force)
+import ctypes
+lib = N.lib()
+if hasattr(lib, 't3d_debug_ed_trace'):
+    names = ['weights/pad', 'expansion', 'barrier', 'dw weights', 'stencil+stores', 'stats', 'barrier2', '-']
+    for H, K, C, s in SHAPES:
+        Ho = (H - 1) // s + 1
+        z = torch.randn(B, H, H, K, device='cuda').to(torch.bfloat16)
+        w1 = (torch.randn(C, K, device='cuda') / K ** 0.5).to(torch.bfloat16)
+        sc, sh = torch.rand(C, device='cuda') + 0.5, torch.randn(C, device='cuda') * 0.5
+        wdw = torch.randn(C, 9, device='cuda') * 0.3
+        y2 = torch.empty(B, Ho, Ho, C, device='cuda', dtype=torch.bfloat16)
+        for _ in range(2):
+            N.call('t3d_expdw_fwd', N.ptr(z), N.ptr(w1), N.ptr(sc), N.ptr(sh), 2, N.ptr(wdw), None, N.ptr(y2), None, B, H, H, K, C, s, N.stream())
+        torch.cuda.synchronize()
+        buf = (ctypes.c_ulonglong * 8)()
+        lib.t3d_debug_ed_trace(buf)
+        tot = sum(buf)
+        print(f'{H:4d}^2 {K:4d}->{C:4d} s{s}: workgroup 0 total {tot / 100:.1f} us: ' + ', '.join(f'{n} {v / 100:.1f}' for n, v in zip(names, buf) if n != '-'))
