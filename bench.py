@@ -383,13 +383,15 @@ def main():
             # gfx950 correction): not measurable from inside this process, so it is quoted with its source, and only
             # for the workload the passes were collected on
             traffic, tsrc = None, None
-            tf = os.path.join(ROOT, 'profiles', 'r2_hbm_traffic_pmc.json')
-            if os.path.exists(tf) and args.model == 'mobilenetv2' and S == 224 and B == 256 and args.dtype == 'bf16' and not args.eval:
+            import glob
+            tfs = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r[0-9]*_hbm_traffic_pmc.json')))
+            tf = tfs[-1] if tfs else ''                  # the latest round's committed PMC pass
+            if tf and args.model == 'mobilenetv2' and S == 224 and B == 256 and args.dtype == 'bf16' and not args.eval:
                 pm = json.load(open(tf))
                 fam_t = pm.get('kernels', {}).get(top['kernel'])
                 if fam_t:
                     traffic = round(fam_t['hbm_bytes_per_step'] / top['launches_per_step'])
-                    tsrc = f"profiles/r2_hbm_traffic_pmc.json (committed rocprofv3 --pmc pass at {pm.get('commit', '?')})"
+                    tsrc = f"profiles/{os.path.basename(tf)} (committed rocprofv3 --pmc pass at {pm.get('commit', '?')})"
             res['roofline'] = {'bound': 'hbm', 'kernel': top['kernel'], 'entry': top['entry'], 'achieved': top['achieved'],
                                'peak': HBM_PEAK / 1e9, 'unit': 'GB/s', 'frac': top['frac'], 'traffic': traffic,
                                'traffic_source': tsrc, 'launches_per_step': top['launches_per_step'],

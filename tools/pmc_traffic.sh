@@ -5,6 +5,7 @@
 cd $GRAFT_REPO_ROOT; export TMPDIR=/tmp
 out=${1:-gpurun_out/hbm_traffic_pmc.json}
 STEPS=3; WARM=2
+export T3D_DEVICE_WARMUP_S=0        # (the clock warm-up copies would count into the all-kernels total)
 for c in FETCH_SIZE WRITE_SIZE; do
   rm -rf gpurun_out/pmc_$c
   rocprofv3 --pmc $c --output-format csv -d gpurun_out/pmc_$c -o p -- python3 bench.py --steps $STEPS --warmup $WARM --no-cpu-baseline > /dev/null 2>&1
