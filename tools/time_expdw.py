@@ -48,7 +48,7 @@ for H, K, C, s in SHAPES:
 import ctypes
 lib = N.lib()
 if hasattr(lib, 't3d_debug_ed_trace'):
-    names = ['weights/pad', 'expansion', 'barrier', 'dw weights', 'stencil+stores', 'stats', 'barrier2', '-']
+    names = ['pad+wait', 'expansion', 'barrier', '-', 'fetch issue+stencil+stores', 'stats', 'barrier2', '-']
     for H, K, C, s in SHAPES:
         Ho = (H - 1) // s + 1
         z = torch.randn(B, H, H, K, device='cuda').to(torch.bfloat16)
