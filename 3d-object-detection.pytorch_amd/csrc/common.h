@@ -158,20 +158,20 @@ __device__ __forceinline__ void t3d_fold_block(const T3dFold* __restrict__ fp, i
 // The batch sums reach memory as a few hundred atomic adds per channel, in whatever order the workgroups finish; fp64
 // addition is not associative, the network at initialisation amplifies a last-bit difference of a sum into a flipped
 // bf16 rounding a few layers later, and two runs of the same step end up 2.5e-3 apart in the loss.  Every partial sum
-// is therefore snapped onto a fixed grid before it is added: with |partial| <= count * 2^12 (activations beyond 4096
-// would just lose the exactness, nothing else) a quantum of P * 2^-38, P = the power of two >= count, keeps every partial
-// and the total below 2^52 quanta -- all adds are then EXACT in fp64, hence independent of their order.  The grid costs
-// < 1e-8 relative on the sums.  (Sums of squares: quantum * 2^12.)
+// is therefore snapped onto a fixed grid before it is added: with |partial| <= count * 2^10 (raw conv outputs beyond 1024
+// would just lose the exactness, nothing else) a quantum of P * 2^-40, P = the power of two >= count, keeps every partial
+// and the total below 2^52 quanta -- all adds are then EXACT in fp64, hence independent of their order.  Sums of squares:
+// quantum * 2^10.  The grid costs ~1e-9 relative on the sums, ~1e-6 on the sums of squares.
 struct T3dQuant { double q, iq; };        // q == 0: off (backward sums: their scale goes with the loss, not with the count)
 static inline T3dQuant t3d_quant_for(long long count) {
   int e = 0;
   while ((1LL << e) < count) ++e;
-  const double q = ldexp(1.0, e - 38);
+  const double q = ldexp(1.0, e - 40);
   return T3dQuant{q, 1.0 / q};
 }
 __device__ __forceinline__ double t3d_snap(float v, const T3dQuant& t, bool squares) {
   if (t.q == 0.0) return (double)v;
-  const double s = squares ? 4096.0 : 1.0;
+  const double s = squares ? 1024.0 : 1.0;
   return rint((double)v * (t.iq * (1.0 / s))) * (t.q * s);
 }
 

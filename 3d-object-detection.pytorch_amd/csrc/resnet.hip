@@ -1,0 +1,467 @@
+// Layers a ResNet-50 backbone needs beside the 1x1 convolutions the regression path already has (BASELINE config 4:
+// "ResNet-50 backbone via torchdet3d.builders"; the reference itself has no ResNet -- SURVEY.md section 0 -- so the
+// architecture is the standard torchvision one and parity is against oracle/resnet.py, unpinned):
+//   * dense k x k convolution (3x3 in the bottlenecks, 7x7 stem) = patch gather + the pointwise GEMM kernels:
+//       t3d_im2col       x [B,H,W,C] (raw, the producer's BatchNorm + activation applied on load, zero padding AFTER the
+//                        activation) -> col [B*Ho*Wo][Kp], column (ky*k + kx)*C + c, columns >= k*k*C zero
+//       t3d_col2im_bwd   gradient of the patch matrix -> gradient at the producer's BatchNorm OUTPUT (times act'), plus
+//                        that BatchNorm's backward sums -- the gather form (each input pixel collects its <= k*k taps)
+//       t3d_pack_conv_weight / t3d_unpack_conv_grad   [N][C][k][k] fp32 <-> [N][Kp] in patch-column order
+//   * 3x3 / stride-2 max-pool over the activated stem output (arg-max kept for the backward)
+//   * the bottleneck's tail  z = relu(BN3(y3) + shortcut)  and its backward  g = dz * [z > 0]  with the BatchNorm-backward
+//     sums of both branches
+//   * stride-2 sub-sampling in front of the shortcut's 1x1 conv, and the zero-filled up-sampling of its gradient.
+// All of them are HBM-bound elementwise / gather kernels: one thread per (pixel, 8-channel vector) where C % 8 == 0,
+// scalar otherwise (the 3-channel stem input).  fp32 or bf16 storage.
+#include "common.h"
+
+namespace {
+
+template <typename T> __device__ __forceinline__ float ldf(const T* p) { return (float)*p; }
+
+// ---- im2col ------------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void im2col_kernel(const T* __restrict__ x, const float* __restrict__ scale,
+                                                     const float* __restrict__ shift, int act, T* __restrict__ col, int B,
+                                                     int H, int W, int C, int k, int stride, int pad, int Ho, int Wo, int Kp) {
+  const long long total = (long long)B * Ho * Wo * Kp;
+  for (long long e = blockIdx.x * 256LL + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
+    const int kc = (int)(e % Kp);
+    const long long m = e / Kp;
+    float v = 0.f;
+    if (kc < k * k * C) {
+      const int c = kc % C, t = kc / C, ky = t / k, kx = t - ky * k;
+      const int ox = (int)(m % Wo), oy = (int)((m / Wo) % Ho), b = (int)(m / ((long long)Wo * Ho));
+      const int iy = oy * stride - pad + ky, ix = ox * stride - pad + kx;
+      if (iy >= 0 && iy < H && ix >= 0 && ix < W) {
+        v = ldf(x + (((size_t)b * H + iy) * W + ix) * C + c);
+        if (scale) v = fmaf(v, scale[c], shift[c]);
+        v = act_apply(v, act);
+      }
+    }
+    col[e] = (T)v;
+  }
+}
+
+// fp32 NCHW image (the reference's input contract) -> patch matrix of the stem
+template <typename T>
+__global__ __launch_bounds__(256) void im2col_nchw_kernel(const float* __restrict__ x, T* __restrict__ col, int B, int H, int W,
+                                                          int C, int k, int stride, int pad, int Ho, int Wo, int Kp) {
+  const long long total = (long long)B * Ho * Wo * Kp;
+  for (long long e = blockIdx.x * 256LL + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
+    const int kc = (int)(e % Kp);
+    const long long m = e / Kp;
+    float v = 0.f;
+    if (kc < k * k * C) {
+      const int c = kc % C, t = kc / C, ky = t / k, kx = t - ky * k;
+      const int ox = (int)(m % Wo), oy = (int)((m / Wo) % Ho), b = (int)(m / ((long long)Wo * Ho));
+      const int iy = oy * stride - pad + ky, ix = ox * stride - pad + kx;
+      if (iy >= 0 && iy < H && ix >= 0 && ix < W) v = x[(((size_t)b * C + c) * H + iy) * W + ix];
+    }
+    col[e] = (T)v;
+  }
+}
+
+// ---- col2im backward (gather form) --------------------------------------------------------------------------------
+// thread = (input pixel, channel); dx = sum over the taps that read this pixel; times act'(scale*x + shift); sums
+template <typename T>
+__global__ __launch_bounds__(256) void col2im_bwd_kernel(const T* __restrict__ dcol, const T* __restrict__ xraw,
+                                                         const float* __restrict__ scale, const float* __restrict__ shift, int act,
+                                                         T* __restrict__ dx, double* __restrict__ stats, int B, int H, int W, int C,
+                                                         int k, int stride, int pad, int Ho, int Wo, int Kp, int nrep, long long rstride) {
+  extern __shared__ float lst[];      // [2][C]
+  for (int i = threadIdx.x; i < 2 * C; i += 256) lst[i] = 0.f;
+  __syncthreads();
+  const long long total = (long long)B * H * W * C;
+  // a thread keeps one channel (stride of the grid is a multiple of C): its sums stay in registers
+  const long long nthr = ((long long)gridDim.x * 256 / C) * C;
+  const long long g0 = blockIdx.x * 256LL + threadIdx.x;
+  float s1 = 0.f, s2 = 0.f;
+  const int c = (int)(g0 % C);
+  if (g0 < nthr) {
+    for (long long e = g0; e < total; e += nthr) {
+      const long long px = e / C;
+      const int ix = (int)(px % W), iy = (int)((px / W) % H), b = (int)(px / ((long long)W * H));
+      float acc = 0.f;
+      for (int ky = 0; ky < k; ++ky) {
+        const int ty = iy + pad - ky;
+        if (ty < 0 || ty % stride) continue;
+        const int oy = ty / stride;
+        if (oy >= Ho) continue;
+        for (int kx = 0; kx < k; ++kx) {
+          const int tx = ix + pad - kx;
+          if (tx < 0 || tx % stride) continue;
+          const int ox = tx / stride;
+          if (ox >= Wo) continue;
+          acc += ldf(dcol + (((size_t)b * Ho + oy) * Wo + ox) * Kp + (ky * k + kx) * C + c);
+        }
+      }
+      const float xr = ldf(xraw + e);
+      const float u = scale ? fmaf(xr, scale[c], shift[c]) : xr;
+      const T o = (T)(acc * act_grad(u, act));
+      dx[e] = o;
+      const float ov = (float)o;
+      s1 += ov;
+      s2 = fmaf(ov, xr, s2);
+    }
+  }
+  if (stats) {
+    if (g0 < nthr) {
+      atomicAdd(lst + c, s1);
+      atomicAdd(lst + C + c, s2);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 2 * C; i += 256)
+      if (lst[i] != 0.f) atomicAdd(stats + (size_t)(blockIdx.x % nrep) * rstride + i, (double)lst[i]);
+  }
+}
+
+// ---- conv weight layout ---------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void pack_conv_kernel(const float* __restrict__ w, T* __restrict__ out, int N, int C, int k, int Kp) {
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  if (e >= N * Kp) return;
+  const int n = e / Kp, kc = e - n * Kp;
+  float v = 0.f;
+  if (kc < k * k * C) {
+    const int c = kc % C, t = kc / C;
+    v = w[((size_t)n * C + c) * k * k + t];
+  }
+  out[e] = (T)v;
+}
+__global__ void unpack_conv_grad_kernel(const float* __restrict__ dwp, float* __restrict__ dw, int N, int C, int k, int Kp) {
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  if (e >= N * C * k * k) return;
+  const int t = e % (k * k), c = (e / (k * k)) % C, n = e / (k * k * C);
+  dw[e] = dwp[(size_t)n * Kp + t * C + c];
+}
+
+// ---- max-pool 3x3 / stride 2 / pad 1 over act(scale*y + shift) ---------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void maxpool_fwd_kernel(const T* __restrict__ y, const float* __restrict__ scale,
+                                                          const float* __restrict__ shift, int act, T* __restrict__ out,
+                                                          unsigned char* __restrict__ idx, int B, int H, int W, int C, int Ho, int Wo) {
+  const long long total = (long long)B * Ho * Wo * C;
+  for (long long e = blockIdx.x * 256LL + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
+    const int c = (int)(e % C);
+    const long long px = e / C;
+    const int ox = (int)(px % Wo), oy = (int)((px / Wo) % Ho), b = (int)(px / ((long long)Wo * Ho));
+    float best = -3.0e38f;
+    int bi = 0;
+    for (int ky = 0; ky < 3; ++ky) {
+      const int iy = 2 * oy - 1 + ky;
+      if (iy < 0 || iy >= H) continue;
+      for (int kx = 0; kx < 3; ++kx) {
+        const int ix = 2 * ox - 1 + kx;
+        if (ix < 0 || ix >= W) continue;
+        float v = ldf(y + (((size_t)b * H + iy) * W + ix) * C + c);
+        if (scale) v = fmaf(v, scale[c], shift[c]);
+        v = act_apply(v, act);
+        if (v > best) { best = v; bi = ky * 3 + kx; }       // first maximum in scan order (PyTorch's choice)
+      }
+    }
+    out[e] = (T)best;
+    idx[e] = (unsigned char)bi;
+  }
+}
+
+// gradient at the BatchNorm output of the pooled tensor's producer: each input pixel collects the windows whose maximum it is
+template <typename T>
+__global__ __launch_bounds__(256) void maxpool_bwd_kernel(const T* __restrict__ dout, const unsigned char* __restrict__ idx,
+                                                          const T* __restrict__ y, const float* __restrict__ scale,
+                                                          const float* __restrict__ shift, int act, T* __restrict__ dy,
+                                                          double* __restrict__ stats, int B, int H, int W, int C, int Ho, int Wo,
+                                                          int nrep, long long rstride) {
+  extern __shared__ float lst[];
+  for (int i = threadIdx.x; i < 2 * C; i += 256) lst[i] = 0.f;
+  __syncthreads();
+  const long long total = (long long)B * H * W * C;
+  const long long nthr = ((long long)gridDim.x * 256 / C) * C;
+  const long long g0 = blockIdx.x * 256LL + threadIdx.x;
+  const int c = (int)(g0 % C);
+  float s1 = 0.f, s2 = 0.f;
+  if (g0 < nthr) {
+    for (long long e = g0; e < total; e += nthr) {
+      const long long px = e / C;
+      const int ix = (int)(px % W), iy = (int)((px / W) % H), b = (int)(px / ((long long)W * H));
+      float acc = 0.f;
+      for (int ky = 0; ky < 3; ++ky) {
+        const int ty = iy + 1 - ky;
+        if (ty < 0 || (ty & 1)) continue;
+        const int oy = ty >> 1;
+        if (oy >= Ho) continue;
+        for (int kx = 0; kx < 3; ++kx) {
+          const int tx = ix + 1 - kx;
+          if (tx < 0 || (tx & 1)) continue;
+          const int ox = tx >> 1;
+          if (ox >= Wo) continue;
+          const size_t o = (((size_t)b * Ho + oy) * Wo + ox) * C + c;
+          if (idx[o] == ky * 3 + kx) acc += ldf(dout + o);
+        }
+      }
+      const float yr = ldf(y + e);
+      const float u = scale ? fmaf(yr, scale[c], shift[c]) : yr;
+      const T o = (T)(acc * act_grad(u, act));
+      dy[e] = o;
+      const float ov = (float)o;
+      s1 += ov;
+      s2 = fmaf(ov, yr, s2);
+    }
+  }
+  if (stats) {
+    if (g0 < nthr) {
+      atomicAdd(lst + c, s1);
+      atomicAdd(lst + C + c, s2);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 2 * C; i += 256)
+      if (lst[i] != 0.f) atomicAdd(stats + (size_t)(blockIdx.x % nrep) * rstride + i, (double)lst[i]);
+  }
+}
+
+// ---- bottleneck tail: z = relu(s3*y3 + t3 + shortcut) ---------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void res_relu_fwd_kernel(const T* __restrict__ y3, const float* __restrict__ s3,
+                                                           const float* __restrict__ t3, const T* __restrict__ sh,
+                                                           const float* __restrict__ ss, const float* __restrict__ ts,
+                                                           T* __restrict__ z, long long total, int C) {
+  for (long long e = blockIdx.x * 256LL + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
+    const int c = (int)(e % C);
+    float v = fmaf(ldf(y3 + e), s3[c], t3[c]);
+    float r = ldf(sh + e);
+    if (ss) r = fmaf(r, ss[c], ts[c]);
+    z[e] = (T)fmaxf(v + r, 0.f);
+  }
+}
+
+// g = dz * [z > 0];  stats3 += sum g, sum g*y3;  statsd += sum g, sum g*yd (projection shortcut only)
+template <typename T>
+__global__ __launch_bounds__(256) void res_relu_bwd_kernel(const T* __restrict__ dz, const T* __restrict__ z,
+                                                           const T* __restrict__ y3, const T* __restrict__ yd, T* __restrict__ g,
+                                                           double* __restrict__ stats3, double* __restrict__ statsd,
+                                                           long long total, int C, int nrep, long long rstride) {
+  extern __shared__ float lst[];      // [4][C]
+  for (int i = threadIdx.x; i < 4 * C; i += 256) lst[i] = 0.f;
+  __syncthreads();
+  const long long nthr = ((long long)gridDim.x * 256 / C) * C;
+  const long long g0 = blockIdx.x * 256LL + threadIdx.x;
+  const int c = (int)(g0 % C);
+  float s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  if (g0 < nthr) {
+    for (long long e = g0; e < total; e += nthr) {
+      const T o = (T)(ldf(z + e) > 0.f ? ldf(dz + e) : 0.f);
+      g[e] = o;
+      const float ov = (float)o;
+      s1 += ov;
+      s2 = fmaf(ov, ldf(y3 + e), s2);
+      if (yd) s3 = fmaf(ov, ldf(yd + e), s3);
+    }
+    atomicAdd(lst + c, s1);
+    atomicAdd(lst + C + c, s2);
+    if (yd) atomicAdd(lst + 2 * C + c, s3);
+  }
+  __syncthreads();
+  const size_t rep = (size_t)(blockIdx.x % nrep) * rstride;
+  for (int i = threadIdx.x; i < 2 * C; i += 256)
+    if (lst[i] != 0.f) atomicAdd(stats3 + rep + i, (double)lst[i]);
+  if (statsd) {
+    for (int i = threadIdx.x; i < C; i += 256) {
+      if (lst[i] != 0.f) atomicAdd(statsd + rep + i, (double)lst[i]);
+      if (lst[2 * C + i] != 0.f) atomicAdd(statsd + rep + C + i, (double)lst[2 * C + i]);
+    }
+  }
+}
+
+// ---- stride-2 sub-sampling / zero-filled up-sampling ------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void subsample_kernel(const T* __restrict__ x, T* __restrict__ out, int B, int H, int W, int C,
+                                                        int s, int Ho, int Wo, int up) {
+  // up == 0: out[b,oy,ox,:] = x[b,s*oy,s*ox,:]   (out is the small tensor)
+  // up == 1: out[b,iy,ix,:] = (iy % s == 0 && ix % s == 0) ? x[b,iy/s,ix/s,:] : 0   (out is the large tensor, x the small one)
+  const long long total = up ? (long long)B * H * W * C : (long long)B * Ho * Wo * C;
+  for (long long e = blockIdx.x * 256LL + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
+    const int c = (int)(e % C);
+    const long long px = e / C;
+    if (!up) {
+      const int ox = (int)(px % Wo), oy = (int)((px / Wo) % Ho), b = (int)(px / ((long long)Wo * Ho));
+      out[e] = x[(((size_t)b * H + oy * s) * W + ox * s) * C + c];
+    } else {
+      const int ix = (int)(px % W), iy = (int)((px / W) % H), b = (int)(px / ((long long)W * H));
+      const bool on = (iy % s == 0) && (ix % s == 0) && iy / s < Ho && ix / s < Wo;
+      out[e] = on ? x[(((size_t)b * Ho + iy / s) * Wo + ix / s) * C + c] : (T)0.f;
+    }
+  }
+}
+
+inline int grid_for(long long total) {
+  long long g = (total + 255) / 256;
+  if (g > 256 * 16) g = 256 * 16;
+  if (g < 1) g = 1;
+  return (int)g;
+}
+// a grid whose thread count is a multiple of C and covers at least one thread per channel
+inline int grid_for_c(long long total, int C) {
+  int g = grid_for(total);
+  while ((long long)g * 256 < C) ++g;
+  return g;
+}
+
+}  // namespace
+
+#define T3D_DISPATCH(dtype, CALL_F32, CALL_BF16) \
+  do {                                            \
+    if ((dtype) == T3D_F32) { CALL_F32; }         \
+    else if ((dtype) == T3D_BF16) { CALL_BF16; }  \
+    else return T3D_ERR_ARG;                      \
+  } while (0)
+
+extern "C" int t3d_im2col(int dtype, const void* x, const t3d_prologue* pro, void* col, int B, int H, int W, int C, int k,
+                          int stride, int pad, int Kp, void* stream) {
+  if (!x || !col || B <= 0 || H <= 0 || W <= 0 || C <= 0 || k <= 0 || stride <= 0 || pad < 0 || Kp < k * k * C) return T3D_ERR_ARG;
+  if (pro && pro->se) return T3D_ERR_UNSUPPORTED;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (pro)
+    if (const int rc = t3d_fold_fallback(pro->scale, st)) return rc;
+  const int Ho = (H + 2 * pad - k) / stride + 1, Wo = (W + 2 * pad - k) / stride + 1;
+  const float* sc = pro ? pro->scale : nullptr;
+  const float* sh = pro ? pro->shift : nullptr;
+  const int act = pro ? pro->act : T3D_ACT_NONE;
+  const int g = grid_for((long long)B * Ho * Wo * Kp);
+  T3D_DISPATCH(dtype,
+               hipLaunchKernelGGL(im2col_kernel<float>, dim3(g), dim3(256), 0, st, (const float*)x, sc, sh, act, (float*)col, B, H, W, C, k, stride, pad, Ho, Wo, Kp),
+               hipLaunchKernelGGL(im2col_kernel<bf16_t>, dim3(g), dim3(256), 0, st, (const bf16_t*)x, sc, sh, act, (bf16_t*)col, B, H, W, C, k, stride, pad, Ho, Wo, Kp));
+  T3D_CHECK_LAUNCH();
+  return T3D_OK;
+}
+
+extern "C" int t3d_im2col_nchw(int dtype, const float* x, void* col, int B, int H, int W, int C, int k, int stride, int pad,
+                               int Kp, void* stream) {
+  if (!x || !col || B <= 0 || H <= 0 || W <= 0 || C <= 0 || k <= 0 || stride <= 0 || pad < 0 || Kp < k * k * C) return T3D_ERR_ARG;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const int Ho = (H + 2 * pad - k) / stride + 1, Wo = (W + 2 * pad - k) / stride + 1;
+  const int g = grid_for((long long)B * Ho * Wo * Kp);
+  T3D_DISPATCH(dtype,
+               hipLaunchKernelGGL(im2col_nchw_kernel<float>, dim3(g), dim3(256), 0, st, x, (float*)col, B, H, W, C, k, stride, pad, Ho, Wo, Kp),
+               hipLaunchKernelGGL(im2col_nchw_kernel<bf16_t>, dim3(g), dim3(256), 0, st, x, (bf16_t*)col, B, H, W, C, k, stride, pad, Ho, Wo, Kp));
+  T3D_CHECK_LAUNCH();
+  return T3D_OK;
+}
+
+extern "C" int t3d_col2im_bwd(int dtype, const void* dcol, const void* x_raw, const t3d_prologue* pro, void* dx, double* stats,
+                              int B, int H, int W, int C, int k, int stride, int pad, int Kp, void* stream) {
+  if (!dcol || !x_raw || !dx || B <= 0 || H <= 0 || W <= 0 || C <= 0 || k <= 0 || stride <= 0 || pad < 0 || Kp < k * k * C) return T3D_ERR_ARG;
+  if (pro && pro->se) return T3D_ERR_UNSUPPORTED;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const int Ho = (H + 2 * pad - k) / stride + 1, Wo = (W + 2 * pad - k) / stride + 1;
+  const float* sc = pro ? pro->scale : nullptr;
+  const float* sh = pro ? pro->shift : nullptr;
+  const int act = pro ? pro->act : T3D_ACT_NONE;
+  const int g = grid_for_c((long long)B * H * W * C, C);
+  const size_t lds = (size_t)2 * C * sizeof(float);
+  T3D_DISPATCH(dtype,
+               hipLaunchKernelGGL(col2im_bwd_kernel<float>, dim3(g), dim3(256), lds, st, (const float*)dcol, (const float*)x_raw, sc, sh, act, (float*)dx, stats, B, H, W, C, k, stride, pad, Ho, Wo, Kp, g_t3d_reduce.nrep, g_t3d_reduce.stats_stride),
+               hipLaunchKernelGGL(col2im_bwd_kernel<bf16_t>, dim3(g), dim3(256), lds, st, (const bf16_t*)dcol, (const bf16_t*)x_raw, sc, sh, act, (bf16_t*)dx, stats, B, H, W, C, k, stride, pad, Ho, Wo, Kp, g_t3d_reduce.nrep, g_t3d_reduce.stats_stride));
+  T3D_CHECK_LAUNCH();
+  return T3D_OK;
+}
+
+extern "C" int t3d_pack_conv_weight(int dtype, const float* w, void* out, int N, int C, int k, int Kp, void* stream) {
+  if (!w || !out || N <= 0 || C <= 0 || k <= 0 || Kp < k * k * C) return T3D_ERR_ARG;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const int g = cdiv(N * Kp, 256);
+  T3D_DISPATCH(dtype, hipLaunchKernelGGL(pack_conv_kernel<float>, dim3(g), dim3(256), 0, st, w, (float*)out, N, C, k, Kp),
+               hipLaunchKernelGGL(pack_conv_kernel<bf16_t>, dim3(g), dim3(256), 0, st, w, (bf16_t*)out, N, C, k, Kp));
+  T3D_CHECK_LAUNCH();
+  return T3D_OK;
+}
+
+extern "C" int t3d_unpack_conv_grad(const float* dw_packed, float* dw, int N, int C, int k, int Kp, void* stream) {
+  if (!dw_packed || !dw || N <= 0 || C <= 0 || k <= 0 || Kp < k * k * C) return T3D_ERR_ARG;
+  hipLaunchKernelGGL(unpack_conv_grad_kernel, dim3(cdiv(N * C * k * k, 256)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                     dw_packed, dw, N, C, k, Kp);
+  T3D_CHECK_LAUNCH();
+  return T3D_OK;
+}
+
+extern "C" int t3d_maxpool_fwd(int dtype, const void* y, const t3d_prologue* pro, void* out, unsigned char* argmax, int B, int H,
+                               int W, int C, void* stream) {
+  if (!y || !out || !argmax || B <= 0 || H <= 0 || W <= 0 || C <= 0) return T3D_ERR_ARG;
+  if (pro && pro->se) return T3D_ERR_UNSUPPORTED;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (pro)
+    if (const int rc = t3d_fold_fallback(pro->scale, st)) return rc;
+  const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
+  const float* sc = pro ? pro->scale : nullptr;
+  const float* sh = pro ? pro->shift : nullptr;
+  const int act = pro ? pro->act : T3D_ACT_NONE;
+  const int g = grid_for((long long)B * Ho * Wo * C);
+  T3D_DISPATCH(dtype,
+               hipLaunchKernelGGL(maxpool_fwd_kernel<float>, dim3(g), dim3(256), 0, st, (const float*)y, sc, sh, act, (float*)out, argmax, B, H, W, C, Ho, Wo),
+               hipLaunchKernelGGL(maxpool_fwd_kernel<bf16_t>, dim3(g), dim3(256), 0, st, (const bf16_t*)y, sc, sh, act, (bf16_t*)out, argmax, B, H, W, C, Ho, Wo));
+  T3D_CHECK_LAUNCH();
+  return T3D_OK;
+}
+
+extern "C" int t3d_maxpool_bwd(int dtype, const void* dout, const unsigned char* argmax, const void* y, const t3d_prologue* pro,
+                               void* dy, double* stats, int B, int H, int W, int C, void* stream) {
+  if (!dout || !argmax || !y || !dy || B <= 0 || H <= 0 || W <= 0 || C <= 0) return T3D_ERR_ARG;
+  if (pro && pro->se) return T3D_ERR_UNSUPPORTED;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
+  const float* sc = pro ? pro->scale : nullptr;
+  const float* sh = pro ? pro->shift : nullptr;
+  const int act = pro ? pro->act : T3D_ACT_NONE;
+  const int g = grid_for_c((long long)B * H * W * C, C);
+  const size_t lds = (size_t)2 * C * sizeof(float);
+  T3D_DISPATCH(dtype,
+               hipLaunchKernelGGL(maxpool_bwd_kernel<float>, dim3(g), dim3(256), lds, st, (const float*)dout, argmax, (const float*)y, sc, sh, act, (float*)dy, stats, B, H, W, C, Ho, Wo, g_t3d_reduce.nrep, g_t3d_reduce.stats_stride),
+               hipLaunchKernelGGL(maxpool_bwd_kernel<bf16_t>, dim3(g), dim3(256), lds, st, (const bf16_t*)dout, argmax, (const bf16_t*)y, sc, sh, act, (bf16_t*)dy, stats, B, H, W, C, Ho, Wo, g_t3d_reduce.nrep, g_t3d_reduce.stats_stride));
+  T3D_CHECK_LAUNCH();
+  return T3D_OK;
+}
+
+extern "C" int t3d_res_relu_fwd(int dtype, const void* y3, const t3d_prologue* pro3, const void* shortcut,
+                                const t3d_prologue* pro_s, void* z, int M, int C, void* stream) {
+  if (!y3 || !pro3 || !pro3->scale || !shortcut || !z || M <= 0 || C <= 0) return T3D_ERR_ARG;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (const int rc = t3d_fold_fallback(pro3->scale, st)) return rc;
+  if (pro_s)
+    if (const int rc = t3d_fold_fallback(pro_s->scale, st)) return rc;
+  const float* ss = pro_s ? pro_s->scale : nullptr;
+  const float* ts = pro_s ? pro_s->shift : nullptr;
+  const long long total = (long long)M * C;
+  const int g = grid_for(total);
+  T3D_DISPATCH(dtype,
+               hipLaunchKernelGGL(res_relu_fwd_kernel<float>, dim3(g), dim3(256), 0, st, (const float*)y3, pro3->scale, pro3->shift, (const float*)shortcut, ss, ts, (float*)z, total, C),
+               hipLaunchKernelGGL(res_relu_fwd_kernel<bf16_t>, dim3(g), dim3(256), 0, st, (const bf16_t*)y3, pro3->scale, pro3->shift, (const bf16_t*)shortcut, ss, ts, (bf16_t*)z, total, C));
+  T3D_CHECK_LAUNCH();
+  return T3D_OK;
+}
+
+extern "C" int t3d_res_relu_bwd(int dtype, const void* dz, const void* z, const void* y3, const void* yd, void* g, double* stats3,
+                                double* statsd, int M, int C, void* stream) {
+  if (!dz || !z || !y3 || !g || !stats3 || M <= 0 || C <= 0 || ((yd == nullptr) != (statsd == nullptr))) return T3D_ERR_ARG;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const long long total = (long long)M * C;
+  const int gr = grid_for_c(total, C);
+  const size_t lds = (size_t)4 * C * sizeof(float);
+  T3D_DISPATCH(dtype,
+               hipLaunchKernelGGL(res_relu_bwd_kernel<float>, dim3(gr), dim3(256), lds, st, (const float*)dz, (const float*)z, (const float*)y3, (const float*)yd, (float*)g, stats3, statsd, total, C, g_t3d_reduce.nrep, g_t3d_reduce.stats_stride),
+               hipLaunchKernelGGL(res_relu_bwd_kernel<bf16_t>, dim3(gr), dim3(256), lds, st, (const bf16_t*)dz, (const bf16_t*)z, (const bf16_t*)y3, (const bf16_t*)yd, (bf16_t*)g, stats3, statsd, total, C, g_t3d_reduce.nrep, g_t3d_reduce.stats_stride));
+  T3D_CHECK_LAUNCH();
+  return T3D_OK;
+}
+
+extern "C" int t3d_subsample(int dtype, const void* x, void* out, int B, int H, int W, int C, int stride, int upsample,
+                             void* stream) {
+  if (!x || !out || B <= 0 || H <= 0 || W <= 0 || C <= 0 || stride <= 0) return T3D_ERR_ARG;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const int Ho = (H - 1) / stride + 1, Wo = (W - 1) / stride + 1;
+  const long long total = upsample ? (long long)B * H * W * C : (long long)B * Ho * Wo * C;
+  const int g = grid_for(total);
+  T3D_DISPATCH(dtype,
+               hipLaunchKernelGGL(subsample_kernel<float>, dim3(g), dim3(256), 0, st, (const float*)x, (float*)out, B, H, W, C, stride, Ho, Wo, upsample),
+               hipLaunchKernelGGL(subsample_kernel<bf16_t>, dim3(g), dim3(256), 0, st, (const bf16_t*)x, (bf16_t*)out, B, H, W, C, stride, Ho, Wo, upsample));
+  T3D_CHECK_LAUNCH();
+  return T3D_OK;
+}

@@ -62,6 +62,16 @@ SIGNATURES = {
     't3d_crop_resize_u8': [_P, _P, _P, _I, _I, _I, _I, _I, _P],
     't3d_pwconv_fwd_mat': [_I, _P, _PP, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
     't3d_ssd_decode_nms': [_I, _I, _P, _P, _P, _P, _P, _P, _P, _I, _I, _F, _F, _I, _F, _F, _P, _P, _P, _P],
+    't3d_im2col': [_I, _P, _PP, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P],
+    't3d_im2col_nchw': [_I, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P],
+    't3d_col2im_bwd': [_I, _P, _P, _PP, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P],
+    't3d_pack_conv_weight': [_I, _P, _P, _I, _I, _I, _I, _P],
+    't3d_unpack_conv_grad': [_P, _P, _I, _I, _I, _I, _P],
+    't3d_maxpool_fwd': [_I, _P, _PP, _P, _P, _I, _I, _I, _I, _P],
+    't3d_maxpool_bwd': [_I, _P, _P, _P, _PP, _P, _P, _I, _I, _I, _I, _P],
+    't3d_res_relu_fwd': [_I, _P, _PP, _P, _PP, _P, _I, _I, _P],
+    't3d_res_relu_bwd': [_I, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P],
+    't3d_subsample': [_I, _P, _P, _I, _I, _I, _I, _I, _I, _P],
     't3d_expdw_fwd': [_P, _P, _P, _P, _I, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
     't3d_ir_block_eval': [_P, _P, _P, _P, _I, _P, _P, _P, _I, _P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _I, _P],
     't3d_stem_fwd': [_I, _P, _I, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P],

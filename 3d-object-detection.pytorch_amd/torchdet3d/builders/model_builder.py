@@ -8,8 +8,9 @@ reference's).  Differences a caller can observe:
     optimizer built by `build_optimizer` is a single fused update and data-parallel training all-reduces one
     buffer; `named_parameters()` therefore has one entry, `state_dict()` keeps the per-layer names;
   * the forward runs on the GPU only ('--device cuda'); there is no CPU fallback;
-  * extra model names: 'mobilenetv2' (north-star throughput model).  The timm / efficientnet-lite names of the
-    reference need un-vendored third-party packages and are not built.
+  * extra model names: 'mobilenetv2' (north-star throughput model) and 'resnet50' (BASELINE config 4; standard torchvision
+    architecture, models/resnet.py).  The timm / efficientnet-lite names of the reference need un-vendored third-party
+    packages and are not built.
   * `regressors`, `cls_fc`, `sigmoid` (model_builder.py:79-87) are views onto the flat buffer, `extract_features`
     (mobilenetv3.py:199-203) and `_glob_feature_vector` (:96-110) are callable but inference-only: training goes
     through `forward`, whose whole graph is one autograd node;
@@ -29,6 +30,7 @@ from torch import nn
 
 from ..models.arch import AVAILABLE_MODELS
 from ..models.engine import Net
+from ..models.resnet import ResNetEngine
 from ..utils.utils import load_pretrained_weights
 
 
@@ -148,14 +150,15 @@ class ModelWrapper(nn.Module):
     sigmoid = property(lambda self: self._sigmoid)
 
     def _make(self, device, state=None):
-        self.net = Net(self.name, self.num_classes, device, self.storage_dtype, self.pooling_mode)
+        engine = ResNetEngine if self.name == 'resnet50' else Net
+        self.net = engine(self.name, self.num_classes, device, self.storage_dtype, self.pooling_mode)
         if state is not None:
             self.net.load_state_dict(state)
         # optional second engine over the SAME parameters / BatchNorm buffers for eval-mode forwards in another storage
         # precision (fp32 validation of a bf16-trained model: the 3-D IoU then equals the fp32 path's)
         self.net_eval = self.net
         if self.eval_storage_dtype is not None and self.eval_storage_dtype != self.storage_dtype and device.type == 'cuda':
-            self.net_eval = Net(self.name, self.num_classes, device, self.eval_storage_dtype, self.pooling_mode, share=self.net)
+            self.net_eval = engine(self.name, self.num_classes, device, self.eval_storage_dtype, self.pooling_mode, share=self.net)
         self.set_input_normalization(*self.input_normalization)
         self.flat = nn.Parameter(self.net.flat)     # shares storage with the engine's master weights
         # one process per GPU (launched by torch.distributed.run): the gradient exchange attaches itself as soon as the

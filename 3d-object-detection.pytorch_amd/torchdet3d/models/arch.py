@@ -20,7 +20,8 @@ MOBILENETV3 = {
 }
 MOBILENETV2 = [(1, 16, 1, 1), (6, 24, 2, 2), (6, 32, 3, 2), (6, 64, 4, 2), (6, 96, 3, 1), (6, 160, 3, 2),
                (6, 320, 1, 1)]
-AVAILABLE_MODELS = ('mobilenetv2', 'mobilenetv3_large', 'mobilenetv3_small')
+AVAILABLE_MODELS = ('mobilenetv2', 'mobilenetv3_large', 'mobilenetv3_small', 'resnet50')
+RESNET50_LAYERS = [(64, 3, 1), (128, 4, 2), (256, 6, 2), (512, 3, 2)]      # (width, blocks, stride of the first block)
 
 
 def make_divisible(v, divisor=8, min_value=None):
@@ -44,10 +45,22 @@ class Block:
 
 class Arch:
     def __init__(self, name):
-        assert name in AVAILABLE_MODELS, f'unknown model {name}'
+        assert name in AVAILABLE_MODELS or name == 'resnet14', f'unknown model {name}'
         self.name = name
         self.blocks = []
-        if name == 'mobilenetv2':
+        self.kind = 'resnet' if name in ('resnet50', 'resnet14') else 'mobilenet'
+        if name == 'resnet14':
+            # test-only: the four bottleneck kinds of ResNet-50 (projection / identity shortcut, stride 1 / 2) in a network
+            # shallow enough for gradient-level comparisons (tests/test_gpu_resnet.py)
+            self.layers = [(64, 2, 1), (128, 2, 2)]
+            self.stem_c, self.stem_act = 64, 'relu'
+            self.last_c, self.last_act, self.classifier, self.feat_c = 512, 'relu', 0, 512
+        elif name == 'resnet50':
+            # standard torchvision ResNet-50 (v1.5): BASELINE config 4; no reference source
+            self.layers = RESNET50_LAYERS
+            self.stem_c, self.stem_act = 64, 'relu'
+            self.last_c, self.last_act, self.classifier, self.feat_c = 2048, 'relu', 0, 2048
+        elif name == 'mobilenetv2':
             self.stem_c, self.stem_act = 32, 'relu6'
             cin = 32
             for t, c, n, s in MOBILENETV2:
@@ -73,6 +86,8 @@ class Arch:
         """Ordered {state-dict key: (shape, kind)}; kind in param | buffer.  Key names and order are the
         reference's (`state_dict()` of ModelWrapper(MobileNetV3))."""
         out = {}
+        if self.kind == 'resnet':
+            return self._resnet_shapes(num_classes)
 
         def bn(p, c):
             out[p + '.weight'] = ((c,), 'param')
@@ -115,6 +130,39 @@ class Arch:
             out['classifier.0.bias'] = ((self.classifier,), 'param')
             bn('classifier.1', self.classifier)
         for k in range(9):                                   # always 9 heads (model_builder.py:78-81)
+            out[f'regressors.{k}.0.weight'] = ((18, self.feat_c), 'param')
+            out[f'regressors.{k}.0.bias'] = ((18,), 'param')
+        out['cls_fc.1.weight'] = ((num_classes, self.feat_c), 'param')
+        out['cls_fc.1.bias'] = ((num_classes,), 'param')
+        return out
+
+    def _resnet_shapes(self, num_classes):
+        """torchvision's ResNet-50 state-dict keys + the wrapper's heads (model_builder.py:79-85)."""
+        out = {}
+
+        def bn(p, c):
+            out[p + '.weight'] = ((c,), 'param')
+            out[p + '.bias'] = ((c,), 'param')
+            out[p + '.running_mean'] = ((c,), 'buffer')
+            out[p + '.running_var'] = ((c,), 'buffer')
+            out[p + '.num_batches_tracked'] = ((), 'buffer')
+        out['conv1.weight'] = ((64, 3, 7, 7), 'param')
+        bn('bn1', 64)
+        cin = 64
+        for li, (w, n, s) in enumerate(self.layers):
+            for i in range(n):
+                p = f'layer{li + 1}.{i}'
+                out[p + '.conv1.weight'] = ((w, cin, 1, 1), 'param')
+                bn(p + '.bn1', w)
+                out[p + '.conv2.weight'] = ((w, w, 3, 3), 'param')
+                bn(p + '.bn2', w)
+                out[p + '.conv3.weight'] = ((4 * w, w, 1, 1), 'param')
+                bn(p + '.bn3', 4 * w)
+                if i == 0:
+                    out[p + '.downsample.0.weight'] = ((4 * w, cin, 1, 1), 'param')
+                    bn(p + '.downsample.1', 4 * w)
+                cin = 4 * w
+        for k in range(9):
             out[f'regressors.{k}.0.weight'] = ((18, self.feat_c), 'param')
             out[f'regressors.{k}.0.bias'] = ((18,), 'param')
         out['cls_fc.1.weight'] = ((num_classes, self.feat_c), 'param')

@@ -321,6 +321,11 @@ class Net:
             self._se_pack_desc = torch.tensor(rows, dtype=torch.int64, device=self.device) if rows else False
         if self._se_pack_desc is not False:
             N.call('t3d_pack_weights_batched', N.F32, N.ptr(self._se_pack_desc), self._se_pack_desc.shape[0], st)
+        self._pack_extra(st)
+        if self.arch.kind != 'mobilenet':
+            self._packed_dirty = False
+            self._packed_version = self.flat._version
+            return
         # stem: [C,3,3,3] -> [C,32] patch-row weights (columns 27..31 zero)
         c0 = self.arch.stem_c
         w32 = self._buf('stem32', (c0, 32), torch.float32)
@@ -336,6 +341,9 @@ class Net:
             N.call('t3d_pack_weight', N.F32, N.ptr(wc), N.ptr(self.wt['classifier']), wc.shape[0], wc.shape[1], 1, st)
         self._packed_dirty = False
         self._packed_version = self.flat._version
+
+    def _pack_extra(self, st):
+        """Hook: weight layouts of architectures with more than 1x1 / depthwise / stem convolutions (models/resnet.py)."""
 
     # ------------------------------------------------------------------ BatchNorm helpers
     def _fold_desc(self, bn, which, count):
@@ -885,7 +893,7 @@ class Net:
         # one launch clears every accumulate-into buffer of the backward: gradients, depthwise replicas, stem patch-row dW
         dw32 = self._buf('dstem32', (a.stem_c, 32), torch.float32)
         if getattr(self, '_zero_desc', None) is None:
-            rows = [[t.data_ptr(), t.numel() * t.element_size()] for t in (self.gflat, self._dwarena, dw32)]
+            rows = [[t.data_ptr(), t.numel() * t.element_size()] for t in (self.gflat, self._dwarena, dw32) if t.numel()]
             assert all(r[1] % 16 == 0 for r in rows)
             self._zero_desc = torch.tensor(rows, dtype=torch.int64, device=self.device)
         N.call('t3d_zero_batched', N.ptr(self._zero_desc), self._zero_desc.shape[0], st)
@@ -921,6 +929,16 @@ class Net:
             dpooled = self._buf('dpooled', (B, a.last_c), torch.float32)
             N.call('t3d_pwconv_dgrad', N.F32, N.ptr(df), N.ptr(yc), bb, N.ptr(self.wt['classifier']), None, None,
                    None, N.ptr(dpooled), None, None, B, 1, a.last_c, a.classifier, st)
+        self._backward_backbone(sv, dpooled, dw32)
+        self._flush_dw()
+        self._join_side()
+        self._maybe_hook(0, force=True)
+        assert not any(b.pend[1] for b in self.bns.values()), 'a BatchNorm backward finalize was never run'
+        self.saved = None
+
+    def _backward_backbone(self, sv, dpooled, dw32):
+        """From the gradient at the pooled feature vector back to the stem (MobileNet layouts; models/resnet.py overrides)."""
+        a, st, dt, B = self.arch, N.stream(), self.dt, sv['B']
         # ---- pool + last conv
         ln = a.last_name
         bnl = self.bns[ln + '.1']
@@ -963,9 +981,6 @@ class Net:
         self._flush_dw()
         self._join_side()
         N.call('t3d_copy_cols', N.ptr(dw32), N.ptr(self.g['features.0.0.weight']), a.stem_c, 32, 27, st)
-        self._maybe_hook(0, force=True)
-        assert not any(b.pend[1] for b in self.bns.values()), 'a BatchNorm backward finalize was never run'
-        self.saved = None
 
     def _pw_dgrad(self, dz, y, bb, wt, x, residual, M, HW, K, Nn, tag, bn=None):
         """Data gradient of a 1x1 conv into its input `x` (a _Src): returns the gradient at the BatchNorm output

@@ -370,6 +370,43 @@ int t3d_ssd_decode_nms(int dtype, int nlevels, const void* const* cls, const voi
                        int num_classes, float score_thr, float iou_thr, int max_per_class, float img_w, float img_h,
                        const float* stds, float* out, int* counts, void* stream);
 
+/* ---- ResNet-50 backbone (BASELINE config 4; the reference has no ResNet -- standard torchvision architecture, parity
+ * against oracle/resnet.py, unpinned).  Dense k x k convolutions run as patch gather + the pointwise GEMM entry points
+ * (t3d_pwconv_fwd / _dgrad / _wgrad with K = Kp); everything below is an HBM-bound gather / elementwise kernel. ---- */
+
+/* nn.Conv2d(C, N, k, stride, pad) input side: x [B,H,W,C] raw tensor read through `pro` (BatchNorm affine + activation of
+ * its producer; NULL: finished tensor), zero padding applied to the ACTIVATED tensor -> col [B*Ho*Wo][Kp],
+ * column (ky*k + kx)*C + c, columns k*k*C .. Kp-1 zero (Kp: multiple of 8).  _nchw: the fp32 NCHW crops of the input
+ * contract (stem). */
+int t3d_im2col(int dtype, const void* x, const t3d_prologue* pro, void* col, int B, int H, int W, int C, int k, int stride,
+               int pad, int Kp, void* stream);
+int t3d_im2col_nchw(int dtype, const float* x, void* col, int B, int H, int W, int C, int k, int stride, int pad, int Kp,
+                    void* stream);
+/* Backward of t3d_im2col: dcol [B*Ho*Wo][Kp] (= dy W, from t3d_pwconv_dgrad) -> dx [B,H,W,C] = gradient at the producer's
+ * BatchNorm output (patch gradients summed per input pixel, times act'(scale*x_raw + shift)); stats [2*C] fp64 or NULL:
+ * += sum(dx), sum(dx * x_raw) (replicas as elsewhere). */
+int t3d_col2im_bwd(int dtype, const void* dcol, const void* x_raw, const t3d_prologue* pro, void* dx, double* stats, int B,
+                   int H, int W, int C, int k, int stride, int pad, int Kp, void* stream);
+/* [N][C][k][k] fp32 master weight -> [N][Kp] GEMM operand in patch-column order (storage dtype), and the gradient back. */
+int t3d_pack_conv_weight(int dtype, const float* w, void* out, int N, int C, int k, int Kp, void* stream);
+int t3d_unpack_conv_grad(const float* dw_packed, float* dw, int N, int C, int k, int Kp, void* stream);
+/* nn.MaxPool2d(3, 2, 1) over act(scale*y + shift): out [B,Ho,Wo,C] finished tensor, argmax [B,Ho,Wo,C] uint8 (window
+ * position 0..8, first maximum in scan order); backward: dy = gradient at y's BatchNorm output + its backward sums. */
+int t3d_maxpool_fwd(int dtype, const void* y, const t3d_prologue* pro, void* out, unsigned char* argmax, int B, int H, int W,
+                    int C, void* stream);
+int t3d_maxpool_bwd(int dtype, const void* dout, const unsigned char* argmax, const void* y, const t3d_prologue* pro, void* dy,
+                    double* stats, int B, int H, int W, int C, void* stream);
+/* Bottleneck tail  z = relu(BN3(y3) + shortcut):  shortcut read through pro_s (projection shortcut: raw 1x1 output +
+ * its BatchNorm) or as it is (identity, pro_s NULL).  Backward: g = dz * [z > 0] (the gradient at BOTH BatchNorm
+ * outputs); stats3 += sum g, sum g*y3; statsd (with yd) += sum g, sum g*yd. */
+int t3d_res_relu_fwd(int dtype, const void* y3, const t3d_prologue* pro3, const void* shortcut, const t3d_prologue* pro_s,
+                     void* z, int M, int C, void* stream);
+int t3d_res_relu_bwd(int dtype, const void* dz, const void* z, const void* y3, const void* yd, void* g, double* stats3,
+                     double* statsd, int M, int C, void* stream);
+/* upsample == 0: out [B,Ho,Wo,C] = x[:, ::stride, ::stride, :] (x [B,H,W,C]);  upsample == 1: out [B,H,W,C] = x [B,Ho,Wo,C]
+ * at the multiples of stride, zero elsewhere (gradient of the former). */
+int t3d_subsample(int dtype, const void* x, void* out, int B, int H, int W, int C, int stride, int upsample, void* stream);
+
 /* Reduction replicas.  Every `+=` reduction output of the kernels (the fp64 BatchNorm sums `stats`, the depthwise
  * weight gradient `dw`) is hit by one atomic per channel per workgroup; with hundreds of workgroups on a few KB of
  * addresses those atomics serialise.  With nrep > 1 the streaming kernels add into replica (workgroup % nrep):

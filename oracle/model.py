@@ -146,6 +146,9 @@ def forward_to_onnx(sd, name, x, num_classes=9):
 
 def state_dict_shapes(name, num_classes=9):
     """Ordered {key: shape} with the reference's state-dict names."""
+    if name in ('resnet50', 'resnet14'):
+        from .resnet import TINY_LAYERS, state_dict_shapes as rs
+        return rs(num_classes, TINY_LAYERS if name == 'resnet14' else None)
     a = arch(name)
     out = {}
 
