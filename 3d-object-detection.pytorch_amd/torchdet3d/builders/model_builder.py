@@ -14,9 +14,8 @@ reference's).  Differences a caller can observe:
   * `regressors`, `cls_fc`, `sigmoid` (model_builder.py:79-87) are views onto the flat buffer, `extract_features`
     (mobilenetv3.py:199-203) and `_glob_feature_vector` (:96-110) are callable but inference-only: training goes
     through `forward`, whose whole graph is one autograd node;
-  * train-mode BatchNorm / Dropout are applied only when a backward can follow (`model.train()` AND grad mode on);
-    a train-mode model called under `torch.no_grad()` evaluates with the running statistics and leaves them alone,
-    where the reference would still use (and update) batch statistics.
+  * a train-mode model called under `torch.no_grad()` behaves like the reference's: batch statistics, running
+    estimates updated, dropout applied -- only the activations are not kept for a backward.
 Config keys read: model.name, model.num_classes, model.pretrained (ignored: no network), model.load_weights,
 model.storage_dtype ('f32' default for parity | 'bf16' throughput mode), model.eval_storage_dtype (storage precision of
 eval-mode forwards; default 'f32' also for a 'bf16' model, so that inference outputs meet the parity bounds -- 'bf16' makes
@@ -238,10 +237,16 @@ class ModelWrapper(nn.Module):
             return self.forward_to_onnx(x)
         if not x.is_cuda:
             raise RuntimeError('the HIP path needs the model and the crops on the GPU (no CPU fallback)')
-        # train-mode BatchNorm / dropout only when a backward can follow (grad mode is off inside Function.forward)
-        train = self.training and torch.is_grad_enabled()
+        train = self.training
         # uint8 NHWC crops go to the stem kernel as they are (normalised there, bf16 storage); anything else as fp32 NCHW
         x = x if x.dtype == torch.uint8 else x.float()
+        if train and not torch.is_grad_enabled():
+            # `model.train()` under torch.no_grad(): the reference's modules still normalise with the BATCH statistics, update
+            # the running estimates and apply dropout -- only autograd is off.  Same here: a train-mode forward whose saved
+            # activations are dropped (no backward can follow).
+            kp, logits = self.net.forward(x, cats, train=True, dropout_mask=dropout_mask)
+            self.net.saved = None
+            return kp, (logits if self.num_classes > 1 else cats.unsqueeze(1))
         if not train and self.net_eval is not self.net:
             with torch.no_grad():
                 kp, logits = self.net_eval.forward(x, cats, train=False)

@@ -345,7 +345,7 @@ def main():
     if rank == 0:
         crops = B * world * args.steps / dt
         res = {
-            'metric': f'regression {"eval" if args.eval else "train"} crops/sec @{S}^2 bs{B} ' + {'mobilenetv2': 'MobileNetV2', 'mobilenetv3_large': 'MobileNetV3-large', 'mobilenetv3_small': 'MobileNetV3-small'}.get(args.model, args.model), 'value': round(crops, 1), 'unit': 'crops/s',
+            'metric': f'regression {"eval" if args.eval else "train"} crops/sec @{S}^2 bs{B} ' + {'mobilenetv2': 'MobileNetV2', 'mobilenetv3_large': 'MobileNetV3-large', 'mobilenetv3_small': 'MobileNetV3-small', 'resnet50': 'ResNet-50'}.get(args.model, args.model), 'value': round(crops, 1), 'unit': 'crops/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(dt / args.steps * 1e3, 3),
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': args.dtype, 'data': 'synthetic',
             'config': {'workload': f'{args.model} 9-class Objectron keypoint regression, '

@@ -143,3 +143,36 @@ def test_trainer_and_evaluator_on_synthetic_loader(tmp_path):
     assert any(r[0] == 'Val/IOU' for r in w.rows)
     per, *_ = ev.val_step(*next(iter(val_loader)))
     assert all(len(row) == 5 for row in per)
+
+
+def test_train_mode_under_no_grad_uses_and_updates_batch_statistics_like_the_reference():
+    """`model.train()` + `torch.no_grad()`: nn.BatchNorm2d still normalises with the batch statistics and moves the running
+    estimates, nn.Dropout still drops (only autograd is off).  Against the oracle's train-mode forward on the same weights."""
+    from oracle import model as OMod
+    from oracle.weights import make_inputs, make_state_dict
+    from torchdet3d.builders import build_model
+    name, B, HW, nc = 'mobilenetv3_large', 8, 96, 9
+    sd = make_state_dict(name, nc)
+    imgs, _, cats = make_inputs(B, HW, HW, nc)
+    m = build_model(_cfg(name))
+    m.load_state_dict(sd)
+    m.to('cuda')
+    m.train()
+    mask = torch.full((B, 1280), 2.0)
+    with torch.no_grad():
+        kp, lg = m(imgs.cuda(), cats.cuda(), dropout_mask=mask.cuda())
+    ref = {k: v.clone() for k, v in sd.items()}
+    with torch.no_grad():
+        kp_o, lg_o = OMod.forward(ref, name, imgs, cats, train=True, num_classes=nc, dropout_mask=mask)
+    np.testing.assert_allclose(kp.cpu().numpy(), kp_o.numpy(), atol=1e-4)
+    np.testing.assert_allclose(lg.cpu().numpy(), lg_o.numpy(), atol=2e-4)
+    got = m.state_dict()
+    for k in ('features.3.conv.4.running_mean', 'features.3.conv.4.running_var', 'conv.1.running_mean'):
+        assert not torch.equal(ref[k], sd[k])                           # the oracle moved them ...
+        np.testing.assert_allclose(got[k].cpu().numpy(), ref[k].numpy(), rtol=1e-4, atol=1e-5)   # ... and so did the engine
+    assert int(got['features.0.1.num_batches_tracked']) == int(sd['features.0.1.num_batches_tracked']) + 1
+    assert not kp.requires_grad
+    m.eval()
+    with torch.no_grad():
+        kp_e, _ = m(imgs.cuda(), cats.cuda())
+    assert (kp_e - kp).abs().max() > 1e-4            # eval mode (running statistics) is a different function
