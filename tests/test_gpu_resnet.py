@@ -137,7 +137,10 @@ def test_resnet50_through_the_api_in_bf16():
     assert kp.shape == (16, 9, 2) and tg.shape == (16, 9) and torch.isfinite(kp).all()
 
 
-@pytest.mark.parametrize('B,H,W,C,k,s,pad', [(2, 12, 12, 16, 3, 1, 1), (2, 13, 11, 8, 3, 2, 1), (1, 9, 9, 8, 7, 2, 3)])
+@pytest.mark.parametrize('B,H,W,C,k,s,pad', [(2, 12, 12, 16, 3, 1, 1), (2, 13, 11, 8, 3, 2, 1), (1, 9, 9, 8, 7, 2, 3),
+                                             (2, 12, 12, 12, 3, 1, 1),            # C % 8 != 0: the scalar forms
+                                             (3, 14, 14, 64, 3, 1, 1), (2, 15, 15, 128, 3, 2, 1), (2, 10, 9, 512, 3, 1, 1),
+                                             (5, 28, 28, 24, 3, 2, 1), (2, 7, 7, 520, 3, 1, 1)])  # 520: C / 8 > 64 -> scalar backward
 def test_im2col_and_its_backward_match_torch_autograd(B, H, W, C, k, s, pad):
     """t3d_im2col (BatchNorm affine + ReLU on load, zero padding after the activation) and t3d_col2im_bwd (gather of the
     patch gradients, times relu', + the BatchNorm-backward sums) against torch autograd of the same function."""
@@ -169,13 +172,47 @@ def test_im2col_and_its_backward_match_torch_autograd(B, H, W, C, k, s, pad):
     np.testing.assert_allclose(dx.cpu().numpy(), ref.numpy(), atol=2e-5)
     np.testing.assert_allclose(stats[:C].cpu().numpy(), ref.sum((0, 1, 2)).double().numpy(), rtol=1e-4, atol=1e-4)
     np.testing.assert_allclose(stats[C:].cpu().numpy(), (ref * x).sum((0, 1, 2)).double().numpy(), rtol=1e-4, atol=1e-4)
+    # bf16 storage through the same entries: inputs rounded to bf16, results within bf16 rounding of the fp32 ones
+    xb, dcb = xd.bfloat16(), dcd.bfloat16()
+    colb = torch.full((B * Ho * Wo, Kp), 7.0, device='cuda', dtype=torch.bfloat16)
+    N.call('t3d_im2col', N.BF16, N.ptr(xb), pro, N.ptr(colb), B, H, W, C, k, s, pad, Kp, N.stream())
+    col32 = torch.empty_like(col)
+    xb32 = xb.float()
+    N.call('t3d_im2col', N.F32, N.ptr(xb32), pro, N.ptr(col32), B, H, W, C, k, s, pad, Kp, N.stream())
+    np.testing.assert_allclose(colb.float().cpu().numpy(), col32.cpu().numpy(), rtol=8e-3, atol=1e-6)
+    dxb = torch.empty(B, H, W, C, device='cuda', dtype=torch.bfloat16)
+    stb = torch.zeros(2 * C, dtype=torch.float64, device='cuda')
+    N.call('t3d_col2im_bwd', N.BF16, N.ptr(dcb), N.ptr(xb), pro, N.ptr(dxb), N.ptr(stb), B, H, W, C, k, s, pad, Kp, N.stream())
+    dc32, dx32 = dcb.float(), torch.empty(B, H, W, C, device='cuda')
+    N.call('t3d_col2im_bwd', N.F32, N.ptr(dc32), N.ptr(xb32), pro, N.ptr(dx32), None, B, H, W, C, k, s, pad, Kp, N.stream())
+    np.testing.assert_allclose(dxb.float().cpu().numpy(), dx32.cpu().numpy(), rtol=8e-3, atol=1e-6)
+    np.testing.assert_allclose(stb[:C].cpu().numpy(), dxb.double().sum((0, 1, 2)).cpu().numpy(), rtol=1e-4, atol=1e-3)
 
 
-def test_maxpool_res_relu_subsample_match_torch_autograd():
+def test_stem_patch_gather_from_nchw_matches_unfold():
+    """t3d_im2col_nchw (the 7x7 / stride-2 stem reads the reference's fp32 NCHW input contract directly)."""
+    import torch.nn.functional as F
+    from torchdet3d import _native as N
+    g = torch.Generator().manual_seed(5)
+    for (B, H, W, C, k, s, pad, Kp) in ((3, 32, 30, 3, 7, 2, 3, 160), (2, 9, 9, 3, 3, 1, 1, 32), (1, 8, 8, 5, 3, 1, 1, 45)):
+        x = torch.randn(B, C, H, W, generator=g)
+        Ho, Wo = (H + 2 * pad - k) // s + 1, (W + 2 * pad - k) // s + 1
+        cols = F.unfold(x, k, padding=pad, stride=s).view(B, C, k * k, Ho * Wo).permute(0, 3, 2, 1).reshape(B * Ho * Wo, k * k * C)
+        xd = x.cuda()
+        col = torch.full((B * Ho * Wo, Kp), 7.0, device='cuda')
+        N.call('t3d_im2col_nchw', N.F32, N.ptr(xd), N.ptr(col), B, H, W, C, k, s, pad, Kp, N.stream())
+        assert torch.equal(col.cpu()[:, :k * k * C], cols)
+        assert (col.cpu()[:, k * k * C:] == 0).all()
+        colb = torch.full((B * Ho * Wo, Kp), 7.0, device='cuda', dtype=torch.bfloat16)
+        N.call('t3d_im2col_nchw', N.BF16, N.ptr(xd), N.ptr(colb), B, H, W, C, k, s, pad, Kp, N.stream())
+        assert torch.equal(colb.cpu()[:, :k * k * C], cols.bfloat16())
+
+
+@pytest.mark.parametrize('B,H,W,C', [(2, 11, 14, 16), (2, 11, 14, 12), (3, 23, 20, 64), (2, 9, 9, 2048)])
+def test_maxpool_res_relu_subsample_match_torch_autograd(B, H, W, C):
     import torch.nn.functional as F
     from torchdet3d import _native as N
     g = torch.Generator().manual_seed(3)
-    B, H, W, C = 2, 11, 14, 16
     y = torch.randn(B, H, W, C, generator=g)
     sc, sh = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g) * 0.3
     yr = y.clone().requires_grad_(True)
@@ -216,6 +253,16 @@ def test_maxpool_res_relu_subsample_match_torch_autograd():
     np.testing.assert_allclose(gg.cpu().numpy(), gr.numpy(), atol=1e-6)
     np.testing.assert_allclose(st3.cpu().numpy(), torch.cat([gr.sum(0), (gr * y3).sum(0)]).double().numpy(), rtol=1e-5, atol=1e-4)
     np.testing.assert_allclose(std.cpu().numpy(), torch.cat([gr.sum(0), (gr * ydn).sum(0)]).double().numpy(), rtol=1e-5, atol=1e-4)
+    # identity shortcut (no projection branch, no second set of sums)
+    zi = F.relu(y3 * s3 + t3 + ydn)
+    N.call('t3d_res_relu_fwd', N.F32, N.ptr(dev[0]), N.prologue(dev[2], dev[3], None, 'none', False), N.ptr(dev[1]), None, N.ptr(z), M, C,
+           N.stream())
+    np.testing.assert_allclose(z.cpu().numpy(), zi.numpy(), atol=1e-6)
+    st3.zero_()
+    N.call('t3d_res_relu_bwd', N.F32, N.ptr(dev[6]), N.ptr(z), N.ptr(dev[0]), None, N.ptr(gg), N.ptr(st3), None, M, C, N.stream())
+    gi = dz * (zi > 0)
+    np.testing.assert_allclose(gg.cpu().numpy(), gi.numpy(), atol=1e-6)
+    np.testing.assert_allclose(st3.cpu().numpy(), torch.cat([gi.sum(0), (gi * y3).sum(0)]).double().numpy(), rtol=1e-5, atol=1e-4)
     # stride-2 sampling and its adjoint
     x = torch.randn(B, H, W, C, generator=g)
     xd = x.cuda()
