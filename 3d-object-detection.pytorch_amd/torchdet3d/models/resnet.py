@@ -136,11 +136,14 @@ class ResNetEngine(Net):
         return out
 
     # ------------------------------------------------------------------ backward
-    def _dgrad(self, dz, y, bb, wt, x_raw, gpro, residual, dx, bn_in, M, HW, K, Nn):
-        """dx [M,K] = (BN-backward of dz through y) W ; with x_raw / gpro: times act'(.) + the producer's backward sums."""
-        N.call('t3d_pwconv_dgrad', self.dt, N.ptr(dz), N.ptr(y), bb, N.ptr(wt), N.ptr(x_raw) if x_raw is not None else None,
-               gpro, N.ptr(residual) if residual is not None else None, N.ptr(dx),
-               self._bst(bn_in) if bn_in is not None else None, None, M, HW, K, Nn, N.stream(), nbytes=M * (K + Nn) * self.esz)
+    def _dgrad(self, dz, y, bb, wt, x_raw, gpro, residual, dx, bn_in, M, HW, K, Nn, bn=None):
+        """dx [M,K] = (BN-backward of dz through y) W ; with x_raw / gpro: times act'(.) + the producer's backward sums.
+        bn: the BatchNorm behind `bb` while its backward finalize is still pending -- the launch derives the coefficients in
+        its prologue and publishes them (engine.py `_c`)."""
+        self._c('t3d_pwconv_dgrad', self.dt, N.ptr(dz), N.ptr(y), bb, N.ptr(wt), N.ptr(x_raw) if x_raw is not None else None,
+                gpro, N.ptr(residual) if residual is not None else None, N.ptr(dx),
+                self._bst(bn_in) if bn_in is not None else None, None, M, HW, K, Nn, N.stream(), bwd=bn,
+                nbytes=M * (K + Nn) * self.esz)
 
     def _backward_backbone(self, sv, dpooled, dw32):
         a, st, dt, B = self.arch, N.stream(), self.dt, sv['B']
@@ -163,11 +166,11 @@ class ResNetEngine(Net):
         bb0 = self._bnb(bn0)
         self._conv_wgrad('conv1.weight', dy0, s0['y'], bb0, s0['col'], M1, H1 * W1, 64, 3, 7)
 
-    def _conv_wgrad(self, key, dz, y, bb, col, M, HW, Nn, C, k):
+    def _conv_wgrad(self, key, dz, y, bb, col, M, HW, Nn, C, k, bn=None):
         """dW of a k x k conv from its patch matrix (second stream), unpacked into the [N,C,k,k] gradient."""
         kp = self._kp(key)
         dwp = self._buf('dwp:' + key, (Nn, kp), torch.float32, zero=True)
-        self._wgrad(self.dt, N.ptr(dz), N.ptr(y), bb, N.ptr(col), None, N.ptr(dwp), M, HW, kp, Nn,
+        self._wgrad(self.dt, N.ptr(dz), N.ptr(y), bb, N.ptr(col), None, N.ptr(dwp), M, HW, kp, Nn, ro=bn,
                     nbytes=M * (kp + Nn) * self.esz)
         self._wgrad(N.ptr(dwp), N.ptr(self.g[key]), Nn, C, k, kp, entry='t3d_unpack_conv_grad')
 
@@ -184,29 +187,34 @@ class ResNetEngine(Net):
         g = self._buf('g:' + p, (M2, 4 * w))
         N.call('t3d_res_relu_bwd', dt, N.ptr(dz), N.ptr(out.t), N.ptr(rec['y3']), N.ptr(rec['yd']) if down else None, N.ptr(g),
                self._bst(bn3), self._bst(bnd) if down else None, M2, 4 * w, st)
-        bb3 = self._bnb(bn3)
+        # BatchNorm-backward coefficients: derived by their first readers (the weight-gradient launch for itself, the
+        # data-gradient launch publishes them) -- a finalize launch of its own waits for a compute-unit slot behind the
+        # second stream's long weight-gradient workgroups (40 us on average, 200 us at worst, 53 of them per step)
+        bb3 = self._bn_bwd(bn3)
         # ---- conv3 (1x1, w -> 4w)
         self._wgrad(dt, N.ptr(g), N.ptr(rec['y3']), bb3, N.ptr(rec['y2']), rec['pro2'], N.ptr(self.g[p + '.conv3.weight']),
-                    M2, HW2, w, 4 * w, nbytes=M2 * 5 * w * self.esz)
+                    M2, HW2, w, 4 * w, ro=bn3, nbytes=M2 * 5 * w * self.esz)
         dv2 = self._buf('dv2:' + p, (M2, w))
-        self._dgrad(g, rec['y3'], bb3, self.wt[p + '.conv3.weight'], rec['y2'], rec['pro2'], None, dv2, bn2, M2, HW2, w, 4 * w)
-        bb2 = self._bnb(bn2)
+        self._dgrad(g, rec['y3'], bb3, self.wt[p + '.conv3.weight'], rec['y2'], rec['pro2'], None, dv2, bn2, M2, HW2, w, 4 * w,
+                    bn=bn3)
+        bb2 = self._bn_bwd(bn2)
         # ---- conv2 (3x3, stride s): GEMM against the patch matrix, gradient back through the gather
         kp = self._kp(p + '.conv2.weight')
-        self._conv_wgrad(p + '.conv2.weight', dv2, rec['y2'], bb2, rec['col'], M2, HW2, w, w, 3)
+        self._conv_wgrad(p + '.conv2.weight', dv2, rec['y2'], bb2, rec['col'], M2, HW2, w, w, 3, bn=bn2)
         dcol = self._buf('dcol:' + p, (M2, kp))
-        self._dgrad(dv2, rec['y2'], bb2, self.wt[p + '.conv2.weight'], None, None, None, dcol, None, M2, HW2, kp, w)
+        self._dgrad(dv2, rec['y2'], bb2, self.wt[p + '.conv2.weight'], None, None, None, dcol, None, M2, HW2, kp, w, bn=bn2)
         d1 = self._buf('d1:' + p, (M, w))
         N.call('t3d_col2im_bwd', dt, N.ptr(dcol), N.ptr(rec['y1']), rec['pro1'], N.ptr(d1), self._bst(bn1), B, H, W, w, 3, s, 1,
                kp, st)
-        bb1 = self._bnb(bn1)
+        bb1 = self._bn_bwd(bn1)
         # ---- shortcut
         if down:
-            bbd = self._bnb(bnd)
+            bbd = self._bn_bwd(bnd)
             self._wgrad(dt, N.ptr(g), N.ptr(rec['yd']), bbd, N.ptr(rec['xs']), None, N.ptr(self.g[p + '.downsample.0.weight']),
-                        M2, HW2, cin, 4 * w, nbytes=M2 * (cin + 4 * w) * self.esz)
+                        M2, HW2, cin, 4 * w, ro=bnd, nbytes=M2 * (cin + 4 * w) * self.esz)
             dxs = self._buf('dxs:' + p, (M2, cin))
-            self._dgrad(g, rec['yd'], bbd, self.wt[p + '.downsample.0.weight'], None, None, None, dxs, None, M2, HW2, cin, 4 * w)
+            self._dgrad(g, rec['yd'], bbd, self.wt[p + '.downsample.0.weight'], None, None, None, dxs, None, M2, HW2, cin, 4 * w,
+                        bn=bnd)
             res = dxs
             if s > 1:
                 res = self._buf('dxu:' + p, (M, cin))
@@ -215,7 +223,7 @@ class ResNetEngine(Net):
             res = g
         # ---- conv1 (1x1, cin -> w); its input is a finished (post-ReLU) tensor: the mask is applied by the block before
         self._wgrad(dt, N.ptr(d1), N.ptr(rec['y1']), bb1, N.ptr(x.t), None, N.ptr(self.g[p + '.conv1.weight']),
-                    M, H * W, cin, w, nbytes=M * (cin + w) * self.esz)
+                    M, H * W, cin, w, ro=bn1, nbytes=M * (cin + w) * self.esz)
         dx = self._buf('dx:' + p, (M, cin))
-        self._dgrad(d1, rec['y1'], bb1, self.wt[p + '.conv1.weight'], None, None, res, dx, None, M, H * W, cin, w)
+        self._dgrad(d1, rec['y1'], bb1, self.wt[p + '.conv1.weight'], None, None, res, dx, None, M, H * W, cin, w, bn=bn1)
         return dx
