@@ -268,8 +268,9 @@ __global__ __launch_bounds__(256) void dw3_bwd_s1_kernel(const Dw3BArgs a) {
     const int rep = (blockIdx.x + blockIdx.y) % a.nrep;
     if (a.dw) {
       for (int i = threadIdx.x; i < 9 * a.C; i += 256) {
-        const float v = lred[i];
-        if (v != 0.f) unsafeAtomicAdd(a.dw + (size_t)rep * a.C * 9 + (size_t)(i % a.C) * 9 + i / a.C, v);
+        // lane -> consecutive addresses of dw [C][9] (tap fastest): a wave's 64 atomics fall into 2-3 cache lines instead of 64
+        const float v = lred[(i % 9) * a.C + i / 9];
+        if (v != 0.f) unsafeAtomicAdd(a.dw + (size_t)rep * a.C * 9 + i, v);
       }
     }
     if (a.stats) {
@@ -695,8 +696,9 @@ __global__ __launch_bounds__(NTH) void dw3_bwd2_kernel(const Dw3BArgs a) {
     const int rep = (blockIdx.x + blockIdx.y) % a.nrep;
     if (a.dw) {
       for (int i = threadIdx.x; i < 9 * Cb; i += NTH) {
-        const float v = lred[i];
-        if (v != 0.f) unsafeAtomicAdd(a.dw + (size_t)rep * a.C * 9 + (size_t)(cbase + i % Cb) * 9 + i / Cb, v);
+        // lane -> consecutive addresses of dw [C][9] (tap fastest): a wave's 64 atomics fall into 2-3 cache lines instead of 64
+        const float v = lred[(i % 9) * Cb + i / 9];
+        if (v != 0.f) unsafeAtomicAdd(a.dw + (size_t)rep * a.C * 9 + (size_t)cbase * 9 + i, v);
       }
     }
     if (a.stats) {
@@ -1056,8 +1058,9 @@ __global__ __launch_bounds__(NTH) void dw3_bwd_s2_kernel(const Dw3BArgs a) {
     const int rep = (blockIdx.x + blockIdx.y) % a.nrep;
     if (a.dw) {
       for (int i = threadIdx.x; i < 9 * Cb; i += NTH) {
-        const float v = lred[i];
-        if (v != 0.f) unsafeAtomicAdd(a.dw + (size_t)rep * a.C * 9 + (size_t)(cbase + i % Cb) * 9 + i / Cb, v);
+        // lane -> consecutive addresses of dw [C][9] (tap fastest): a wave's 64 atomics fall into 2-3 cache lines instead of 64
+        const float v = lred[(i % 9) * Cb + i / 9];
+        if (v != 0.f) unsafeAtomicAdd(a.dw + (size_t)rep * a.C * 9 + (size_t)cbase * 9 + i, v);
       }
     }
     if (a.stats) {

@@ -230,8 +230,9 @@ __global__ __launch_bounds__(256) void dw5_bwd_s2_kernel(const Dw5BArgs a) {
     const int rep = (blockIdx.x + blockIdx.y) % a.nrep;
     if (a.dw) {
       for (int i = threadIdx.x; i < 25 * Cb; i += 256) {
-        const float v = lred[i];
-        if (v != 0.f) unsafeAtomicAdd(a.dw + (size_t)rep * a.C * 25 + (size_t)(cbase + i % Cb) * 25 + i / Cb, v);
+        // lane -> consecutive addresses of dw [C][25] (tap fastest): a wave's 64 atomics fall into 2-3 cache lines instead of 64
+        const float v = lred[(i % 25) * Cb + i / 25];
+        if (v != 0.f) unsafeAtomicAdd(a.dw + (size_t)rep * a.C * 25 + (size_t)cbase * 25 + i, v);
       }
     }
     if (a.stats) {
@@ -414,8 +415,9 @@ __global__ __launch_bounds__(256) void dw5_bwd_s1_kernel(const Dw5BArgs a) {
     const int rep = (blockIdx.x + blockIdx.y) % a.nrep;
     if (a.dw) {
       for (int i = threadIdx.x; i < 25 * Cb; i += 256) {
-        const float v = lred[i];
-        if (v != 0.f) unsafeAtomicAdd(a.dw + (size_t)rep * a.C * 25 + (size_t)(cbase + i % Cb) * 25 + i / Cb, v);
+        // lane -> consecutive addresses of dw [C][25] (tap fastest): a wave's 64 atomics fall into 2-3 cache lines instead of 64
+        const float v = lred[(i % 25) * Cb + i / 25];
+        if (v != 0.f) unsafeAtomicAdd(a.dw + (size_t)rep * a.C * 25 + (size_t)cbase * 25 + i, v);
       }
     }
     if (a.stats) {
