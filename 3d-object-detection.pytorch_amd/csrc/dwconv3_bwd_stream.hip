@@ -732,8 +732,11 @@ int launch_s1c(Dw3BArgs& a, hipStream_t st) {
   a.nrep = g_t3d_reduce.nrep;
   a.rstride = g_t3d_reduce.stats_stride;
   const int nth = 256;   // 512-thread blocks measured 4-5x slower (register budget)
-  // slab mapping (a wave = 64 consecutive channel groups of one column) only when it wastes < 8 % of the lanes
-  const bool flat = CG < 64 || (cdiv(CG, 64) * 64 - CG) * 100 > 8 * cdiv(CG, 64) * 64;
+  // slab mapping (a wave = 64 consecutive channel groups of one column) only when it wastes < 12 % of the lanes
+  // (12 %: 14x14x576 -- 288 channel pairs, 5 slabs -- is 5 % faster in slabs than flattened, where every workgroup flushes
+  // sums of up to 512 channels instead of 128)
+  static const int waste_pct = getenv("T3D_DW_SLAB_WASTE") ? atoi(getenv("T3D_DW_SLAB_WASTE")) : 12;
+  const bool flat = CG < 64 || (cdiv(CG, 64) * 64 - CG) * 100 > waste_pct * cdiv(CG, 64) * 64;
   if (flat) {
     a.slab = 0;
     a.nitems = a.B * a.nchunks;
