@@ -73,8 +73,17 @@ __global__ __launch_bounds__(256) void yfree_combine_kernel(const float* __restr
   if (e >= N * K) return;
   const int n = e / K, k = e % K;
   const float* G = tmp + (size_t)N * K;
+  // (8 weights per 16-byte load and 8 independent Gram loads per round: the one-load-per-multiply loop was K dependent
+  //  round trips, 24 us for K = 96)
   float wg = 0.f;
-  for (int k2 = 0; k2 < K; ++k2) wg = fmaf((float)w[(size_t)n * K + k2], G[(size_t)k2 * K + k], wg);
+  for (int k2 = 0; k2 < K; k2 += 8) {
+    const bf16x8 wv = *reinterpret_cast<const bf16x8*>(w + (size_t)n * K + k2);
+    float g[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) g[j] = G[(size_t)(k2 + j) * K + k];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) wg = fmaf((float)wv[j], g[j], wg);
+  }
   dw[e] += alpha[n] * tmp[e] + beta[n] * wg + gamma[n] * tmp[(size_t)(N + K) * K + k];
 }
 
