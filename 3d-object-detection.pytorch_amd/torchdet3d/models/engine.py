@@ -372,10 +372,14 @@ class Net:
     # that reads the coefficients either derives them in its own prologue (`_c(..., fwd=bn)` / `bwd=bn`: a request to the
     # entry points that implement it -- they fall back to a finalize launch of their own on paths without the prologue)
     # or is preceded by the standalone finalize (`_settle_f` / `_settle_b`: every other reader).
-    # (the depthwise kernels implement the derive prologue too -- T3D_LAZY_DW=1 -- but every one of their 500-700 persistent
-    # workgroups then starts with the ~3-us round trip to the sums: same step time, depthwise launches 3-4 us longer)
+    # (the depthwise kernels too -- T3D_LAZY_DW=0 | fwd | bwd | 1 --: every one of their 500-700 persistent workgroups then starts
+    # with the ~3-us round trip to the sums, so their launches get 2-4 us longer, but the 5-us finalize launch and the ~6-us
+    # dispatch gap behind it go: 7.90 -> 7.83 ms per step on one box, 8.00 -> 7.97 on another (round 3b); the forward half
+    # gives most of it and is the default, the backward half costs the s=1 backward kernel 2 % of its own rate for 0.01 ms)
+    _LAZY_DW = os.environ.get('T3D_LAZY_DW', 'fwd')
     DERIVING = frozenset(('t3d_pwconv_fwd', 't3d_pwconv_fwd_mat', 't3d_bn_apply', 't3d_pool_fwd', 't3d_pwconv_dgrad', 't3d_pwconv_yfree_prep')
-                         + (('t3d_dwconv_fwd', 't3d_dwconv_bwd') if os.environ.get('T3D_LAZY_DW') else ()))
+                         + (('t3d_dwconv_fwd',) if _LAZY_DW in ('1', 'fwd') else ())
+                         + (('t3d_dwconv_bwd',) if _LAZY_DW in ('1', 'bwd') else ()))
 
     def _c(self, entry, *args, fwd=None, bwd=None, **kw):
         """N.call of a coefficient-reading entry point: fwd / bwd = the BatchNorm whose forward / backward coefficients
