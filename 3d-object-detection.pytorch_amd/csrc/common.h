@@ -25,7 +25,10 @@ static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 // Reduction replicas (t3d_set_reduction_replicas, misc.hip): contended atomics into one small array run an order of
 // magnitude below the chip's atomic rate, so block b adds its BatchNorm sums / depthwise weight gradient into
 // replica b % nrep; the finalize kernels (and the caller, for dw) sum the replicas.
-struct T3dReduceCfg { int nrep; long long stats_stride; };
+struct T3dReduceCfg {
+  int nrep; long long stats_stride;
+  int dw_slots; int* dw_used;      // t3d_set_dw_slots: one depthwise weight-gradient slot per workgroup (no atomics), see t3d_dw_flush
+};
 extern T3dReduceCfg g_t3d_reduce;
 
 // Scratch workspace in device memory (t3d_set_workspace, misc.hip): partial results of split reductions (the pointwise
@@ -301,4 +304,35 @@ __device__ __forceinline__ double wave_sum_d(double v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
   return v;
+}
+
+// ---- end of a depthwise-backward workgroup -------------------------------------------------------------------------
+// lacc [K2 + 2][Cb] fp64 in LDS: the workgroup's weight-gradient taps (rows 0 .. K2-1) and sum(dx), sum(dx*x) of its
+// channel range [cbase, cbase + Cb), accumulated with fp64 LDS atomics of the lanes' fp32 partials (exact adds in any
+// order for all but absurd dynamic ranges -- the fp32 LDS atomics of rounds 1-3a made two backward passes on one saved
+// forward differ by 1e-2 in the gradients, through one BatchNorm coefficient ulp and bf16 rounding downstream).
+//   weight gradient, slots > 0: STORED into the workgroup's own slot of dw [slots][C][K2] -- no atomics; the caller adds the
+//     slots in index order (t3d_sum_slots_batched): bit-reproducible, and the flush is plain coalesced stores;
+//   slots == 0: fp32 atomics into replica (workgroup % nrep), lanes along consecutive addresses (tap fastest: a wave's 64
+//     adds fall into 2-3 cache lines; channel-fastest they were 64 lines and 12 % of the s=1 backward);
+//   sums: fp64 atomics into the BatchNorm's replicas.
+template <int K2, int NTH>
+__device__ __forceinline__ void t3d_dw_flush(const double* lacc, int Cb, int cbase, int C, float* dw, double* stats, int nrep,
+                                             long long rstride, int slots, int slot, int* used) {
+  const int rep = (blockIdx.x + blockIdx.y) % nrep;
+  if (dw) {
+    float* dst = dw + (size_t)(slots > 0 ? slot : rep) * C * K2 + (size_t)cbase * K2;
+    for (int i = threadIdx.x; i < K2 * Cb; i += NTH) {
+      const float v = (float)lacc[(i % K2) * Cb + i / K2];
+      if (slots > 0) dst[i] = v;
+      else if (v != 0.f) unsafeAtomicAdd(dst + i, v);
+    }
+    if (used && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *used = slots > 0 ? slots : nrep;
+  }
+  if (stats) {
+    for (int i = threadIdx.x; i < 2 * Cb; i += NTH) {
+      const double v = lacc[K2 * Cb + i];
+      if (v != 0.0) atomicAdd(stats + (size_t)rep * rstride + (size_t)(i / Cb) * C + cbase + i % Cb, v);
+    }
+  }
 }

@@ -36,6 +36,8 @@ struct Dw3BArgs {
   int rows_per_chunk, nchunks, slab, nitems;
   int nrep;
   long long rstride;
+  int dw_slots;  // > 0: the weight gradient goes to one slot per workgroup (t3d_set_dw_slots; common.h: t3d_dw_flush)
+  int* dw_used;
   int noflush;   // profiling ablation only (T3D_DEBUG_NOFLUSH): skip the end-of-block reduction
   const T3dFold* fold;  // requested BatchNorm-backward finalize of (alpha, beta, gamma), derived in the prologue (common.h)
 };
@@ -249,36 +251,24 @@ __global__ __launch_bounds__(256) void dw3_bwd_s1_kernel(const Dw3BArgs a) {
   // ---- block-level reduction of the weight gradient and the BatchNorm-backward sums
   const int nred = (a.dw ? 9 : 0) + (a.stats ? 2 : 0);
   if (nred && !a.noflush) {
-    for (int i = threadIdx.x; i < 11 * a.C; i += 256) lred[i] = 0.f;
+    double* lacc = reinterpret_cast<double*>(lred);       // [9 + 2][a.C] fp64 accumulators (common.h: t3d_dw_flush)
+    for (int i = threadIdx.x; i < 11 * a.C; i += 256) lacc[i] = 0.0;
     __syncthreads();
     if (on) {
 #pragma unroll
       for (int i = 0; i < CH; ++i) {
         if (a.dw) {
 #pragma unroll
-          for (int t = 0; t < 9; ++t) atomicAdd(lred + t * a.C + c0 + i, wacc[t][i]);
+          for (int t = 0; t < 9; ++t) atomicAdd(lacc + t * a.C + c0 + i, (double)wacc[t][i]);
         }
         if (a.stats) {
-          atomicAdd(lred + 9 * a.C + c0 + i, psum[i]);
-          atomicAdd(lred + 10 * a.C + c0 + i, psq[i]);
+          atomicAdd(lacc + 9 * a.C + c0 + i, (double)psum[i]);
+          atomicAdd(lacc + 10 * a.C + c0 + i, (double)psq[i]);
         }
       }
     }
     __syncthreads();
-    const int rep = (blockIdx.x + blockIdx.y) % a.nrep;
-    if (a.dw) {
-      for (int i = threadIdx.x; i < 9 * a.C; i += 256) {
-        // lane -> consecutive addresses of dw [C][9] (tap fastest): a wave's 64 atomics fall into 2-3 cache lines instead of 64
-        const float v = lred[(i % 9) * a.C + i / 9];
-        if (v != 0.f) unsafeAtomicAdd(a.dw + (size_t)rep * a.C * 9 + i, v);
-      }
-    }
-    if (a.stats) {
-      for (int i = threadIdx.x; i < 2 * a.C; i += 256) {
-        const float v = lred[9 * a.C + i];
-        if (v != 0.f) atomicAdd(a.stats + (size_t)rep * a.rstride + i, (double)v);
-      }
-    }
+    t3d_dw_flush<9, 256>(lacc, a.C, 0, a.C, a.dw, a.stats, a.nrep, a.rstride, a.dw_slots, (int)(blockIdx.y * gridDim.x + blockIdx.x), a.dw_used);
   }
 }
 
@@ -674,7 +664,8 @@ __global__ __launch_bounds__(NTH) void dw3_bwd2_kernel(const Dw3BArgs a) {
   __syncthreads();
   const int nred = (a.dw ? 9 : 0) + (a.stats ? 2 : 0);
   if (nred && !a.noflush) {
-    for (int i = threadIdx.x; i < 11 * Cb; i += NTH) lred[i] = 0.f;
+    double* lacc = reinterpret_cast<double*>(lred);       // [9 + 2][Cb] fp64 accumulators (common.h: t3d_dw_flush)
+    for (int i = threadIdx.x; i < 11 * Cb; i += NTH) lacc[i] = 0.0;
     __syncthreads();
     if (on) {
 #pragma unroll
@@ -684,29 +675,16 @@ __global__ __launch_bounds__(NTH) void dw3_bwd2_kernel(const Dw3BArgs a) {
           const int c = c0 - cbase + 2 * h + e;
           if (a.dw) {
 #pragma unroll
-            for (int t = 0; t < 9; ++t) atomicAdd(lred + t * Cb + c, wacc[t][h][e]);
+            for (int t = 0; t < 9; ++t) atomicAdd(lacc + t * Cb + c, (double)wacc[t][h][e]);
           }
           if (a.stats) {
-            atomicAdd(lred + 9 * Cb + c, psum[2 * h + e]);
-            atomicAdd(lred + 10 * Cb + c, psq[2 * h + e]);
+            atomicAdd(lacc + 9 * Cb + c, (double)psum[2 * h + e]);
+            atomicAdd(lacc + 10 * Cb + c, (double)psq[2 * h + e]);
           }
         }
     }
     __syncthreads();
-    const int rep = (blockIdx.x + blockIdx.y) % a.nrep;
-    if (a.dw) {
-      for (int i = threadIdx.x; i < 9 * Cb; i += NTH) {
-        // lane -> consecutive addresses of dw [C][9] (tap fastest): a wave's 64 atomics fall into 2-3 cache lines instead of 64
-        const float v = lred[(i % 9) * Cb + i / 9];
-        if (v != 0.f) unsafeAtomicAdd(a.dw + (size_t)rep * a.C * 9 + (size_t)cbase * 9 + i, v);
-      }
-    }
-    if (a.stats) {
-      for (int i = threadIdx.x; i < 2 * Cb; i += NTH) {
-        const float v = lred[9 * Cb + i];
-        if (v != 0.f) atomicAdd(a.stats + (size_t)rep * a.rstride + (size_t)(i / Cb) * a.C + cbase + i % Cb, (double)v);
-      }
-    }
+    t3d_dw_flush<9, NTH>(lacc, Cb, cbase, a.C, a.dw, a.stats, a.nrep, a.rstride, a.dw_slots, a.slab ? (int)blockIdx.x : (int)(blockIdx.y * gridDim.x + blockIdx.x), a.dw_used);
   }
 }
 
@@ -755,7 +733,12 @@ int launch_s1c(Dw3BArgs& a, hipStream_t st) {
     grid = dim3(gx, ns);
   }
   if (two_col && (size_t)a.B * a.H * a.W * a.C * sizeof(T) >= (1ull << 32)) return T3D_ERR_UNSUPPORTED;   // 32-bit buffer offsets
-  const size_t lds = (size_t)12 * a.C * sizeof(float);     // [11][C] reduction scratch; [9 .. 12)[Cb]: derived coefficients
+  {   // depthwise weight gradient: one slot per workgroup when the caller provides enough of them (t3d_set_dw_slots)
+    const int needed = (two_col && a.slab) ? (int)grid.x : (int)(grid.x * grid.y);
+    a.dw_slots = (a.dw && g_t3d_reduce.dw_slots >= needed) ? needed : 0;
+    a.dw_used = a.dw ? g_t3d_reduce.dw_used : nullptr;
+  }
+  const size_t lds = (size_t)22 * ((two_col && a.slab) ? 64 * CH : a.C) * sizeof(float);   // [11][Cb] fp64 reduction scratch (before it: [9][Cb] weights, [3][Cb] derived coefficients)
   a.noflush = getenv("T3D_DEBUG_NOFLUSH") ? 1 : 0;
   // a pending BatchNorm-backward finalize of this launch's gradient coefficients is derived in the two-column kernel
   if (two_col && !a.per_sample) {
@@ -1039,7 +1022,8 @@ __global__ __launch_bounds__(NTH) void dw3_bwd_s2_kernel(const Dw3BArgs a) {
 
   const int nred = (a.dw ? 9 : 0) + (a.stats ? 2 : 0);
   if (nred && !a.noflush) {
-    for (int i = threadIdx.x; i < 11 * Cb; i += NTH) lred[i] = 0.f;
+    double* lacc = reinterpret_cast<double*>(lred);       // [9 + 2][Cb] fp64 accumulators (common.h: t3d_dw_flush)
+    for (int i = threadIdx.x; i < 11 * Cb; i += NTH) lacc[i] = 0.0;
     __syncthreads();
     if (on) {
 #pragma unroll
@@ -1049,29 +1033,16 @@ __global__ __launch_bounds__(NTH) void dw3_bwd_s2_kernel(const Dw3BArgs a) {
           const int c = c0 - cbase + 2 * h + e;
           if (a.dw) {
 #pragma unroll
-            for (int t = 0; t < 9; ++t) atomicAdd(lred + t * Cb + c, wacc[t][h][e]);
+            for (int t = 0; t < 9; ++t) atomicAdd(lacc + t * Cb + c, (double)wacc[t][h][e]);
           }
           if (a.stats) {
-            atomicAdd(lred + 9 * Cb + c, psum[2 * h + e]);
-            atomicAdd(lred + 10 * Cb + c, psq[2 * h + e]);
+            atomicAdd(lacc + 9 * Cb + c, (double)psum[2 * h + e]);
+            atomicAdd(lacc + 10 * Cb + c, (double)psq[2 * h + e]);
           }
         }
     }
     __syncthreads();
-    const int rep = (blockIdx.x + blockIdx.y) % a.nrep;
-    if (a.dw) {
-      for (int i = threadIdx.x; i < 9 * Cb; i += NTH) {
-        // lane -> consecutive addresses of dw [C][9] (tap fastest): a wave's 64 atomics fall into 2-3 cache lines instead of 64
-        const float v = lred[(i % 9) * Cb + i / 9];
-        if (v != 0.f) unsafeAtomicAdd(a.dw + (size_t)rep * a.C * 9 + (size_t)cbase * 9 + i, v);
-      }
-    }
-    if (a.stats) {
-      for (int i = threadIdx.x; i < 2 * Cb; i += NTH) {
-        const float v = lred[9 * Cb + i];
-        if (v != 0.f) atomicAdd(a.stats + (size_t)rep * a.rstride + (size_t)(i / Cb) * a.C + cbase + i % Cb, (double)v);
-      }
-    }
+    t3d_dw_flush<9, NTH>(lacc, Cb, cbase, a.C, a.dw, a.stats, a.nrep, a.rstride, a.dw_slots, a.slab ? (int)blockIdx.x : (int)(blockIdx.y * gridDim.x + blockIdx.x), a.dw_used);
   }
 }
 
@@ -1110,7 +1081,12 @@ int launch_s2(Dw3BArgs& a, hipStream_t st) {
     if (gx < 1) gx = 1;
     grid = dim3(gx, ns);
   }
-  const size_t lds = (size_t)11 * (a.slab ? 64 * CH : a.C) * sizeof(float);
+  {   // depthwise weight gradient: one slot per workgroup when the caller provides enough of them (t3d_set_dw_slots)
+    const int needed = a.slab ? (int)grid.x : (int)(grid.x * grid.y);
+    a.dw_slots = (a.dw && g_t3d_reduce.dw_slots >= needed) ? needed : 0;
+    a.dw_used = a.dw ? g_t3d_reduce.dw_used : nullptr;
+  }
+  const size_t lds = (size_t)22 * (a.slab ? 64 * CH : a.C) * sizeof(float);   // [11][Cb] fp64
   a.noflush = getenv("T3D_DEBUG_NOFLUSH") ? 1 : 0;
   if (!a.per_sample) {
     a.fold = t3d_take_fold(a.alpha);

@@ -27,6 +27,8 @@ struct Dw5BArgs {
   int rows_per_chunk, nchunks, slab, nitems;
   int nrep;
   long long rstride;
+  int dw_slots;  // > 0: the weight gradient goes to one slot per workgroup (t3d_set_dw_slots; common.h: t3d_dw_flush)
+  int* dw_used;
 };
 
 template <typename T, int CH> using rawvec = T __attribute__((ext_vector_type(CH)));
@@ -210,7 +212,8 @@ __global__ __launch_bounds__(256) void dw5_bwd_s2_kernel(const Dw5BArgs a) {
 
   const int nred = (a.dw ? 25 : 0) + (a.stats ? 2 : 0);
   if (nred) {
-    for (int i = threadIdx.x; i < 27 * Cb; i += 256) lred[i] = 0.f;
+    double* lacc = reinterpret_cast<double*>(lred);       // [25 + 2][Cb] fp64 accumulators (common.h: t3d_dw_flush)
+    for (int i = threadIdx.x; i < 27 * Cb; i += 256) lacc[i] = 0.0;
     __syncthreads();
     if (on) {
 #pragma unroll
@@ -218,29 +221,16 @@ __global__ __launch_bounds__(256) void dw5_bwd_s2_kernel(const Dw5BArgs a) {
         const int c = c0 - cbase + e;
         if (a.dw) {
 #pragma unroll
-          for (int t = 0; t < 25; ++t) atomicAdd(lred + t * Cb + c, wacc[t][e]);
+          for (int t = 0; t < 25; ++t) atomicAdd(lacc + t * Cb + c, (double)wacc[t][e]);
         }
         if (a.stats) {
-          atomicAdd(lred + 25 * Cb + c, psum[e]);
-          atomicAdd(lred + 26 * Cb + c, psq[e]);
+          atomicAdd(lacc + 25 * Cb + c, (double)psum[e]);
+          atomicAdd(lacc + 26 * Cb + c, (double)psq[e]);
         }
       }
     }
     __syncthreads();
-    const int rep = (blockIdx.x + blockIdx.y) % a.nrep;
-    if (a.dw) {
-      for (int i = threadIdx.x; i < 25 * Cb; i += 256) {
-        // lane -> consecutive addresses of dw [C][25] (tap fastest): a wave's 64 atomics fall into 2-3 cache lines instead of 64
-        const float v = lred[(i % 25) * Cb + i / 25];
-        if (v != 0.f) unsafeAtomicAdd(a.dw + (size_t)rep * a.C * 25 + (size_t)cbase * 25 + i, v);
-      }
-    }
-    if (a.stats) {
-      for (int i = threadIdx.x; i < 2 * Cb; i += 256) {
-        const float v = lred[25 * Cb + i];
-        if (v != 0.f) atomicAdd(a.stats + (size_t)rep * a.rstride + (size_t)(i / Cb) * a.C + cbase + i % Cb, (double)v);
-      }
-    }
+    t3d_dw_flush<25, 256>(lacc, Cb, cbase, a.C, a.dw, a.stats, a.nrep, a.rstride, a.dw_slots, a.slab ? (int)blockIdx.x : (int)(blockIdx.y * gridDim.x + blockIdx.x), a.dw_used);
   }
 }
 
@@ -395,7 +385,8 @@ __global__ __launch_bounds__(256) void dw5_bwd_s1_kernel(const Dw5BArgs a) {
 
   const int nred = (a.dw ? 25 : 0) + (a.stats ? 2 : 0);
   if (nred) {
-    for (int i = threadIdx.x; i < 27 * Cb; i += 256) lred[i] = 0.f;
+    double* lacc = reinterpret_cast<double*>(lred);       // [25 + 2][Cb] fp64 accumulators (common.h: t3d_dw_flush)
+    for (int i = threadIdx.x; i < 27 * Cb; i += 256) lacc[i] = 0.0;
     __syncthreads();
     if (on) {
 #pragma unroll
@@ -403,29 +394,16 @@ __global__ __launch_bounds__(256) void dw5_bwd_s1_kernel(const Dw5BArgs a) {
         const int c = c0 - cbase + e;
         if (a.dw) {
 #pragma unroll
-          for (int t = 0; t < 25; ++t) atomicAdd(lred + t * Cb + c, wacc[t][e]);
+          for (int t = 0; t < 25; ++t) atomicAdd(lacc + t * Cb + c, (double)wacc[t][e]);
         }
         if (a.stats) {
-          atomicAdd(lred + 25 * Cb + c, psum[e]);
-          atomicAdd(lred + 26 * Cb + c, psq[e]);
+          atomicAdd(lacc + 25 * Cb + c, (double)psum[e]);
+          atomicAdd(lacc + 26 * Cb + c, (double)psq[e]);
         }
       }
     }
     __syncthreads();
-    const int rep = (blockIdx.x + blockIdx.y) % a.nrep;
-    if (a.dw) {
-      for (int i = threadIdx.x; i < 25 * Cb; i += 256) {
-        // lane -> consecutive addresses of dw [C][25] (tap fastest): a wave's 64 atomics fall into 2-3 cache lines instead of 64
-        const float v = lred[(i % 25) * Cb + i / 25];
-        if (v != 0.f) unsafeAtomicAdd(a.dw + (size_t)rep * a.C * 25 + (size_t)cbase * 25 + i, v);
-      }
-    }
-    if (a.stats) {
-      for (int i = threadIdx.x; i < 2 * Cb; i += 256) {
-        const float v = lred[25 * Cb + i];
-        if (v != 0.f) atomicAdd(a.stats + (size_t)rep * a.rstride + (size_t)(i / Cb) * a.C + cbase + i % Cb, (double)v);
-      }
-    }
+    t3d_dw_flush<25, 256>(lacc, Cb, cbase, a.C, a.dw, a.stats, a.nrep, a.rstride, a.dw_slots, a.slab ? (int)blockIdx.x : (int)(blockIdx.y * gridDim.x + blockIdx.x), a.dw_used);
   }
 }
 
@@ -447,7 +425,7 @@ int launch5_s1(Dw5BArgs& a, hipStream_t st) {
   a.rstride = g_t3d_reduce.stats_stride;
   dim3 grid;
   bool flat = CG < 64 || (cdiv(CG, 64) * 64 - CG) * 100 > 8 * cdiv(CG, 64) * 64;
-  if (flat && CG >= 64 && (size_t)27 * a.C * sizeof(float) > 64 * 1024) flat = false;   // the reduction scratch must fit LDS
+  if (flat && CG >= 64 && (size_t)54 * a.C * sizeof(float) > 64 * 1024) flat = false;   // the reduction scratch must fit LDS
   if (flat) {
     a.slab = 0;
     a.nitems = a.B * a.nchunks;
@@ -465,7 +443,12 @@ int launch5_s1(Dw5BArgs& a, hipStream_t st) {
     if (gx < 1) gx = 1;
     grid = dim3(gx, ns);
   }
-  const size_t lds = (size_t)27 * (a.slab ? 64 * CH : a.C) * sizeof(float);
+  {   // depthwise weight gradient: one slot per workgroup when the caller provides enough of them (t3d_set_dw_slots)
+    const int needed = a.slab ? (int)grid.x : (int)(grid.x * grid.y);
+    a.dw_slots = (a.dw && g_t3d_reduce.dw_slots >= needed) ? needed : 0;
+    a.dw_used = a.dw ? g_t3d_reduce.dw_used : nullptr;
+  }
+  const size_t lds = (size_t)54 * (a.slab ? 64 * CH : a.C) * sizeof(float);   // [27][Cb] fp64
   if (lds > 64 * 1024) return T3D_ERR_UNSUPPORTED;
   hipLaunchKernelGGL((dw5_bwd_s1_kernel<T>), grid, dim3(256), lds, st, a);
   T3D_CHECK_LAUNCH();
@@ -490,7 +473,7 @@ int launch5_s2(Dw5BArgs& a, hipStream_t st) {
   a.rstride = g_t3d_reduce.stats_stride;
   dim3 grid;
   bool flat = CG < 64 || (cdiv(CG, 64) * 64 - CG) * 100 > 8 * cdiv(CG, 64) * 64;
-  if (flat && CG >= 64 && (size_t)27 * a.C * sizeof(float) > 64 * 1024) flat = false;   // the reduction scratch must fit LDS
+  if (flat && CG >= 64 && (size_t)54 * a.C * sizeof(float) > 64 * 1024) flat = false;   // the reduction scratch must fit LDS
   if (flat) {
     a.slab = 0;
     a.nitems = a.B * a.nchunks;
@@ -508,7 +491,12 @@ int launch5_s2(Dw5BArgs& a, hipStream_t st) {
     if (gx < 1) gx = 1;
     grid = dim3(gx, ns);
   }
-  const size_t lds = (size_t)27 * (a.slab ? 64 * CH : a.C) * sizeof(float);
+  {   // depthwise weight gradient: one slot per workgroup when the caller provides enough of them (t3d_set_dw_slots)
+    const int needed = a.slab ? (int)grid.x : (int)(grid.x * grid.y);
+    a.dw_slots = (a.dw && g_t3d_reduce.dw_slots >= needed) ? needed : 0;
+    a.dw_used = a.dw ? g_t3d_reduce.dw_used : nullptr;
+  }
+  const size_t lds = (size_t)54 * (a.slab ? 64 * CH : a.C) * sizeof(float);   // [27][Cb] fp64
   if (lds > 64 * 1024) return T3D_ERR_UNSUPPORTED;
   hipLaunchKernelGGL((dw5_bwd_s2_kernel<T, PF>), grid, dim3(256), lds, st, a);
   T3D_CHECK_LAUNCH();

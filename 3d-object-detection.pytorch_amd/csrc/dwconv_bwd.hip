@@ -31,6 +31,7 @@ struct DwBwdArgs {
   int TH, TW, tiles_x, tiles_y, cgb, pix_stride;
   int a_off, d_off;                    // byte offsets of the A and D tiles
   int nrep;                            // reduction replicas (common.h)
+  int* dw_used;                        // t3d_set_dw_slots: this kernel adds into the first nrep slots and says so
   long long rstride;
 };
 
@@ -214,6 +215,7 @@ __global__ __launch_bounds__(256) void dw_bwd_kernel(const DwBwdArgs a) {
 
   // ---- block-level reductions ------------------------------------------------------------
   if (a.dw) {
+    if (a.dw_used && blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) *a.dw_used = a.nrep;   // (atomics into the first nrep slots)
     __syncthreads();
     // scratch [slot][cg][kx][8]
     if (slot < nslots) {
@@ -263,6 +265,7 @@ template <typename T>
 int launch(const DwBwdArgs& a0, int k, int s, hipStream_t st) {
   DwBwdArgs a = a0;
   a.nrep = g_t3d_reduce.nrep;
+  a.dw_used = a.dw ? g_t3d_reduce.dw_used : nullptr;
   a.rstride = g_t3d_reduce.stats_stride;
   const int P = (k - 1) / 2, DLO = P / s, DHI = (s - 1 + P) / s;
   const int CG = a.C / 8;

@@ -45,6 +45,25 @@ __global__ void sum_replicas_batched_kernel(const long long* __restrict__ desc, 
   }
 }
 
+// desc[t] = {src [slots][count] fp32, dst [count] fp32, count, used (device int*)}: dst = sum over the first *used slots, in
+// index order (overwrites) -- the deterministic end of the depthwise weight gradient (t3d_set_dw_slots)
+__global__ void sum_slots_batched_kernel(const long long* __restrict__ desc) {
+  const long long* d = desc + (size_t)blockIdx.x * 4;
+  const float* __restrict__ src = reinterpret_cast<const float*>(d[0]);
+  float* __restrict__ dst = reinterpret_cast<float*>(d[1]);
+  const int n = (int)d[2], nslots = *reinterpret_cast<const int*>(d[3]);
+  for (int i = blockIdx.y * blockDim.x + threadIdx.x; i < n; i += gridDim.y * blockDim.x) {
+    float s = 0.f;
+    int r = 0;
+    for (; r + 4 <= nslots; r += 4) {       // four loads in flight, added in index order
+      const float a = src[(size_t)r * n + i], b = src[(size_t)(r + 1) * n + i], c = src[(size_t)(r + 2) * n + i], e = src[(size_t)(r + 3) * n + i];
+      s += a; s += b; s += c; s += e;
+    }
+    for (; r < nslots; ++r) s += src[(size_t)r * n + i];
+    dst[i] = s;
+  }
+}
+
 // AdamW over one flat fp32 buffer (torch.optim.AdamW semantics, decoupled weight decay, no amsgrad):
 //   p *= 1 - lr*wd;  m = lerp(m, g, 1-b1);  v = b2*v + (1-b2)*g*g;  p -= (lr/bc1) * m / (sqrt(v)/sqrt(bc2) + eps)
 // 16 B per lane per array; the bias corrections are computed on the host in fp64.
@@ -214,6 +233,13 @@ extern "C" int t3d_zero_batched(const long long* desc, int n, void* stream) {
   return T3D_OK;
 }
 
+extern "C" int t3d_sum_slots_batched(const long long* desc, int n, void* stream) {
+  if (!desc || n <= 0) return T3D_ERR_ARG;
+  hipLaunchKernelGGL(sum_slots_batched_kernel, dim3(n, 16), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), desc);
+  T3D_CHECK_LAUNCH();
+  return T3D_OK;
+}
+
 extern "C" int t3d_sum_replicas_batched(const long long* desc, int n, int nrep, void* stream) {
   if (!desc || n <= 0 || nrep < 1) return T3D_ERR_ARG;
   hipLaunchKernelGGL(sum_replicas_batched_kernel, dim3(n, 8), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), desc, nrep);
@@ -247,7 +273,14 @@ extern "C" int t3d_pack_weight(int dtype, const float* w, void* out, int rows, i
   return T3D_OK;
 }
 
-T3dReduceCfg g_t3d_reduce = {1, 0};
+T3dReduceCfg g_t3d_reduce = {1, 0, 0, nullptr};
+
+extern "C" int t3d_set_dw_slots(int capacity, int* used_out) {
+  if (capacity < 0 || (capacity > 0 && !used_out)) return T3D_ERR_ARG;
+  g_t3d_reduce.dw_slots = capacity;
+  g_t3d_reduce.dw_used = capacity > 0 ? used_out : nullptr;
+  return T3D_OK;
+}
 
 extern "C" int t3d_set_reduction_replicas(int nrep, long long stats_stride) {
   if (nrep < 1 || nrep > 16 || (nrep > 1 && stats_stride <= 0)) return T3D_ERR_ARG;

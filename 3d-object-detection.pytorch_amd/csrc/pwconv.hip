@@ -39,8 +39,8 @@ __global__ __launch_bounds__(256, 2) void pw_gemm_kernel(const GemmArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   T* As = reinterpret_cast<T*>(smem);                         // [BM][LDK]
   T* Ws = As + BM * LDK;                                      // [BN][LDK]
-  float* lstat = reinterpret_cast<float*>(Ws + BN * LDK);     // [BN][2]
-  float* coef = lstat + BN * 2;                               // [3][kpad]
+  double* lstat = reinterpret_cast<double*>(Ws + BN * LDK);   // [BN][2] fp64: adds of the tiles' fp32 partial sums in any order
+  float* coef = reinterpret_cast<float*>(lstat + BN * 2);     // [3][kpad]
   const int kpad = (a.Kin + BK - 1) / BK * BK;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -51,7 +51,7 @@ __global__ __launch_bounds__(256, 2) void pw_gemm_kernel(const GemmArgs a) {
   const T* __restrict__ Wg = reinterpret_cast<const T*>(a.w);
   T* __restrict__ out = reinterpret_cast<T*>(a.out);
 
-  for (int i = tid; i < BN * 2; i += 256) lstat[i] = 0.f;
+  for (int i = tid; i < BN * 2; i += 256) lstat[i] = 0.0;
   for (int i = tid; i < kpad; i += 256) {
     const bool v = i < a.Kin;
     if (!a.dgrad) {
@@ -261,8 +261,8 @@ __global__ __launch_bounds__(256, 2) void pw_gemm_kernel(const GemmArgs a) {
               s1 = row16_sum(s1);
               s2 = row16_sum(s2);
               if (lc == 0) {
-                atomicAdd(lstat + (n - n0 + j) * 2, s1);
-                atomicAdd(lstat + (n - n0 + j) * 2 + 1, s2);
+                atomicAdd(lstat + (n - n0 + j) * 2, (double)s1);
+                atomicAdd(lstat + (n - n0 + j) * 2 + 1, (double)s2);
               }
             }
           }
@@ -275,7 +275,7 @@ __global__ __launch_bounds__(256, 2) void pw_gemm_kernel(const GemmArgs a) {
     __syncthreads();
     for (int i = tid; i < BN * 2; i += 256) {
       const int n = n0 + (i >> 1);
-      if (n < a.Nout) atomicAdd(a.stats + (size_t)(i & 1) * a.Nout + n, (double)lstat[i]);
+      if (n < a.Nout) atomicAdd(a.stats + (size_t)(i & 1) * a.Nout + n, lstat[i]);
     }
   }
 }
@@ -313,7 +313,7 @@ template <typename T, int NT>
 int launch_nt(GemmArgs& a, hipStream_t st) {
   constexpr int BN = NT * 16;
   const int kpad = (a.Kin + MM<T>::BK - 1) / MM<T>::BK * MM<T>::BK;
-  const size_t lds = (size_t)(BM + BN) * MM<T>::LDK * sizeof(T) + BN * 2 * 4 + (size_t)3 * kpad * 4;
+  const size_t lds = (size_t)(BM + BN) * MM<T>::LDK * sizeof(T) + BN * 2 * 8 + (size_t)3 * kpad * 4;
   a.mtiles = cdiv(a.M, BM);
   const int ny = cdiv(a.Nout, BN);
   int gx = a.mtiles < 2048 / ny ? a.mtiles : 2048 / ny;

@@ -332,61 +332,71 @@ __global__ __launch_bounds__(256 * G) void pw_wgrad_tr_kernel(const WgtArgs a) {
       }
 }
 
-// dw[n][k] += sum over splits of the partial tiles.  grid.y chunks of the split range run in parallel (a small dW
-// with hundreds of splits would otherwise be summed by a handful of threads); each chunk adds its sum atomically
-// (<= 16 adds per element).
+// dw[n][k] += sum over the S pixel splits of the partial tiles, in a FIXED order (bit-reproducible weight gradients): the
+// split range is divided over SP thread groups of one workgroup (not over workgroups adding atomically, as rounds 1-3a did:
+// up to 16 fp32 atomics per element in arrival order), each thread sums its partials i = sp, sp + SP, ... and the SP sums
+// meet in LDS in index order.  Every element has one owner, so the final add into dW is a plain read-modify-write.
+template <int SP>
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw, int N, int K,
-                                                           int swap, int PB, int QB, int qtiles, int tiles, int S) {
-  // threads run along the Q axis of the partial tiles (the contiguous one), whatever the orientation of dW: the S
-  // partial reads per element are coalesced; the transposed case pays with scattered atomics into the small dW
-  const int P = swap ? K : N, Q = swap ? N : K, Qpad = qtiles * QB;
-  const int e = blockIdx.x * 256 + threadIdx.x;
+                                                           int PB, int QB, int qtiles, int tiles, int S) {
+  // straight orientation (P = N, Q = K): threads run along q = k, the contiguous axis of both the partial tiles and dW
+  constexpr int EL = 256 / SP;
+  __shared__ float red[SP][EL];
+  const int Qpad = qtiles * QB;
+  const int el = threadIdx.x % EL, sp = threadIdx.x / EL;
+  const int e = blockIdx.x * EL + el;
   const int p = e / Qpad, q = e % Qpad;
-  if (p >= P || q >= Q) return;
-  const int tile = (p / PB) * qtiles + q / QB;
-  const float* src = ws + (size_t)tile * (PB * QB) + (size_t)(p % PB) * QB + q % QB;
-  const size_t stride = (size_t)tiles * PB * QB;
-  const int per = (S + gridDim.y - 1) / gridDim.y;
-  const int i0 = blockIdx.y * per, i1 = min(S, i0 + per);
+  const bool live = p < N && q < K;
   float s = 0.f;
+  if (live) {
+    const float* src = ws + (size_t)((p / PB) * qtiles + q / QB) * (PB * QB) + (size_t)(p % PB) * QB + q % QB;
+    const size_t stride = (size_t)tiles * PB * QB;
 #pragma unroll 8
-  for (int i = i0; i < i1; ++i) s += src[(size_t)i * stride];
-  const int n = swap ? q : p, k = swap ? p : q;
-  if (i0 < i1) unsafeAtomicAdd(dw + (size_t)n * K + k, s);
+    for (int i = sp; i < S; i += SP) s += src[(size_t)i * stride];
+  }
+  if (SP > 1) {
+    red[sp][el] = s;
+    __syncthreads();
+    if (sp == 0) {
+#pragma unroll
+      for (int j = 1; j < SP; ++j) s += red[j][el];
+    }
+  }
+  if (sp == 0 && live) dw[(size_t)p * K + q] += s;
 }
 
 // the transposed orientation (dW [N][K] with the partial tiles' contiguous axis q = n): a 32 x 32 patch per workgroup goes
 // through LDS, so the partial reads stay coalesced along q AND the adds into dW run along k -- lanes along q added at a
 // stride of K floats (64 cache lines per wave instruction; 1.2 M such atomics for the 320 x 960 layer of the 7x7 stage:
-// 47 us, now a few).
-__global__ __launch_bounds__(256) void wgrad_reduce_tr_kernel(const float* __restrict__ ws, float* __restrict__ dw, int N, int K,
-                                                              int PB, int QB, int qtiles, int tiles, int S) {
-  __shared__ float tile[32][33];
+// 47 us, now a few).  1024 threads = 32 (q) x 32 / SP (p rows, SP of them per thread) x SP split groups.
+template <int SP>
+__global__ __launch_bounds__(1024) void wgrad_reduce_tr_kernel(const float* __restrict__ ws, float* __restrict__ dw, int N, int K,
+                                                               int PB, int QB, int qtiles, int tiles, int S) {
+  __shared__ float part[SP][32][33];
+  constexpr int TY = 32 / SP;
   const int Qpad = qtiles * QB, nq = (Qpad + 31) / 32;
   const int p0 = (blockIdx.x / nq) * 32, q0 = (blockIdx.x % nq) * 32;
-  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  const int tx = threadIdx.x & 31, rest = threadIdx.x >> 5, sz = rest % SP, ty = rest / SP;
   const size_t stride = (size_t)tiles * PB * QB;
-  const int per = (S + gridDim.y - 1) / gridDim.y;
-  const int i0 = blockIdx.y * per, i1 = min(S, i0 + per);
-  if (i0 >= i1) return;
   const int q = q0 + tx;
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const int p = p0 + ty + 8 * j;
+  for (int j = 0; j < SP; ++j) {
+    const int pl = ty + TY * j, p = p0 + pl;
     float s = 0.f;
     if (p < K && q < N) {                  // (swap: P = K, Q = N)
       const float* src = ws + (size_t)((p / PB) * qtiles + q / QB) * (PB * QB) + (size_t)(p % PB) * QB + q % QB;
 #pragma unroll 8
-      for (int i = i0; i < i1; ++i) s += src[(size_t)i * stride];
+      for (int i = sz; i < S; i += SP) s += src[(size_t)i * stride];
     }
-    tile[ty + 8 * j][tx] = s;
+    part[sz][pl][tx] = s;
   }
   __syncthreads();
-  const int k = p0 + tx;
+  const int k = p0 + tx, n = q0 + rest;     // one element per thread, lanes along k
+  if (k < K && n < N) {
+    float s = part[0][tx][rest];
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const int n = q0 + ty + 8 * j;
-    if (k < K && n < N) unsafeAtomicAdd(dw + (size_t)n * K + k, tile[tx][ty + 8 * j]);
+    for (int j = 1; j < SP; ++j) s += part[j][tx][rest];
+    dw[(size_t)n * K + k] += s;
   }
 }
 
@@ -424,13 +434,20 @@ int launch_d(WgtArgs& a, hipStream_t st) {
   a.nsplit = S;
   hipLaunchKernelGGL((pw_wgrad_tr_kernel<NTPW, NTQ, SWAP, G, D, GEN, YF, STEM>), dim3(tiles * S), dim3(256 * G), lds, st, a);
   if (use_ws) {
-    const int gy = S >= 64 ? 16 : (S >= 8 ? 4 : 1);
-    if (SWAP)
-      hipLaunchKernelGGL(wgrad_reduce_tr_kernel, dim3(cdiv(a.K, 32) * cdiv(a.qtiles * QB, 32), gy), dim3(256), 0, st, a.ws, a.dw, a.N, a.K,
-                         PB, QB, a.qtiles, tiles, S);
-    else
-      hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(cdiv(a.N * a.qtiles * QB, 256), gy), dim3(256), 0, st, a.ws, a.dw, a.N, a.K, 0, PB, QB,
-                         a.qtiles, tiles, S);
+    // split groups inside the workgroup: enough parallelism for a small dW with hundreds of splits
+#define T3D_WGR(SPV)                                                                                                              \
+  do {                                                                                                                            \
+    if (SWAP)                                                                                                                     \
+      hipLaunchKernelGGL(wgrad_reduce_tr_kernel<(SPV > 8 ? 8 : SPV)>, dim3(cdiv(a.K, 32) * cdiv(a.qtiles * QB, 32)), dim3(1024), 0, st, \
+                         a.ws, a.dw, a.N, a.K, PB, QB, a.qtiles, tiles, S);                                                       \
+    else                                                                                                                          \
+      hipLaunchKernelGGL(wgrad_reduce_kernel<SPV>, dim3(cdiv(a.N * a.qtiles * QB, 256 / SPV)), dim3(256), 0, st, a.ws, a.dw, a.N, \
+                         a.K, PB, QB, a.qtiles, tiles, S);                                                                        \
+  } while (0)
+    if (S >= 64) T3D_WGR(16);
+    else if (S >= 8) T3D_WGR(4);
+    else T3D_WGR(1);
+#undef T3D_WGR
   }
   T3D_CHECK_LAUNCH();
   return T3D_OK;

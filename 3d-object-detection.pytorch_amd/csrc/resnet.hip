@@ -398,14 +398,16 @@ __global__ __launch_bounds__(256) void im2col_nchw_v_kernel(const float* __restr
   }
 }
 
-// block-level tail of the backward forms: per-lane register sums -> LDS -> one double atomic per channel and workgroup
+// block-level tail of the backward forms: per-lane fp32 register sums -> fp64 LDS accumulators (exact adds in any order: the
+// BatchNorm-backward coefficients, and with them every gradient downstream, are bit-reproducible) -> one fp64 atomic per
+// channel and workgroup
 template <int NS>
-__device__ __forceinline__ void flush_sums(float* lst, int C, int c, bool active, const float (*s)[8]) {
+__device__ __forceinline__ void flush_sums(double* lst, int C, int c, bool active, const float (*s)[8]) {
   if (active) {
 #pragma unroll
     for (int j = 0; j < NS; ++j)
 #pragma unroll
-      for (int i = 0; i < 8; ++i) atomicAdd(lst + j * C + c + i, s[j][i]);
+      for (int i = 0; i < 8; ++i) atomicAdd(lst + j * C + c + i, (double)s[j][i]);
   }
   __syncthreads();
 }
@@ -416,8 +418,8 @@ __global__ __launch_bounds__(256) void col2im_bwd_v_kernel(const T* __restrict__
                                                            T* __restrict__ dx, double* __restrict__ stats, int B, int H, int W, int C,
                                                            int k, int pad, int Ho, int Wo, int Kp, int nrep, long long rstride,
                                                            int px_per_wave) {
-  extern __shared__ float lst[];      // [2][C] sums
-  for (int i = threadIdx.x; i < 2 * C; i += 256) lst[i] = 0.f;
+  extern __shared__ double lacc[];      // [2][C] sums
+  for (int i = threadIdx.x; i < 2 * C; i += 256) lacc[i] = 0.0;
   __syncthreads();
   const int lane = threadIdx.x & 63, C8 = C >> 3;                    // host guarantees C8 <= 64
   const int sub = lane / C8, c = (lane - sub * C8) << 3, PPI = 64 / C8;
@@ -467,9 +469,9 @@ __global__ __launch_bounds__(256) void col2im_bwd_v_kernel(const T* __restrict__
     }
   }
   if (stats) {
-    flush_sums<2>(lst, C, c, active, s);
+    flush_sums<2>(lacc, C, c, active, s);
     for (int i = threadIdx.x; i < 2 * C; i += 256)
-      if (lst[i] != 0.f) atomicAdd(stats + (size_t)(blockIdx.x % nrep) * rstride + i, (double)lst[i]);
+      if (lacc[i] != 0.f) atomicAdd(stats + (size_t)(blockIdx.x % nrep) * rstride + i, (double)lacc[i]);
   }
 }
 
@@ -524,8 +526,8 @@ __global__ __launch_bounds__(256) void maxpool_bwd_v_kernel(const T* __restrict_
                                                             const float* __restrict__ shift, int act, T* __restrict__ dy,
                                                             double* __restrict__ stats, int B, int H, int W, int C, int Ho, int Wo,
                                                             int nrep, long long rstride, int px_per_wave) {
-  extern __shared__ float lst[];
-  for (int i = threadIdx.x; i < 2 * C; i += 256) lst[i] = 0.f;
+  extern __shared__ double lacc[];
+  for (int i = threadIdx.x; i < 2 * C; i += 256) lacc[i] = 0.0;
   __syncthreads();
   const int lane = threadIdx.x & 63, C8 = C >> 3;
   const int sub = lane / C8, c = (lane - sub * C8) << 3, PPI = 64 / C8;
@@ -576,9 +578,9 @@ __global__ __launch_bounds__(256) void maxpool_bwd_v_kernel(const T* __restrict_
     }
   }
   if (stats) {
-    flush_sums<2>(lst, C, c, active, s);
+    flush_sums<2>(lacc, C, c, active, s);
     for (int i = threadIdx.x; i < 2 * C; i += 256)
-      if (lst[i] != 0.f) atomicAdd(stats + (size_t)(blockIdx.x % nrep) * rstride + i, (double)lst[i]);
+      if (lacc[i] != 0.f) atomicAdd(stats + (size_t)(blockIdx.x % nrep) * rstride + i, (double)lacc[i]);
   }
 }
 
@@ -613,8 +615,8 @@ __global__ __launch_bounds__(256) void res_relu_bwd_v_kernel(const T* __restrict
                                                              const T* __restrict__ y3, const T* __restrict__ yd, T* __restrict__ g,
                                                              double* __restrict__ stats3, double* __restrict__ statsd,
                                                              long long total8, int C, int nrep, long long rstride) {
-  extern __shared__ float lst[];      // [3][C]
-  for (int i = threadIdx.x; i < 3 * C; i += 256) lst[i] = 0.f;
+  extern __shared__ double lacc[];      // [3][C]
+  for (int i = threadIdx.x; i < 3 * C; i += 256) lacc[i] = 0.0;
   __syncthreads();
   const int C8 = C >> 3;
   const long long nthr = ((long long)gridDim.x * 256 / C8) * C8;
@@ -641,14 +643,14 @@ __global__ __launch_bounds__(256) void res_relu_bwd_v_kernel(const T* __restrict
       Vec8<T>::store(g + e * 8, d);
     }
   }
-  flush_sums<PROJ ? 3 : 2>(lst, C, c, active, s);
+  flush_sums<PROJ ? 3 : 2>(lacc, C, c, active, s);
   const size_t rep = (size_t)(blockIdx.x % nrep) * rstride;
   for (int i = threadIdx.x; i < 2 * C; i += 256)
-    if (lst[i] != 0.f) atomicAdd(stats3 + rep + i, (double)lst[i]);
+    if (lacc[i] != 0.f) atomicAdd(stats3 + rep + i, (double)lacc[i]);
   if (PROJ) {
     for (int i = threadIdx.x; i < C; i += 256) {
-      if (lst[i] != 0.f) atomicAdd(statsd + rep + i, (double)lst[i]);
-      if (lst[2 * C + i] != 0.f) atomicAdd(statsd + rep + C + i, (double)lst[2 * C + i]);
+      if (lacc[i] != 0.f) atomicAdd(statsd + rep + i, (double)lacc[i]);
+      if (lacc[2 * C + i] != 0.f) atomicAdd(statsd + rep + C + i, (double)lacc[2 * C + i]);
     }
   }
 }
@@ -773,7 +775,7 @@ extern "C" int t3d_col2im_bwd(int dtype, const void* dcol, const void* x_raw, co
   const float* sc = pro ? pro->scale : nullptr;
   const float* sh = pro ? pro->shift : nullptr;
   const int act = pro ? pro->act : T3D_ACT_NONE;
-  const size_t lds = (size_t)2 * C * sizeof(float);
+  const size_t lds = (size_t)2 * C * sizeof(double);    // (the scalar forms use the first half as floats)
   if (C % 8 == 0 && C / 8 <= 64 && Kp % 8 == 0 && (stride == 1 || stride == 2) && fits_u32((long long)B * H * W)) {
     int ppw;
     const int g = runs_for((long long)B * H * W, 4096, &ppw), nrep = g_t3d_reduce.nrep;
@@ -848,7 +850,7 @@ extern "C" int t3d_maxpool_bwd(int dtype, const void* dout, const unsigned char*
   const float* sc = pro ? pro->scale : nullptr;
   const float* sh = pro ? pro->shift : nullptr;
   const int act = pro ? pro->act : T3D_ACT_NONE;
-  const size_t lds = (size_t)2 * C * sizeof(float);
+  const size_t lds = (size_t)2 * C * sizeof(double);    // (the scalar form uses the first half as floats)
   if (C % 8 == 0 && C / 8 <= 64 && fits_u32((long long)B * H * W)) {
     int ppw;
     const int g = runs_for((long long)B * H * W, 4096, &ppw), nrep = g_t3d_reduce.nrep;
@@ -904,7 +906,7 @@ extern "C" int t3d_res_relu_bwd(int dtype, const void* dz, const void* z, const 
     // at least 8 vectors per thread, at most 1024 workgroups: the double atomics at the end are 2C..3C per workgroup
     int gv = (int)std::min<long long>(1024, (total / 8 + 256 * 8 - 1) / (256 * 8));
     while ((long long)gv * 256 < C / 8) ++gv;
-    const size_t ldsv = (size_t)3 * C * sizeof(float);
+    const size_t ldsv = (size_t)3 * C * sizeof(double);
     const int nrep = g_t3d_reduce.nrep;
     const long long rs = g_t3d_reduce.stats_stride;
 #define T3D_RRB(TT, PP) hipLaunchKernelGGL((res_relu_bwd_v_kernel<TT, PP>), dim3(gv), dim3(256), ldsv, st, (const TT*)dz, (const TT*)z, (const TT*)y3, (const TT*)yd, (TT*)g, stats3, statsd, total / 8, C, nrep, rs)

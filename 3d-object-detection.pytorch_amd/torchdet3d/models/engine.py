@@ -31,6 +31,7 @@ from .arch import Arch
 
 BN_EPS, BN_MOM = 1e-5, 0.1      # PyTorch defaults the reference relies on
 NREP = 16                       # reduction replicas (include/t3d.h: t3d_set_reduction_replicas)
+DW_SLOTS = int(os.environ.get('T3D_DW_SLOTS', '512'))   # depthwise weight-gradient slots per layer (>= the workgroups of a t3d_dwconv_bwd launch)
 WORKSPACE_BYTES = 64 << 20      # partial weight-gradient tiles (include/t3d.h: t3d_set_workspace)
 MAIN_WORKSPACE_BYTES = 16 << 20
 # y-free expand-layer backward (csrc/pwconv_yfree.hip): minimum M*N elements of the expanded tensor; 0 disables
@@ -882,6 +883,7 @@ class Net:
             return self._backward(dkp, dlogits)
         finally:
             N.call('t3d_set_reduction_replicas', 1, 0)
+            N.call('t3d_set_dw_slots', 0, None)
             self._cur_nrep = None
             N.call('t3d_set_workspace', None, 0)
             self._main_scratch(False)
@@ -897,7 +899,9 @@ class Net:
         # one launch clears every accumulate-into buffer of the backward: gradients, depthwise replicas, stem patch-row dW
         dw32 = self._buf('dstem32', (a.stem_c, 32), torch.float32)
         if getattr(self, '_zero_desc', None) is None:
-            rows = [[t.data_ptr(), t.numel() * t.element_size()] for t in (self.gflat, self._dwarena, dw32) if t.numel()]
+            rows = [[t.data_ptr(), t.numel() * t.element_size()] for t in (self.gflat, dw32) if t.numel()]
+            # (of a depthwise layer's slots only the first NREP: what a launch without slot support adds into)
+            rows += [[v.data_ptr(), NREP * self.p[k].numel() * 4] for k, v in self._dwviews.items()]
             assert all(r[1] % 16 == 0 for r in rows)
             self._zero_desc = torch.tensor(rows, dtype=torch.int64, device=self.device)
         N.call('t3d_zero_batched', N.ptr(self._zero_desc), self._zero_desc.shape[0], st)
@@ -1002,29 +1006,38 @@ class Net:
 
     # ---- depthwise weight-gradient replicas: one zero fill per step, one batched sum per gradient bucket
     def _dw_arena_init(self):
+        """One SLOT per workgroup for every depthwise weight gradient (include/t3d.h: t3d_set_dw_slots): the kernels store
+        their partials, `_flush_dw` adds a layer's used slots in index order -- no atomics, bit-reproducible.  Only the first
+        NREP slots of a layer are zeroed per step (what a kernel without slot support adds into)."""
         names = [k for k, (sh, kind) in self.shapes.items() if kind == 'param' and len(sh) == 4 and sh[1] == 1 and sh[2] > 1]
-        tot = sum(NREP * self.p[k].numel() for k in names)
-        self._dwarena = torch.empty(tot, device=self.device, dtype=torch.float32)
-        self._dwviews, off = {}, 0
+        tot = sum(DW_SLOTS * self.p[k].numel() for k in names)
+        self._dwarena = torch.zeros(tot, device=self.device, dtype=torch.float32)
+        self._dwused = torch.zeros(max(len(names), 1), device=self.device, dtype=torch.int32)
+        self._dwviews, self._dwidx, off = {}, {}, 0
         for k in names:
             n = self.p[k].numel()
-            self._dwviews[k] = self._dwarena[off:off + NREP * n]
-            off += NREP * n
+            self._dwviews[k] = self._dwarena[off:off + DW_SLOTS * n]
+            off += DW_SLOTS * n
         # descriptor rows in BACKWARD order (the order the layers finish): a flush is a contiguous row range
         self._dworder = list(reversed(names))
-        rows = [[self._dwviews[k].data_ptr(), self.g[k].data_ptr(), self.p[k].numel()] for k in self._dworder]
-        self._dwdesc = torch.tensor(rows, dtype=torch.int64, device=self.device)
+        rows = []
+        for i, k in enumerate(self._dworder):
+            self._dwidx[k] = i
+            rows.append([self._dwviews[k].data_ptr(), self.g[k].data_ptr(), self.p[k].numel(), self._dwused[i:i + 1].data_ptr()])
+        self._dwdesc = torch.tensor(rows, dtype=torch.int64, device=self.device) if rows else None
 
     def _dw_replicas(self, name):
         assert self._dworder[self._dwflushed + self._dwpending] == name
         self._dwpending += 1
+        i = self._dwidx[name]
+        N.call('t3d_set_dw_slots', DW_SLOTS, N.ptr(self._dwused[i:i + 1]))      # for the t3d_dwconv_bwd launch that follows
         return self._dwviews[name]
 
     def _flush_dw(self):
-        """Replica sums -> gradient buffer for every depthwise layer finished since the last flush (one launch)."""
+        """Slot sums -> gradient buffer for every depthwise layer finished since the last flush (one launch)."""
         if not self._dwpending:
             return
-        N.call('t3d_sum_replicas_batched', self._dwdesc[self._dwflushed:].data_ptr(), self._dwpending, NREP, N.stream())
+        N.call('t3d_sum_slots_batched', self._dwdesc[self._dwflushed:].data_ptr(), self._dwpending, N.stream())
         self._dwflushed += self._dwpending
         self._dwpending = 0
 

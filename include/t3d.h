@@ -415,6 +415,19 @@ int t3d_subsample(int dtype, const void* x, void* out, int B, int H, int W, int 
  * Process-wide setting (default 1 = plain behaviour); kernels that do not implement replicas use replica 0. */
 int t3d_set_reduction_replicas(int nrep, long long stats_stride);
 
+/* Depthwise weight gradient without atomics (bit-reproducible).  With capacity > 0 the NEXT t3d_dwconv_bwd launches treat
+ * `dw` as [capacity][C][k*k] fp32 SLOTS: every workgroup of a streaming kernel stores (does not add) its partial weight
+ * gradient into its own slot and *used_out (device memory) receives the number of slots the launch filled; the caller adds
+ * slots 0 .. *used_out-1 in index order (t3d_sum_slots_batched), which no longer depends on the arrival order of ~500
+ * workgroups (torch's autograd makes no such promise for models/mobilenetv3.py:151 either; this is about run-to-run
+ * reproducibility of the training step).  A launch that needs more workgroups than `capacity`, and the LDS-tiled fallback
+ * kernel, add atomically into the first nrep slots (t3d_set_reduction_replicas) and report *used_out = nrep: those slots
+ * must be zero before the launch.  capacity == 0 (default): the replica behaviour above.  Process-wide setting. */
+int t3d_set_dw_slots(int capacity, int* used_out);
+/* desc = n rows of int64 {src [slots][count] fp32, dst [count] fp32, count, used (device int*)}:
+ * dst = src[0] + src[1] + ... + src[*used - 1], in that order (overwrites dst). */
+int t3d_sum_slots_batched(const long long* desc, int n, void* stream);
+
 /* BatchNorm finalize derived by the CONSUMER.  t3d_bn_finalize / t3d_bn_bwd_finalize are 5-us launches that sit
  * between every convolution and its consumer (~100 per training step, all on the critical stream: 0.64 ms of an
  * 8.4-ms MobileNetV2 step with the launch gaps).  A fold request names a coefficient array (`key`: the `scale` pointer

@@ -42,6 +42,8 @@ for r in range(reps):
     nz = sum(1 for v, k in rows if v > 0)
     tot = sum((g[k] - first[k]).norm().item() ** 2 for k in g) ** .5 / sum(first[k].norm().item() ** 2 for k in g) ** .5
     print(r, f'total {tot:.2e} differing {nz}/{len(rows)} worst', [(f'{v:.2e}', k) for v, k in rows[-3:]], flush=True)
+    if os.environ.get('DBG_NAMES'):
+        print('   differing:', sorted(k for k in g if not torch.equal(g[k], first[k])))
     if os.environ.get('DBG_LIST') and tot > 1e-3:
         for k in g:
             d = (g[k] - first[k]).norm().item() / max(first[k].norm().item(), 1e-30)
