@@ -117,6 +117,8 @@ __global__ __launch_bounds__(256) void head_bwd_data_kernel(const HeadArgs a) {
 
 // weight gradient: grid (10, ceil(F/256), S); blockIdx.x < 9: regressor of that class, == 9: class head; blockIdx.z
 // takes a contiguous slice of the batch and ADDS its part (the caller's gradient buffer is zeroed once per step).
+// (One workgroup per (class, 256 features) walks the whole batch: the 8-way batch split of rounds 1-3a added its partial sums
+// with fp32 atomics in arrival order -- the last place where two runs of one training step could differ.)
 // The samples a block needs are first compacted (in ascending order: the sum stays deterministic) into LDS, then
 // consumed eight at a time so that eight feature loads are in flight per thread (the serial one-load-per-sample loop
 // took ~1 us per sample).
@@ -306,7 +308,7 @@ extern "C" int t3d_head_bwd(const float* f, const t3d_prologue* pro, const int64
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   hipLaunchKernelGGL(head_bwd_data_kernel, dim3(B), dim3(256), 0, st, a);
   if (dwreg)        // NULL: data gradient only, the weight gradients follow through t3d_head_bwd_weights
-    hipLaunchKernelGGL(head_bwd_weight_kernel, dim3(10, cdiv(F, 256), B >= 64 ? 8 : 1), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(head_bwd_weight_kernel, dim3(10, cdiv(F, 256), 1), dim3(256), 0, st, a);
   T3D_CHECK_LAUNCH();
   return T3D_OK;
 }
@@ -323,7 +325,7 @@ extern "C" int t3d_head_bwd_weights(const float* f, const t3d_prologue* pro, con
   a.f = f; a.cats = cats; a.mask = mask; a.dlogits = dlogits; a.dpre = const_cast<float*>(dpre);
   a.dwreg = dwreg; a.dbreg = dbreg; a.dwcls = dwcls; a.dbcls = dbcls; a.B = B; a.F = F; a.ncls = ncls;
   fill(a, pro);
-  hipLaunchKernelGGL(head_bwd_weight_kernel, dim3(10, cdiv(F, 256), B >= 64 ? 8 : 1), dim3(256), 0,
+  hipLaunchKernelGGL(head_bwd_weight_kernel, dim3(10, cdiv(F, 256), 1), dim3(256), 0,
                      reinterpret_cast<hipStream_t>(stream), a);
   T3D_CHECK_LAUNCH();
   return T3D_OK;

@@ -6,7 +6,7 @@ from torchdet3d.models import engine as E
 from torchdet3d import _native as N
 from tests.test_gpu_engine import _loss_cfg
 name = sys.argv[1] if len(sys.argv) > 1 else 'mobilenetv2'
-B, HW, nc, steps = 32, 128, 9, int(sys.argv[2]) if len(sys.argv) > 2 else 4
+B, HW, nc, steps = int(os.environ.get("RB", 32)), int(os.environ.get("RHW", 128)), 9, int(sys.argv[2]) if len(sys.argv) > 2 else 4
 gen = torch.Generator().manual_seed(0)
 imgs, gt_kp = torch.randn(B, 3, HW, HW, generator=gen).cuda(), torch.rand(B, 9, 2, generator=gen).cuda()
 cats = torch.randint(0, nc, (B,), generator=gen).cuda()
