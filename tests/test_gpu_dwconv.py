@@ -160,3 +160,60 @@ def test_dwconv_bwd(B, C, H, W, k, s, dt, mode):
         np.testing.assert_allclose(st[0].numpy(), got.double().sum(dim=(0, 2, 3)).numpy(), rtol=1e-5, atol=1e-4 * n ** .5)
         np.testing.assert_allclose(st[1].numpy(), (got.double() * xq.double()).sum(dim=(0, 2, 3)).numpy(), rtol=1e-5,
                                    atol=1e-4 * n ** .5)
+
+
+@pytest.mark.parametrize('B,C,H,W,k,s', [(8, 32, 56, 56, 3, 1), (4, 144, 28, 28, 3, 1), (4, 192, 28, 28, 3, 2), (2, 960, 7, 7, 3, 1),
+                                         (4, 120, 28, 28, 5, 1), (4, 240, 14, 14, 5, 2), (2, 48, 14, 14, -5, 1)])
+def test_dwconv_bwd_weight_gradient_slots_are_exactly_reproducible(B, C, H, W, k, s, monkeypatch):
+    """t3d_set_dw_slots (include/t3d.h): every workgroup stores its partial depthwise weight gradient into its own slot and
+    t3d_sum_slots_batched adds the used slots in index order -- same result as the atomic replica form to fp32 rounding,
+    bit-identical from launch to launch (the atomic form is not), `used` = the slots the launch filled (or the replica count
+    for the kernels without slot support: k = -5 runs the 5x5 case through the LDS-tiled fallback, T3D_DW_TILED=1)."""
+    from torchdet3d import _native as N
+    tiled = k < 0
+    k = abs(k)
+    if tiled:
+        monkeypatch.setenv('T3D_DW_TILED', '1')
+    g = torch.Generator().manual_seed(C + k)
+    dtype = torch.bfloat16
+    Ho, Wo = (H + 2 * (k // 2) - k) // s + 1, (W + 2 * (k // 2) - k) // s + 1
+    x, res = _nhwc(torch.randn(B, C, H, W, generator=g), dtype), None
+    dz, y = _nhwc(torch.randn(B, C, Ho, Wo, generator=g), dtype), _nhwc(torch.randn(B, C, Ho, Wo, generator=g), dtype)
+    w = (torch.randn(C, k * k, generator=g) * 0.3).cuda()
+    keep = [t.cuda() for t in (torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g) * 0.2, torch.randn(C, generator=g) * 0.1,
+                               torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g) * 0.3)]
+    bb, pro = N.bnbwd(keep[0], keep[1], keep[2], False), N.prologue(keep[3], keep[4], None, 'relu6', False)
+    dx = torch.empty(B, H, W, C, device='cuda', dtype=dtype)
+
+    def launch(dw, stats):
+        N.call('t3d_dwconv_bwd', N.BF16, N.ptr(dz), N.ptr(y), bb, N.ptr(w), N.ptr(x), pro, None, N.ptr(dx), N.ptr(stats), N.ptr(dw),
+               B, H, W, C, k, s, N.stream())
+    ref, st_ref = torch.zeros(C, k * k, device='cuda'), torch.zeros(2 * C, device='cuda', dtype=torch.float64)
+    launch(ref, st_ref)                                           # plain form: one replica, atomics
+    SLOTS = 512
+    results = []
+    try:
+        for rep in range(3):
+            slots = torch.full((SLOTS, C, k * k), float('nan'), device='cuda')
+            slots[:16].zero_()                                    # what a launch without slot support adds into
+            used = torch.zeros(1, dtype=torch.int32, device='cuda')
+            st = torch.zeros(2 * C, device='cuda', dtype=torch.float64)
+            N.call('t3d_set_reduction_replicas', 16, 2 * C)
+            N.call('t3d_set_dw_slots', SLOTS, N.ptr(used))
+            st16 = torch.zeros(16, 2 * C, device='cuda', dtype=torch.float64)
+            launch(slots, st16)
+            out = torch.empty(C, k * k, device='cuda')
+            desc = torch.tensor([[slots.data_ptr(), out.data_ptr(), C * k * k, used.data_ptr()]], dtype=torch.int64, device='cuda')
+            N.call('t3d_sum_slots_batched', N.ptr(desc), 1, N.stream())
+            torch.cuda.synchronize()
+            results.append((out.clone(), int(used.item()), st16.sum(0)))
+    finally:
+        N.call('t3d_set_dw_slots', 0, None)
+        N.call('t3d_set_reduction_replicas', 1, 0)
+    out, nused, st = results[0]
+    assert 1 <= nused <= SLOTS and (not tiled or nused == 16)
+    np.testing.assert_allclose(out.cpu().numpy(), ref.cpu().numpy(), rtol=2e-4, atol=2e-4 * ref.abs().max().item())
+    np.testing.assert_allclose(st.cpu().numpy(), st_ref.cpu().numpy(), rtol=1e-9, atol=1e-9)
+    if not tiled:
+        for o, n, _ in results[1:]:
+            assert n == nused and torch.equal(o, out)
