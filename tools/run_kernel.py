@@ -26,7 +26,7 @@ if kind in ('dwfwd', 'dwbwd'):
     stats = torch.zeros(nrep, 2 * C, device=dev, dtype=torch.float64)
     N.call('t3d_set_reduction_replicas', nrep, 2 * C)
     if kind == 'dwfwd':
-        fn = lambda: N.call('t3d_dwconv_fwd', N.dtype_code(x), N.ptr(x), pro, N.ptr(w), N.ptr(y), N.ptr(stats), None,
+        fn = lambda: N.call('t3d_dwconv_fwd', N.dtype_code(x), N.ptr(x), pro, N.ptr(w), N.ptr(y), None if '--nostats' in sys.argv else N.ptr(stats), None,
                             B, H, W, C, k, s, N.stream())
         nbytes = (x.numel() + y.numel()) * x.element_size()
     else:
