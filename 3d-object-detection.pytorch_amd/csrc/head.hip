@@ -125,7 +125,8 @@ __global__ __launch_bounds__(256) void head_bwd_data_kernel(const HeadArgs a) {
 __global__ __launch_bounds__(256) void head_bwd_weight_kernel(const HeadArgs a) {
   constexpr int CHUNK = 512, U = 8;
   __shared__ int lst[CHUNK];
-  __shared__ int nsel;
+  __shared__ int nsel, wcnt[4];
+  __shared__ float ldp[CHUNK * NKP];      // staged gradient rows (class blocks) / logit gradients (classifier block)
   const int cls = blockIdx.x, j = blockIdx.y * 256 + threadIdx.x;
   const bool jon = j < a.F;
   if (cls < 9) {
@@ -136,18 +137,37 @@ __global__ __launch_bounds__(256) void head_bwd_weight_kernel(const HeadArgs a) 
     const int per = (a.B + gridDim.z - 1) / gridDim.z, zb0 = blockIdx.z * per, zb1 = min(a.B, zb0 + per);
     for (int b0 = zb0; b0 < zb1; b0 += CHUNK) {
       __syncthreads();
-      if (threadIdx.x == 0) {
-        int n = 0;
+      // compaction in ascending sample order by the whole workgroup (ballot + prefix counts; one thread walking the chunk
+      // was 256 dependent-latency loads: 100 us of this launch)
+      {
         const int b1 = min(zb1, b0 + CHUNK);
-        for (int b = b0; b < b1; ++b) {
-          int c = (int)a.cats[b];
-          c = c < 0 ? 0 : (c > 8 ? 8 : c);
-          if (c == cls) lst[n++] = b;
+        const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+        int n = 0;
+        for (int s0 = b0; s0 < b1; s0 += 256) {
+          const int b = s0 + threadIdx.x;
+          bool hit = false;
+          if (b < b1) {
+            int c = (int)a.cats[b];
+            c = c < 0 ? 0 : (c > 8 ? 8 : c);
+            hit = c == cls;
+          }
+          const unsigned long long m = __ballot(hit);
+          if (lane == 0) wcnt[wv] = __popcll(m);
+          __syncthreads();
+          int off = n;
+          for (int w2 = 0; w2 < wv; ++w2) off += wcnt[w2];
+          if (hit) lst[off + __popcll(m & ((1ull << lane) - 1ull))] = b;
+          n += wcnt[0] + wcnt[1] + wcnt[2] + wcnt[3];
+          __syncthreads();
         }
-        nsel = n;
+        if (threadIdx.x == 0) nsel = n;
       }
       __syncthreads();
       const int n = nsel;
+      // gradient rows of the selected samples -> LDS (coalesced), read back as broadcasts (as global loads they were 18
+      // same-address vector loads per sample and thread: most of this launch's 180 us)
+      for (int i = threadIdx.x; i < n * NKP; i += 256) ldp[i] = a.dpre[(size_t)lst[i / NKP] * NKP + i % NKP];
+      __syncthreads();
       for (int i0 = 0; i0 < n; i0 += U) {
         float x[U];
         int bb[U];
@@ -168,8 +188,8 @@ __global__ __launch_bounds__(256) void head_bwd_weight_kernel(const HeadArgs a) 
         for (int u = 0; u < U; ++u) {
           if (i0 + u < n) {       // block-uniform
 #pragma unroll
-            for (int r = 0; r < NKP; ++r) acc[r] = fmaf(a.dpre[(size_t)bb[u] * NKP + r], x[u], acc[r]);
-            if (bias_thread) bacc += a.dpre[(size_t)bb[u] * NKP + threadIdx.x];
+            for (int r = 0; r < NKP; ++r) acc[r] = fmaf(ldp[(i0 + u) * NKP + r], x[u], acc[r]);
+            if (bias_thread) bacc += ldp[(i0 + u) * NKP + threadIdx.x];
           }
         }
       }
@@ -185,31 +205,47 @@ __global__ __launch_bounds__(256) void head_bwd_weight_kernel(const HeadArgs a) 
 #pragma unroll
       for (int q = 0; q < 16; ++q) acc[q] = 0.f;
       const int per = (a.B + gridDim.z - 1) / gridDim.z, zb0 = blockIdx.z * per, zb1 = min(a.B, zb0 + per);
-      for (int b0 = zb0; b0 < zb1; b0 += U) {
-        float x[U], mk[U];
-        const int jc = min(j, a.F - 1);
-#pragma unroll
-        for (int u = 0; u < U; ++u) x[u] = a.f[(size_t)min(b0 + u, a.B - 1) * a.F + jc];
-        if (a.mask) {
-#pragma unroll
-          for (int u = 0; u < U; ++u) mk[u] = a.mask[(size_t)min(b0 + u, a.B - 1) * a.F + jc];
-        } else {
-#pragma unroll
-          for (int u = 0; u < U; ++u) mk[u] = 1.f;
+      constexpr int SB = 128;                  // samples whose logit gradients are staged in LDS at a time ([SB][16])
+      for (int s0 = zb0; s0 < zb1; s0 += SB) {
+        const int s1 = min(zb1, s0 + SB);
+        __syncthreads();
+        for (int i = threadIdx.x; i < (s1 - s0) * 16; i += 256) {
+          const int b = s0 + (i >> 4), q = q0 + (i & 15);
+          ldp[i] = q < a.ncls ? a.dlogits[(size_t)b * a.ncls + q] : 0.f;
         }
-        if (a.scale) {
-          const float sc = a.scale[jc], sh = a.shift[jc];
+        __syncthreads();
+        for (int b0 = s0; b0 < s1; b0 += U) {
+          float x[U], mk[U];
+          const int jc = min(j, a.F - 1);
 #pragma unroll
-          for (int u = 0; u < U; ++u) x[u] = act_apply(x[u] * sc + sh, a.act);
-        }
+          for (int u = 0; u < U; ++u) x[u] = a.f[(size_t)min(b0 + u, a.B - 1) * a.F + jc];
+          if (a.mask) {
 #pragma unroll
-        for (int u = 0; u < U; ++u) x[u] = (jon && b0 + u < zb1) ? x[u] * mk[u] : 0.f;
+            for (int u = 0; u < U; ++u) mk[u] = a.mask[(size_t)min(b0 + u, a.B - 1) * a.F + jc];
+          } else {
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-          if (b0 + u < zb1) {
+            for (int u = 0; u < U; ++u) mk[u] = 1.f;
+          }
+          if (a.scale) {
+            const float sc = a.scale[jc], sh = a.shift[jc];
 #pragma unroll
-            for (int q = 0; q < 16; ++q)
-              if (q0 + q < a.ncls) acc[q] = fmaf(a.dlogits[(size_t)(b0 + u) * a.ncls + q0 + q], x[u], acc[q]);
+            for (int u = 0; u < U; ++u) x[u] = act_apply(x[u] * sc + sh, a.act);
+          }
+#pragma unroll
+          for (int u = 0; u < U; ++u) x[u] = (jon && b0 + u < s1) ? x[u] * mk[u] : 0.f;
+#pragma unroll
+          for (int u = 0; u < U; ++u) {
+            if (b0 + u < s1) {
+              const float4* dl = reinterpret_cast<const float4*>(ldp + (b0 + u - s0) * 16);
+#pragma unroll
+              for (int q4 = 0; q4 < 4; ++q4) {
+                const float4 d = dl[q4];
+                acc[4 * q4] = fmaf(d.x, x[u], acc[4 * q4]);
+                acc[4 * q4 + 1] = fmaf(d.y, x[u], acc[4 * q4 + 1]);
+                acc[4 * q4 + 2] = fmaf(d.z, x[u], acc[4 * q4 + 2]);
+                acc[4 * q4 + 3] = fmaf(d.w, x[u], acc[4 * q4 + 3]);
+              }
+            }
           }
         }
       }
