@@ -31,6 +31,7 @@ from .arch import Arch
 
 BN_EPS, BN_MOM = 1e-5, 0.1      # PyTorch defaults the reference relies on
 NREP = 16                       # reduction replicas (include/t3d.h: t3d_set_reduction_replicas)
+FUSED_EVAL_MIN_B = int(os.environ.get('T3D_FUSED_EVAL_MIN_B', '96'))
 DW_SLOTS = int(os.environ.get('T3D_DW_SLOTS', '512'))   # depthwise weight-gradient slots per layer (>= the workgroups of a t3d_dwconv_bwd launch)
 WORKSPACE_BYTES = 64 << 20      # partial weight-gradient tiles (include/t3d.h: t3d_set_workspace)
 MAIN_WORKSPACE_BYTES = 16 << 20
@@ -678,8 +679,11 @@ class Net:
 
     def _fused_eval_ok(self, blk, x):
         """Inference mode, bf16: may this block run as ONE launch (csrc/block_eval.hip: expanded tensors stay in LDS)?"""
-        # one workgroup per image: below ~100 images the launch-per-layer path fills the chip better
-        if self.training or not self._fused_eval or self.dt != N.BF16 or x.pro is not None or x.B < 96:
+        # one workgroup per image: below ~100 images the launch-per-layer path fills the chip better.  The two paths round at
+        # the same points but sum in different orders, so bf16 inference of one sample is not bit-identical across the
+        # threshold (last partial validation batch vs full ones); T3D_FUSED_EVAL_MIN_B fixes the choice for a run
+        # (0: always fused where the shapes allow, a huge value: never).  fp32 inference (the default) never takes this path.
+        if self.training or not self._fused_eval or self.dt != N.BF16 or x.pro is not None or x.B < FUSED_EVAL_MIN_B:
             return False
         if not blk.expand or blk.se or blk.s != 1 or blk.k != 3 or blk.cin % 32 or blk.cexp % 64 or blk.cout % 16:
             return False
