@@ -47,20 +47,36 @@ __global__ void sum_replicas_batched_kernel(const long long* __restrict__ desc, 
 
 // desc[t] = {src [slots][count] fp32, dst [count] fp32, count, used (device int*)}: dst = sum over the first *used slots, in
 // index order (overwrites) -- the deterministic end of the depthwise weight gradient (t3d_set_dw_slots)
-__global__ void sum_slots_batched_kernel(const long long* __restrict__ desc) {
+__global__ __launch_bounds__(256) void sum_slots_batched_kernel(const long long* __restrict__ desc) {
+  // 16 elements x 16 slot groups per workgroup: group g adds slots g, g + 16, ... in that order, the 16 group sums meet in
+  // LDS in index order (a thread per element over up to 512 slots was a 128-round latency chain for the small layers:
+  // 120 us beside the stem's weight gradient at the very end of the backward)
+  __shared__ float part[16][17];
   const long long* d = desc + (size_t)blockIdx.x * 4;
   const float* __restrict__ src = reinterpret_cast<const float*>(d[0]);
   float* __restrict__ dst = reinterpret_cast<float*>(d[1]);
   const int n = (int)d[2], nslots = *reinterpret_cast<const int*>(d[3]);
-  for (int i = blockIdx.y * blockDim.x + threadIdx.x; i < n; i += gridDim.y * blockDim.x) {
+  const int el = threadIdx.x & 15, g = threadIdx.x >> 4;
+  for (int i0 = blockIdx.y * 16; i0 < n; i0 += gridDim.y * 16) {
+    const int i = i0 + el;
     float s = 0.f;
-    int r = 0;
-    for (; r + 4 <= nslots; r += 4) {       // four loads in flight, added in index order
-      const float a = src[(size_t)r * n + i], b = src[(size_t)(r + 1) * n + i], c = src[(size_t)(r + 2) * n + i], e = src[(size_t)(r + 3) * n + i];
-      s += a; s += b; s += c; s += e;
+    if (i < n) {
+      int r = g;
+      for (; r + 48 < nslots; r += 64) {       // four loads in flight, added in index order
+        const float a = src[(size_t)r * n + i], b = src[(size_t)(r + 16) * n + i], c = src[(size_t)(r + 32) * n + i], e = src[(size_t)(r + 48) * n + i];
+        s += a; s += b; s += c; s += e;
+      }
+      for (; r < nslots; r += 16) s += src[(size_t)r * n + i];
     }
-    for (; r < nslots; ++r) s += src[(size_t)r * n + i];
-    dst[i] = s;
+    part[g][el] = s;
+    __syncthreads();
+    if (g == 0 && i < n) {
+      float t = part[0][el];
+#pragma unroll
+      for (int q = 1; q < 16; ++q) t += part[q][el];
+      dst[i] = t;
+    }
+    __syncthreads();
   }
 }
 
@@ -235,7 +251,7 @@ extern "C" int t3d_zero_batched(const long long* desc, int n, void* stream) {
 
 extern "C" int t3d_sum_slots_batched(const long long* desc, int n, void* stream) {
   if (!desc || n <= 0) return T3D_ERR_ARG;
-  hipLaunchKernelGGL(sum_slots_batched_kernel, dim3(n, 16), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), desc);
+  hipLaunchKernelGGL(sum_slots_batched_kernel, dim3(n, 32), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), desc);
   T3D_CHECK_LAUNCH();
   return T3D_OK;
 }

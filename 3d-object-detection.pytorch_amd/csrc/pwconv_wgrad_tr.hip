@@ -57,11 +57,14 @@ __device__ __forceinline__ bf16x8 tr_frag(const bf16_t* tile, int rs, int ch0, i
 // NTPW: 16-row tiles per wave on the P side (block: 64*NTPW rows); NTQ: 16-column tiles on the Q side
 // G: independent 4-wave pipelines per block, taking alternate 32-pixel steps (own LDS buffers, own accumulators);
 // they are summed through LDS before the block's single flush -- twice the per-block throughput for one flush.
-template <int NTPW, int NTQ, bool SWAP, int G, int D, bool GEN, bool YF, bool STEM = false>
+// SK: 32-pixel contraction sub-steps per barrier-separated step.  The narrow tiles of the wide, shallow layers (16 ... 144
+// channels on each side) stage only 4-12 KB per 32 pixels -- a quarter of the threads has a vector to move and the barrier
+// comes every few hundred bytes per thread; SK = 2 / 4 stages 64 / 128 pixels per step instead.
+template <int NTPW, int NTQ, bool SWAP, int G, int D, bool GEN, bool YF, bool STEM = false, int SK = 1>
 __global__ __launch_bounds__(256 * G) void pw_wgrad_tr_kernel(const WgtArgs a) {
   constexpr int PB = 64 * NTPW, QB = 16 * NTQ;
   constexpr int RSP = PB + 8, RSQ = QB + 8;            // LDS row strides (elements): +16 B against bank conflicts
-  constexpr int STEP = 32;
+  constexpr int STEP = 32 * SK;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int BUFE = STEP * (RSP + RSQ);              // elements per buffer: P tile then Q tile
   const int grp = threadIdx.x >> 8;
@@ -270,14 +273,17 @@ __global__ __launch_bounds__(256 * G) void pw_wgrad_tr_kernel(const WgtArgs a) {
         gload(rr[u], step_m(it + D));
         const bf16_t* pcur = tiles + buf * BUFE;
         const bf16_t* qcur = pcur + STEP * RSP;
-        bf16x8 qf[NTQ];
 #pragma unroll
-        for (int j = 0; j < NTQ; ++j) qf[j] = tr_frag(qcur, RSQ, j * 16, lane);
+        for (int kk = 0; kk < SK; ++kk) {
+          bf16x8 qf[NTQ];
 #pragma unroll
-        for (int i = 0; i < NTPW; ++i) {
-          const bf16x8 pf = tr_frag(pcur, RSP, (wave + 4 * i) * 16, lane);
+          for (int j = 0; j < NTQ; ++j) qf[j] = tr_frag(qcur + kk * 32 * RSQ, RSQ, j * 16, lane);
 #pragma unroll
-          for (int j = 0; j < NTQ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pf, qf[j], acc[i][j], 0, 0, 0);
+          for (int i = 0; i < NTPW; ++i) {
+            const bf16x8 pf = tr_frag(pcur + kk * 32 * RSP, RSP, (wave + 4 * i) * 16, lane);
+#pragma unroll
+            for (int j = 0; j < NTQ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pf, qf[j], acc[i][j], 0, 0, 0);
+          }
         }
         lstore(rr[(u + 1) % D], step_m(it + 1), buf ^ 1);
         __syncthreads();
@@ -400,16 +406,17 @@ __global__ __launch_bounds__(1024) void wgrad_reduce_tr_kernel(const float* __re
   }
 }
 
-template <int NTPW, int NTQ, bool SWAP, int D, bool GEN, bool YF = false, bool STEM = false>
+template <int NTPW, int NTQ, bool SWAP, int D, bool GEN, bool YF = false, bool STEM = false, int SK = 1>
 int launch_d(WgtArgs& a, hipStream_t st) {
   constexpr int G = 2;
+  constexpr int STEP = 32 * SK;
   constexpr int PB = 64 * NTPW, QB = 16 * NTQ;
   const int P = a.swap ? a.K : a.N, Q = a.swap ? a.N : a.K;
   a.ptiles = cdiv(P, PB);
   a.qtiles = cdiv(Q, QB);
   const int tiles = a.ptiles * a.qtiles;
   const int dyB = a.swap ? QB : PB, aB = a.swap ? PB : QB;
-  const size_t lds = (size_t)G * 2 * 32 * ((PB + 8) + (QB + 8)) * 2 + (size_t)(3 * dyB + 2 * aB) * 4;
+  const size_t lds = (size_t)G * 2 * STEP * ((PB + 8) + (QB + 8)) * 2 + (size_t)(3 * dyB + 2 * aB) * 4;
   // pixel splits: fill the chip (2 blocks per CU), but keep the partial-dW flush (S * N*K atomics) below ~8 MB
   static const int tgt_blocks = getenv("T3D_WG_BLOCKS") ? atoi(getenv("T3D_WG_BLOCKS")) : 256;
   static const long long cap_mb = getenv("T3D_WG_FLUSH_MB") ? atoi(getenv("T3D_WG_FLUSH_MB")) : 8;
@@ -423,16 +430,16 @@ int launch_d(WgtArgs& a, hipStream_t st) {
     const long long flush_cap = (cap_mb << 20) / ((long long)a.N * a.K * 4 + 1);
     if (S > flush_cap) S = (int)(flush_cap < 1 ? 1 : flush_cap);
   }
-  const int maxs = cdiv(a.M, 32 * 4 * G);
+  const int maxs = cdiv(a.M, STEP * 4 * G);
   if (S > maxs) S = maxs;
   if (S < 1) S = 1;
-  a.rows_per_split = cdiv(cdiv(a.M, S), 32) * 32;
+  a.rows_per_split = cdiv(cdiv(a.M, S), STEP) * STEP;
   S = cdiv(a.M, a.rows_per_split);
   a.ws = use_ws ? reinterpret_cast<float*>(g_t3d_ws.ptr) : nullptr;
   if (lds > 64 * 1024)
-    (void)hipFuncSetAttribute((const void*)pw_wgrad_tr_kernel<NTPW, NTQ, SWAP, G, D, GEN, YF, STEM>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute((const void*)pw_wgrad_tr_kernel<NTPW, NTQ, SWAP, G, D, GEN, YF, STEM, SK>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   a.nsplit = S;
-  hipLaunchKernelGGL((pw_wgrad_tr_kernel<NTPW, NTQ, SWAP, G, D, GEN, YF, STEM>), dim3(tiles * S), dim3(256 * G), lds, st, a);
+  hipLaunchKernelGGL((pw_wgrad_tr_kernel<NTPW, NTQ, SWAP, G, D, GEN, YF, STEM, SK>), dim3(tiles * S), dim3(256 * G), lds, st, a);
   if (use_ws) {
     // split groups inside the workgroup: enough parallelism for a small dW with hundreds of splits
 #define T3D_WGR(SPV)                                                                                                              \
@@ -457,11 +464,28 @@ template <int NTPW, int NTQ, bool SWAP>
 int launch_sw(WgtArgs& a, hipStream_t st) {
   static const int depth = getenv("T3D_WG_DEPTH") ? atoi(getenv("T3D_WG_DEPTH")) : 2;   // 2 measured best (1: -12 %, 3: -2 %)
   if (a.yfree) {
-    if constexpr (!SWAP) return launch_d<NTPW, NTQ, false, 2, false, true>(a, st);
+    if constexpr (!SWAP) {
+      static const int sk_env = getenv("T3D_WG_SK") ? atoi(getenv("T3D_WG_SK")) : 0;
+      constexpr int width = 64 * NTPW + 16 * NTQ;
+      if constexpr (width <= 288) {
+        const int sk = sk_env ? sk_env : (a.M >= (1 << 20) ? 2 : 1);
+        if (sk >= 2) return launch_d<NTPW, NTQ, false, 2, false, true, false, 2>(a, st);
+      }
+      return launch_d<NTPW, NTQ, false, 2, false, true>(a, st);
+    }
     else return T3D_ERR_UNSUPPORTED;
   }
   if (a.per_sample || a.se) return launch_d<NTPW, NTQ, SWAP, 1, true>(a, st);   // SE layers: per-sample coefficients / gates
   if (depth == 1) return launch_d<NTPW, NTQ, SWAP, 1, false>(a, st);
+  // pixels per step (see the kernel): wider steps for the narrow tiles of the layers with many pixels per workgroup
+  static const int sk_env = getenv("T3D_WG_SK") ? atoi(getenv("T3D_WG_SK")) : 0;
+  constexpr int width = 64 * NTPW + 16 * NTQ;
+  // (isolated, B = 256: 112x112 32 -> 16: 181 -> 141 us, 32 -> 32: 174 -> 138 us; the 56x56 / 28x28 layers do not move or lose)
+  if constexpr (width <= 288) {
+    const int sk = sk_env ? sk_env : (a.M >= (1 << 20) ? 2 : 1);
+    if (sk >= 4 && width <= 128) return launch_d<NTPW, NTQ, SWAP, 2, false, false, false, 4>(a, st);
+    if (sk >= 2) return launch_d<NTPW, NTQ, SWAP, 2, false, false, false, 2>(a, st);
+  }
   return launch_d<NTPW, NTQ, SWAP, 2, false>(a, st);
 }
 
@@ -524,8 +548,8 @@ int t3d_pw_wgrad_tr_stem(const void* dz, const void* y, const t3d_bnbwd* bb, con
   a.alpha = bb->alpha; a.beta = bb->beta; a.gamma = bb->gamma; a.per_sample = bb->per_sample;
   a.dw = dw; a.M = M; a.HW = HW; a.K = 32; a.N = N;
   a.stem = src;
-  if (N == 32) { a.swap = 0; return launch_d<1, 2, false, 2, false, false, true>(a, st); }     // P = N = 32, Q = K = 32
-  if (N == 16) { a.swap = 1; return launch_d<1, 1, true, 2, false, false, true>(a, st); }      // P = K = 32, Q = N = 16
+  if (N == 32) { a.swap = 0; return launch_d<1, 2, false, 2, false, false, true, 4>(a, st); }     // P = N = 32, Q = K = 32
+  if (N == 16) { a.swap = 1; return launch_d<1, 1, true, 2, false, false, true, 4>(a, st); }      // P = K = 32, Q = N = 16
   return T3D_ERR_UNSUPPORTED;
 }
 
