@@ -38,6 +38,7 @@ MAIN_WORKSPACE_BYTES = 16 << 20
 # y-free expand-layer backward (csrc/pwconv_yfree.hip): minimum M*N elements of the expanded tensor; 0 disables
 YFREE_MIN_ELEMS = int(os.environ.get('T3D_YFREE_MIN', 8 << 20))
 HOOK_MIN = 1 << 20              # gradient-exchange granularity (elements): parallel.GradSync's bucket size
+HOOK_ON_SIDE = os.environ.get('T3D_HOOK_ON_SIDE', '1') != '0'
 
 
 class _BN:
@@ -1053,8 +1054,19 @@ class Net:
             return
         if force or self._hook_hi - lo >= HOOK_MIN:
             self._flush_dw()
-            self._join_side()
-            self.grad_hook(lo)
+            if self._side is not None and HOOK_ON_SIDE and not force:      # (the last bucket: nothing left to overlap)
+                # the exchange has to see the weight gradients of the SECOND stream and the sums / BatchNorm gradients of the
+                # main one: issue it with the second stream current, after that stream has been made to wait for the main
+                # one -- the collective's own stream then waits for both, and the main stream waits for nobody (joining the
+                # streams here, as rounds 1-3a did, stalled the data-gradient chain three or four times per step until the
+                # weight-gradient backlog had drained)
+                self._side.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(self._side):
+                    self.grad_hook(lo)
+                self._side_busy = True
+            else:
+                self._join_side()
+                self.grad_hook(lo)
             self._hook_hi = lo
 
     def _yfree_ok(self, x, M, K, Nn):
