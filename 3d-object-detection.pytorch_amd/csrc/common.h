@@ -1,6 +1,7 @@
 // Shared device helpers for the gfx950 kernels (wave64, NHWC activations).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stdint.h>
 #include <type_traits>
 #include "../../include/t3d.h"
@@ -30,6 +31,22 @@ struct T3dReduceCfg {
   int dw_slots; int* dw_used;      // t3d_set_dw_slots: one depthwise weight-gradient slot per workgroup (no atomics), see t3d_dw_flush
 };
 extern T3dReduceCfg g_t3d_reduce;
+
+// Kernel-exact timing of the NEXT depthwise launch (t3d_set_launch_events, misc.hip): the two events are attached to the
+// kernel's own dispatch (hipExtLaunchKernelGGL), so their difference is the kernel's begin-to-end time -- what rocprofv3
+// reports -- and not that plus the ~5-9 us of event-record packets and dispatch latency an event pair AROUND the launch
+// call measures (bench.py's roofline block; the depthwise launches are 50-200 us long).
+struct T3dLaunchEvents { hipEvent_t start, stop; };
+extern T3dLaunchEvents g_t3d_time;
+#define T3D_LAUNCH_TIMED(kernel, grid, block, lds, st, ...)                                                              \
+  do {                                                                                                                   \
+    if (g_t3d_time.start) {                                                                                              \
+      hipExtLaunchKernelGGL(kernel, grid, block, lds, st, g_t3d_time.start, g_t3d_time.stop, 0, __VA_ARGS__);            \
+      g_t3d_time.start = g_t3d_time.stop = nullptr;                                                                      \
+    } else {                                                                                                             \
+      hipLaunchKernelGGL(kernel, grid, block, lds, st, __VA_ARGS__);                                                     \
+    }                                                                                                                    \
+  } while (0)
 
 // Scratch workspace in device memory (t3d_set_workspace, misc.hip): partial results of split reductions (the pointwise
 // weight gradient) are written there with plain stores and summed by a second small kernel instead of leaving as atomics.

@@ -752,13 +752,13 @@ int launch_s1c(Dw3BArgs& a, hipStream_t st) {
   //  0.1 % -- the kernel is bound by the latency two resident waves per SIMD can hide)
   if (two_col) {
     switch (a.act) {
-      case T3D_ACT_RELU: hipLaunchKernelGGL((dw3_bwd2_kernel<T, PF, 256, CH, T3D_ACT_RELU>), grid, dim3(256), lds, st, a); break;
-      case T3D_ACT_RELU6: hipLaunchKernelGGL((dw3_bwd2_kernel<T, PF, 256, CH, T3D_ACT_RELU6>), grid, dim3(256), lds, st, a); break;
-      case T3D_ACT_HSWISH: hipLaunchKernelGGL((dw3_bwd2_kernel<T, PF, 256, CH, T3D_ACT_HSWISH>), grid, dim3(256), lds, st, a); break;
-      default: hipLaunchKernelGGL((dw3_bwd2_kernel<T, PF, 256, CH, T3D_ACT_NONE>), grid, dim3(256), lds, st, a); break;
+      case T3D_ACT_RELU: T3D_LAUNCH_TIMED((dw3_bwd2_kernel<T, PF, 256, CH, T3D_ACT_RELU>), grid, dim3(256), lds, st, a); break;
+      case T3D_ACT_RELU6: T3D_LAUNCH_TIMED((dw3_bwd2_kernel<T, PF, 256, CH, T3D_ACT_RELU6>), grid, dim3(256), lds, st, a); break;
+      case T3D_ACT_HSWISH: T3D_LAUNCH_TIMED((dw3_bwd2_kernel<T, PF, 256, CH, T3D_ACT_HSWISH>), grid, dim3(256), lds, st, a); break;
+      default: T3D_LAUNCH_TIMED((dw3_bwd2_kernel<T, PF, 256, CH, T3D_ACT_NONE>), grid, dim3(256), lds, st, a); break;
     }
   }
-  else hipLaunchKernelGGL((dw3_bwd_s1_kernel<T, CH, PF>), grid, dim3(256), lds, st, a);
+  else T3D_LAUNCH_TIMED((dw3_bwd_s1_kernel<T, CH, PF>), grid, dim3(256), lds, st, a);
   T3D_CHECK_LAUNCH();
   return T3D_OK;
 }
@@ -1095,7 +1095,7 @@ int launch_s2(Dw3BArgs& a, hipStream_t st) {
     a.fold = nullptr;
   }
   // (a compile-time activation, as in the stride-1 kernel, pushes this one over 256 VGPRs -> 1 wave/SIMD: slower)
-  hipLaunchKernelGGL((dw3_bwd_s2_kernel<T, PF, 256>), grid, dim3(256), lds, st, a);
+  T3D_LAUNCH_TIMED((dw3_bwd_s2_kernel<T, PF, 256>), grid, dim3(256), lds, st, a);
   T3D_CHECK_LAUNCH();
   return T3D_OK;
 }

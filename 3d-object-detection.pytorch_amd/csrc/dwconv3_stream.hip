@@ -513,9 +513,9 @@ int launch_ch(Dw3Args& a, int s, hipStream_t st) {
   // perturbation between the parity mode and the reference)
   a.quant = (a.stats && std::is_same<T, bf16_t>::value && !getenv("T3D_NO_SNAP")) ? t3d_quant_for((long long)a.B * a.Ho * a.Wo)
                                                                                   : T3dQuant{0.0, 0.0};
-  if (use2) hipLaunchKernelGGL((dw3_fwd2_kernel<T, PF>), grid, dim3(256), lds, st, a);
-  else if (s == 1) hipLaunchKernelGGL((dw3_fwd_kernel<T, 1, CH, PF>), grid, dim3(256), lds, st, a);
-  else hipLaunchKernelGGL((dw3_fwd_kernel<T, 2, CH, PF>), grid, dim3(256), lds, st, a);
+  if (use2) T3D_LAUNCH_TIMED((dw3_fwd2_kernel<T, PF>), grid, dim3(256), lds, st, a);
+  else if (s == 1) T3D_LAUNCH_TIMED((dw3_fwd_kernel<T, 1, CH, PF>), grid, dim3(256), lds, st, a);
+  else T3D_LAUNCH_TIMED((dw3_fwd_kernel<T, 2, CH, PF>), grid, dim3(256), lds, st, a);
   T3D_CHECK_LAUNCH();
   return T3D_OK;
 }

@@ -450,7 +450,7 @@ int launch5_s1(Dw5BArgs& a, hipStream_t st) {
   }
   const size_t lds = (size_t)54 * (a.slab ? 64 * CH : a.C) * sizeof(float);   // [27][Cb] fp64
   if (lds > 64 * 1024) return T3D_ERR_UNSUPPORTED;
-  hipLaunchKernelGGL((dw5_bwd_s1_kernel<T>), grid, dim3(256), lds, st, a);
+  T3D_LAUNCH_TIMED((dw5_bwd_s1_kernel<T>), grid, dim3(256), lds, st, a);
   T3D_CHECK_LAUNCH();
   return T3D_OK;
 }
@@ -498,7 +498,7 @@ int launch5_s2(Dw5BArgs& a, hipStream_t st) {
   }
   const size_t lds = (size_t)54 * (a.slab ? 64 * CH : a.C) * sizeof(float);   // [27][Cb] fp64
   if (lds > 64 * 1024) return T3D_ERR_UNSUPPORTED;
-  hipLaunchKernelGGL((dw5_bwd_s2_kernel<T, PF>), grid, dim3(256), lds, st, a);
+  T3D_LAUNCH_TIMED((dw5_bwd_s2_kernel<T, PF>), grid, dim3(256), lds, st, a);
   T3D_CHECK_LAUNCH();
   return T3D_OK;
 }

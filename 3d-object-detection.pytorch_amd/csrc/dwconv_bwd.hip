@@ -308,7 +308,7 @@ int launch(const DwBwdArgs& a0, int k, int s, hipStream_t st) {
     if (lds > 64 * 1024)                                                                            \
       (void)hipFuncSetAttribute((const void*)dw_bwd_kernel<T, KK, SS>,                              \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);              \
-    hipLaunchKernelGGL((dw_bwd_kernel<T, KK, SS>), grid, dim3(256), lds, st, a);                    \
+    T3D_LAUNCH_TIMED((dw_bwd_kernel<T, KK, SS>), grid, dim3(256), lds, st, a);                    \
   }
   T3D_DWB(3, 1) else T3D_DWB(3, 2) else T3D_DWB(5, 1) else T3D_DWB(5, 2) else return T3D_ERR_UNSUPPORTED;
 #undef T3D_DWB

@@ -239,7 +239,7 @@ int launch(const DwFwdArgs& a0, int k, int s, hipStream_t st) {
     if (lds > 64 * 1024)                                                                        \
       (void)hipFuncSetAttribute((const void*)dw_fwd_kernel<T, KK, SS>,                                \
                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                \
-    hipLaunchKernelGGL((dw_fwd_kernel<T, KK, SS>), grid, dim3(256), lds, st, a);                \
+    T3D_LAUNCH_TIMED((dw_fwd_kernel<T, KK, SS>), grid, dim3(256), lds, st, a);                \
   }
   T3D_DW(3, 1) else T3D_DW(3, 2) else T3D_DW(5, 1) else T3D_DW(5, 2) else return T3D_ERR_UNSUPPORTED;
 #undef T3D_DW

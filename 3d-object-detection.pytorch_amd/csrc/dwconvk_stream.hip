@@ -209,7 +209,7 @@ int launch_ks(DwkArgs& a, hipStream_t st) {
     grid = dim3(gx, ns);
   }
   const size_t lds = (size_t)2 * (a.slab ? 64 * CH : a.C) * sizeof(float);
-  hipLaunchKernelGGL((dwk_fwd_kernel<T, K, S>), grid, dim3(256), lds, st, a);
+  T3D_LAUNCH_TIMED((dwk_fwd_kernel<T, K, S>), grid, dim3(256), lds, st, a);
   T3D_CHECK_LAUNCH();
   return T3D_OK;
 }

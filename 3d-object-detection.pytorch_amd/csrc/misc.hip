@@ -291,6 +291,15 @@ extern "C" int t3d_pack_weight(int dtype, const float* w, void* out, int rows, i
 
 T3dReduceCfg g_t3d_reduce = {1, 0, 0, nullptr};
 
+T3dLaunchEvents g_t3d_time = {nullptr, nullptr};
+
+extern "C" int t3d_set_launch_events(void* start_event, void* stop_event) {
+  if ((start_event == nullptr) != (stop_event == nullptr)) return T3D_ERR_ARG;
+  g_t3d_time.start = reinterpret_cast<hipEvent_t>(start_event);
+  g_t3d_time.stop = reinterpret_cast<hipEvent_t>(stop_event);
+  return T3D_OK;
+}
+
 extern "C" int t3d_set_dw_slots(int capacity, int* used_out) {
   if (capacity < 0 || (capacity > 0 && !used_out)) return T3D_ERR_ARG;
   g_t3d_reduce.dw_slots = capacity;

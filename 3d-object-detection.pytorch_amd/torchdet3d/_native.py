@@ -52,6 +52,7 @@ SIGNATURES = {
     't3d_pack_weight': [_I, _P, _P, _I, _I, _I, _P],
     't3d_sum_replicas_batched': [_P, _I, _I, _P],
     't3d_set_dw_slots': [_I, _P],
+    't3d_set_launch_events': [_P, _P],
     't3d_sum_slots_batched': [_P, _I, _P],
     't3d_dwconv_bwd': [_I, _P, _P, _BP, _P, _P, _PP, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
     't3d_pwconv_wgrad': [_I, _P, _P, _BP, _P, _PP, _P, _I, _I, _I, _I, _P],
@@ -161,8 +162,8 @@ class KernelTimer:
     """Optional per-launch device timing (HIP events on the launch stream), used by bench.py.
     `only`: set of entry-point names to time (None = all).  Events are resolved after a sync."""
 
-    def __init__(self, only=None, prealloc=0):
-        self.only, self.rec, self.sig = only, [], []
+    def __init__(self, only=None, prealloc=0, kernel_exact=False):
+        self.only, self.rec, self.sig, self.kernel_exact = only, [], [], kernel_exact
         # events created (and recorded once, which is when torch really creates them) ahead of the timed region
         self.pool = [torch.cuda.Event(enable_timing=True) for _ in range(prealloc)]
         for e in self.pool:
@@ -188,6 +189,7 @@ class KernelTimer:
 
 
 timer = None    # set to a KernelTimer to time launches
+_KERNEL_TIMED = frozenset(('t3d_dwconv_fwd', 't3d_dwconv_bwd'))     # entry points whose main kernel takes t3d_set_launch_events
 # measurement aid (tools/ablate.sh): entry points whose launches are SKIPPED -- the results are then garbage, only the
 # step time means something (an upper bound on what removing / fusing that family of launches can buy)
 _ABLATE = frozenset(x for x in os.environ.get('T3D_ABLATE', '').split(',') if x)
@@ -202,9 +204,15 @@ def call(name, *args, nbytes=None):
     t = timer
     if t is not None and (t.only is None or name in t.only):
         e0, e1 = t.event(), t.event()
-        e0.record()
-        rc = fn(*args)
-        e1.record()
+        if name in _KERNEL_TIMED and t.kernel_exact:
+            # the events ride on the entry point's main kernel dispatch: begin-to-end of the kernel itself (include/t3d.h)
+            lib().t3d_set_launch_events(e0.cuda_event, e1.cuda_event)
+            rc = fn(*args)
+            lib().t3d_set_launch_events(None, None)
+        else:
+            e0.record()
+            rc = fn(*args)
+            e1.record()
         t.rec.append((name, nbytes, e0, e1))
         t.sig.append(tuple(a for a in args[:-1] if isinstance(a, int) and not isinstance(a, bool) and 0 <= a < (1 << 31)))
     else:

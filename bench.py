@@ -313,7 +313,9 @@ def main():
 
     # ---- timed region: exactly K steps; the depthwise launches (main stream) carry HIP-event pairs
     every = max(1, args.roofline_every)
-    rtimer = N.KernelTimer(set(DW_ENTRIES), prealloc=2 * 40 * ((args.steps + every - 1) // every))
+    # kernel_exact: the event pair is attached to the depthwise kernel's own dispatch (begin-to-end of the kernel, as rocprofv3
+    # reports it), not recorded around the launch call (which adds 5-9 us of event packets and dispatch latency)
+    rtimer = N.KernelTimer(set(DW_ENTRIES), prealloc=2 * 40 * ((args.steps + every - 1) // every), kernel_exact=not os.environ.get('T3D_EVENTS_AROUND'))
     N.timer = None
     # no cyclic-GC pass inside the timed region: one in three fresh processes had a single 36-44 ms step in it
     # (config.step_ms_min_med_max), i.e. +12 % on the 30-step average, from a collection over the freshly imported heap

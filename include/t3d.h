@@ -424,6 +424,12 @@ int t3d_set_reduction_replicas(int nrep, long long stats_stride);
  * kernel, add atomically into the first nrep slots (t3d_set_reduction_replicas) and report *used_out = nrep: those slots
  * must be zero before the launch.  capacity == 0 (default): the replica behaviour above.  Process-wide setting. */
 int t3d_set_dw_slots(int capacity, int* used_out);
+
+/* Measurement aid (bench.py's roofline block): attach two hipEvent_t (created with timing enabled, recorded at least once) to
+ * the NEXT depthwise-convolution kernel launch -- t3d_dwconv_fwd / t3d_dwconv_bwd -- so that hipEventElapsedTime(start, stop)
+ * is that kernel's own begin-to-end time (hipExtLaunchKernelGGL; what rocprofv3 --kernel-trace reports).  The pair is
+ * consumed by the launch; NULL, NULL clears it. */
+int t3d_set_launch_events(void* start_event, void* stop_event);
 /* desc = n rows of int64 {src [slots][count] fp32, dst [count] fp32, count, used (device int*)}:
  * dst = src[0] + src[1] + ... + src[*used - 1], in that order (overwrites dst). */
 int t3d_sum_slots_batched(const long long* desc, int n, void* stream);
