@@ -252,3 +252,41 @@ def test_eval_storage_dtype_runs_validation_in_fp32_over_the_bf16_trained_parame
         kp2, _ = m(im, ca)
         kpr2, _ = ref(im, ca)
     assert torch.equal(kp2, kpr2) and not torch.equal(kp2, kp)
+
+
+def test_launch_events_time_the_depthwise_kernel_itself():
+    """t3d_set_launch_events (include/t3d.h; bench.py's roofline block): the pair rides on the kernel's own dispatch, so it
+    reads the kernel's begin-to-end time -- positive, and no longer than a pair recorded around the same launch call."""
+    from torchdet3d import _native as N
+    B, H, W, C = 64, 56, 56, 144
+    g = torch.Generator(device='cuda').manual_seed(0)
+    x = torch.randn(B * H * W, C, device='cuda', generator=g).bfloat16()
+    w = torch.randn(C, 9, device='cuda', generator=g) * 0.3
+    sc, sh = torch.rand(C, device='cuda') + 0.5, torch.randn(C, device='cuda') * 0.2
+    pro = N.prologue(sc, sh, None, 'relu6', False)
+    y = torch.empty_like(x)
+    stats = torch.zeros(2 * C, device='cuda', dtype=torch.float64)
+
+    def launch():
+        N.call('t3d_dwconv_fwd', N.BF16, N.ptr(x), pro, N.ptr(w), N.ptr(y), N.ptr(stats), None, B, H, W, C, 3, 1, N.stream())
+    for _ in range(3):
+        launch()
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+    for e in ev:
+        e.record()                                   # (torch creates the HIP event at its first record)
+    torch.cuda.synchronize()
+    inner, outer = [], []
+    for _ in range(10):
+        ev[0].record()
+        N.call('t3d_set_launch_events', ev[2].cuda_event, ev[3].cuda_event)
+        launch()
+        ev[1].record()
+        torch.cuda.synchronize()
+        inner.append(ev[2].elapsed_time(ev[3]))
+        outer.append(ev[0].elapsed_time(ev[1]))
+    ref = y.clone()
+    launch()                                          # the pair was consumed: a plain launch again, same result
+    torch.cuda.synchronize()
+    assert torch.equal(ref, y)
+    mi, mo = sorted(inner)[len(inner) // 2], sorted(outer)[len(outer) // 2]
+    assert 0.005 < mi <= mo * 1.02, (mi, mo)          # ms
