@@ -376,10 +376,10 @@ class Net:
     # entry points that implement it -- they fall back to a finalize launch of their own on paths without the prologue)
     # or is preceded by the standalone finalize (`_settle_f` / `_settle_b`: every other reader).
     # (the depthwise kernels too -- T3D_LAZY_DW=0 | fwd | bwd | 1 --: every one of their 500-700 persistent workgroups then starts
-    # with the ~3-us round trip to the sums, so their launches get 2-4 us longer, but the 5-us finalize launch and the ~6-us
-    # dispatch gap behind it go: 7.90 -> 7.83 ms per step on one box, 8.00 -> 7.97 on another (round 3b); the forward half
-    # gives most of it and is the default, the backward half costs the s=1 backward kernel 2 % of its own rate for 0.01 ms)
-    _LAZY_DW = os.environ.get('T3D_LAZY_DW', 'fwd')
+    # with the ~3-us round trip to the sums, but the 5-us finalize launch and the ~6-us dispatch gap behind it go: 7.90 -> 7.83
+    # ms per step on one box, 8.00 -> 7.97 on another (round 3b, forward half); with the atomics-free flush of round 3c the
+    # backward half costs nothing either (7.64 ms both ways, 18 launches fewer), so both are on)
+    _LAZY_DW = os.environ.get('T3D_LAZY_DW', '1')
     DERIVING = frozenset(('t3d_pwconv_fwd', 't3d_pwconv_fwd_mat', 't3d_bn_apply', 't3d_pool_fwd', 't3d_pwconv_dgrad', 't3d_pwconv_yfree_prep')
                          + (('t3d_dwconv_fwd',) if _LAZY_DW in ('1', 'fwd') else ())
                          + (('t3d_dwconv_bwd',) if _LAZY_DW in ('1', 'bwd') else ()))
