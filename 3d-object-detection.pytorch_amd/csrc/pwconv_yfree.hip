@@ -25,11 +25,20 @@ namespace {
 // part; 256 threads.  The K x K block Q = W^T diag(beta) W is the only part with real work (N multiply-adds per entry):
 // thread (k2, g) sums the n = g (mod 16) terms, the 16 partial sums meet in LDS.  (Small blocks on purpose: the kernel
 // runs while the side stream keeps the CUs busy, and a 1024-thread block waits for a whole free CU.)
-__global__ __launch_bounds__(256) void yfree_prep_kernel(const bf16_t* __restrict__ w, const float* __restrict__ alpha,
-                                                         const float* __restrict__ beta, const float* __restrict__ gamma,
+__global__ __launch_bounds__(256) void yfree_prep_kernel(const bf16_t* __restrict__ w, const float* __restrict__ alpha_g,
+                                                         const float* __restrict__ beta_g, const float* __restrict__ gamma_g,
                                                          bf16_t* __restrict__ wcat, float* __restrict__ cvec, int K, int N,
-                                                         int NP, int KP) {
+                                                         int NP, int KP, const T3dFold* __restrict__ fold) {
   __shared__ float part[256];
+  extern __shared__ float fco[];      // [3][N] derived (alpha, beta, gamma) when a finalize request rides on this launch
+  const float *alpha = alpha_g, *beta = beta_g, *gamma = gamma_g;
+  if (fold) {
+    // every workgroup needs all N coefficients: each derives them from the replica sums (common.h), workgroup (0, 0)
+    // publishes -- 3 us in every workgroup's prologue against a 5-us finalize launch and the dispatch gap behind it
+    t3d_fold_block(fold, 0, N, fco, N, blockIdx.x == 0 && blockIdx.y == 0);
+    __syncthreads();
+    alpha = fco; beta = fco + N; gamma = fco + 2 * N;
+  }
   constexpr int G = 16;
   const int k = blockIdx.x, c = blockIdx.y, nc = gridDim.y, tot = NP + KP, t = threadIdx.x;
   for (int j = c * 256 + t; j < NP; j += nc * 256)
@@ -97,11 +106,13 @@ extern "C" int t3d_pwconv_yfree_prep(const void* w, const t3d_bnbwd* bb, void* w
   if (!w || !bb || !bb->alpha || !bb->beta || !bb->gamma || !wcat || !cvec || K <= 0 || N <= 0 || (K % 8) || (N % 8))
     return T3D_ERR_ARG;
   if (bb->per_sample) return T3D_ERR_UNSUPPORTED;
-  // every workgroup reads all N coefficients: a requested finalize runs as a launch of its own ahead of this kernel
-  if (const int rc = t3d_fold_fallback(bb->alpha, reinterpret_cast<hipStream_t>(stream))) return rc;
-  hipLaunchKernelGGL(yfree_prep_kernel, dim3(K, rup32(K) / 16), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
-                     reinterpret_cast<const bf16_t*>(w), bb->alpha, bb->beta, bb->gamma, reinterpret_cast<bf16_t*>(wcat),
-                     cvec, K, N, rup32(N), rup32(K));
+  static const bool derive = !getenv("T3D_YFREE_PREP_NO_DERIVE");
+  const T3dFold* fold = nullptr;
+  if (derive) fold = t3d_take_fold(bb->alpha);
+  else if (const int rc = t3d_fold_fallback(bb->alpha, reinterpret_cast<hipStream_t>(stream))) return rc;
+  hipLaunchKernelGGL(yfree_prep_kernel, dim3(K, rup32(K) / 16), dim3(256), fold ? (size_t)3 * N * sizeof(float) : 0,
+                     reinterpret_cast<hipStream_t>(stream), reinterpret_cast<const bf16_t*>(w), bb->alpha, bb->beta, bb->gamma,
+                     reinterpret_cast<bf16_t*>(wcat), cvec, K, N, rup32(N), rup32(K), fold);
   T3D_CHECK_LAUNCH();
   return T3D_OK;
 }
