@@ -14,8 +14,9 @@
 //   wgrad: dw[ky][kx] += dy[r][x] * a[r+ky-1][x+kx-1] using the previous row's activations and centre
 //          gradient kept in registers (36 accumulators per thread for the thread's whole life).
 // Zero padding: out-of-image columns are cancelled by zeroed stencil weights / activations, rows by
-// wave-uniform skips.  Block-level reduction of dw (9*C) and the sums (2*C) through LDS, then fp32 / fp64
-// atomics once per block.
+// wave-uniform skips.  Block-level reduction of dw (9*C) and the sums (2*C) through fp64 LDS accumulators; the sums leave
+// as fp64 atomics once per block, the weight gradient as a plain store into the block's own slot (common.h:
+// t3d_dw_flush -- bit-reproducible; fp32 atomics into replicas when the caller provides no slots).
 #include <cstdlib>
 #include <type_traits>
 #include "common.h"
@@ -46,7 +47,7 @@ template <typename T, int CH> using rawvec = T __attribute__((ext_vector_type(CH
 
 template <typename T, int CH, int PF>
 __global__ __launch_bounds__(256) void dw3_bwd_s1_kernel(const Dw3BArgs a) {
-  extern __shared__ float lred[];  // [11][C]: dw taps 0..8, sum(dx), sum(dx*x)
+  extern __shared__ float lred[];  // end of kernel: [11][C] fp64 accumulators: dw taps 0..8, sum(dx), sum(dx*x)
   using RV = rawvec<T, CH>;
   const int CG = a.C / CH;
   int cg, ox_fixed = 0, q0, qstride;
@@ -308,7 +309,7 @@ __device__ __forceinline__ void bufstore(const RV& v, __amdgpu_buffer_rsrc_t r, 
 template <typename T, int PF, int NTH, int CH, int ACT>
 __global__ __launch_bounds__(NTH) void dw3_bwd2_kernel(const Dw3BArgs a) {
   constexpr int H2 = CH / 2;
-  extern __shared__ float lred[];       // [11][C] reduction scratch (end of kernel); first [9][C]: weights by tap
+  extern __shared__ float lred[];       // [9][Cb] weights by tap, [3][Cb] derived coefficients; end of kernel: [11][Cb] fp64 accumulators
   using RV = rawvec<T, CH>;
   const int CG = a.C / CH, Wp = (a.W + 1) / 2;
   int cg, xp_fixed = 0, q0, qstride;
@@ -784,7 +785,7 @@ int launch_s1(Dw3BArgs& a, hipStream_t st) {
 template <typename T, int PF, int NTH>
 __global__ __launch_bounds__(NTH) void dw3_bwd_s2_kernel(const Dw3BArgs a) {
   constexpr int CH = 4, H2 = 2;
-  extern __shared__ float lred[];       // [11][Cb] reduction scratch
+  extern __shared__ float lred[];       // end of kernel: [11][Cb] fp64 accumulators
   using RV = rawvec<T, CH>;
   const int CG = a.C / CH, Ho = (a.H - 1) / 2 + 1, Wo = (a.W - 1) / 2 + 1;
   int cg, ow_fixed = 0, q0, qstride;

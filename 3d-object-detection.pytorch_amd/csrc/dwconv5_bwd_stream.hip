@@ -36,7 +36,7 @@ template <typename T, int CH> using rawvec = T __attribute__((ext_vector_type(CH
 template <typename T, int PF>
 __global__ __launch_bounds__(256) void dw5_bwd_s2_kernel(const Dw5BArgs a) {
   constexpr int CH = 2, K = 5;
-  extern __shared__ float lred[];       // [27][Cb] reduction scratch
+  extern __shared__ float lred[];       // end of kernel: [27][Cb] fp64 accumulators (common.h: t3d_dw_flush)
   using RV = rawvec<T, CH>;
   const int CG = a.C / CH, Ho = (a.H - 1) / 2 + 1, Wo = (a.W - 1) / 2 + 1;
   int cg, ow_fixed = 0, q0, qstride;
@@ -244,7 +244,7 @@ __global__ __launch_bounds__(256) void dw5_bwd_s2_kernel(const Dw5BArgs a) {
 template <typename T>
 __global__ __launch_bounds__(256) void dw5_bwd_s1_kernel(const Dw5BArgs a) {
   constexpr int CH = 2, K = 5, U = 5, AHEAD = 2;
-  extern __shared__ float lred[];       // [27][Cb] reduction scratch
+  extern __shared__ float lred[];       // end of kernel: [27][Cb] fp64 accumulators (common.h: t3d_dw_flush)
   using RV = rawvec<T, CH>;
   const int CG = a.C / CH;
   int cg, ix_fixed = 0, q0, qstride;
