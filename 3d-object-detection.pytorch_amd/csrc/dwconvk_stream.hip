@@ -10,6 +10,7 @@
 // Zero padding applies to the ACTIVATED tensor: out-of-image columns are masked per item, out-of-image rows skipped
 // (wave-uniform); loads are unconditional from clamped addresses.
 #include <cstdlib>
+#include <type_traits>
 #include "common.h"
 
 namespace {
@@ -26,6 +27,7 @@ struct DwkArgs {
   int rows_per_chunk, nchunks, slab, nitems;
   int nrep;
   long long rstride;
+  T3dQuant quant;  // BatchNorm sums snapped onto a fixed grid: order-independent (common.h)
 };
 
 template <typename T, int CH> using rawvec = T __attribute__((ext_vector_type(CH)));
@@ -36,7 +38,7 @@ constexpr int floordiv(int a, int n) { return (a - floormod(a, n)) / n; }
 template <typename T, int K, int S>
 __global__ __launch_bounds__(256) void dwk_fwd_kernel(const DwkArgs a) {
   constexpr int CH = 2, PAD = (K - 1) / 2, NA = (K + S - 1) / S, U = NA * S;
-  extern __shared__ float lstat[];  // [2][Cb]
+  extern __shared__ double lstat[];  // [2][Cb] fp64: exact adds of the snapped partial sums (common.h)
   using RV = rawvec<T, CH>;
   const int CG = a.C / CH;
   int cg, ox_fixed = 0, q0, qstride;
@@ -156,20 +158,20 @@ __global__ __launch_bounds__(256) void dwk_fwd_kernel(const DwkArgs a) {
   if (a.stats) {
     const int cbase = a.slab ? blockIdx.y * 64 * CH : 0;
     const int Cb = a.slab ? min(64 * CH, a.C - cbase) : a.C;
-    for (int i = threadIdx.x; i < 2 * Cb; i += 256) lstat[i] = 0.f;
+    for (int i = threadIdx.x; i < 2 * Cb; i += 256) lstat[i] = 0.0;
     __syncthreads();
     if (on) {
 #pragma unroll
       for (int i = 0; i < CH; ++i) {
-        atomicAdd(lstat + c0 - cbase + i, psum[i]);
-        atomicAdd(lstat + Cb + c0 - cbase + i, psq[i]);
+        atomicAdd(lstat + c0 - cbase + i, t3d_snap(psum[i], a.quant, false));
+        atomicAdd(lstat + Cb + c0 - cbase + i, t3d_snap(psq[i], a.quant, true));
       }
     }
     __syncthreads();
     for (int i = threadIdx.x; i < 2 * Cb; i += 256)
-      if (lstat[i] != 0.f)
+      if (lstat[i] != 0.0)
         atomicAdd(a.stats + (size_t)((blockIdx.x + blockIdx.y) % a.nrep) * a.rstride + (size_t)(i / Cb) * a.C + cbase + i % Cb,
-                  (double)lstat[i]);
+                  lstat[i]);
   }
 }
 
@@ -208,7 +210,10 @@ int launch_ks(DwkArgs& a, hipStream_t st) {
     if (gx < 1) gx = 1;
     grid = dim3(gx, ns);
   }
-  const size_t lds = (size_t)2 * (a.slab ? 64 * CH : a.C) * sizeof(float);
+  const size_t lds = (size_t)2 * (a.slab ? 64 * CH : a.C) * sizeof(double);
+  // (throughput mode only, as in dwconv3_stream.hip)
+  a.quant = (a.stats && std::is_same<T, bf16_t>::value && !getenv("T3D_NO_SNAP")) ? t3d_quant_for((long long)a.B * a.Ho * a.Wo)
+                                                                                  : T3dQuant{0.0, 0.0};
   T3D_LAUNCH_TIMED((dwk_fwd_kernel<T, K, S>), grid, dim3(256), lds, st, a);
   T3D_CHECK_LAUNCH();
   return T3D_OK;
