@@ -29,6 +29,7 @@ static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 struct T3dReduceCfg {
   int nrep; long long stats_stride;
   int dw_slots; int* dw_used;      // t3d_set_dw_slots: one depthwise weight-gradient slot per workgroup (no atomics), see t3d_dw_flush
+  int pool_exact;                  // t3d_set_exact_pool: squeeze-excite pooled sums as int64 fixed point (t3d_pool_add / t3d_pool_get)
 };
 extern T3dReduceCfg g_t3d_reduce;
 
@@ -321,6 +322,22 @@ __device__ __forceinline__ double wave_sum_d(double v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
   return v;
+}
+
+// ---- squeeze-excite pooled sums (per sample and channel, accumulated by many work items) ---------------------------
+// exact == 0: fp32 atomics into float [B][C] (the plain semantics; arrival order moves the last bits).  exact != 0
+// (t3d_set_exact_pool): the SAME pointer addresses int64 [B][C] in units of 2^-24 -- integer adds are associative, so the
+// sums, the gates computed from them and everything downstream are bit-reproducible; one partial is rounded to 6e-8
+// absolute, far below an fp32 accumulation's own error.
+#define T3D_POOL_LSB 16777216.0
+__device__ __forceinline__ void t3d_pool_add(float* gap, size_t idx, float v, int exact) {
+  if (exact)
+    atomicAdd(reinterpret_cast<unsigned long long*>(gap) + idx, (unsigned long long)__double2ll_rn((double)v * T3D_POOL_LSB));
+  else
+    unsafeAtomicAdd(gap + idx, v);
+}
+__device__ __forceinline__ float t3d_pool_get(const float* gap, size_t idx, int exact) {
+  return exact ? (float)((double)reinterpret_cast<const long long*>(gap)[idx] * (1.0 / T3D_POOL_LSB)) : gap[idx];
 }
 
 // ---- end of a depthwise-backward workgroup -------------------------------------------------------------------------

@@ -24,6 +24,7 @@ struct DwFwdArgs {
   const float* se;
   double* stats;
   float* gap;
+  int gapq;     // pooled sums as int64 fixed point (common.h: t3d_pool_add)
   int act, se_after;
   int B, H, W, C, Ho, Wo;
   int TH, TW, tiles_x, tiles_y;  // output tile, tiles per image
@@ -174,7 +175,7 @@ __global__ __launch_bounds__(256) void dw_fwd_kernel(const DwFwdArgs a) {
         if (c < a.C) {
           float s = 0.f;
           for (int q = 0; q < nslots; ++q) s += scratch[q * CB + tid];
-          unsafeAtomicAdd(a.gap + (size_t)b * a.C + c, s);
+          t3d_pool_add(a.gap, (size_t)b * a.C + c, s, a.gapq);
         }
       }
     }
@@ -282,7 +283,7 @@ extern "C" int t3d_dwconv_fwd(int dtype, const void* x, const t3d_prologue* pro,
   DwFwdArgs a{};
   a.x = x; a.y = y; a.w = w;
   if (pro) { a.scale = pro->scale; a.shift = pro->shift; a.se = pro->se; a.act = pro->act; a.se_after = pro->se_after_act; }
-  a.stats = stats; a.gap = gap_sum;
+  a.stats = stats; a.gap = gap_sum; a.gapq = g_t3d_reduce.pool_exact;
   a.B = B; a.H = H; a.W = W; a.C = C;
   const int pad = (k - 1) / 2;
   a.Ho = (H + 2 * pad - k) / stride + 1;

@@ -22,7 +22,8 @@ struct DwkArgs {
   const float *scale, *shift;
   int act;
   double* stats;
-  float* gap;      // [B][C] per-sample sums of the (rounded) output, or null
+  float* gap;      // [B][C] per-sample sums of the (rounded) output, or null (int64 fixed point when gapq: common.h)
+  int gapq;
   int B, H, W, C, Ho, Wo;
   int rows_per_chunk, nchunks, slab, nitems;
   int nrep;
@@ -151,7 +152,7 @@ __global__ __launch_bounds__(256) void dwk_fwd_kernel(const DwkArgs a) {
     }
     if (a.gap) {
 #pragma unroll
-      for (int i = 0; i < CH; ++i) unsafeAtomicAdd(a.gap + (size_t)b * a.C + c0 + i, gs[i]);
+      for (int i = 0; i < CH; ++i) t3d_pool_add(a.gap, (size_t)b * a.C + c0 + i, gs[i], a.gapq);
     }
   }  // item loop
 
@@ -234,7 +235,7 @@ int launch_t(DwkArgs& a, int k, int s, hipStream_t st) {
 int t3d_dwk_fwd_stream(int dtype, const void* x, const t3d_prologue* pro, const float* w, void* y, double* stats,
                        float* gap_sum, int B, int H, int W, int C, int k, int stride, hipStream_t st) {
   DwkArgs a{};
-  a.x = x; a.y = y; a.w = w; a.stats = stats; a.gap = gap_sum;
+  a.x = x; a.y = y; a.w = w; a.stats = stats; a.gap = gap_sum; a.gapq = g_t3d_reduce.pool_exact;
   if (pro) { a.scale = pro->scale; a.shift = pro->shift; a.act = pro->act; }
   a.B = B; a.H = H; a.W = W; a.C = C;
   const int pad = (k - 1) / 2;

@@ -289,7 +289,12 @@ extern "C" int t3d_pack_weight(int dtype, const float* w, void* out, int rows, i
   return T3D_OK;
 }
 
-T3dReduceCfg g_t3d_reduce = {1, 0, 0, nullptr};
+T3dReduceCfg g_t3d_reduce = {1, 0, 0, nullptr, 0};
+
+extern "C" int t3d_set_exact_pool(int on) {
+  g_t3d_reduce.pool_exact = on ? 1 : 0;
+  return T3D_OK;
+}
 
 T3dLaunchEvents g_t3d_time = {nullptr, nullptr};
 

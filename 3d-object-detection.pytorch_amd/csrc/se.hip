@@ -22,6 +22,7 @@ struct SeArgs {
   double* stats;     // [2][C]
   float *dw1, *db1, *dw2, *db2;
   int B, C, R, HW;
+  int gapq;          // `gap` holds int64 fixed point (t3d_set_exact_pool; common.h: t3d_pool_get)
 };
 
 // ---- small dense layers as tiled products (one workgroup per sample re-read both weight matrices, 1.8 MB, 256 times:
@@ -75,7 +76,7 @@ __global__ __launch_bounds__(256) void se_fc1_kernel(const SeArgs a) {
   __shared__ float lin[64][65], lw[OT][65];
   const int o0 = blockIdx.x * OT, b0 = blockIdx.y * 64;
   const float inv = 1.f / (float)a.HW;
-  auto in = [&](int b, int c) { return a.scale[c] * (a.gap[(size_t)b * a.C + c] * inv) + a.shift[c]; };
+  auto in = [&](int b, int c) { return a.scale[c] * (t3d_pool_get(a.gap, (size_t)b * a.C + c, a.gapq) * inv) + a.shift[c]; };
   const int per = ((a.C + KSPLIT - 1) / KSPLIT + 63) / 64 * 64;
   float acc[PT];
   fc_tile<false>(in, a.w1, a.C, a.R, b0, o0, a.B, acc, lin, lw, blockIdx.z * per, (blockIdx.z + 1) * per);
@@ -175,7 +176,7 @@ __global__ __launch_bounds__(256) void se_dm_kernel(const SeArgs a) {
       a.g[i] = gu;
       const float s = a.s[i], p1 = a.ps[2 * i], p2 = a.ps[2 * i + 1];
       v1 = s * p1 + (float)a.HW * gu;
-      v2 = s * p2 + gu * a.gap[i];
+      v2 = s * p2 + gu * t3d_pool_get(a.gap, i, a.gapq);
     }
     v1 = wave_sum(v1);
     v2 = wave_sum(v2);
@@ -306,7 +307,7 @@ __global__ __launch_bounds__(SE_T) void se_fwd_group_kernel(const SeArgs a, cons
     const int c = i / SPG, s = i % SPG, b = b0 + s;
     float v = 0.f;
     if (b < a.B) {
-      v = a.scale[c] * (a.gap[(size_t)b * a.C + c] * inv) + a.shift[c];
+      v = a.scale[c] * (t3d_pool_get(a.gap, (size_t)b * a.C + c, a.gapq) * inv) + a.shift[c];
       a.m[(size_t)b * a.C + c] = v;
     }
     ms[i] = v;
@@ -378,7 +379,7 @@ __global__ __launch_bounds__(SE_T) void se_bwd_group_kernel(const SeArgs a, cons
         a.g[k] = gu;
         const float sg = a.s[k], p1 = a.ps[2 * k], p2 = a.ps[2 * k + 1];
         v1 += sg * p1 + (float)a.HW * gu;
-        v2 += sg * p2 + gu * a.gap[k];
+        v2 += sg * p2 + gu * t3d_pool_get(a.gap, k, a.gapq);
       }
     }
     // one add per (workgroup, channel): spread over the reduction replicas (64 blocks on one address made this launch 3x
@@ -400,7 +401,7 @@ extern "C" int t3d_se_fwd(const float* gap_sum, const float* scale, const float*
       HW <= 0)
     return T3D_ERR_ARG;
   SeArgs a{};
-  a.gap = gap_sum; a.scale = scale; a.shift = shift; a.w1 = w1; a.b1 = b1; a.w2 = w2; a.b2 = b2;
+  a.gap = gap_sum; a.gapq = g_t3d_reduce.pool_exact; a.scale = scale; a.shift = shift; a.w1 = w1; a.b1 = b1; a.w2 = w2; a.b2 = b2;
   a.m = m; a.h = h; a.q = q; a.s = s; a.B = B; a.C = C; a.R = R; a.HW = HW;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   if (hipMemsetAsync(h, 0, (size_t)B * R * sizeof(float), st) != hipSuccess) return T3D_ERR_LAUNCH;
@@ -419,7 +420,7 @@ extern "C" int t3d_se_bwd(const float* ps_stats, const float* gap_sum, const flo
       !dw1 || !db1 || !dw2 || !db2 || B <= 0 || C <= 0 || R <= 0 || HW <= 0)
     return T3D_ERR_ARG;
   SeArgs a{};
-  a.ps = ps_stats; a.gap = gap_sum; a.scale = scale; a.shift = shift; a.w1 = w1; a.w2 = w2;
+  a.ps = ps_stats; a.gap = gap_sum; a.gapq = g_t3d_reduce.pool_exact; a.scale = scale; a.shift = shift; a.w1 = w1; a.w2 = w2;
   a.m = const_cast<float*>(m); a.h = const_cast<float*>(h); a.q = const_cast<float*>(q); a.s = const_cast<float*>(s);
   a.g = g; a.dq = dq; a.dp = dp; a.stats = stats; a.dw1 = dw1; a.db1 = db1; a.dw2 = dw2; a.db2 = db2;
   a.B = B; a.C = C; a.R = R; a.HW = HW;
@@ -447,7 +448,7 @@ extern "C" int t3d_se_fwd_fused(const float* gap_sum, const float* scale, const 
       HW <= 0)
     return T3D_ERR_ARG;
   SeArgs a{};
-  a.gap = gap_sum; a.scale = scale; a.shift = shift; a.b1 = b1; a.b2 = b2;
+  a.gap = gap_sum; a.gapq = g_t3d_reduce.pool_exact; a.scale = scale; a.shift = shift; a.b1 = b1; a.b2 = b2;
   a.m = m; a.h = h; a.q = q; a.s = s; a.B = B; a.C = C; a.R = R; a.HW = HW;
   const size_t lds = se_group_lds(C, R);
   static bool attr = false;
@@ -468,7 +469,7 @@ extern "C" int t3d_se_bwd_data(const float* ps_stats, const float* gap_sum, cons
       R <= 0 || HW <= 0)
     return T3D_ERR_ARG;
   SeArgs a{};
-  a.ps = ps_stats; a.gap = gap_sum; a.scale = scale; a.shift = shift; a.w1 = w1; a.w2 = w2;
+  a.ps = ps_stats; a.gap = gap_sum; a.gapq = g_t3d_reduce.pool_exact; a.scale = scale; a.shift = shift; a.w1 = w1; a.w2 = w2;
   a.h = const_cast<float*>(h); a.q = const_cast<float*>(q); a.s = const_cast<float*>(s);
   a.g = g; a.dq = dq; a.dp = dp; a.stats = stats; a.B = B; a.C = C; a.R = R; a.HW = HW;
   static bool attr = false;

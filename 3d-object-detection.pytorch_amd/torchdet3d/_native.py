@@ -52,6 +52,7 @@ SIGNATURES = {
     't3d_pack_weight': [_I, _P, _P, _I, _I, _I, _P],
     't3d_sum_replicas_batched': [_P, _I, _I, _P],
     't3d_set_dw_slots': [_I, _P],
+    't3d_set_exact_pool': [_I],
     't3d_set_launch_events': [_P, _P],
     't3d_sum_slots_batched': [_P, _I, _P],
     't3d_dwconv_bwd': [_I, _P, _P, _BP, _P, _P, _PP, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],

@@ -126,6 +126,7 @@ class Net:
         # end of `gflat` towards its start): lets a data-parallel wrapper start the RCCL all-reduce of that
         # tail while the rest of the backward is still being computed
         self.grad_hook = None
+        self._cur_pool_exact = False
         self._side = None
         if self.device.type == 'cuda' and not os.environ.get('T3D_NO_SIDE_STREAM'):
             self._side = _concurrent_stream(self.device)
@@ -404,6 +405,11 @@ class Net:
         if req and N.lib().t3d_fold_pending():
             raise RuntimeError(f'{entry} left a BatchNorm finalize request unserved (engine / library mismatch)')
 
+    def _pool_exact(self, on):
+        if on != self._cur_pool_exact:
+            N.call('t3d_set_exact_pool', int(on))
+            self._cur_pool_exact = on
+
     def _replicas(self, n):
         if n != self._cur_nrep:
             N.call('t3d_set_reduction_replicas', n, self._stat_stride)
@@ -492,6 +498,7 @@ class Net:
             return self._forward(imgs, cats, train, dropout_mask, all_heads)
         finally:
             N.call('t3d_set_reduction_replicas', 1, 0)
+            self._pool_exact(False)
             self._cur_nrep = None
             self._main_scratch(False)
 
@@ -780,7 +787,10 @@ class Net:
         M2 = B * Ho * Wo
         bn2 = self.bns[bnn]
         y2 = self._buf(f'y2:{i}', (M2, blk.cexp))
-        gap = self._buf(f'gap:{i}', (B, blk.cexp), torch.float32, zero=True) if (blk.se and not se_after) else None
+        # squeeze-excite pooled sums: int64 fixed point (include/t3d.h: t3d_set_exact_pool) -- the depthwise kernel's work items
+        # add integers, so the sums, the gate and everything behind it no longer depend on their arrival order
+        gap = self._buf(f'gap:{i}', (B, blk.cexp), torch.int64, zero=True) if (blk.se and not se_after) else None
+        self._pool_exact(gap is not None)
         self._c('t3d_dwconv_fwd', dt, N.ptr(src.t), src.pro, N.ptr(self.p[dwn]), N.ptr(y2), self._st(bn2), N.ptr(gap),
                 B, H, W, blk.cexp, blk.k, blk.s, st, nbytes=(B * H * W + M2) * blk.cexp * self.esz,
                 fwd=src.bn if src.pro is not None else None)
@@ -797,6 +807,7 @@ class Net:
                       h=self._buf(f'se_h:{i}', (B, R), torch.float32), q=self._buf(f'se_q:{i}', (B, C), torch.float32),
                       s=self._buf(f'se_s:{i}', (B, C), torch.float32), name=sen, HW=Ho * Wo, after=True, pro2n=pro2)
             ones, zeros = self._const(C, 1.0), self._const(C, 0.0)
+            self._pool_exact(False)
             N.call('t3d_se_fwd_fused', N.ptr(pooled), N.ptr(ones), N.ptr(zeros), N.ptr(self.wt[sen + '.fc.0.weight']),
                    N.ptr(self.p[sen + '.fc.0.bias']), N.ptr(self.wt[sen + '.fc.2.weight']),
                    N.ptr(self.p[sen + '.fc.2.bias']), N.ptr(se['m']), N.ptr(se['h']), N.ptr(se['q']), N.ptr(se['s']),
@@ -808,6 +819,7 @@ class Net:
             se = dict(gap=gap, m=self._buf(f'se_m:{i}', (B, C), torch.float32),
                       h=self._buf(f'se_h:{i}', (B, R), torch.float32), q=self._buf(f'se_q:{i}', (B, C), torch.float32),
                       s=self._buf(f'se_s:{i}', (B, C), torch.float32), name=sen, HW=Ho * Wo)
+            self._pool_exact(True)
             N.call('t3d_se_fwd_fused', N.ptr(gap), N.ptr(bn2.scale), N.ptr(bn2.shift), N.ptr(self.wt[sen + '.fc.0.weight']),
                    N.ptr(self.p[sen + '.fc.0.bias']), N.ptr(self.wt[sen + '.fc.2.weight']),
                    N.ptr(self.p[sen + '.fc.2.bias']), N.ptr(se['m']), N.ptr(se['h']), N.ptr(se['q']), N.ptr(se['s']),
@@ -889,6 +901,7 @@ class Net:
         finally:
             N.call('t3d_set_reduction_replicas', 1, 0)
             N.call('t3d_set_dw_slots', 0, None)
+            self._pool_exact(False)
             self._cur_nrep = None
             N.call('t3d_set_workspace', None, 0)
             self._main_scratch(False)
@@ -1138,6 +1151,7 @@ class Net:
             dq = self._buf(f'se_dq:{i}', (B, C), torch.float32)
             dp = self._buf(f'se_dp:{i}', (B, R), torch.float32)
             ones, zeros = self._const(C, 1.0), self._const(C, 0.0)
+            self._pool_exact(False)
             N.call('t3d_se_bwd_data', N.ptr(ps), N.ptr(se['gap']), N.ptr(zeros), N.ptr(ones),
                    N.ptr(self.p[sen + '.fc.0.weight']), N.ptr(self.p[sen + '.fc.2.weight']),
                    N.ptr(se['h']), N.ptr(se['q']), N.ptr(se['s']), N.ptr(g), N.ptr(dq), N.ptr(dp), None,
@@ -1160,6 +1174,7 @@ class Net:
             dq = self._buf(f'se_dq:{i}', (B, C), torch.float32)
             dp = self._buf(f'se_dp:{i}', (B, R), torch.float32)
             bn2 = s2.bn
+            self._pool_exact(True)
             N.call('t3d_se_bwd_data', N.ptr(ps), N.ptr(se['gap']), N.ptr(bn2.scale), N.ptr(bn2.shift),
                    N.ptr(self.p[sen + '.fc.0.weight']), N.ptr(self.p[sen + '.fc.2.weight']),
                    N.ptr(se['h']), N.ptr(se['q']), N.ptr(se['s']), N.ptr(g), N.ptr(dq), N.ptr(dp), self._bst(bn2),

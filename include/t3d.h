@@ -425,6 +425,13 @@ int t3d_set_reduction_replicas(int nrep, long long stats_stride);
  * must be zero before the launch.  capacity == 0 (default): the replica behaviour above.  Process-wide setting. */
 int t3d_set_dw_slots(int capacity, int* used_out);
 
+/* Squeeze-excite pooled sums without order noise.  on != 0: every `pooled` / `gap_sum` argument of the NEXT t3d_dwconv_fwd,
+ * t3d_se_fwd(_fused), t3d_se_bwd(_data) calls addresses int64 [B][C] in units of 2^-24 instead of float [B][C] (zero it
+ * before the depthwise launch, as before): the depthwise kernel's work items add integers, which is associative, so the
+ * sums -- and the gate torch computes from `y.mean((2, 3))` at models/mobilenetv3.py:100-104 -- are bit-reproducible from
+ * run to run.  on == 0 (default): fp32 atomics into float [B][C].  Process-wide setting. */
+int t3d_set_exact_pool(int on);
+
 /* Measurement aid (bench.py's roofline block): attach two hipEvent_t (created with timing enabled, recorded at least once) to
  * the NEXT depthwise-convolution kernel launch -- t3d_dwconv_fwd / t3d_dwconv_bwd -- so that hipEventElapsedTime(start, stop)
  * is that kernel's own begin-to-end time (hipExtLaunchKernelGGL; what rocprofv3 --kernel-trace reports).  The pair is
