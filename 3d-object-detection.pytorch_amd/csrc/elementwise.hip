@@ -78,20 +78,22 @@ __device__ __forceinline__ void load_affine(const EwArgs& a, int c0, float sc[8]
   }
 }
 
-// block-level merge of per-thread (sum, sumsq-like) pairs for a fixed channel group per thread
-__device__ __forceinline__ void flush_stats(float* lstat, int C, int c0, bool on, const float s1[8],
+// block-level merge of per-thread (sum, sumsq-like) pairs for a fixed channel group per thread: fp64 LDS accumulators (the
+// threads' fp32 partials add exactly in any order -- bit-reproducible sums), one fp64 atomic per channel and workgroup
+__device__ __forceinline__ void flush_stats(float* lraw, int C, int c0, bool on, const float s1[8],
                                             const float s2[8], double* stats) {
-  for (int i = threadIdx.x; i < 2 * C; i += blockDim.x) lstat[i] = 0.f;
+  double* lstat = reinterpret_cast<double*>(lraw);
+  for (int i = threadIdx.x; i < 2 * C; i += blockDim.x) lstat[i] = 0.0;
   __syncthreads();
   if (on) {
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
-      atomicAdd(lstat + c0 + i, s1[i]);
-      atomicAdd(lstat + C + c0 + i, s2[i]);
+      atomicAdd(lstat + c0 + i, (double)s1[i]);
+      atomicAdd(lstat + C + c0 + i, (double)s2[i]);
     }
   }
   __syncthreads();
-  for (int i = threadIdx.x; i < 2 * C; i += blockDim.x) atomicAdd(stats + i, (double)lstat[i]);
+  for (int i = threadIdx.x; i < 2 * C; i += blockDim.x) atomicAdd(stats + i, lstat[i]);
 }
 
 // z = act(scale*y + shift) + res
@@ -441,7 +443,7 @@ extern "C" int t3d_bn_act_bwd(int dtype, const void* dz, const void* y, const t3
   int grid = ew_grid((size_t)M * (C / 8));
   if (grid > 1024) grid = 1024;
   if ((size_t)grid * 256 < (size_t)(C / 8)) return T3D_ERR_UNSUPPORTED;
-  const size_t lds = (size_t)2 * C * sizeof(float);
+  const size_t lds = (size_t)2 * C * sizeof(double);
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   if (dtype == T3D_F32) hipLaunchKernelGGL(bn_act_bwd_kernel<float>, dim3(grid), dim3(256), lds, st, a);
   else if (dtype == T3D_BF16) hipLaunchKernelGGL(bn_act_bwd_kernel<bf16_t>, dim3(grid), dim3(256), lds, st, a);
@@ -477,7 +479,7 @@ extern "C" int t3d_se_after_apply(int dtype, const void* dv, const void* y, cons
   int grid = ew_grid((size_t)a.M * (C / 8));
   if (grid > 1024) grid = 1024;
   if ((size_t)grid * 256 < (size_t)(C / 8)) return T3D_ERR_UNSUPPORTED;
-  const size_t lds = (size_t)2 * C * sizeof(float);
+  const size_t lds = (size_t)2 * C * sizeof(double);
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   if (dtype == T3D_F32) hipLaunchKernelGGL(se_after_apply_kernel<float>, dim3(grid), dim3(256), lds, st, a);
   else if (dtype == T3D_BF16) hipLaunchKernelGGL(se_after_apply_kernel<bf16_t>, dim3(grid), dim3(256), lds, st, a);

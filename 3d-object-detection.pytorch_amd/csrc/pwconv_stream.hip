@@ -454,17 +454,17 @@ __global__ __launch_bounds__(512, KU > 2 ? 1 : 2) void pw_stream_kernel(const Ge
       for (int j = 0; j < 8; ++j) {
         const float s1 = row16_sum(st1[q][j]), s2 = row16_sum(st2[q][j]);
         st1[q][j] = st2[q][j] = 0.f;
-        if (lc == 0 && n < a.Nout && g_begin < g_end) {
-          atomicAdd(lstat + (n - n0 + j) * 2, s1);
-          atomicAdd(lstat + (n - n0 + j) * 2 + 1, s2);
+        if (lc == 0 && n < a.Nout && g_begin < g_end) {      // (fp64: the waves' fp32 partials add exactly, in any order)
+          atomicAdd(dstat + (n - n0 + j) * 2, (double)s1);
+          atomicAdd(dstat + (n - n0 + j) * 2 + 1, (double)s2);
         }
       }
     }
     __syncthreads();
     for (int i = tid; i < BN * 2; i += nthr) {
       const int n = n0 + (i >> 1);
-      if (n < a.Nout) a.ps_stats[((size_t)sb * a.Nout + n) * 2 + (i & 1)] = lstat[i];
-      lstat[i] = 0.f;
+      if (n < a.Nout) a.ps_stats[((size_t)sb * a.Nout + n) * 2 + (i & 1)] = (float)dstat[i];
+      dstat[i] = 0.0;
     }
     __syncthreads();
   }

@@ -259,15 +259,17 @@ def test_bf16_train_forward_is_bit_reproducible(name, B, HW):
             assert torch.equal(a, b)
 
 
-@pytest.mark.parametrize('name,B,HW', [('mobilenetv2', 64, 224), ('mobilenetv2', 16, 96), ('resnet50', 8, 96)])
+@pytest.mark.parametrize('name,B,HW', [('mobilenetv2', 64, 224), ('mobilenetv2', 16, 96), ('resnet50', 8, 96),
+                                       ('mobilenetv3_large', 64, 224), ('mobilenetv3_large', 16, 96), ('mobilenetv3_small', 32, 128)])
 def test_bf16_training_is_bit_reproducible_run_to_run(name, B, HW):
     """VERDICT r2 #7 (deterministic reductions; tools/debug_backward_determinism.py as a test).  Two backward passes on ONE
     saved forward used to differ by 1.2e-2 of the gradient norm in bf16 storage: fp32 LDS atomics in the depthwise backward
     moved a BatchNorm-backward sum by an ulp, one coefficient with it, and bf16 rounding amplified that down the chain; the
     leaves (depthwise / pointwise weight gradients) were fp32 atomics in arrival order.  Now every sum on the data path goes
     through fp64 accumulators, the depthwise weight gradient through one slot per workgroup added in index order, the
-    pointwise partial tiles through a fixed-order reduction: three optimizer steps through the reference-shaped API, run
-    twice from the same seed, end in identical weights, gradients and losses -- bit for bit."""
+    pointwise partial tiles through a fixed-order reduction, the squeeze-excite pooled sums of MobileNetV3 through int64
+    fixed point (t3d_set_exact_pool) and its per-sample sums through fp64: three optimizer steps through the
+    reference-shaped API, run twice from the same seed, end in identical weights, gradients and losses -- bit for bit."""
     from test_host_logic import _cfg
     from oracle.weights import make_inputs, make_state_dict
     from torchdet3d.builders import build_loss, build_model, build_optimizer
