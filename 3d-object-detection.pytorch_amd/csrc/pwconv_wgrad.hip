@@ -26,6 +26,7 @@ struct WgArgs {
   int act, se_after;
   float* dw;  // [N][K]
   int M, HW, K, N, rows_per_split;
+  float* ws;  // partial tiles [split][tile][64][64] (plain stores; summed in a fixed order afterwards) or null (atomics into dw)
 };
 
 // LDS element offset of (row, m) in a transposed bf16 tile: [row][8 blocks of 8][pad]
@@ -169,6 +170,14 @@ __global__ __launch_bounds__(256, 2) void pw_wgrad_kernel(const WgArgs a) {
     }
   }
   // D[row = 4*lg + reg -> n][col = lc -> k]
+  if (a.ws) {
+    float* wsb = a.ws + (((size_t)blockIdx.z * gridDim.x + blockIdx.x) * gridDim.y + blockIdx.y) * (TN * TK);
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) wsb[(wave * 16 + lg * 4 + r) * TK + t * 16 + lc] = acc[t][r];
+    return;
+  }
 #pragma unroll
   for (int t = 0; t < 4; ++t) {
     const int k = k0 + t * 16 + lc;
@@ -184,6 +193,8 @@ __global__ __launch_bounds__(256, 2) void pw_wgrad_kernel(const WgArgs a) {
 
 int t3d_pw_wgrad_tr_entry(const void* dz, const void* y, const t3d_bnbwd* bb, const void* x, const t3d_prologue* pro,
                           float* dw, int M, int HW, int K, int N, hipStream_t st);   // pwconv_wgrad_tr.hip (bf16)
+// fixed-order sum of partial tiles ws [S][tiles][PB][QB] into dw [N][K] (pwconv_wgrad_tr.hip)
+int t3d_pw_wgrad_reduce(const float* ws, float* dw, int N, int K, int PB, int QB, int qtiles, int tiles, int S, hipStream_t st);
 
 extern "C" int t3d_pwconv_wgrad(int dtype, const void* dz, const void* y, const t3d_bnbwd* bb, const void* x,
                                 const t3d_prologue* pro, float* dw, int M, int HW, int K, int N, void* stream) {
@@ -205,6 +216,10 @@ extern "C" int t3d_pwconv_wgrad(int dtype, const void* dz, const void* y, const 
   a.rows_per_split = cdiv(cdiv(M, S), BMK) * BMK;
   S = cdiv(M, a.rows_per_split);
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  // with a workspace (t3d_set_workspace) the pixel splits leave as plain stores and are added in a fixed order:
+  // bit-reproducible weight gradients in the parity mode too
+  const size_t need = (size_t)S * tn * tk * TN * TK * sizeof(float);
+  a.ws = (S > 1 && g_t3d_ws.ptr && (size_t)g_t3d_ws.bytes >= need && !getenv("T3D_WG_ATOMIC")) ? reinterpret_cast<float*>(g_t3d_ws.ptr) : nullptr;
   if (dtype == T3D_F32)
     hipLaunchKernelGGL(pw_wgrad_kernel<float>, dim3(tn, tk, S), dim3(256), 0, st, a);
   else if (dtype == T3D_BF16)
@@ -212,6 +227,7 @@ extern "C" int t3d_pwconv_wgrad(int dtype, const void* dz, const void* y, const 
   else
     return T3D_ERR_ARG;
   T3D_CHECK_LAUNCH();
+  if (a.ws) return t3d_pw_wgrad_reduce(a.ws, dw, N, K, TN, TK, tk, tn * tk, S, st);
   return T3D_OK;
 }
 

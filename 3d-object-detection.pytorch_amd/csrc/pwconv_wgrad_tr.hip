@@ -524,6 +524,16 @@ static int choose_and_launch(WgtArgs& a, hipStream_t st) {
 
 }  // namespace
 
+// fixed-order sum of partial tiles (straight orientation) for the fp32 parity kernel of pwconv_wgrad.hip
+int t3d_pw_wgrad_reduce(const float* ws, float* dw, int N, int K, int PB, int QB, int qtiles, int tiles, int S, hipStream_t st) {
+  const int blocks = [&](int sp) { return cdiv(N * qtiles * QB, 256 / sp); }(S >= 64 ? 16 : (S >= 8 ? 4 : 1));
+  if (S >= 64) hipLaunchKernelGGL(wgrad_reduce_kernel<16>, dim3(blocks), dim3(256), 0, st, ws, dw, N, K, PB, QB, qtiles, tiles, S);
+  else if (S >= 8) hipLaunchKernelGGL(wgrad_reduce_kernel<4>, dim3(blocks), dim3(256), 0, st, ws, dw, N, K, PB, QB, qtiles, tiles, S);
+  else hipLaunchKernelGGL(wgrad_reduce_kernel<1>, dim3(blocks), dim3(256), 0, st, ws, dw, N, K, PB, QB, qtiles, tiles, S);
+  T3D_CHECK_LAUNCH();
+  return T3D_OK;
+}
+
 // bf16 path of t3d_pwconv_wgrad (pwconv_wgrad.hip keeps the fp32 parity kernel)
 int t3d_pw_wgrad_tr_entry(const void* dz, const void* y, const t3d_bnbwd* bb, const void* x, const t3d_prologue* pro,
                           float* dw, int M, int HW, int K, int N, hipStream_t st) {
