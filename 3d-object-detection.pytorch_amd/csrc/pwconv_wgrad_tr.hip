@@ -375,34 +375,37 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
 // through LDS, so the partial reads stay coalesced along q AND the adds into dW run along k -- lanes along q added at a
 // stride of K floats (64 cache lines per wave instruction; 1.2 M such atomics for the 320 x 960 layer of the 7x7 stage:
 // 47 us, now a few).  1024 threads = 32 (q) x 32 / SP (p rows, SP of them per thread) x SP split groups.
-template <int SP>
-__global__ __launch_bounds__(1024) void wgrad_reduce_tr_kernel(const float* __restrict__ ws, float* __restrict__ dw, int N, int K,
+template <int SG>
+__global__ __launch_bounds__(256) void wgrad_reduce_tr_kernel(const float* __restrict__ ws, float* __restrict__ dw, int N, int K,
                                                                int PB, int QB, int qtiles, int tiles, int S) {
-  __shared__ float part[SP][32][33];
-  constexpr int TY = 32 / SP;
+  // 256 threads = 32 (q) x PT (p rows) x SG (split groups), PT * SG = 8: one row and S / SG partials per thread.  Many
+  // splits mean a small dW (a 112x112 layer's 96 x 24): narrow patches (PT = 1 for SG = 8) give it enough workgroups --
+  // with 32 x 32 patches three workgroups walked 256 partials per thread, 83 us of pure load latency.  (256 threads, not
+  // 1024: a 1024-thread workgroup waits for a whole free CU beside the main stream's persistent kernels.)
+  constexpr int PT = 8 / SG;
+  __shared__ float part[8][33];           // [sg * PT + pl][q]
   const int Qpad = qtiles * QB, nq = (Qpad + 31) / 32;
-  const int p0 = (blockIdx.x / nq) * 32, q0 = (blockIdx.x % nq) * 32;
-  const int tx = threadIdx.x & 31, rest = threadIdx.x >> 5, sz = rest % SP, ty = rest / SP;
+  const int p0 = (blockIdx.x / nq) * PT, q0 = (blockIdx.x % nq) * 32;
+  const int tx = threadIdx.x & 31, rest = threadIdx.x >> 5, sg = rest / PT, pl = rest % PT;
   const size_t stride = (size_t)tiles * PB * QB;
-  const int q = q0 + tx;
-#pragma unroll
-  for (int j = 0; j < SP; ++j) {
-    const int pl = ty + TY * j, p = p0 + pl;
-    float s = 0.f;
-    if (p < K && q < N) {                  // (swap: P = K, Q = N)
-      const float* src = ws + (size_t)((p / PB) * qtiles + q / QB) * (PB * QB) + (size_t)(p % PB) * QB + q % QB;
+  const int q = q0 + tx, p = p0 + pl;
+  float s = 0.f;
+  if (p < K && q < N) {                    // (swap: P = K, Q = N)
+    const float* src = ws + (size_t)((p / PB) * qtiles + q / QB) * (PB * QB) + (size_t)(p % PB) * QB + q % QB;
 #pragma unroll 8
-      for (int i = sz; i < S; i += SP) s += src[(size_t)i * stride];
-    }
-    part[sz][pl][tx] = s;
+    for (int i = sg; i < S; i += SG) s += src[(size_t)i * stride];
   }
+  part[rest][tx] = s;
   __syncthreads();
-  const int k = p0 + tx, n = q0 + rest;     // one element per thread, lanes along k
-  if (k < K && n < N) {
-    float s = part[0][tx][rest];
+  if (threadIdx.x < 32 * PT) {             // one element per thread, lanes along k (p) first
+    const int pl2 = threadIdx.x % PT, ql = threadIdx.x / PT;
+    const int k = p0 + pl2, n = q0 + ql;
+    if (k < K && n < N) {
+      float t = part[pl2][ql];
 #pragma unroll
-    for (int j = 1; j < SP; ++j) s += part[j][tx][rest];
-    dw[(size_t)n * K + k] += s;
+      for (int g = 1; g < SG; ++g) t += part[g * PT + pl2][ql];
+      dw[(size_t)n * K + k] += t;
+    }
   }
 }
 
@@ -445,7 +448,7 @@ int launch_d(WgtArgs& a, hipStream_t st) {
 #define T3D_WGR(SPV)                                                                                                              \
   do {                                                                                                                            \
     if (SWAP)                                                                                                                     \
-      hipLaunchKernelGGL(wgrad_reduce_tr_kernel<(SPV > 8 ? 8 : SPV)>, dim3(cdiv(a.K, 32) * cdiv(a.qtiles * QB, 32)), dim3(1024), 0, st, \
+      hipLaunchKernelGGL(wgrad_reduce_tr_kernel<(SPV == 16 ? 8 : SPV)>, dim3(cdiv(a.K, 8 / (SPV == 16 ? 8 : SPV)) * cdiv(a.qtiles * QB, 32)), dim3(256), 0, st, \
                          a.ws, a.dw, a.N, a.K, PB, QB, a.qtiles, tiles, S);                                                       \
     else                                                                                                                          \
       hipLaunchKernelGGL(wgrad_reduce_kernel<SPV>, dim3(cdiv(a.N * a.qtiles * QB, 256 / SPV)), dim3(256), 0, st, a.ws, a.dw, a.N, \
