@@ -103,7 +103,18 @@ def model_golden(td3, name, B, HW, num_classes, loss_names, coeffs, tag, big=Fal
     from torchdet3d.builders import build_model, build_loss
     from torchdet3d.losses import LossManager
     cfg = cfg_for(name, num_classes, loss_names, coeffs)
-    net = build_model(cfg)
+    if name == 'mobilenetv3_mnv2rows':
+        # not a name of the reference's build_model: its MobileNetV3 class (models/mobilenetv3.py:169-197) takes any row
+        # table, so it is instantiated -- through the reference's own model_wrapper (builders/model_builder.py:73-152),
+        # exactly as build_model does for 'mobilenetv3_large' (:43-46) -- with MobileNetV2's (t, c, n, s) table as rows
+        # (k=3, SE=0, HS=0): from 112x112x96 on every depthwise / pointwise layer has the headline model's shape
+        from torchdet3d.builders.model_builder import model_wrapper
+        from torchdet3d.models.mobilenetv3 import MobileNetV3
+        from oracle.specs import MNV3_ROWS
+        net = model_wrapper(model_class=MobileNetV3, output_channels=1280, num_classes=num_classes,
+                            cfgs=[list(r) for r in MNV3_ROWS[name]], mode='large')
+    else:
+        net = build_model(cfg)
     sd = make_state_dict(name, num_classes)
     assert list(net.state_dict().keys()) == list(sd.keys()), 'state-dict key mismatch'
     net.load_state_dict(sd)
@@ -166,7 +177,8 @@ def model_golden(td3, name, B, HW, num_classes, loss_names, coeffs, tag, big=Fal
     for k, p in net.named_parameters():
         g = p.grad if p.grad is not None else torch.zeros_like(p)
         out['gsum:' + k] = np.array([g.double().sum().item(), g.double().abs().sum().item()])
-        if k in full or k.startswith('features.1.') or k.startswith('features.5.') or k.startswith('classifier'):
+        if k in full or k.startswith('features.1.') or k.startswith('features.5.') or k.startswith('classifier') \
+                or (name == 'mobilenetv3_mnv2rows' and k.startswith(('features.2.', 'features.3.', 'features.14.'))):
             if g.numel() <= 40000:
                 out['grad:' + k] = g.numpy()
             else:                       # keep fixtures small: leading rows only
@@ -290,6 +302,7 @@ def main():
     model_golden(td3, 'mobilenetv3_large', 2, 224, 9, ['smoothl1', 'wing', 'cross_entropy'],
                  ([1., .3], [.5]), tag='mnv3_large_b2_224')
     model_golden(td3, 'mobilenetv3_large', 32, 224, 9, *default, tag='mnv3_large_b32_224', big=True)
+    model_golden(td3, 'mobilenetv3_mnv2rows', 32, 224, 9, *default, tag='mnv2rows_b32_224', big=True)
     losses_golden(td3)
     metrics_golden(td3)
     alwa_golden(td3)

@@ -23,6 +23,9 @@ MNV3_ROWS = {
 
 MNV2_TCNS = [(1, 16, 1, 1), (6, 24, 2, 2), (6, 32, 3, 2), (6, 64, 4, 2),
              (6, 96, 3, 1), (6, 160, 3, 2), (6, 320, 1, 1)]
+# the reference's MobileNetV3 class fed MobileNetV2's table as rows (k=3, no SE, ReLU): a model the REAL reference can
+# build (mobilenetv3.py:169-197 takes any row table) whose layers from 112x112x96 on have the headline model's shapes
+MNV3_ROWS['mobilenetv3_mnv2rows'] = [(3, t, c, 0, 0, s if i == 0 else 1) for t, c, n, s in MNV2_TCNS for i in range(n)]
 
 
 def make_divisible(v, divisor=8, min_value=None):
@@ -50,7 +53,7 @@ def arch(name):
                                act='hswish' if hs else 'relu',
                                res=(s == 1 and cin == cout)))
             cin = cout
-        feat = 1280 if name.endswith('large') else 1024
+        feat = 1024 if name.endswith('small') else 1280
         return dict(name=name, stem_c=make_divisible(16), stem_act='hswish', blocks=blocks,
                     last_c=cexp, last_act='hswish', classifier=feat, feat_c=feat)
     if name == 'mobilenetv2':

@@ -62,14 +62,18 @@ def _iou_gate(ref_kp, kp, what, kp32=None, tol=TOL):
             assert abs(iou_bf - iou_ref) < gate, (sigma, iou_bf, iou_ref)
 
 
-def test_bf16_mnv3_large_b32_224_metrics_vs_reference_golden(golden_dir):
+@pytest.mark.parametrize('tag,name', [('mnv3_large_b32_224', 'mobilenetv3_large'),
+                                      # the reference's MobileNetV3 class over MobileNetV2's row table: the headline model's
+                                      # layer shapes, outputs written by the REAL reference (oracle/gen_golden.py)
+                                      ('mnv2rows_b32_224', 'mobilenetv3_mnv2rows')])
+def test_bf16_b32_224_metrics_vs_reference_golden(golden_dir, tag, name):
     from oracle.weights import make_inputs, make_state_dict
     from torchdet3d.models.engine import Net
-    g = np.load(os.path.join(golden_dir, 'mnv3_large_b32_224.npz'))
+    g = np.load(os.path.join(golden_dir, tag + '.npz'))
     B, HW, nc = 32, 224, 9
     imgs, gt_kp, cats = make_inputs(B, HW, HW, nc)
-    net = Net('mobilenetv3_large', nc, 'cuda', torch.bfloat16)
-    net.load_state_dict(make_state_dict('mobilenetv3_large', nc))
+    net = Net(name, nc, 'cuda', torch.bfloat16)
+    net.load_state_dict(make_state_dict(name, nc))
     kp, lg = net.forward(imgs.cuda(), cats.cuda(), train=False)
     kp, lg = kp.clone(), lg.clone()
     ref_kp = torch.from_numpy(g['eval_kp'])
@@ -78,7 +82,7 @@ def test_bf16_mnv3_large_b32_224_metrics_vs_reference_golden(golden_dir):
     assert abs(a - g['eval_add_sadd'][0]) < TOL, (a, g['eval_add_sadd'])
     assert abs(s - g['eval_add_sadd'][1]) < TOL, (s, g['eval_add_sadd'])
     agree = (lg.argmax(1).cpu().numpy() == g['eval_argmax']).mean()
-    print(f'bf16 mnv3_large b32@224: dADD {a - g["eval_add_sadd"][0]:+.2e} dSADD {s - g["eval_add_sadd"][1]:+.2e} '
+    print(f'bf16 {name} b32@224: dADD {a - g["eval_add_sadd"][0]:+.2e} dSADD {s - g["eval_add_sadd"][1]:+.2e} '
           f'acc {acc} (ref {float(g["eval_acc"])}) argmax agreement {agree:.3f} '
           f'max|dkp| {(kp.cpu() - ref_kp).abs().max().item():.2e}')
     assert abs(acc - float(g['eval_acc'])) <= 1.0 / B + 1e-9      # at most one near-tie flips
@@ -95,9 +99,9 @@ def test_bf16_mnv3_large_b32_224_metrics_vs_reference_golden(golden_dir):
     N.call('t3d_loss_fwd_bwd', _loss_cfg(['l1', 'add_loss', 'cross_entropy'], ([1., .1], [.2])), N.ptr(kpt), N.ptr(gtd),
            N.ptr(lgt), N.ptr(cd), N.ptr(out), N.ptr(dkp), N.ptr(dlg), B, nc, N.stream())
     print(f'   train loss bf16 {out[0].item():.6f} reference {g["loss"][0]:.6f}')
-    # train mode: the float atomics of the squeeze-excite pooled sums make the bf16 forward itself vary run to run, and
-    # ~50 train-mode BatchNorm layers amplify that (five runs: 1.1321 .. 1.1349 against the reference's 1.1343)
-    assert abs(out[0].item() - g['loss'][0]) < 5e-3
+    # the bf16 train-mode forward is bit-reproducible since round 3 (exact pooled sums, snapped BatchNorm sums): one value per
+    # model, every run -- bounded at 2e-3 absolute (it was 5e-3 while float atomics made the value wander)
+    assert abs(out[0].item() - g['loss'][0]) < 2e-3
 
 
 def test_bf16_mnv2_b256_224_eval_metrics_vs_cpu_oracle():

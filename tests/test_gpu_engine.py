@@ -260,6 +260,7 @@ def test_bf16_train_forward_is_bit_reproducible(name, B, HW):
 
 
 @pytest.mark.parametrize('name,B,HW,storage', [('mobilenetv2', 64, 224, 'bf16'), ('mobilenetv2', 16, 96, 'bf16'), ('resnet50', 8, 96, 'bf16'),
+                                               ('resnet50', 64, 224, 'bf16'),      # BASELINE config 4's per-GPU workload
                                                ('mobilenetv3_large', 64, 224, 'bf16'), ('mobilenetv3_large', 16, 96, 'bf16'),
                                                ('mobilenetv3_small', 32, 128, 'bf16'), ('mobilenetv2', 32, 128, 'f32')])
 def test_bf16_training_is_bit_reproducible_run_to_run(name, B, HW, storage):

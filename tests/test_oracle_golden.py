@@ -14,7 +14,9 @@ from oracle.weights import make_inputs, make_state_dict
 CASES = [('mnv3_large_b4_96', 'mobilenetv3_large', 4, 96, 9, ['l1', 'add_loss', 'cross_entropy'], ([1., .1], [.2])),
          ('mnv3_small_b4_96', 'mobilenetv3_small', 4, 96, 9, ['l1', 'add_loss', 'cross_entropy'], ([1., .1], [.2])),
          ('mnv3_large_c1_b8_96', 'mobilenetv3_large', 8, 96, 1, ['mse', 'diag_loss', 'add_loss'], ([1., .5, .1], [])),
-         ('mnv3_large_b2_224', 'mobilenetv3_large', 2, 224, 9, ['smoothl1', 'wing', 'cross_entropy'], ([1., .3], [.5]))]
+         ('mnv3_large_b2_224', 'mobilenetv3_large', 2, 224, 9, ['smoothl1', 'wing', 'cross_entropy'], ([1., .3], [.5])),
+         # the reference's MobileNetV3 class over MobileNetV2's row table (the headline model's layer shapes), 32 crops @224
+         ('mnv2rows_b32_224', 'mobilenetv3_mnv2rows', 32, 224, 9, ['l1', 'add_loss', 'cross_entropy'], ([1., .1], [.2]))]
 
 
 @pytest.mark.parametrize('tag,name,B,HW,nc,lnames,coeffs', CASES)
