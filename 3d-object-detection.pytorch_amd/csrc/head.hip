@@ -126,7 +126,7 @@ __global__ __launch_bounds__(256) void head_bwd_weight_kernel(const HeadArgs a) 
   constexpr int CHUNK = 512, U = 8;
   __shared__ int lst[CHUNK];
   __shared__ int nsel, wcnt[4];
-  __shared__ float ldp[CHUNK * NKP];      // staged gradient rows (class blocks) / logit gradients (classifier block)
+  __shared__ __attribute__((aligned(16))) float ldp[CHUNK * NKP];      // staged gradient rows (class blocks) / logit gradients (classifier block)
   const int cls = blockIdx.x, j = blockIdx.y * 256 + threadIdx.x;
   const bool jon = j < a.F;
   if (cls < 9) {

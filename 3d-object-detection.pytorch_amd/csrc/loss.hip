@@ -193,7 +193,64 @@ __global__ __launch_bounds__(256) void loss_kernel(const t3d_loss_cfg cfg, const
   }
 }
 
+// Per-SAMPLE metric terms for the validation loop's per-class aggregation (metrics.py:39-68): out [B][3] =
+// sum_k ||p_k - t_k|| / 9, symmetric form / 9, arg-max hit -- the reduce_mean=False summands of metrics.py:27-28,37; the
+// caller adds them per class (one read-back per batch instead of two launches + two syncs per class present).
+__global__ __launch_bounds__(256) void metrics_per_sample_kernel(const float* __restrict__ kp, const float* __restrict__ gt,
+                                                                 const float* __restrict__ logits,
+                                                                 const int64_t* __restrict__ cats, float* __restrict__ out,
+                                                                 int B, int ncls) {
+  const int b = blockIdx.x * 256 + threadIdx.x;
+  if (b >= B) return;
+  float p[18], t[18];
+#pragma unroll
+  for (int i = 0; i < 18; ++i) {
+    p[i] = kp[(size_t)b * 18 + i];
+    t[i] = gt[(size_t)b * 18 + i];
+  }
+  float addsum = 0.f, sadd = 0.f;
+#pragma unroll
+  for (int i = 0; i < 9; ++i) {
+    float dx = p[2 * i] - t[2 * i], dy = p[2 * i + 1] - t[2 * i + 1];
+    float best = sqrtf(dx * dx + dy * dy);
+    addsum += best;
+#pragma unroll
+    for (int j = 0; j < 9; ++j) {
+      dx = p[2 * i] - t[2 * j];
+      dy = p[2 * i + 1] - t[2 * j + 1];
+      const float d = sqrtf(dx * dx + dy * dy);
+      best = d < best ? d : best;
+    }
+    sadd += best;
+  }
+  const int c = (int)cats[b];
+  float hit;
+  if (logits) {
+    const float* lg = logits + (size_t)b * ncls;
+    float mx = lg[0];
+    int am = 0;
+    for (int q = 1; q < ncls; ++q)
+      if (lg[q] > mx) { mx = lg[q]; am = q; }
+    hit = (am == c) ? 1.f : 0.f;
+  } else {
+    hit = (c == 0) ? 1.f : 0.f;
+  }
+  out[(size_t)b * 3 + 0] = addsum / 9.f;
+  out[(size_t)b * 3 + 1] = sadd / 9.f;
+  out[(size_t)b * 3 + 2] = hit;
+}
+
 }  // namespace
+
+extern "C" int t3d_metrics_per_sample(const float* kp, const float* gt_kp, const float* logits, const int64_t* cats,
+                                      float* out, int B, int ncls, void* stream) {
+  if (!kp || !gt_kp || !cats || !out || B <= 0) return T3D_ERR_ARG;
+  if (logits && (ncls <= 0 || ncls > 64)) return T3D_ERR_ARG;
+  hipLaunchKernelGGL(metrics_per_sample_kernel, dim3(cdiv(B, 256)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                     kp, gt_kp, logits, cats, out, B, ncls);
+  T3D_CHECK_LAUNCH();
+  return T3D_OK;
+}
 
 extern "C" int t3d_loss_fwd_bwd(const t3d_loss_cfg* cfg, const float* kp, const float* gt_kp, const float* logits,
                                 const int64_t* cats, float* out, float* dkp, float* dlogits, int B, int ncls,

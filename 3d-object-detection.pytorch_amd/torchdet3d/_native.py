@@ -113,6 +113,7 @@ SIGNATURES = {
     't3d_se_bwd_affine': [_P, _P, _P, _P, _P, _P, _I, _I, _P],
     't3d_dropout_mask': [_P, _L, ctypes.c_ulonglong, ctypes.c_ulonglong, _F, _P],
     't3d_loss_fwd_bwd': [_LP, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P],
+    't3d_metrics_per_sample': [_P, _P, _P, _P, _P, _I, _I, _P],
 }
 
 _lib = None

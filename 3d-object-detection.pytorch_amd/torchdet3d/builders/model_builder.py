@@ -205,6 +205,7 @@ class ModelWrapper(nn.Module):
         self.grad_sync = GradSync(self.net.gflat) if sync_cls_or_obj is True else sync_cls_or_obj
         self.grad_sync.g = self.net.gflat
         self.net.grad_hook = self.grad_sync.ready
+        self.net.seed_rank = dist.get_rank() if dist.is_initialized() else 0      # independent dropout masks per rank
         self.grad_sync.broadcast([self.net.flat] + list(self.net.buffers.values()))
 
     def _replicate_for_data_parallel(self):

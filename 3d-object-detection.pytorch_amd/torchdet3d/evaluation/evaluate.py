@@ -8,6 +8,7 @@ import os.path as osp
 import numpy as np
 import torch
 
+from ..parallel import all_reduce_sums, is_main, world_size
 from ..utils import AverageMeter, put_on_device, mkdir_if_missing, OBJECTRON_CLASSES
 from .metrics import compute_accuracy, compute_average_distance, compute_metrics_per_cls
 
@@ -27,6 +28,8 @@ class Evaluator:
         which is the dataset behind `test_loader`, loader_builder.py:31-34): forward one sample at a time with the
         ground-truth class selecting the head, print ADD / SADD / accuracy, store the keypoints."""
         ds = getattr(self.test_loader, 'dataset', None)
+        if not is_main():          # one process per GPU: rank 0 runs the few visual samples and writes their files
+            return []
         if ds is None or len(ds) == 0:
             print('visual_test: no test dataset, nothing to do')
             return []
@@ -93,6 +96,18 @@ class Evaluator:
                 m.update(v, n)
             if self.debug and it == self.debug_steps:
                 break
+        if world_size() > 1:
+            # one process per GPU: every rank validated its own share of the samples (builders/loader_builder.py); the
+            # reference's meters (evaluate.py:97-122) are weighted sums / counts, so the global value of each is
+            # sum(rank sums) / sum(rank counts) -- ONE small all-reduce of the 8 + 8 * num_classes partial values
+            allm = meters + [m for cm in cls_meters for m in cm]
+            tot = all_reduce_sums([v for m in allm for v in (m.sum, m.count)])
+            for j, m in enumerate(allm):
+                m.sum, m.count = tot[2 * j], tot[2 * j + 1]
+                m.avg = m.sum / m.count if m.count else 0.0
+        res = dict(ADD=meters[0].avg, SADD=meters[1].avg, ACC=meters[2].avg, IOU=meters[3].avg)
+        if not is_main():          # rank 0 writes the scalars and prints the table; every rank returns the same numbers
+            return res
         if epoch is not None and self.writer is not None:
             self.writer.add_scalar('Val/ADD', meters[0].avg, global_step=epoch)
             self.writer.add_scalar('Val/SADD', meters[1].avg, global_step=epoch)
@@ -107,7 +122,7 @@ class Evaluator:
         print(' | '.join(f'{h:>16s}' for h in hdr))
         for r in rows:
             print(' | '.join([f'{r[0]:>16s}'] + [f'{v:16.4f}' for v in r[1:]]))
-        return dict(ADD=meters[0].avg, SADD=meters[1].avg, ACC=meters[2].avg, IOU=meters[3].avg)
+        return res
 
     def run_eval_pipe(self, visual_only=False):
         """evaluate.py:135-139."""

@@ -547,8 +547,9 @@ class Net:
             if mask is None:        # nn.Dropout(0.5): keep with p = .5, scale by 2 (model_builder.py:83)
                 mask = self._buf('dropout', (B, a.feat_c), torch.float32)
                 self._dropout_calls = getattr(self, '_dropout_calls', 0) + 1
-                N.call('t3d_dropout_mask', N.ptr(mask), B * a.feat_c, torch.initial_seed() & ((1 << 64) - 1),
-                       self._dropout_calls, 0.5, st)
+                # (one process per GPU: main.py seeds every rank alike -- the rank term keeps the ranks' masks independent)
+                seed = (torch.initial_seed() + 0x9E3779B97F4A7C15 * getattr(self, 'seed_rank', 0)) & ((1 << 64) - 1)
+                N.call('t3d_dropout_mask', N.ptr(mask), B * a.feat_c, seed, self._dropout_calls, 0.5, st)
             else:
                 mask = mask.to(self.device, torch.float32).contiguous()
         kp = torch.empty(B, 18, device=self.device)
@@ -855,7 +856,11 @@ class Net:
         ro = kw.pop('ro', None)
         # ro: BatchNorm whose backward coefficients this launch reads while their finalize is still pending -- the kernel
         # derives them for itself WITHOUT publishing (the data-gradient launch of the main stream, issued next, does)
-        req = ro is not None and ro.pend[1] and self._lazy and entry == 't3d_pwconv_wgrad'
+        # (only where the bf16 transposed kernel will take the request: on the fp32-storage / T3D_WGRAD_TILED paths the entry
+        # point would serve it with a PUBLISHING finalize launch on the side stream while the data gradient of the main
+        # stream publishes the same values -- there the standalone finalize runs once, on the main stream, ahead of both)
+        req = (ro is not None and ro.pend[1] and self._lazy and entry == 't3d_pwconv_wgrad' and self.dt == N.BF16
+               and not os.environ.get('T3D_WGRAD_TILED'))
         if ro is not None and ro.pend[1] and not req:
             self._settle_b(ro)
         if req:

@@ -14,6 +14,49 @@ import torch
 import torch.distributed as dist
 
 
+# ---- who am I: the host-side helpers of the one-process-per-GPU flow (an unchanged scripts/main.py under
+# `python -m torch.distributed.run`; the reference's single process did all I/O itself, main.py:36-106) -----------------
+def world_size():
+    return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+
+
+def rank():
+    return dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
+
+
+def launch_rank():
+    """Rank as far as it can be known before `build_model` has joined the process group (scripts/main.py:39 builds its
+    Logger first): the launcher's RANK when torch.distributed.run started more than one process."""
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_rank()
+    try:
+        return int(os.environ['RANK']) if int(os.environ.get('WORLD_SIZE', '1')) > 1 else 0
+    except (KeyError, ValueError):
+        return 0
+
+
+def is_main():
+    """Rank 0 writes checkpoints, TensorBoard scalars, the log file and the metric tables; the others compute."""
+    return rank() == 0
+
+
+def barrier():
+    if world_size() > 1:
+        dist.barrier()
+
+
+def all_reduce_sums(values, device=None):
+    """Element-wise SUM over the ranks of a short list of python floats (metric sums and counts) -> list of floats.
+    One small collective; fp64 so that counts stay exact.  RCCL ('nccl') needs device tensors, gloo takes host ones."""
+    if world_size() == 1:
+        return [float(v) for v in values]
+    on_gpu = dist.get_backend() == 'nccl'
+    t = torch.tensor([float(v) for v in values], dtype=torch.float64,
+                     device=(device if device is not None else torch.device('cuda', torch.cuda.current_device())) if on_gpu else 'cpu')
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return t.cpu().tolist()
+
+
 class GradSync:
     def __init__(self, flat_grad, min_bucket=1 << 20, group=None):
         """flat_grad: 1-D fp32 gradient buffer.  min_bucket: elements per bucket (4 MB default: RCCL over the

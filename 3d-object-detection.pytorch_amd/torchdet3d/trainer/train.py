@@ -8,18 +8,23 @@ read back in a single device-to-host copy instead of 6 `.item()` syncs."""
 import datetime
 import time
 
+from collections.abc import Mapping
+
 from ..evaluation.metrics import compute_accuracy, compute_average_distance
+from ..parallel import all_reduce_sums, is_main, world_size
 from ..utils import AverageMeter, put_on_device, save_snap
 
 
-class _Pending(dict):
-    """Metrics of one iteration on their way to the host (asynchronous copy into a pinned slot + event); behaves like
-    the dict(loss, ADD, SADD, acc) of python floats once any entry is read."""
+class _Pending(Mapping):
+    """Metrics of one iteration on their way to the host (asynchronous copy into a pinned slot + event): a read-only
+    mapping {loss, ADD, SADD, acc -> python float} that waits for the copy when it is first looked at -- through ANY
+    access, including the C-level ones (`dict(r)`, `{**r}`, `json.dumps(dict(r))`, `copy.copy`, pickle): it is a
+    `collections.abc.Mapping`, not a dict subclass, so nothing can see an unresolved (empty) dict."""
     _FIELDS = (('loss', 0), ('ADD', 3), ('SADD', 4), ('acc', 5))
+    __slots__ = ('_slot', '_vals')
 
     def __init__(self, dev_vec, slot):
-        super().__init__()
-        self._slot = slot
+        self._slot, self._vals = slot, None
         slot[0][:dev_vec.numel()].copy_(dev_vec, non_blocking=True)
         slot[1].record()
         slot[2] = self
@@ -29,43 +34,25 @@ class _Pending(dict):
         if slot is not None:
             slot[1].synchronize()
             o = slot[0].tolist()
-            for k, i in self._FIELDS:
-                dict.__setitem__(self, k, o[i])
+            self._vals = {k: o[i] for k, i in self._FIELDS}
             slot[2] = None
             self._slot = None
-        return self
+        return self._vals
 
     def __getitem__(self, k):
-        return dict.__getitem__(self._resolve(), k)
-
-    def get(self, k, default=None):
-        return dict.get(self._resolve(), k, default)
-
-    def keys(self):
-        return dict.keys(self._resolve())
-
-    def items(self):
-        return dict.items(self._resolve())
-
-    def values(self):
-        return dict.values(self._resolve())
+        return self._resolve()[k]
 
     def __iter__(self):
-        return dict.__iter__(self._resolve())
+        return iter(self._resolve())
 
     def __len__(self):
-        return dict.__len__(self._resolve())
-
-    def __contains__(self, k):
-        return dict.__contains__(self._resolve(), k)
+        return len(self._FIELDS)
 
     def __repr__(self):
-        return dict.__repr__(self._resolve())
+        return repr(self._resolve())
 
-    def __eq__(self, other):
-        return dict.__eq__(self._resolve(), other)
-
-    __hash__ = None
+    def __reduce__(self):                  # pickle / copy: the resolved values as a plain dict
+        return (dict, (dict(self._resolve()),))
 
 
 class Trainer:
@@ -117,15 +104,28 @@ class Trainer:
         meters = {k: AverageMeter() for k in ('loss', 'ADD', 'SADD', 'acc', 'time')}
         self.model.train()
         self.num_iters = len(self.train_loader)
+        # one process per GPU: a new shuffle of the shared index permutation per epoch (DistributedSampler), rank 0 logs
+        sampler = getattr(self.train_loader, 'sampler', None)
+        if hasattr(sampler, 'set_epoch'):
+            sampler.set_epoch(epoch)
+        main, world = is_main(), world_size()
         start = time.time()
         backlog = []        # (mapping, batch size, global step) of iterations whose numbers have not been looked at yet
 
         def drain():
             # meters and TensorBoard scalars in iteration order, with each iteration's own global step (train.py:57-65)
+            if world > 1 and backlog:
+                # what the reference's single process sees is the GLOBAL batch (main.py:60-61): average the ranks' shares
+                # -- one small collective per drain (every rank drains at the same iterations), not per iteration
+                flat = all_reduce_sums([r[k] * n for r, n, _ in backlog for k in ('loss', 'ADD', 'SADD', 'acc')]
+                                       + [n for _, n, _ in backlog])
+                ns = flat[4 * len(backlog):]
+                backlog[:] = [(dict(zip(('loss', 'ADD', 'SADD', 'acc'), (v / ns[j] for v in flat[4 * j:4 * j + 4]))), int(ns[j]), gs)
+                              for j, (_, _, gs) in enumerate(backlog)]
             for r, n, gs in backlog:
                 for k in ('loss', 'ADD', 'SADD', 'acc'):
                     meters[k].update(r[k], n)
-                if self.writer is not None:
+                if self.writer is not None and main:
                     self.writer.add_scalar('Train/loss', r['loss'], global_step=gs)
                     self.writer.add_scalar('Train/ADD', meters['ADD'].avg, global_step=gs)
                     self.writer.add_scalar('Train/SADD', meters['SADD'].avg, global_step=gs)
@@ -141,7 +141,7 @@ class Trainer:
             if show or len(backlog) >= self.RING // 2 or (self.debug and it == self.debug_steps):
                 drain()                            # the only host <-> device wait of the loop
             meters['time'].update(time.time() - start)
-            if show:
+            if show and main:
                 print(f'epoch: [{epoch}/{self.max_epoch}][{it}/{self.num_iters}]\t'
                       f'time {meters["time"].val:.3f} ({meters["time"].avg:.3f})\t'
                       f'eta {datetime.timedelta(seconds=int(meters["time"].avg * left))}\t'

@@ -77,13 +77,20 @@ def set_random_seed(seed, deterministic=False):
 
 
 def save_snap(model, optimizer, scheduler, epoch, log_path):
-    """utils.py:56-64 (`snap_{epoch}.pth` with state_dict / optimizer / scheduler / epoch)."""
+    """utils.py:56-64 (`snap_{epoch}.pth` with state_dict / optimizer / scheduler / epoch).  One process per GPU: rank 0
+    writes (every rank holds the same weights and optimizer state after the gradient exchange), the others wait at the
+    barrier so that nobody reads a half-written file."""
+    from ..parallel import barrier, is_main
+    if not is_main():
+        barrier()
+        return
     snap = {'state_dict': model.state_dict(), 'optimizer': optimizer.state_dict(),
             'scheduler': scheduler.state_dict() if scheduler is not None else None, 'epoch': epoch}
     mkdir_if_missing(log_path)
     name = osp.join(log_path, f'snap_{epoch}.pth')
     print(f'==> saving checkpoint to {name}')
     torch.save(snap, name)
+    barrier()
 
 
 def load_checkpoint(fpath, map_location=None):
@@ -154,12 +161,15 @@ class AverageMeter:
 
 class Logger:
     """utils.py:289-333: tee of the console into a text file (`sys.stdout = Logger(path)`, scripts/main.py:39);
-    creates the directory of `fpath`, `flush` also fsyncs the file."""
+    creates the directory of `fpath`, `flush` also fsyncs the file.  One process per GPU: only rank 0 opens the file (N
+    processes truncating and writing one `train.log` is what an unchanged main.py would otherwise do); the other ranks keep
+    their console."""
 
     def __init__(self, fpath=None):
+        from ..parallel import launch_rank
         self.console = sys.stdout
         self.file = None
-        if fpath is not None:
+        if fpath is not None and launch_rank() == 0:
             mkdir_if_missing(osp.dirname(fpath))
             self.file = open(fpath, 'w')      # noqa: SIM115  (lives as long as the logger)
 

@@ -81,7 +81,8 @@ def api_objects(args, dev):
     from torchdet3d.trainer import Trainer
     from torchdet3d.utils.utils import AttrDict
     cfg = AttrDict(dict(
-        model=dict(name=args.model, num_classes=9, pretrained=False, load_weights='', storage_dtype=args.dtype),
+        model=dict(name=args.model, num_classes=9, pretrained=False, load_weights='', storage_dtype=args.dtype,
+                   eval_storage_dtype=args.eval_dtype or None),
         data=dict(normalization=dict(mean=[0.5931, 0.4690, 0.4229], std=[0.2471, 0.2214, 0.2157])),
         data_parallel=dict(use_parallel=False),
         optim=dict(name='adam', lr=1e-3, wd=1e-4, betas=(0.9, 0.999)),          # default_config.py:18
@@ -95,6 +96,11 @@ def api_objects(args, dev):
     lm = LossManager(build_loss(cfg), cfg.loss.coeffs, cfg.loss.alwa)
     tr = Trainer(model, None, opt, None, lm, None, 1, '', device=dev, save_chkpt=False)
     model.train()
+    if args.eval:
+        # the validation loop's body (evaluation/evaluate.py:88-95): eval-mode forward + per-class metrics incl. the 3-D IoU
+        from torchdet3d.evaluation import Evaluator
+        model.eval()
+        return model, Evaluator(model=model, val_loader=None, cfg=cfg, device=dev)
     return model, tr
 
 
@@ -111,8 +117,11 @@ def parse():
     ap.add_argument('--cpu-batch', type=int, default=16)
     ap.add_argument('--cpu-steps', type=int, default=60)
     ap.add_argument('--cpu-baseline-only', action='store_true', help=argparse.SUPPRESS)
-    ap.add_argument('--eval', action='store_true', help='time the inference forward (Evaluator.val_step: running BatchNorm '
-                    'statistics, values-only losses + metrics) instead of the train step')
+    ap.add_argument('--eval', action='store_true', help='time the validation step instead of the train step: `Evaluator.val_step` '
+                    'of a model built by build_model (eval-mode forward on the engine `model.eval_storage_dtype` selects -- fp32 '
+                    'storage by default, also for a bf16 model -- + ADD / SADD / accuracy / 3-D IoU per class)')
+    ap.add_argument('--eval-dtype', default='', choices=['', 'bf16', 'f32'], help="model.eval_storage_dtype for --eval; 'bf16' is "
+                    'the OPT-IN throughput inference, outside the 1e-3 3-D-IoU bound for MobileNetV2 (labelled in the output)')
     ap.add_argument('--engine', action='store_true', help='drive models.engine.Net + the loss / optimizer kernels directly '
                     'instead of going through the reference-shaped API (build_model / build_optimizer / LossManager / '
                     'Trainer.train_step), which is what the headline number is measured through')
@@ -206,7 +215,7 @@ def main():
 
     B, S = args.batch, args.size
     dtype = torch.bfloat16 if args.dtype == 'bf16' else torch.float32
-    use_api = not args.eval and not args.engine
+    use_api = not args.engine
     torch.manual_seed(5)
     if use_api:
         model, trainer = api_objects(args, dev)
@@ -234,13 +243,16 @@ def main():
     out = torch.zeros(16, device=dev)
     dkp, dlg = torch.empty(B, 18, device=dev), torch.empty(B, 9, device=dev)
 
+    last = [None]
+
     def eval_step(i):
         j = i % nb
+        if use_api:
+            last[0] = trainer.val_step(imgs[j], gts[j].view(B, 9, 2), cats[j], compute_iou=True)     # (trainer = the Evaluator)
+            return
         kp, lg = net.forward(imgs[j], cats[j], train=False)
         N.call('t3d_loss_fwd_bwd', cfg, N.ptr(kp), N.ptr(gts[j]), N.ptr(lg), N.ptr(cats[j]), N.ptr(out), None, None, B, 9,
                N.stream())
-
-    last = [None]
 
     def step(i):
         if args.eval:
@@ -341,22 +353,28 @@ def main():
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = t.item()
-    loss = last[0]['loss'] if use_api else out[0].item()
+    loss = (last[0][1] if args.eval else last[0]['loss']) if use_api else out[0].item()      # (--eval through the API: the batch's ADD)
     assert loss == loss or os.environ.get('T3D_ABLATE'), 'loss is NaN'
 
+    eval_dt = None
+    if args.eval:
+        eval_dt = ('bf16' if model.net_eval.dtype == torch.bfloat16 else 'f32') if use_api else args.dtype
     if rank == 0:
         crops = B * world * args.steps / dt
         res = {
             'metric': f'regression {"eval" if args.eval else "train"} crops/sec @{S}^2 bs{B} ' + {'mobilenetv2': 'MobileNetV2', 'mobilenetv3_large': 'MobileNetV3-large', 'mobilenetv3_small': 'MobileNetV3-small', 'resnet50': 'ResNet-50'}.get(args.model, args.model), 'value': round(crops, 1), 'unit': 'crops/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(dt / args.steps * 1e3, 3),
-            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': args.dtype, 'data': 'synthetic',
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': eval_dt if args.eval else args.dtype, 'data': 'synthetic',
             'config': {'workload': f'{args.model} 9-class Objectron keypoint regression, '
-                                   + ('inference forward (running BatchNorm statistics) + loss / metric values'
+                                   + ((f'validation step (Evaluator.val_step: eval-mode forward in {eval_dt} storage + per-class ADD / SADD / '
+                                       'accuracy / 3-D IoU, one read-back per batch)' if use_api else
+                                       'inference forward (running BatchNorm statistics) + loss / metric values')
                                       if args.eval else
                                       f'train step (fwd + l1/add/CE losses + bwd + AdamW{" + RCCL grad all-reduce" if world > 1 else ""})')
                                    + f', {S}x{S} crops, per-GPU batch {B}', 'global_batch': B * world, 'parallelism': f'dp{world}',
                        'final_loss': round(loss, 5), 'host_issue_ms_per_step': round(t_issue * 1e3, 3),
-                       'driven_through': ('torchdet3d.builders.build_model / build_optimizer / LossManager / Trainer.train_step'
+                       'driven_through': (('torchdet3d.builders.build_model / Evaluator.val_step' if args.eval else
+                                           'torchdet3d.builders.build_model / build_optimizer / LossManager / Trainer.train_step')
                                           if use_api else 'models.engine.Net + loss / optimizer entry points'),
                        'roofline_sampled_steps': nsampled,
                        'device_warmup_s': device_warmup_s, 'step_ms_min_med_max': [round(per_step[0], 3), round(per_step[len(per_step) // 2], 3), round(per_step[-1], 3)], 'side_stream_probe': list(__import__('torchdet3d.models.engine', fromlist=['x'])._concurrent_stream.log), 'rccl_ranks': world if dist.is_initialized() else 0},
@@ -407,8 +425,15 @@ def main():
                                'depthwise': rows}
         if args.model == 'mobilenetv2' and S == 224 and args.dtype == 'bf16':
             per_crop = 26.89 if args.eval else MNV2_TRAIN_MB_PER_CROP     # forward / train MB per crop
+            if args.eval and eval_dt == 'f32':
+                per_crop *= 2                                              # fp32 storage: 4 B per element
             res['config']['step_hbm_roofline_frac'] = round(crops / world * per_crop * 1e6 / HBM_PEAK, 4)
-        if world == 1 and not args.no_cpu_baseline:
+        if args.eval and eval_dt == 'bf16' and args.model == 'mobilenetv2':
+            # the opt-in bf16 INFERENCE of this model is outside the north-star's 3-D-IoU bound: say so next to the number
+            res['config']['parity_note'] = ('bf16 inference is NOT parity-gated: 3-D IoU deviates by 2e-3 (sigma 0.024) .. 4e-3 from the fp32 '
+                                            'oracle (bound 1e-3; tests/test_gpu_bf16_gate.py); the default eval engine (fp32 storage) '
+                                            'meets it')
+        if world == 1 and not args.no_cpu_baseline and not args.eval:
             res['cpu_baseline'] = cpu_baseline_guarded(args)
         print(json.dumps(res), flush=True)
     if dist.is_initialized():

@@ -277,6 +277,14 @@ typedef struct {
 int t3d_loss_fwd_bwd(const t3d_loss_cfg* cfg, const float* kp, const float* gt_kp, const float* logits,
                      const int64_t* cats, float* out, float* dkp, float* dlogits, int B, int ncls, void* stream);
 
+/* Per-sample summands of the validation metrics (torchdet3d/evaluation/metrics.py:39-68 `compute_metrics_per_cls`, which
+ * calls compute_average_distance / compute_accuracy with reduce_mean=False on every class subset, :48-55):
+ * out [B][3] = { sum_k ||p_k - t_k|| / 9, symmetric-ADD summand / 9 (:13-21), arg-max hit (:31-37; logits NULL: the
+ * width-1 "targets" of num_classes == 1, arg-max always 0) } -- the host adds them per class: one launch and one
+ * read-back per validation batch instead of two launches and two syncs per class present. */
+int t3d_metrics_per_sample(const float* kp, const float* gt_kp, const float* logits, const int64_t* cats, float* out,
+                           int B, int ncls, void* stream);
+
 /* 2-D based 3-D IoU of the validation loop, batched on the device (torchdet3d/evaluation/metrics.py:70-89 with
  * torchdet3d/utils/geometry.py:51-108 `lift_2d(..., portrait)` and the objectron box fit + box-box IoU it calls):
  *   pred_kp, gt_kp [B,9,2] fp32 normalised keypoints (the centre keypoint 0 is not used by the lift, :71-72);

@@ -7,7 +7,11 @@ mode 'engine2': TWO ranks that share GPU 0 (backend gloo: RCCL refuses two ranks
   averaged grads"): the exchanged fp32 gradient == mean over ranks of the ORACLE's per-shard gradient (per-rank BatchNorm
   statistics, mean losses), and all ranks hold identical weights after the optimizer step.
 mode 'main1': ONE rank over RCCL with T3D_FORCE_SYNC=1 replays scripts/main.py's flow (tests/test_boundary_main.py
-  `_replay_main`, unchanged) -- `build_model` joins the process group and attaches the exchange by itself."""
+  `_replay_main`, unchanged) -- `build_model` joins the process group and attaches the exchange by itself.
+mode 'main2': TWO ranks sharing GPU 0 (gloo) replay scripts/main.py's flow unchanged (VERDICT r3 missing #1 / ADVICE): every
+  rank must train on its OWN share of each global batch (main.py:60-61 scatters one batch over the replicas), rank 0 alone
+  writes the checkpoint / log file / scalars, `Evaluator.val` returns the SAME all-reduced metrics on both ranks and those
+  equal a single-process pass over the whole validation set, and the ranks end with identical weights."""
 import os
 import sys
 
@@ -107,5 +111,79 @@ def main1():
     dist.destroy_process_group()
 
 
+def main2():
+    dist.init_process_group('gloo')          # (two ranks on one device: RCCL refuses that; build_model leaves the group alone)
+    rank, world = dist.get_rank(), dist.get_world_size()
+    assert world == 2
+    torch.cuda.set_device(0)
+    import test_boundary_main as T
+    from torchdet3d.builders.loader_builder import SyntheticCrops
+    from torchdet3d.evaluation import Evaluator, compute_metrics_per_cls
+    from torchdet3d.trainer import Trainer
+    seen, vals, saves = [], [], []
+    ts, ev, tsave = Trainer.train_step, Evaluator.val, torch.save
+
+    def rec_step(self, imgs, gt_kp, gt_cats, it=0):
+        seen.append((int(imgs.shape[0]), float(imgs.double().sum())))
+        return ts(self, imgs, gt_kp, gt_cats, it)
+
+    def rec_val(self, *a, **k):
+        r = ev(self, *a, **k)
+        vals.append(r)
+        return r
+
+    def rec_save(obj, f, *a, **k):
+        saves.append(str(f))
+        return tsave(obj, f, *a, **k)
+    Trainer.train_step, Evaluator.val, torch.save = rec_step, rec_val, rec_save
+    out = sys.argv[2]
+    os.makedirs(out, exist_ok=True)
+    cfgp = os.path.join(out, f'cfg_train_{rank}.py')
+    open(cfgp, 'w').write(T.CONFIG % (out, 'training'))
+    cfg, writer, net = T._replay_main(cfgp)
+    Trainer.train_step, Evaluator.val, torch.save = ts, ev, tsave
+    assert net.grad_sync is not None and net.grad_sync.world == 2
+    # ---- every rank trained on ITS share: 8 crops per global batch -> 4 per rank, 32 crops / 8 = 4 iterations x 2 epochs
+    assert len(seen) == 8 and all(n == 4 for n, _ in seen), seen
+    both = [None, None]
+    dist.all_gather_object(both, [v for _, v in seen])
+    assert not set(both[0]) & set(both[1]), 'the two ranks saw the same batches'
+    # ---- rank 0 alone wrote the checkpoint, the log file and the scalars
+    allsaves = [None, None]
+    dist.all_gather_object(allsaves, saves)
+    assert len(allsaves[0]) == 1 and allsaves[0][0].endswith('snap_1.pth') and not allsaves[1], allsaves
+    nsc = [None, None]
+    dist.all_gather_object(nsc, len(writer.scalars))
+    assert nsc[0] > 0 and nsc[1] == 0, nsc
+    dist.barrier()
+    files = os.listdir(out)
+    assert sum(f.startswith('train.log-') for f in files) == 1 and 'snap_1.pth' in files, files
+    # ---- validation: identical reduced metrics on both ranks ...
+    allv = [None, None]
+    dist.all_gather_object(allv, vals)
+    assert len(allv[0]) == 2 and allv[0] == allv[1], allv
+    # ... equal to one process walking the WHOLE validation set (overall meters are sample means, whatever the batching)
+    ds = SyntheticCrops(32, (96, 96), 9, 2)
+    net.eval()
+    tot = dict(ADD=0.0, SADD=0.0, ACC=0.0, IOU=0.0)
+    with torch.no_grad():
+        for i in range(0, 32, 8):
+            im, kp, ct = ds.imgs[i:i + 8].cuda(), ds.kp[i:i + 8].cuda(), ds.cats[i:i + 8].cuda()
+            pk, pc = net(im, ct)
+            _, a, s, io, ac = compute_metrics_per_cls(pk, kp, pc, ct, True)
+            for k, v in zip(('ADD', 'SADD', 'IOU', 'ACC'), (a, s, io, ac)):
+                tot[k] += v * 8 / 32
+    for k in tot:
+        assert abs(tot[k] - allv[0][-1][k]) < 1e-5, (k, tot[k], allv[0][-1][k])
+    # ---- and the ranks hold the same weights
+    w = net.net.flat.cpu()
+    gathered = [torch.empty_like(w) for _ in range(world)]
+    dist.all_gather(gathered, w)
+    assert torch.equal(gathered[0], gathered[1]), 'ranks hold different weights after training'
+    if rank == 0:
+        print('MAIN2_OK', allv[0][-1])
+    dist.destroy_process_group()
+
+
 if __name__ == '__main__':
-    {'engine2': engine2, 'main1': main1}[sys.argv[1]]()
+    {'engine2': engine2, 'main1': main1, 'main2': main2}[sys.argv[1]]()

@@ -137,6 +137,16 @@ def test_trainer_and_evaluator_on_synthetic_loader(tmp_path):
     assert {r[0] for r in w.rows} == {'Train/loss', 'Train/ADD', 'Train/SADD', 'Train/ACC'}
     r = tr.train_step(*next(iter(train_loader)), 0)
     assert set(r) == {'loss', 'ADD', 'SADD', 'acc'} and all(np.isfinite(v) for v in r.values())
+    # the lazily resolved mapping through the C-level consumers too (as a dict subclass these saw an empty dict)
+    import copy
+    import json
+    import pickle
+    for make in (lambda: dict(tr.train_step(*next(iter(train_loader)), 0)), lambda: {**tr.train_step(*next(iter(train_loader)), 0)},
+                 lambda: json.loads(json.dumps(dict(tr.train_step(*next(iter(train_loader)), 0)))),
+                 lambda: copy.copy(tr.train_step(*next(iter(train_loader)), 0)),
+                 lambda: pickle.loads(pickle.dumps(tr.train_step(*next(iter(train_loader)), 0)))):
+        d = make()
+        assert set(d) == {'loss', 'ADD', 'SADD', 'acc'} and all(np.isfinite(v) for v in d.values()), d
     ev = Evaluator(model=net, val_loader=val_loader, cfg=cfg, writer=w, max_epoch=3, device='cuda')
     res = ev.val(epoch=2, compute_iou=True)
     assert 0 <= res['ADD'] <= 2 and 0 <= res['IOU'] <= 1 and 0 <= res['ACC'] <= 1
