@@ -151,7 +151,8 @@ def main2():
     # ---- rank 0 alone wrote the checkpoint, the log file and the scalars
     allsaves = [None, None]
     dist.all_gather_object(allsaves, saves)
-    assert len(allsaves[0]) == 1 and allsaves[0][0].endswith('snap_1.pth') and not allsaves[1], allsaves
+    # (save_freq = 10: epoch 0 and the last epoch are written, train.py:108-110)
+    assert [os.path.basename(f) for f in allsaves[0]] == ['snap_0.pth', 'snap_1.pth'] and not allsaves[1], allsaves
     nsc = [None, None]
     dist.all_gather_object(nsc, len(writer.scalars))
     assert nsc[0] > 0 and nsc[1] == 0, nsc

@@ -73,7 +73,7 @@ def test_hip_path_matches_reference_golden(golden_dir, tag, name, B, HW, nc, lna
     np.testing.assert_allclose(dkp.cpu().numpy().reshape(B, 9, 2), g['dkp'], atol=5e-5, rtol=2e-2)
     net.backward(dkp, dlg)
     torch.cuda.synchronize()
-    bad, l2s = [], []
+    bad, l2s, l2s64 = [], [], []
     gmax = max(float(np.abs(g[f]).max()) for f in g.files if f.startswith('grad:'))
     for k in [f for f in g.files if f.startswith('grad:') or f.startswith('gradrows:')]:
         name_ = k.split(':', 1)[1]
@@ -83,7 +83,20 @@ def test_hip_path_matches_reference_golden(golden_dir, tag, name, B, HW, nc, lna
             got = got[:6]
         scale = max(np.abs(ref).max(), 1e-3)
         err = np.abs(got - ref).max() / scale
-        if not err < GRAD_TOL.get(tag, 5e-2):
+        # conditioning of THIS tensor's comparison, measured by the generator: relative L2 distance of the reference's own fp32
+        # gradient from the same model's fp64 gradient (`g64l2:`; production-resolution fixtures only).  Two fp32
+        # implementations that sum in different orders cannot agree better than a small multiple of it: 0.01-0.05 % for
+        # mobilenetv3_large, 0.4-0.8 % for the MobileNetV2-shaped ReLU network (every tensor: the difference is made in the
+        # top blocks and inherited by everything below)
+        cond = float(g['g64l2:' + name_]) if ('g64l2:' + name_) in g.files else 0.0
+        k64 = k.replace('grad:', 'grad64:').replace('gradrows:', 'gradrows64:')
+        if k64 in g.files:
+            # max-norm, same principle: against the fp64 gradient, at most 2.5x the reference's own fp32 max-norm error
+            err = np.abs(got - g[k64]).max() / scale
+            cmax = np.abs(ref - g[k64]).max() / scale
+            if not err < max(GRAD_TOL.get(tag, 5e-2), 2.5 * cmax):
+                bad.append((name_, 'max-norm against the fp64 gradient', err, 'reference fp32', cmax))
+        elif not err < GRAD_TOL.get(tag, 5e-2):
             bad.append((name_, err))
         # ... and in the L2 sense, which one flipped activation kink barely moves (the max-norm bound above has to leave room
         # for it): a systematic backward error of a per cent would show here
@@ -91,14 +104,23 @@ def test_hip_path_matches_reference_golden(golden_dir, tag, name, B, HW, nc, lna
         # against the fixture's overall gradient scale, not against their own round-off-level norm)
         l2 = np.linalg.norm((got - ref).ravel()) / max(np.linalg.norm(ref.ravel()), 1e-3 * gmax * ref.size ** 0.5)
         l2s.append((float(l2), name_))
-        if tag in GRAD_L2_TOL and not l2 < GRAD_L2_TOL[tag]:
-            bad.append((name_, 'relative L2', l2))
+        if tag in GRAD_L2_TOL:
+            # held to the EXACT gradient (the reference model run in fp64 by the generator): the HIP path may be at most 2.5x as
+            # far from it as the reference's own fp32 CPU path is (and never needs to be closer than 5e-3)
+            ref64 = g[k64]
+            l2_64 = np.linalg.norm((got - ref64).ravel()) / max(np.linalg.norm(ref64.ravel()), 1e-3 * float(g['g64max']) * ref64.size ** 0.5)
+            l2s64.append((float(l2_64), round(cond, 5), name_))
+            if not l2_64 < max(GRAD_L2_TOL[tag], 2.5 * cond):
+                bad.append((name_, 'relative L2 against the fp64 gradient', l2_64, 'reference fp32', cond))
     for k in [f for f in g.files if f.startswith('gsum:')]:
         ref = g[k][1]
         got = net.g[k[5:]].double().abs().sum().item()
-        if abs(got - ref) > GRAD_TOL.get(tag, 5e-2) * max(ref, 1e-2):
+        cond = float(g['g64l2:' + k[5:]]) if ('g64l2:' + k[5:]) in g.files else 0.0
+        if abs(got - ref) > max(GRAD_TOL.get(tag, 5e-2), 3 * cond) * max(ref, 1e-2):
             bad.append((k, got, ref))
     print(f'   {tag}: gradient relative-L2 errors, worst three: {[(round(a, 5), b) for a, b in sorted(l2s, reverse=True)[:3]]}')
+    if l2s64:
+        print(f'   {tag}: against the fp64 gradient (HIP, reference fp32), worst three: {[(round(a, 5), b, c) for a, b, c in sorted(l2s64, reverse=True)[:3]]}')
     assert not bad, bad[:10]
     for k in [f for f in g.files if f.startswith('rm:')]:
         bn = k[3:]
