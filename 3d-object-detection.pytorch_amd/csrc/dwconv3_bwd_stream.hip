@@ -306,7 +306,10 @@ __device__ __forceinline__ void bufstore(const RV& v, __amdgpu_buffer_rsrc_t r, 
 
 // ACT: the input's activation as a compile-time constant (a runtime switch in the row loop costs a scalar branch chain
 // and a register-merge of all variants per row: ~10 % of the instructions)
-template <typename T, int PF, int NTH, int CH, int ACT>
+// RES: a skip-connection gradient is added to dx (compile time: its two loads per row ride in the prefetch ring -- loaded on
+// demand in the epilogue, as rounds 2-3 did, each one sat behind `s_waitcnt vmcnt(0)`, i.e. drained the whole ring twice per
+// row in 10 of the 13 stride-1 launches of MobileNetV2; found in the ISA, round 4)
+template <typename T, int PF, int NTH, int CH, int ACT, bool RES>
 __global__ __launch_bounds__(NTH) void dw3_bwd2_kernel(const Dw3BArgs a) {
   constexpr int H2 = CH / 2;
   extern __shared__ float lred[];       // [9][Cb] weights by tap, [3][Cb] derived coefficients; end of kernel: [11][Cb] fp64 accumulators
@@ -423,6 +426,9 @@ __global__ __launch_bounds__(NTH) void dw3_bwd2_kernel(const Dw3BArgs a) {
     const size_t imgrow = (size_t)b * a.H; // rows before this image
 
     RV rz[PF][4], ry[PF][4], rx[PF][4];
+    RV rres[PF][RES ? 2 : 1];              // skip-connection gradient of dx row r-1 (the row that completes at dy row r), own columns
+    const unsigned OOB = 0x80000000u;                        // beyond num_records of every tensor here (< 2 GB)
+    const unsigned stA = on ? vst : OOB, stB = (on && validB) ? vst + (unsigned)(a.C * sizeof(T)) : OOB;
     // buffer loads: descriptor (scalar) + 32-bit scalar row offset + 32-bit lane offset -- no vector address arithmetic
     auto fetch = [&](int r, int slot) {
       const unsigned so = (unsigned)((imgrow + min(max(r, 0), a.H - 1)) * a.W * a.C * sizeof(T));   // scalar; tensors < 4 GB
@@ -431,6 +437,13 @@ __global__ __launch_bounds__(NTH) void dw3_bwd2_kernel(const Dw3BArgs a) {
         rz[slot][c] = bufload<RV>(rsz, voff[c], so);
         ry[slot][c] = bufload<RV>(rsy, voff[c], so);
         rx[slot][c] = bufload<RV>(rsx, voff[c], so);
+      }
+      if constexpr (RES) {
+        // (out-of-tile lanes / the missing odd column carry the dropped-lane offset of the store: they read zeros and can
+        // never touch memory past the tensor)
+        const unsigned sr = (unsigned)((imgrow + min(max(r - 1, 0), a.H - 1)) * a.W * a.C * sizeof(T));
+        rres[slot][0] = bufload<RV>(rsr, stA, sr);
+        rres[slot][1] = bufload<RV>(rsr, stB, sr);
       }
     };
     const int rf = r0 - 1, rl = r1;
@@ -469,8 +482,6 @@ __global__ __launch_bounds__(NTH) void dw3_bwd2_kernel(const Dw3BArgs a) {
     // rows -- no predicates, no exec-mask branches (out-of-tile lanes are steered to an out-of-range buffer offset,
     // which the hardware drops).  The predicates were a third of the row loop's instructions (SALU compares / selects
     // / branches); an item walks one general group, then FAST groups, then one or two general groups.
-    const unsigned OOB = 0x80000000u;                        // beyond num_records of every tensor here (< 2 GB)
-    const unsigned stA = on ? vst : OOB, stB = (on && validB) ? vst + (unsigned)(a.C * sizeof(T)) : OOB;
     const float mA = on ? 1.f : 0.f, mB = (on && validB) ? 1.f : 0.f;
     auto group = [&](auto fast_tag, const int base) {
       constexpr bool FAST = decltype(fast_tag)::value;
@@ -493,6 +504,16 @@ __global__ __launch_bounds__(NTH) void dw3_bwd2_kernel(const Dw3BArgs a) {
           for (int c = 0; c < 4; ++c)
 #pragma unroll
             for (int h = 0; h < H2; ++h) asm volatile("" : "+v"(dy[c][h]), "+v"(av[c][h]));
+          f32x2 resf[2][H2];
+          if constexpr (RES) {
+#pragma unroll
+            for (int col = 0; col < 2; ++col)
+#pragma unroll
+              for (int h = 0; h < H2; ++h) {
+                resf[col][h] = f32x2{(float)rres[u][col][2 * h], (float)rres[u][col][2 * h + 1]};
+                asm volatile("" : "+v"(resf[col][h]));
+              }
+          }
           __builtin_amdgcn_sched_barrier(0);
           fetch(r + PF, u);
           __builtin_amdgcn_sched_barrier(0);
@@ -619,12 +640,12 @@ __global__ __launch_bounds__(NTH) void dw3_bwd2_kernel(const Dw3BArgs a) {
               }
               const size_t rowo = (imgrow + iy) * a.W * a.C;     // scalar
               const unsigned lo = col == 0 ? stA : stB;           // out-of-tile lanes / the missing odd column: dropped
-              if (rb) {
-                // same dropped-lane offset as the store: the missing odd column of the last row would otherwise be read
-                // one pixel past the end of the tensor
-                const RV rr = bufload<RV>(rsr, lo, (unsigned)(rowo * sizeof(T)));
+              if constexpr (RES) {
 #pragma unroll
-                for (int i = 0; i < CH; ++i) g[i] += (float)rr[i];
+                for (int h = 0; h < H2; ++h) {
+                  g[2 * h] += resf[col][h][0];
+                  g[2 * h + 1] += resf[col][h][1];
+                }
               }
               const float mcol = col == 0 ? mA : mB;
               RV o;
@@ -751,12 +772,17 @@ int launch_s1c(Dw3BArgs& a, hipStream_t st) {
   // (forcing 3-4 waves/SIMD through launch bounds spills to scratch: 3-7x slower)
   // (a 6-row prefetch ring needs AGPR spill space -> 1 wave/SIMD: 40 % slower; PMC: VALU busy 46 %, memory unit stalled
   //  0.1 % -- the kernel is bound by the latency two resident waves per SIMD can hide)
+#define T3D_DWB2(ACTV)                                                                                              \
+  do {                                                                                                              \
+    if (a.res) T3D_LAUNCH_TIMED((dw3_bwd2_kernel<T, PF, 256, CH, ACTV, true>), grid, dim3(256), lds, st, a);        \
+    else T3D_LAUNCH_TIMED((dw3_bwd2_kernel<T, PF, 256, CH, ACTV, false>), grid, dim3(256), lds, st, a);             \
+  } while (0)
   if (two_col) {
     switch (a.act) {
-      case T3D_ACT_RELU: T3D_LAUNCH_TIMED((dw3_bwd2_kernel<T, PF, 256, CH, T3D_ACT_RELU>), grid, dim3(256), lds, st, a); break;
-      case T3D_ACT_RELU6: T3D_LAUNCH_TIMED((dw3_bwd2_kernel<T, PF, 256, CH, T3D_ACT_RELU6>), grid, dim3(256), lds, st, a); break;
-      case T3D_ACT_HSWISH: T3D_LAUNCH_TIMED((dw3_bwd2_kernel<T, PF, 256, CH, T3D_ACT_HSWISH>), grid, dim3(256), lds, st, a); break;
-      default: T3D_LAUNCH_TIMED((dw3_bwd2_kernel<T, PF, 256, CH, T3D_ACT_NONE>), grid, dim3(256), lds, st, a); break;
+      case T3D_ACT_RELU: T3D_DWB2(T3D_ACT_RELU); break;
+      case T3D_ACT_RELU6: T3D_DWB2(T3D_ACT_RELU6); break;
+      case T3D_ACT_HSWISH: T3D_DWB2(T3D_ACT_HSWISH); break;
+      default: T3D_DWB2(T3D_ACT_NONE); break;
     }
   }
   else T3D_LAUNCH_TIMED((dw3_bwd_s1_kernel<T, CH, PF>), grid, dim3(256), lds, st, a);

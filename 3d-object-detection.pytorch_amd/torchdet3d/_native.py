@@ -9,7 +9,8 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(os.path.dirname(_HERE), 'libt3d_hip.so')
+# T3D_LIB: another build of the same library (A/B timing of one kernel file: tools/ab_lib.sh); the product loads the in-tree one
+LIB_PATH = os.environ.get('T3D_LIB') or os.path.join(os.path.dirname(_HERE), 'libt3d_hip.so')
 
 F32, BF16 = 0, 1
 ACT = {'none': 0, 'relu': 1, 'relu6': 2, 'hswish': 3}

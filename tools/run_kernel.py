@@ -1,5 +1,5 @@
 """Profiling aid: launch ONE conv entry point repeatedly on a given shape (for rocprofv3 --pmc / --kernel-trace).
-usage: run_kernel.py dwfwd|dwbwd|pwfwd|pwdgrad|pwwgrad  B H W C [k s] | M HW K N   [--reps R] [--f32]"""
+usage: run_kernel.py dwfwd|dwbwd|pwfwd|pwdgrad|pwwgrad  B H W C [k s] | M HW K N   [--reps R] [--f32] [--res]"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, '3d-object-detection.pytorch_amd')]
@@ -34,7 +34,8 @@ if kind in ('dwfwd', 'dwbwd'):
         al, be, ga = torch.rand(C, device=dev) + 0.5, rnd(C) * 0.1, rnd(C) * 0.1
         bb = N.bnbwd(al, be, ga, False)
         dx = torch.empty_like(x); dw = torch.zeros(nrep, C, k * k, device=dev)
-        fn = lambda: N.call('t3d_dwconv_bwd', N.dtype_code(x), N.ptr(dz), N.ptr(yy), bb, N.ptr(w), N.ptr(x), pro, None,
+        res = rnd(B * H * W, C).to(dt) if '--res' in sys.argv else None      # skip-connection gradient (stride-1 residual blocks)
+        fn = lambda: N.call('t3d_dwconv_bwd', N.dtype_code(x), N.ptr(dz), N.ptr(yy), bb, N.ptr(w), N.ptr(x), pro, N.ptr(res),
                             N.ptr(dx), N.ptr(stats), N.ptr(dw), B, H, W, C, k, s, N.stream())
         nbytes = 2 * (x.numel() + y.numel()) * x.element_size()
 else:
