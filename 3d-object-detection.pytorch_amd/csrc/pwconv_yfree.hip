@@ -21,55 +21,94 @@ int t3d_pw_wgrad_tr_yfree(const void* dz, const void* x, float* tmp, int M, int 
 
 namespace {
 
-// grid (K, KP/16): output channel k of the data gradient x a 16-wide slice of the concatenated contraction axis's Q
-// part; 256 threads.  The K x K block Q = W^T diag(beta) W is the only part with real work (N multiply-adds per entry):
-// thread (k2, g) sums the n = g (mod 16) terms, the 16 partial sums meet in LDS.  (Small blocks on purpose: the kernel
-// runs while the side stream keeps the CUs busy, and a 1024-thread block waits for a whole free CU.)
-__global__ __launch_bounds__(256) void yfree_prep_kernel(const bf16_t* __restrict__ w, const float* __restrict__ alpha_g,
+// Wcat [K][NP + KP] (bf16) = [ alpha_n W[n][k]  (n < N, zero padded to NP) | Q[k][k2] = sum_n W[n][k] beta_n W[n][k2]  (zero
+// padded to KP) ],  c[k] = sum_n gamma_n W[n][k].  The launch sits on the critical path between the depthwise backward (whose
+// sums give beta, gamma) and the expand layer's data gradient, 13 times per step -- round 3's version (one workgroup per
+// (k, 16 columns): up to 576 workgroups, EACH deriving all N BatchNorm coefficients from the replica sums, scalar 2-byte
+// weight loads) took 14 us per launch in the step.  Now: one workgroup per 16 x 16 tile of Q on the matrix cores, from the
+// TRANSPOSED weight copy wt [K][N] (rows contiguous in n, so both MFMA operands are 16-byte row reads): the four waves split
+// the contraction over n, meet in LDS; (K/16)^2 workgroups derive the coefficients instead of K * KP/16.
+__global__ __launch_bounds__(256) void yfree_prep_kernel(const bf16_t* __restrict__ wt, const float* __restrict__ alpha_g,
                                                          const float* __restrict__ beta_g, const float* __restrict__ gamma_g,
                                                          bf16_t* __restrict__ wcat, float* __restrict__ cvec, int K, int N,
                                                          int NP, int KP, const T3dFold* __restrict__ fold) {
-  __shared__ float part[256];
-  extern __shared__ float fco[];      // [3][N] derived (alpha, beta, gamma) when a finalize request rides on this launch
-  const float *alpha = alpha_g, *beta = beta_g, *gamma = gamma_g;
+  extern __shared__ float fco[];      // [3][N] (alpha, beta, gamma): derived here when a finalize request rides on this launch
+  __shared__ f32x4 red[3][64];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6, lg = lane >> 4, lc = lane & 15;
   if (fold) {
-    // every workgroup needs all N coefficients: each derives them from the replica sums (common.h), workgroup (0, 0)
-    // publishes -- 3 us in every workgroup's prologue against a 5-us finalize launch and the dispatch gap behind it
-    t3d_fold_block(fold, 0, N, fco, N, blockIdx.x == 0 && blockIdx.y == 0);
+    t3d_fold_block(fold, 0, N, fco, N, blockIdx.x == 0 && blockIdx.y == 0);     // (ends with a barrier)
+  } else {
+    for (int i = t; i < N; i += 256) { fco[i] = alpha_g[i]; fco[N + i] = beta_g[i]; fco[2 * N + i] = gamma_g[i]; }
     __syncthreads();
-    alpha = fco; beta = fco + N; gamma = fco + 2 * N;
   }
-  constexpr int G = 16;
-  const int k = blockIdx.x, c = blockIdx.y, nc = gridDim.y, tot = NP + KP, t = threadIdx.x;
-  for (int j = c * 256 + t; j < NP; j += nc * 256)
-    wcat[(size_t)k * tot + j] = (bf16_t)(j < N ? alpha[j] * (float)w[(size_t)j * K + k] : 0.f);
-  const int k2 = c * 16 + (t & 15), g = t >> 4;
-  float acc = 0.f;
-  if (k2 < K) {
-    int n = g;
-    for (; n + 3 * G < N; n += 4 * G) {      // four independent loads in flight
-      const float b0 = beta[n], b1 = beta[n + G], b2 = beta[n + 2 * G], b3 = beta[n + 3 * G];
-      const float u0 = (float)w[(size_t)n * K + k2], u1 = (float)w[(size_t)(n + G) * K + k2];
-      const float u2 = (float)w[(size_t)(n + 2 * G) * K + k2], u3 = (float)w[(size_t)(n + 3 * G) * K + k2];
-      const float v0 = (float)w[(size_t)n * K + k], v1 = (float)w[(size_t)(n + G) * K + k];
-      const float v2 = (float)w[(size_t)(n + 2 * G) * K + k], v3 = (float)w[(size_t)(n + 3 * G) * K + k];
-      acc = fmaf(b0 * u0, v0, acc); acc = fmaf(b1 * u1, v1, acc); acc = fmaf(b2 * u2, v2, acc); acc = fmaf(b3 * u3, v3, acc);
-    }
-    for (; n < N; n += G) acc = fmaf(beta[n] * (float)w[(size_t)n * K + k2], (float)w[(size_t)n * K + k], acc);
-  }
-  part[t] = acc;
-  __syncthreads();
-  if (t < 16) {
-    float v = 0.f;
+  const float *alpha = fco, *beta = fco + N, *gamma = fco + 2 * N;
+  const int tot = NP + KP;
+  const int k0 = blockIdx.x * 16, q0 = blockIdx.y * 16;        // tile rows k0.. (data-gradient output channels), columns q0..
+  // ---- Q tile: D[m = k][n = k2] = sum_n A[m][n] B[n][k2],  A = wt rows, B = beta * wt rows (bf16 operands, fp32 accumulate)
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  const int nsteps = (N + 31) / 32;
+  const int ka = min(k0 + lc, K - 1), kb = min(q0 + lc, K - 1);
+  const bf16_t* ra = wt + (size_t)ka * N;
+  const bf16_t* rb = wt + (size_t)kb * N;
+  constexpr int U = 4;                  // k-steps in flight per wave
+  for (int s0 = wave; s0 < nsteps; s0 += 4 * U) {
+    bf16x8 fa[U], fb[U];
 #pragma unroll
-    for (int gg = 0; gg < G; ++gg) v += part[gg * 16 + t];
-    wcat[(size_t)k * tot + NP + c * 16 + t] = (bf16_t)v;     // k2 >= K: zero padding (acc stayed 0)
+    for (int u = 0; u < U; ++u) {
+      const int n = min((s0 + 4 * u) * 32 + 8 * lg, N - 8);      // (steps past N re-read a valid address; their beta is zeroed)
+      fa[u] = *reinterpret_cast<const bf16x8*>(ra + n);
+      fb[u] = *reinterpret_cast<const bf16x8*>(rb + n);
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int st = s0 + 4 * u, n = st * 32 + 8 * lg;
+      const bool live = st < nsteps && n < N;                     // (N % 8 == 0: whole 8-groups are in or out)
+      bf16x8 b;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) b[j] = (bf16_t)(live ? beta[min(n, N - 8) + j] * (float)fb[u][j] : 0.f);
+      acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[u], b, acc, 0, 0, 0);
+    }
   }
-  if (c == 0 && t >= 192) {     // last wave of the first slice: c[k] = sum_n gamma_n W[n][k]
+  if (wave) red[wave - 1][lane] = acc;
+  __syncthreads();
+  if (wave == 0) {
+    acc += red[0][lane];
+    acc += red[1][lane];
+    acc += red[2][lane];
+    // D[row = 4*lg + r -> k][col = lc -> k2]
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int k = k0 + 4 * lg + r, k2 = q0 + lc;
+      if (k < K) wcat[(size_t)k * tot + NP + k2] = (bf16_t)((k2 < K) ? acc[r] : 0.f);     // k2 in [K, KP): zero padding
+    }
+  }
+  // ---- alpha . W part and c: the workgroups of tile column 0 own rows k0 .. k0+15 (row k = wt row k scaled by alpha)
+  if (blockIdx.y == 0) {
+    for (int i = t; i < 16 * (NP / 8); i += 256) {
+      const int k = k0 + i / (NP / 8), n = (i % (NP / 8)) * 8;
+      if (k >= K) continue;
+      bf16x8 o;
+      if (n < N) {
+        const bf16x8 v = *reinterpret_cast<const bf16x8*>(wt + (size_t)k * N + n);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = (bf16_t)(alpha[n + j] * (float)v[j]);
+      } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = (bf16_t)0.f;
+      }
+      *reinterpret_cast<bf16x8*>(wcat + (size_t)k * tot + n) = o;
+    }
+    // c[k] = sum_n gamma_n W[n][k]: 16 lanes per row
+    const int row = t >> 4, sub = t & 15, k = k0 + row;
     float s2 = 0.f;
-    for (int n = t - 192; n < N; n += 64) s2 = fmaf(gamma[n], (float)w[(size_t)n * K + k], s2);
-    s2 = wave_sum(s2);
-    if (t == 192) cvec[k] = s2;
+    if (k < K)
+      for (int n = sub * 8; n < N; n += 128) {
+        const bf16x8 v = *reinterpret_cast<const bf16x8*>(wt + (size_t)k * N + n);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) s2 = fmaf(gamma[n + j], (float)v[j], s2);
+      }
+    s2 = row16_sum(s2);
+    if (sub == 0 && k < K) cvec[k] = s2;
   }
 }
 
@@ -101,8 +140,9 @@ __global__ __launch_bounds__(256) void yfree_combine_kernel(const float* __restr
 static inline int rup32(int v) { return (v + 31) / 32 * 32; }
 
 // include/t3d.h
-extern "C" int t3d_pwconv_yfree_prep(const void* w, const t3d_bnbwd* bb, void* wcat, float* cvec, int K, int N,
+extern "C" int t3d_pwconv_yfree_prep(const void* wt, const t3d_bnbwd* bb, void* wcat, float* cvec, int K, int N,
                                      void* stream) {
+  const void* w = wt;
   if (!w || !bb || !bb->alpha || !bb->beta || !bb->gamma || !wcat || !cvec || K <= 0 || N <= 0 || (K % 8) || (N % 8))
     return T3D_ERR_ARG;
   if (bb->per_sample) return T3D_ERR_UNSUPPORTED;
@@ -110,7 +150,7 @@ extern "C" int t3d_pwconv_yfree_prep(const void* w, const t3d_bnbwd* bb, void* w
   const T3dFold* fold = nullptr;
   if (derive) fold = t3d_take_fold(bb->alpha);
   else if (const int rc = t3d_fold_fallback(bb->alpha, reinterpret_cast<hipStream_t>(stream))) return rc;
-  hipLaunchKernelGGL(yfree_prep_kernel, dim3(K, rup32(K) / 16), dim3(256), fold ? (size_t)3 * N * sizeof(float) : 0,
+  hipLaunchKernelGGL(yfree_prep_kernel, dim3(rup32(K) / 16, rup32(K) / 16), dim3(256), (size_t)3 * N * sizeof(float),
                      reinterpret_cast<hipStream_t>(stream), reinterpret_cast<const bf16_t*>(w), bb->alpha, bb->beta, bb->gamma,
                      reinterpret_cast<bf16_t*>(wcat), cvec, K, N, rup32(N), rup32(K), fold);
   T3D_CHECK_LAUNCH();

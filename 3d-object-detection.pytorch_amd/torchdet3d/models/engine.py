@@ -1101,7 +1101,7 @@ class Net:
         wcat = self._buf(f'wcat:{i}', (K, tot))
         cvec = self._buf(f'cvec:{i}', (K,), torch.float32)
         HW = x.H * x.W
-        self._c('t3d_pwconv_yfree_prep', N.ptr(self.w[wname]), bb1, N.ptr(wcat), N.ptr(cvec), K, Nn, st, bwd=bn1)
+        self._c('t3d_pwconv_yfree_prep', N.ptr(self.wt[wname]), bb1, N.ptr(wcat), N.ptr(cvec), K, Nn, st, bwd=bn1)
         self._wgrad(N.ptr(d1), N.ptr(x.t), bb1, N.ptr(self.w[wname]), N.ptr(self.g[wname]), M, HW, K, Nn,
                     entry='t3d_pwconv_wgrad_yfree', nbytes=M * (K + Nn) * self.esz)
         dx = self._buf(f'dzin:{i}', (M, K))

@@ -123,11 +123,11 @@ int t3d_pwconv_wgrad(int dtype, const void* dz, const void* y, const t3d_bnbwd* 
  *   dx = [dz | x] Wcat^T + c,           Wcat = [alpha.W | W^T diag(beta) W] (bf16 [K][rup32(N)+rup32(K)]), c = gamma^T W
  *   dW += alpha.(dz^T x) + beta.(W (x^T x)) + gamma (1^T x)
  * Same sums as t3d_pwconv_dgrad / t3d_pwconv_wgrad, reassociated; bf16 storage only, per-channel bb only.
- *   _prep: w [N,K] bf16 (the packed weights the forward used) -> wcat, cvec [K] fp32;
+ *   _prep: wt [K,N] bf16 (the TRANSPOSED packed weights, as the data gradient reads them) -> wcat, cvec [K] fp32;
  *   _dgrad_yfree: x_raw / pro_in / residual / stats exactly as in t3d_pwconv_dgrad (x itself is the finished tensor the
  *     conv read; x_raw the raw tensor of its producer, for that producer's BatchNorm-backward sums); dx [M,K] bf16;
  *   _wgrad_yfree: needs t3d_set_workspace (returns T3D_ERR_UNSUPPORTED without it); dw [N,K] fp32 is accumulated. */
-int t3d_pwconv_yfree_prep(const void* w, const t3d_bnbwd* bb, void* wcat, float* cvec, int K, int N, void* stream);
+int t3d_pwconv_yfree_prep(const void* wt, const t3d_bnbwd* bb, void* wcat, float* cvec, int K, int N, void* stream);
 int t3d_pwconv_dgrad_yfree(const void* dz, const void* x, const void* wcat, const float* cvec, const void* x_raw,
                            const t3d_prologue* pro_in, const void* residual, void* dx, double* stats, int M, int HW,
                            int K, int N, void* stream);

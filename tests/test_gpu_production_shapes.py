@@ -231,7 +231,8 @@ def test_pw_yfree_pair_production_shape():
     ws = torch.empty(64 << 20, device='cuda', dtype=torch.uint8)
     N.call('t3d_set_workspace', N.ptr(ws), ws.numel())
     try:
-        N.call('t3d_pwconv_yfree_prep', N.ptr(wd), bb, N.ptr(wcat), N.ptr(cvec), K, Nn, N.stream())
+        wtd = wd.t().contiguous()
+        N.call('t3d_pwconv_yfree_prep', N.ptr(wtd), bb, N.ptr(wcat), N.ptr(cvec), K, Nn, N.stream())
         N.call('t3d_pwconv_dgrad_yfree', N.ptr(dz), N.ptr(x), N.ptr(wcat), N.ptr(cvec), None, None, N.ptr(res), N.ptr(dx),
                None, M, HW, K, Nn, N.stream())
         N.call('t3d_pwconv_wgrad_yfree', N.ptr(dz), N.ptr(x), bb, N.ptr(wd), N.ptr(dw), M, HW, K, Nn, N.stream())

@@ -219,7 +219,15 @@ def test_pw_yfree_backward(M, HW, K, N, res):
     NP, KP = (N + 31) // 32 * 32, (K + 31) // 32 * 32
     wcat = torch.empty(K, NP + KP, device=dev, dtype=bf)
     cvec = torch.empty(K, device=dev)
-    N_.call('t3d_pwconv_yfree_prep', N_.ptr(wd), bb, N_.ptr(wcat), N_.ptr(cvec), K, N, N_.stream())
+    wtd = wd.t().contiguous()           # the transposed packed copy (engine: Net.wt)
+    N_.call('t3d_pwconv_yfree_prep', N_.ptr(wtd), bb, N_.ptr(wcat), N_.ptr(cvec), K, N, N_.stream())
+    # Wcat itself: [alpha.W | W^T diag(beta) W] and c = gamma^T W against fp64 on the stored weights (bf16 output)
+    wq = w.double()
+    np.testing.assert_allclose(wcat[:, :N].float().cpu().numpy(), (alpha.double()[:, None] * wq).t().numpy(), rtol=1e-2, atol=1e-3)
+    Qref = wq.t() @ (beta.double()[:, None] * wq)
+    np.testing.assert_allclose(wcat[:, NP:NP + K].float().cpu().numpy(), Qref.numpy(), rtol=2e-2, atol=2e-2 * float(Qref.abs().max()))
+    assert not wcat[:, N:NP].float().abs().sum().item() and not wcat[:, NP + K:].float().abs().sum().item()      # zero padding
+    np.testing.assert_allclose(cvec.cpu().numpy(), (gamma.double() @ wq).numpy(), rtol=1e-4, atol=1e-5)
     dx = torch.empty(M, K, device=dev, dtype=bf)
     yraw = torch.randn(M, K, generator=g).to(bf).to(dev)      # raw tensor of x's producer (BatchNorm-backward sums)
     st1 = torch.zeros(2 * K, device=dev, dtype=torch.float64)

@@ -61,13 +61,15 @@ else:
         stats = torch.zeros(nrep, 2 * max(K, Nn), device=dev, dtype=torch.float64)
         fn = lambda: N.call('t3d_pwconv_dgrad', N.dtype_code(x), N.ptr(dz), N.ptr(yy), bb, N.ptr(wt), N.ptr(x), pro, None,
                             N.ptr(dx), N.ptr(stats), None, M, HW, K, Nn, N.stream())
-    elif kind in ('pwdgrad_yf', 'pwwgrad_yf'):
+    elif kind in ('pwdgrad_yf', 'pwwgrad_yf', 'yfprep'):
         NP, KP = (Nn + 31) // 32 * 32, (K + 31) // 32 * 32
         wcat = torch.empty(K, NP + KP, device=dev, dtype=dt); cvec = torch.empty(K, device=dev)
-        N.call('t3d_pwconv_yfree_prep', N.ptr(wq), bb, N.ptr(wcat), N.ptr(cvec), K, Nn, N.stream())
+        N.call('t3d_pwconv_yfree_prep', N.ptr(wt), bb, N.ptr(wcat), N.ptr(cvec), K, Nn, N.stream())
         stats = torch.zeros(nrep, 2 * max(K, Nn), device=dev, dtype=torch.float64)
         dw = torch.zeros(Nn, K, device=dev)
-        if kind == 'pwdgrad_yf':
+        if kind == 'yfprep':
+            fn = lambda: N.call('t3d_pwconv_yfree_prep', N.ptr(wt), bb, N.ptr(wcat), N.ptr(cvec), K, Nn, N.stream())
+        elif kind == 'pwdgrad_yf':
             fn = lambda: N.call('t3d_pwconv_dgrad_yfree', N.ptr(dz), N.ptr(x), N.ptr(wcat), N.ptr(cvec), N.ptr(x), None,
                                 None, N.ptr(dx), N.ptr(stats), M, HW, K, Nn, N.stream())
         else:
