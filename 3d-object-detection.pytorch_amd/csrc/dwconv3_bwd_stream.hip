@@ -280,6 +280,15 @@ __global__ __launch_bounds__(256) void dw3_bwd_s1_kernel(const Dw3BArgs a) {
 // v_pk_fma_f32, and the 9 x CH stencil weights are read from LDS per use (saves 36 registers for the two
 // accumulator sets).  Padding: 0/1 masks per out-of-image column, wave-uniform row skips.
 // raw buffer load of one register vector: scalar descriptor + scalar byte offset + per-lane byte offset
+// relu6(s x + t) = 6 clamp01((s/6) x + t/6) in one packed instruction (v_pk_fma_f32 with the clamp modifier; bf16 storage
+// only, dwconv3_stream.hip has the note): the activated operand a' = a/6 feeds the weight gradient (the 6 is applied once,
+// when the accumulators are flushed) and IS the derivative mask of the own columns (0 < a' < 1)
+__device__ __forceinline__ f32x2 pk_fma_clamp01(f32x2 a, f32x2 b, f32x2 c) {
+  f32x2 d;
+  asm("v_pk_fma_f32 %0, %1, %2, %3 clamp" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+  return d;
+}
+
 template <typename RV>
 __device__ __forceinline__ RV bufload(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
   if constexpr (sizeof(RV) == 4) {
@@ -312,6 +321,7 @@ __device__ __forceinline__ void bufstore(const RV& v, __amdgpu_buffer_rsrc_t r, 
 template <typename T, int PF, int NTH, int CH, int ACT, bool RES>
 __global__ __launch_bounds__(NTH) void dw3_bwd2_kernel(const Dw3BArgs a) {
   constexpr int H2 = CH / 2;
+  constexpr bool C6 = std::is_same<T, bf16_t>::value && ACT == T3D_ACT_RELU6;
   extern __shared__ float lred[];       // [9][Cb] weights by tap, [3][Cb] derived coefficients; end of kernel: [11][Cb] fp64 accumulators
   using RV = rawvec<T, CH>;
   const int CG = a.C / CH, Wp = (a.W + 1) / 2;
@@ -417,7 +427,8 @@ __global__ __launch_bounds__(NTH) void dw3_bwd2_kernel(const Dw3BArgs a) {
       for (int h = 0; h < H2; ++h) {
         const f32x2 mm = {m[c], m[c]};
         alm[c][h] = al2[h] * mm; bem[c][h] = be2[h] * mm; gam[c][h] = ga2[h] * mm;
-        scm[c][h] = sc2[h] * mm; shm[c][h] = sh2[h] * mm;
+        const f32x2 m6 = C6 ? mm * f32x2{T3D_SIXTH, T3D_SIXTH} : mm;
+        scm[c][h] = sc2[h] * m6; shm[c][h] = sh2[h] * m6;
       }
     unsigned voff[4];                      // lane part of the load addresses (BYTES, unsigned: scalar base + 32-bit offset)
 #pragma unroll
@@ -522,7 +533,12 @@ __global__ __launch_bounds__(NTH) void dw3_bwd2_kernel(const Dw3BArgs a) {
             xr[0][h] = av[1][h];
             xr[1][h] = av[2][h];
           }
-          if (affine) {
+          if (C6) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+#pragma unroll
+              for (int h = 0; h < H2; ++h) av[c][h] = pk_fma_clamp01(av[c][h], scm[c][h], shm[c][h]);
+          } else if (affine) {
 #pragma unroll
             for (int c = 0; c < 4; ++c)
 #pragma unroll
@@ -629,7 +645,15 @@ __global__ __launch_bounds__(NTH) void dw3_bwd2_kernel(const Dw3BArgs a) {
                 g[2 * h] = acc[h][0]; g[2 * h + 1] = acc[h][1];
                 xv[2 * h] = xr_prev[col][h][0]; xv[2 * h + 1] = xr_prev[col][h][1];
               }
-              if (affine) {
+              if (C6) {
+                // the activated value of dx row r-1, own column (kept for the ky = 0 weight-gradient taps) is its own mask
+#pragma unroll
+                for (int h = 0; h < H2; ++h) {
+                  const f32x2 ap = a_prev[col + 1][h];
+                  g[2 * h] = (ap[0] > 0.f && ap[0] < 1.f) ? g[2 * h] : 0.f;
+                  g[2 * h + 1] = (ap[1] > 0.f && ap[1] < 1.f) ? g[2 * h + 1] : 0.f;
+                }
+              } else if (affine) {
                 float scf[CH], shf[CH];
 #pragma unroll
                 for (int h = 0; h < H2; ++h) {
@@ -697,7 +721,7 @@ __global__ __launch_bounds__(NTH) void dw3_bwd2_kernel(const Dw3BArgs a) {
           const int c = c0 - cbase + 2 * h + e;
           if (a.dw) {
 #pragma unroll
-            for (int t = 0; t < 9; ++t) atomicAdd(lacc + t * Cb + c, (double)wacc[t][h][e]);
+            for (int t = 0; t < 9; ++t) atomicAdd(lacc + t * Cb + c, (double)wacc[t][h][e] * (C6 ? 6.0 : 1.0));
           }
           if (a.stats) {
             atomicAdd(lacc + 9 * Cb + c, (double)psum[2 * h + e]);
@@ -808,8 +832,11 @@ int launch_s1(Dw3BArgs& a, hipStream_t st) {
 //   dx[2oh+1][2ow+1] = w22 T0 + w20 T1 + w02 N0 + w00 N1    (and the four matching dw terms)
 // (T = gradient row oh, N = row oh+1; 0/1 = column ow / ow+1.)  9 + 9 packed FMAs per four input pixels, the full-
 // resolution x is read once and dx written once, the quarter-resolution dz / y are read twice (neighbour column; L2).
-template <typename T, int PF, int NTH>
+// ACT: compile-time activation of the input (round 4: the runtime switch sat in the row loop four times per step, once per
+// input pixel of the 2x2 block); C6: ReLU6 through the clamp modifier (pk_fma_clamp01)
+template <typename T, int PF, int NTH, int ACT>
 __global__ __launch_bounds__(NTH) void dw3_bwd_s2_kernel(const Dw3BArgs a) {
+  constexpr bool C6 = std::is_same<T, bf16_t>::value && ACT == T3D_ACT_RELU6;
   constexpr int CH = 4, H2 = 2;
   extern __shared__ float lred[];       // end of kernel: [11][Cb] fp64 accumulators
   using RV = rawvec<T, CH>;
@@ -831,7 +858,7 @@ __global__ __launch_bounds__(NTH) void dw3_bwd_s2_kernel(const Dw3BArgs a) {
     qstride = gridDim.x * (NTH / 64);
   }
   const int c0 = cg * CH;
-  const bool affine = a.scale != nullptr || a.act != T3D_ACT_NONE;
+  const bool affine = a.scale != nullptr || ACT != T3D_ACT_NONE;
   const int cbase = a.slab ? blockIdx.y * 64 * CH : 0;
   const int Cb = a.slab ? min(64 * CH, a.C - cbase) : a.C;
   // requested BatchNorm-backward finalize of the gradient's coefficients, derived here (see dw3_bwd2_kernel)
@@ -874,6 +901,9 @@ __global__ __launch_bounds__(NTH) void dw3_bwd_s2_kernel(const Dw3BArgs a) {
 #pragma unroll
   for (int i = 0; i < CH; ++i) psum[i] = psq[i] = 0.f;
   float scf[CH] = {sc2[0][0], sc2[0][1], sc2[1][0], sc2[1][1]}, shf[CH] = {sh2[0][0], sh2[0][1], sh2[1][0], sh2[1][1]};
+  f32x2 sc6[H2], sh6[H2];
+#pragma unroll
+  for (int h = 0; h < H2; ++h) { sc6[h] = sc2[h] * f32x2{T3D_SIXTH, T3D_SIXTH}; sh6[h] = sh2[h] * f32x2{T3D_SIXTH, T3D_SIXTH}; }
 
   for (int q = q0; q < a.nitems && on; q += qstride) {
     int ow, rest;
@@ -951,12 +981,17 @@ __global__ __launch_bounds__(NTH) void dw3_bwd_s2_kernel(const Dw3BArgs a) {
           for (int p = 0; p < 4; ++p)
 #pragma unroll
             for (int h = 0; h < H2; ++h) av[p][h] = xr[p][h];
-          if (affine) {
+          if (C6) {
+#pragma unroll
+            for (int p = 0; p < 4; ++p)
+#pragma unroll
+              for (int h = 0; h < H2; ++h) av[p][h] = pk_fma_clamp01(av[p][h], sc6[h], sh6[h]);
+          } else if (affine) {
 #pragma unroll
             for (int p = 0; p < 4; ++p)
 #pragma unroll
               for (int h = 0; h < H2; ++h) av[p][h] = pk_fma(av[p][h], sc2[h], sh2[h]);
-            switch (a.act) {
+            switch (ACT) {
               case T3D_ACT_RELU:
 #pragma unroll
                 for (int p = 0; p < 4; ++p)
@@ -1020,7 +1055,16 @@ __global__ __launch_bounds__(NTH) void dw3_bwd_s2_kernel(const Dw3BArgs a) {
               gv[2 * h] = g[p][h][0]; gv[2 * h + 1] = g[p][h][1];
               xv[2 * h] = xr[p][h][0]; xv[2 * h + 1] = xr[p][h][1];
             }
-            if (affine) act_grad_affine_vec<CH>(gv, xv, scf, shf, a.act);
+            if (C6) {
+#pragma unroll
+              for (int h = 0; h < H2; ++h) {
+                const f32x2 ap = av[p][h];       // (masked to 0 outside an odd-sized image: the gradient there is dropped anyway)
+                gv[2 * h] = (ap[0] > 0.f && ap[0] < 1.f) ? gv[2 * h] : 0.f;
+                gv[2 * h + 1] = (ap[1] > 0.f && ap[1] < 1.f) ? gv[2 * h + 1] : 0.f;
+              }
+            } else if (affine) {
+              act_grad_affine_vec<CH>(gv, xv, scf, shf, ACT);
+            }
             const size_t off = ((size_t)(2 * o + (p >> 1)) * a.W + ix + (p & 1)) * a.C;
             if (rg) {
               const RV rr = *reinterpret_cast<const RV*>(rg + off);
@@ -1060,7 +1104,7 @@ __global__ __launch_bounds__(NTH) void dw3_bwd_s2_kernel(const Dw3BArgs a) {
           const int c = c0 - cbase + 2 * h + e;
           if (a.dw) {
 #pragma unroll
-            for (int t = 0; t < 9; ++t) atomicAdd(lacc + t * Cb + c, (double)wacc[t][h][e]);
+            for (int t = 0; t < 9; ++t) atomicAdd(lacc + t * Cb + c, (double)wacc[t][h][e] * (C6 ? 6.0 : 1.0));
           }
           if (a.stats) {
             atomicAdd(lacc + 9 * Cb + c, (double)psum[2 * h + e]);
@@ -1122,7 +1166,12 @@ int launch_s2(Dw3BArgs& a, hipStream_t st) {
     a.fold = nullptr;
   }
   // (a compile-time activation, as in the stride-1 kernel, pushes this one over 256 VGPRs -> 1 wave/SIMD: slower)
-  T3D_LAUNCH_TIMED((dw3_bwd_s2_kernel<T, PF, 256>), grid, dim3(256), lds, st, a);
+  switch (a.act) {
+    case T3D_ACT_RELU: T3D_LAUNCH_TIMED((dw3_bwd_s2_kernel<T, PF, 256, T3D_ACT_RELU>), grid, dim3(256), lds, st, a); break;
+    case T3D_ACT_RELU6: T3D_LAUNCH_TIMED((dw3_bwd_s2_kernel<T, PF, 256, T3D_ACT_RELU6>), grid, dim3(256), lds, st, a); break;
+    case T3D_ACT_HSWISH: T3D_LAUNCH_TIMED((dw3_bwd_s2_kernel<T, PF, 256, T3D_ACT_HSWISH>), grid, dim3(256), lds, st, a); break;
+    default: T3D_LAUNCH_TIMED((dw3_bwd_s2_kernel<T, PF, 256, T3D_ACT_NONE>), grid, dim3(256), lds, st, a); break;
+  }
   T3D_CHECK_LAUNCH();
   return T3D_OK;
 }

@@ -48,6 +48,31 @@ __device__ __forceinline__ void activate(const rawvec<T, CH>& r, const float* sc
   if (affine) act_affine_vec<CH>(v, sc, sh, act);
 }
 
+// ReLU6 of a BatchNorm affine in ONE packed instruction (bf16 storage): relu6(s x + t) = 6 clamp01((s/6) x + t/6), and
+// v_pk_fma_f32 takes the clamp modifier (result clamped to [0, 1] per half; probed on the box, tools/scratch/pkclamp.hip).
+// The caller scales (s, t) by 1/6 once per thread and folds the 6 into whatever multiplies the activated value next (the
+// stencil weights): two v_med3_f32 per channel pair leave the row loop.  fp32 storage keeps the exact form.
+__device__ __forceinline__ f32x2 pk_fma_clamp01(f32x2 a, f32x2 b, f32x2 c) {
+  f32x2 d;
+  asm("v_pk_fma_f32 %0, %1, %2, %3 clamp" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+  return d;
+}
+
+// rounded store of one output vector + its BatchNorm sums, packed (two channels per v_pk_add / v_pk_fma)
+template <typename T, int CH>
+__device__ __forceinline__ void store_round2(T* p, const f32x2* acc, f32x2* psum, f32x2* psq) {
+  rawvec<T, CH> o;
+#pragma unroll
+  for (int h = 0; h < CH / 2; ++h) {
+    o[2 * h] = (T)acc[h][0];
+    o[2 * h + 1] = (T)acc[h][1];
+    const f32x2 r = {(float)o[2 * h], (float)o[2 * h + 1]};
+    psum[h] = psum[h] + r;
+    psq[h] = pk_fma(r, r, psq[h]);
+  }
+  *reinterpret_cast<rawvec<T, CH>*>(p) = o;
+}
+
 template <typename T, int CH>
 __device__ __forceinline__ void store_round(T* p, const float* acc, float* psum, float* psq) {
   rawvec<T, CH> o;
@@ -253,9 +278,12 @@ __global__ __launch_bounds__(256) void dw3_fwd_kernel(const Dw3Args a) {
 // Here a thread owns columns (2p, 2p+1): four column loads feed two outputs (each element is activated twice instead
 // of three times, address / loop overhead is shared), and all multiply-adds are packed (v_pk_fma_f32: two channels per
 // issue slot).  Zero padding: a 0/1 mask per out-of-image column (per item), skipped rows.
-template <typename T, int PF>
+// ACT: the input's activation as a compile-time constant (round 4; the runtime switch kept every variant's code in the row
+// loop behind scalar branches); C6: ReLU6 through the clamp modifier (pk_fma_clamp01 above)
+template <typename T, int PF, int ACT>
 __global__ __launch_bounds__(256) void dw3_fwd2_kernel(const Dw3Args a) {
   constexpr int CH = 4, H2 = CH / 2;
+  constexpr bool C6 = std::is_same<T, bf16_t>::value && ACT == T3D_ACT_RELU6;
   extern __shared__ __attribute__((aligned(16))) float lstat[];  // [2][C] doubles at the end of the kernel (sums); floats for a derived finalize
   using RV = rawvec<T, CH>;
   const int CG = a.C / CH, Wp = (a.Wo + 1) / 2;
@@ -276,11 +304,11 @@ __global__ __launch_bounds__(256) void dw3_fwd2_kernel(const Dw3Args a) {
     qstride = gridDim.x * 4;
   }
   const int c0 = cg * CH;
-  const bool affine = a.scale != nullptr || a.act != T3D_ACT_NONE;
+  const bool affine = a.scale != nullptr || ACT != T3D_ACT_NONE;
   // requested BatchNorm finalize of the producer: derived here (see dw3_fwd_kernel)
   const int fbase = a.slab ? blockIdx.y * 64 * CH : 0, fCb = a.slab ? min(64 * CH, a.C - fbase) : a.C;
   f32x2 w2[9][H2], sc2[H2], sh2[H2];
-  float psum[CH], psq[CH];
+  f32x2 psum[H2], psq[H2];
   {
     float wb[CH * 9];
     auto load_w = [&]() {
@@ -305,9 +333,14 @@ __global__ __launch_bounds__(256) void dw3_fwd2_kernel(const Dw3Args a) {
       }
 #pragma unroll
       for (int t = 0; t < 9; ++t) w2[t][h] = f32x2{wb[(2 * h) * 9 + t], wb[(2 * h + 1) * 9 + t]};
-    }
+      if (C6) {                        // relu6(s x + t) = 6 clamp01((s/6) x + t/6): the 6 rides on the stencil weights
+        sc2[h] = sc2[h] * f32x2{T3D_SIXTH, T3D_SIXTH};
+        sh2[h] = sh2[h] * f32x2{T3D_SIXTH, T3D_SIXTH};
 #pragma unroll
-    for (int i = 0; i < CH; ++i) psum[i] = psq[i] = 0.f;
+        for (int t = 0; t < 9; ++t) w2[t][h] = w2[t][h] * f32x2{6.f, 6.f};
+      }
+      psum[h] = psq[h] = f32x2{0.f, 0.f};
+    }
   }
   if (a.fold) __syncthreads();      // the scratch is zeroed again at the end of the kernel
 
@@ -322,6 +355,8 @@ __global__ __launch_bounds__(256) void dw3_fwd2_kernel(const Dw3Args a) {
     const bool validB = x0 + 1 < a.W;
     // input columns x0-1 .. x0+2; 0/1 masks for the ones outside the image (column x0 is always inside)
     const float m0 = x0 - 1 >= 0 ? 1.f : 0.f, m2 = validB ? 1.f : 0.f, m3 = x0 + 2 < a.W ? 1.f : 0.f;
+    // (interior waves skip the mask multiplies altogether: wave-uniform)
+    const bool edge = __any(x0 - 1 < 0 || x0 + 2 >= a.W);
     int coff[4];
 #pragma unroll
     for (int c = 0; c < 4; ++c) coff[c] = min(max(x0 - 1 + c, 0), a.W - 1) * a.C;
@@ -367,12 +402,17 @@ __global__ __launch_bounds__(256) void dw3_fwd2_kernel(const Dw3Args a) {
           __builtin_amdgcn_sched_barrier(0);
           fetch(iy + PF, ring[u]);
           __builtin_amdgcn_sched_barrier(0);
-          if (affine) {
+          if (C6) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+#pragma unroll
+              for (int h = 0; h < H2; ++h) v[c][h] = pk_fma_clamp01(v[c][h], sc2[h], sh2[h]);
+          } else if (affine) {
 #pragma unroll
             for (int c = 0; c < 4; ++c)
 #pragma unroll
               for (int h = 0; h < H2; ++h) v[c][h] = pk_fma(v[c][h], sc2[h], sh2[h]);
-            switch (a.act) {   // wave-uniform, once per row
+            switch (ACT) {
               case T3D_ACT_RELU:
 #pragma unroll
                 for (int c = 0; c < 4; ++c)
@@ -399,11 +439,13 @@ __global__ __launch_bounds__(256) void dw3_fwd2_kernel(const Dw3Args a) {
               default: break;
             }
           }
+          if (edge) {
 #pragma unroll
-          for (int h = 0; h < H2; ++h) {   // zero padding of the activated tensor
-            v[0][h] = v[0][h] * f32x2{m0, m0};
-            v[2][h] = v[2][h] * f32x2{m2, m2};
-            v[3][h] = v[3][h] * f32x2{m3, m3};
+            for (int h = 0; h < H2; ++h) {   // zero padding of the activated tensor
+              v[0][h] = v[0][h] * f32x2{m0, m0};
+              v[2][h] = v[2][h] * f32x2{m2, m2};
+              v[3][h] = v[3][h] * f32x2{m3, m3};
+            }
           }
           f32x2* aA = accA[u % 3];
           f32x2* aB = accB[u % 3];
@@ -428,15 +470,9 @@ __global__ __launch_bounds__(256) void dw3_fwd2_kernel(const Dw3Args a) {
           }
           const int oy = iy - 1;
           if (oy >= oy0 && oy < oy1) {
-            float oa[CH], ob[CH];
-#pragma unroll
-            for (int h = 0; h < H2; ++h) {
-              oa[2 * h] = aA[h][0]; oa[2 * h + 1] = aA[h][1];
-              ob[2 * h] = aB[h][0]; ob[2 * h + 1] = aB[h][1];
-            }
             T* yp = y + ((size_t)oy * a.Wo + x0) * a.C;
-            store_round<T, CH>(yp, oa, psum, psq);
-            if (validB) store_round<T, CH>(yp + a.C, ob, psum, psq);
+            store_round2<T, CH>(yp, aA, psum, psq);
+            if (validB) store_round2<T, CH>(yp + a.C, aB, psum, psq);
           }
 #pragma unroll
           for (int h = 0; h < H2; ++h) aA[h] = aB[h] = f32x2{0.f, 0.f};
@@ -455,8 +491,8 @@ __global__ __launch_bounds__(256) void dw3_fwd2_kernel(const Dw3Args a) {
     if (on) {
 #pragma unroll
       for (int i = 0; i < CH; ++i) {
-        atomicAdd(dstat + c0 - cbase + i, t3d_snap(psum[i], a.quant, false));
-        atomicAdd(dstat + Cb + c0 - cbase + i, t3d_snap(psq[i], a.quant, true));
+        atomicAdd(dstat + c0 - cbase + i, t3d_snap(psum[i / 2][i % 2], a.quant, false));
+        atomicAdd(dstat + Cb + c0 - cbase + i, t3d_snap(psq[i / 2][i % 2], a.quant, true));
       }
     }
     __syncthreads();
@@ -513,7 +549,14 @@ int launch_ch(Dw3Args& a, int s, hipStream_t st) {
   // perturbation between the parity mode and the reference)
   a.quant = (a.stats && std::is_same<T, bf16_t>::value && !getenv("T3D_NO_SNAP")) ? t3d_quant_for((long long)a.B * a.Ho * a.Wo)
                                                                                   : T3dQuant{0.0, 0.0};
-  if (use2) T3D_LAUNCH_TIMED((dw3_fwd2_kernel<T, PF>), grid, dim3(256), lds, st, a);
+  if (use2) {
+    switch (a.act) {
+      case T3D_ACT_RELU: T3D_LAUNCH_TIMED((dw3_fwd2_kernel<T, PF, T3D_ACT_RELU>), grid, dim3(256), lds, st, a); break;
+      case T3D_ACT_RELU6: T3D_LAUNCH_TIMED((dw3_fwd2_kernel<T, PF, T3D_ACT_RELU6>), grid, dim3(256), lds, st, a); break;
+      case T3D_ACT_HSWISH: T3D_LAUNCH_TIMED((dw3_fwd2_kernel<T, PF, T3D_ACT_HSWISH>), grid, dim3(256), lds, st, a); break;
+      default: T3D_LAUNCH_TIMED((dw3_fwd2_kernel<T, PF, T3D_ACT_NONE>), grid, dim3(256), lds, st, a); break;
+    }
+  }
   else if (s == 1) T3D_LAUNCH_TIMED((dw3_fwd_kernel<T, 1, CH, PF>), grid, dim3(256), lds, st, a);
   else T3D_LAUNCH_TIMED((dw3_fwd_kernel<T, 2, CH, PF>), grid, dim3(256), lds, st, a);
   T3D_CHECK_LAUNCH();
