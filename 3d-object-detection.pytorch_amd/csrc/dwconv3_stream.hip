@@ -87,8 +87,12 @@ __device__ __forceinline__ void store_round(T* p, const float* acc, float* psum,
 }
 
 // CH channels per thread (8 -> 16-B bf16 vectors, 4 -> 8-B: more resident waves), PF input rows in flight
-template <typename T, int S, int CH, int PF>
+// ACT: compile-time activation (round 4); stride 2 in bf16 storage with ReLU6: the clamp form (pk_fma_clamp01) and packed
+// stencil math -- a.act is only read by the launcher
+template <typename T, int S, int CH, int PF, int ACT>
 __global__ __launch_bounds__(256) void dw3_fwd_kernel(const Dw3Args a) {
+  constexpr bool C6 = std::is_same<T, bf16_t>::value && ACT == T3D_ACT_RELU6 && S == 2;
+  constexpr int H2 = CH / 2;
   extern __shared__ __attribute__((aligned(16))) float lstat[];  // [2][C] doubles at the end of the kernel (sums); floats for a derived finalize
   using RV = rawvec<T, CH>;
   const int CG = a.C / CH;
@@ -114,7 +118,7 @@ __global__ __launch_bounds__(256) void dw3_fwd_kernel(const Dw3Args a) {
     qstride = gridDim.x * 4;
   }
   const int c0 = cg * CH;
-  const bool affine = a.scale != nullptr || a.act != T3D_ACT_NONE;
+  const bool affine = a.scale != nullptr || ACT != T3D_ACT_NONE;
   // the producer's BatchNorm finalize, derived here when requested (common.h): the block's own channel range through
   // the statistics scratch (free until the end of the kernel); one block per channel range publishes
   const int fbase = a.slab ? blockIdx.y * 64 * CH : 0, fCb = a.slab ? min(64 * CH, a.C - fbase) : a.C;
@@ -136,9 +140,13 @@ __global__ __launch_bounds__(256) void dw3_fwd_kernel(const Dw3Args a) {
       sh[i] = a.fold ? lstat[fCb + c0 - fbase + i] : (a.scale ? a.shift[c0 + i] : 0.f);
       psum[i] = psq[i] = 0.f;
 #pragma unroll
-      for (int t = 0; t < 9; ++t) wt[t][i] = wb[i * 9 + t];
+      for (int t = 0; t < 9; ++t) wt[t][i] = wb[i * 9 + t] * (C6 ? 6.f : 1.f);
+      if (C6) { sc[i] *= T3D_SIXTH; sh[i] *= T3D_SIXTH; }
     }
   }
+  f32x2 sc2[H2], sh2[H2];
+#pragma unroll
+  for (int h = 0; h < H2; ++h) { sc2[h] = f32x2{sc[2 * h], sc[2 * h + 1]}; sh2[h] = f32x2{sh[2 * h], sh[2 * h + 1]}; }
   if (a.fold) __syncthreads();      // the scratch is zeroed again at the end of the kernel
   for (int q = q0; q < a.nitems && on; q += qstride) {
   int ox, rest;
@@ -186,8 +194,19 @@ __global__ __launch_bounds__(256) void dw3_fwd_kernel(const Dw3Args a) {
         if (iy <= iy_last) {
           const bool rok = iy >= 0 && iy < a.H;   // wave-uniform in the slab mapping, near-uniform otherwise
           float v[3][CH];
+          if (C6) {
 #pragma unroll
-          for (int c = 0; c < 3; ++c) activate<T, CH>(ring[u][c], sc, sh, a.act, affine, v[c]);
+            for (int c = 0; c < 3; ++c)
+#pragma unroll
+              for (int h = 0; h < H2; ++h) {
+                const f32x2 t = pk_fma_clamp01(f32x2{(float)ring[u][c][2 * h], (float)ring[u][c][2 * h + 1]}, sc2[h], sh2[h]);
+                v[c][2 * h] = t[0];
+                v[c][2 * h + 1] = t[1];
+              }
+          } else {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) activate<T, CH>(ring[u][c], sc, sh, ACT, affine, v[c]);
+          }
           fetch(iy + PF, ring[u]);   // refill this slot: PF rows ahead
           if constexpr (S == 1) {
             float* accA = acc[u % 3];
@@ -557,8 +576,19 @@ int launch_ch(Dw3Args& a, int s, hipStream_t st) {
       default: T3D_LAUNCH_TIMED((dw3_fwd2_kernel<T, PF, T3D_ACT_NONE>), grid, dim3(256), lds, st, a); break;
     }
   }
-  else if (s == 1) T3D_LAUNCH_TIMED((dw3_fwd_kernel<T, 1, CH, PF>), grid, dim3(256), lds, st, a);
-  else T3D_LAUNCH_TIMED((dw3_fwd_kernel<T, 2, CH, PF>), grid, dim3(256), lds, st, a);
+  else {
+#define T3D_DWF(SV, ACTV) T3D_LAUNCH_TIMED((dw3_fwd_kernel<T, SV, CH, PF, ACTV>), grid, dim3(256), lds, st, a)
+#define T3D_DWF_S(SV)                                          \
+  switch (a.act) {                                             \
+    case T3D_ACT_RELU: T3D_DWF(SV, T3D_ACT_RELU); break;       \
+    case T3D_ACT_RELU6: T3D_DWF(SV, T3D_ACT_RELU6); break;     \
+    case T3D_ACT_HSWISH: T3D_DWF(SV, T3D_ACT_HSWISH); break;   \
+    default: T3D_DWF(SV, T3D_ACT_NONE); break;                 \
+  }
+    if (s == 1) { T3D_DWF_S(1) } else { T3D_DWF_S(2) }
+#undef T3D_DWF_S
+#undef T3D_DWF
+  }
   T3D_CHECK_LAUNCH();
   return T3D_OK;
 }

@@ -143,6 +143,26 @@ class Detector:
         img, shape = self._enqueue(frame)
         return self._decode_detections(self.model.detect(img)[0], shape)
 
+    def get_detections_batch(self, frames):
+        """BASELINE config 5 ("batched on 1 MI355X"): F equally sized frames per launch chain -- `frames` [F,H,W,3] uint8 (a
+        device tensor, or anything torch.as_tensor takes) -> list of F detection lists, each as `get_detections` returns it.
+        One resize launch for the whole stack (the stack is one tall frame to `t3d_crop_resize_u8`: frame f is the crop
+        rows f*H .. (f+1)*H), one pass of the detector over the F x 300 x 300 batch, one decode + NMS launch, one read-back."""
+        from ..models.ssd import INPUT_SIZE
+        if not torch.is_tensor(frames):
+            frames = torch.from_numpy(np.ascontiguousarray(frames))
+        frames = frames.to(self.device, non_blocking=True).contiguous()
+        F, H, W = int(frames.shape[0]), int(frames.shape[1]), int(frames.shape[2])
+        key = (F, H, W)
+        if getattr(self, '_batch_key', None) != key:
+            ys = torch.arange(F, dtype=torch.int32) * H
+            self._batch_rects = torch.stack([torch.zeros_like(ys), ys, torch.full_like(ys, W), ys + H], 1).contiguous().to(self.device)
+            self._batch_imgs = torch.empty(F, INPUT_SIZE, INPUT_SIZE, 3, dtype=torch.uint8, device=self.device)
+            self._batch_key = key
+        N.call('t3d_crop_resize_u8', N.ptr(frames), N.ptr(self._batch_rects), N.ptr(self._batch_imgs), F, F * H, W, INPUT_SIZE,
+               INPUT_SIZE, N.stream())
+        return [self._decode_detections(rows, (H, W)) for rows in self.model.detect(self._batch_imgs)]
+
     def _decode_detections(self, rows, frame_shape):
         """ie_wrappers.py:94-120 on rows (x1, y1, x2, y2 normalised, confidence, label)."""
         detections = []

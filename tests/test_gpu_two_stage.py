@@ -202,6 +202,10 @@ def test_detector_then_regressor_is_the_whole_two_stage_pipeline():
     det.run_async(frame)
     assert det.wait_and_grab() == dets
     assert len(dets) > 0
+    # BASELINE config 5, "batched": several frames through ONE launch chain give each frame's own detections
+    frame2 = rng.integers(0, 256, (1080, 1920, 3), dtype=np.uint8)
+    both = det.get_detections_batch(np.stack([frame, frame2, frame]))
+    assert both[0] == dets and both[2] == dets and both[1] == det.get_detections(frame2) and both[1] != dets
     for left, top, right, bottom, conf, label in dets:
         assert 0 <= left <= right <= 1920 and 0 <= top <= bottom <= 1080 and 0.3 < conf <= 1 and 0 <= label < 9
     cfg = _cfg('mobilenetv2')

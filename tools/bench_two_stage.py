@@ -14,6 +14,8 @@ ap.add_argument('--model', default='mobilenetv2')
 ap.add_argument('--dets', type=int, default=16)
 ap.add_argument('--frames', type=int, default=200)
 ap.add_argument('--dtype', default='bf16')
+ap.add_argument('--batch-frames', type=int, nargs='*', default=[8, 32], help='with --detector: frames per launch chain of the '
+                'batched detector stage (Detector.get_detections_batch; BASELINE config 5 says "batched on 1 MI355X")')
 ap.add_argument('--detector', action='store_true', help='time the whole pipeline: SSD300-MobileNetV2 detector (models/ssd.py) '
                 'on the frame, then the regression stage on its detections (scripts/demo.py:48-90)')
 args = ap.parse_args()
@@ -91,11 +93,40 @@ if args.detector:
             det.get_detections(fd)
         torch.cuda.synchronize()
         return (time.perf_counter() - t) / frames
+    def detector_batched(fb, reps):
+        stack = fd.unsqueeze(0).repeat(fb, 1, 1, 1).contiguous()
+        det.get_detections_batch(stack)
+        torch.cuda.synchronize()
+        t = time.perf_counter()
+        for _ in range(reps):
+            out = det.get_detections_batch(stack)
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t) / (reps * fb), out
+
+    def pipeline_batched(fb, reps):
+        # detector over fb frames in one chain, then the regression stage frame by frame on its detections
+        stack = fd.unsqueeze(0).repeat(fb, 1, 1, 1).contiguous()
+        torch.cuda.synchronize()
+        t = time.perf_counter()
+        for _ in range(reps):
+            for f, dets in enumerate(det.get_detections_batch(stack)):
+                if dets:
+                    reg.get_detections(stack[f], dets[:n])
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t) / (reps * fb)
     pipeline(5)
     tp, nd = pipeline(max(20, args.frames // 4))
     td = detector_only(max(20, args.frames // 4))
+    batched = {}
+    one = det.get_detections(fd)
+    for fb in args.batch_frames:
+        tb, outb = detector_batched(fb, max(5, args.frames // (4 * fb)))
+        assert all(o == one for o in outb), 'batched detections differ from the one-frame path'
+        tpb = pipeline_batched(fb, max(3, args.frames // (8 * fb)))
+        batched[str(fb)] = {'detector_ms_per_frame': round(tb * 1e3, 3), 'detector_frames_per_s': round(1 / tb, 1),
+                            'pipeline_ms_per_frame': round(tpb * 1e3, 3), 'pipeline_frames_per_s': round(1 / tpb, 1)}
     extra = {'pipeline_ms_per_frame': round(tp * 1e3, 3), 'pipeline_frames_per_s': round(1 / tp, 1), 'detections_regressed_per_frame': round(nd, 1),
-             'detector_ms_per_frame': round(td * 1e3, 3), 'detector': 'SSD300-MobileNetV2 (random weights), one frame per launch chain, host read-back of the detections'}
+             'detector_ms_per_frame': round(td * 1e3, 3), 'batched_frames_per_launch_chain': batched, 'detector': 'SSD300-MobileNetV2 (random weights), one frame per launch chain, host read-back of the detections'}
 print(json.dumps({**extra, 'metric': f'two-stage regression stage, {n} detections per 1080x1920 frame, {args.model}', 'frames_per_s': round(1 / t_res, 1),
                   'crops_per_s': round(n / t_res, 1), 'ms_per_frame': round(t_res * 1e3, 3), 'frames_per_s_with_h2d': round(1 / t_up, 1),
                   'crop_resize_us': round(t_crop * 1e6, 1), 'dtype': args.dtype,
