@@ -38,6 +38,24 @@ struct Dw3Args {
 
 template <typename T, int CH> using rawvec = T __attribute__((ext_vector_type(CH)));
 
+// raw buffer loads / stores: scalar descriptor + 32-bit scalar row offset + 32-bit lane offset -- no 64-bit vector address
+// arithmetic in the row loop (20 v_lshl_add_u64 + 8 v_mul_lo_u32 per three rows of the s=1 forward before); an offset beyond
+// num_records reads zeros / drops the store, which also replaces the store predicates of edge lanes
+template <typename RV>
+__device__ __forceinline__ RV bufload(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+  if constexpr (sizeof(RV) == 4) return __builtin_bit_cast(RV, __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
+  else if constexpr (sizeof(RV) == 8) return __builtin_bit_cast(RV, __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0));
+  else return __builtin_bit_cast(RV, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
+}
+template <typename RV>
+__device__ __forceinline__ void bufstore(const RV& v, __amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+  typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+  typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+  if constexpr (sizeof(RV) == 4) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, voff, soff, 0);
+  else if constexpr (sizeof(RV) == 8) __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, v), r, voff, soff, 0);
+  else __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, voff, soff, 0);
+}
+
 // raw vector -> activated fp32.  Zero padding applies to the ACTIVATED tensor: taps outside the image are removed by
 // zeroing the WEIGHTS of an out-of-image column (per item) and by skipping out-of-image rows (wave-uniform).
 template <typename T, int CH>
@@ -60,17 +78,17 @@ __device__ __forceinline__ f32x2 pk_fma_clamp01(f32x2 a, f32x2 b, f32x2 c) {
 
 // rounded store of one output vector + its BatchNorm sums, packed (two channels per v_pk_add / v_pk_fma)
 template <typename T, int CH>
-__device__ __forceinline__ void store_round2(T* p, const f32x2* acc, f32x2* psum, f32x2* psq) {
+__device__ __forceinline__ rawvec<T, CH> round_sums2(const f32x2* acc, f32x2* psum, f32x2* psq, float m) {
   rawvec<T, CH> o;
 #pragma unroll
   for (int h = 0; h < CH / 2; ++h) {
     o[2 * h] = (T)acc[h][0];
     o[2 * h + 1] = (T)acc[h][1];
-    const f32x2 r = {(float)o[2 * h], (float)o[2 * h + 1]};
+    const f32x2 r = f32x2{(float)o[2 * h], (float)o[2 * h + 1]} * f32x2{m, m};      // (m = 0: a lane without this column)
     psum[h] = psum[h] + r;
     psq[h] = pk_fma(r, r, psq[h]);
   }
-  *reinterpret_cast<rawvec<T, CH>*>(p) = o;
+  return o;
 }
 
 template <typename T, int CH>
@@ -114,7 +132,7 @@ __global__ __launch_bounds__(256) void dw3_fwd_kernel(const Dw3Args a) {
     cg = blockIdx.y * 64 + (threadIdx.x & 63);
     on = cg < CG;
     if (!on) cg = 0;
-    q0 = blockIdx.x * 4 + (threadIdx.x >> 6);
+    q0 = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);      // wave-uniform: scalar item decode
     qstride = gridDim.x * 4;
   }
   const int c0 = cg * CH;
@@ -148,12 +166,20 @@ __global__ __launch_bounds__(256) void dw3_fwd_kernel(const Dw3Args a) {
 #pragma unroll
   for (int h = 0; h < H2; ++h) { sc2[h] = f32x2{sc[2 * h], sc[2 * h + 1]}; sh2[h] = f32x2{sh[2 * h], sh[2 * h + 1]}; }
   if (a.fold) __syncthreads();      // the scratch is zeroed again at the end of the kernel
+  // raw buffer addressing (scalar row offsets + 32-bit lane offsets) when the tensors allow it (< 2 GB); else 64-bit pointers
+  const size_t xbytes = (size_t)a.B * a.H * a.W * a.C * sizeof(T), ybytes = (size_t)a.B * a.Ho * a.Wo * a.C * sizeof(T);
+  constexpr bool CANBUF = sizeof(RV) <= 16;      // (fp32 storage with 8 channels per thread: 32-byte vectors keep the pointer path)
+  const bool buf = CANBUF && xbytes < (1ull << 31);
+  const __amdgpu_buffer_rsrc_t rsx = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.x), 0, (int)xbytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsy = __builtin_amdgcn_make_buffer_rsrc(a.y, 0, (int)ybytes, 0x00020000);
   for (int q = q0; q < a.nitems && on; q += qstride) {
   int ox, rest;
   if (!a.slab) { ox = ox_fixed; rest = q; } else { ox = q % a.Wo; rest = q / a.Wo; }
   const int chunk = rest % a.nchunks, b = rest / a.nchunks;
   const T* __restrict__ x = reinterpret_cast<const T*>(a.x) + (size_t)b * a.H * a.W * a.C + c0;
   T* __restrict__ y = reinterpret_cast<T*>(a.y) + (size_t)b * a.Ho * a.Wo * a.C + c0;
+  const size_t imgrow = (size_t)b * a.H, outrow = (size_t)b * a.Ho;
+  const unsigned vst = (unsigned)(ox * a.C + c0) * (unsigned)sizeof(T);
   const int oy0 = chunk * a.rows_per_chunk;
   const int oy1 = min(a.Ho, oy0 + a.rows_per_chunk);
   const int ix0 = ox * S - 1;
@@ -172,10 +198,40 @@ __global__ __launch_bounds__(256) void dw3_fwd_kernel(const Dw3Args a) {
 #pragma unroll
   for (int c = 0; c < 3; ++c) coff[c] = min(max(ix0 + c, 0), a.W - 1) * a.C;
   RV ring[PF][3];
-  auto fetch = [&](int iy, RV* dst) {
-    const T* rp = x + (size_t)min(max(iy, 0), a.H - 1) * a.W * a.C;
+  unsigned boff[3];
 #pragma unroll
-    for (int c = 0; c < 3; ++c) dst[c] = *reinterpret_cast<const RV*>(rp + coff[c]);
+  for (int c = 0; c < 3; ++c) boff[c] = (unsigned)(coff[c] + c0) * (unsigned)sizeof(T);
+  auto fetch = [&](int iy, RV* dst) {
+    if constexpr (CANBUF) {
+      if (buf) {
+        const unsigned so = (unsigned)((imgrow + min(max(iy, 0), a.H - 1)) * a.W * a.C * sizeof(T));     // scalar
+#pragma unroll
+        for (int c = 0; c < 3; ++c) dst[c] = bufload<RV>(rsx, boff[c], so);
+        return;
+      }
+    }
+    {
+      const T* rp = x + (size_t)min(max(iy, 0), a.H - 1) * a.W * a.C;
+#pragma unroll
+      for (int c = 0; c < 3; ++c) dst[c] = *reinterpret_cast<const RV*>(rp + coff[c]);
+    }
+  };
+  auto put = [&](int oy, const float* acc) {       // rounded store + BatchNorm sums of one output vector
+    if constexpr (CANBUF) {
+      if (buf) {
+        RV o;
+#pragma unroll
+        for (int i = 0; i < CH; ++i) {
+          o[i] = (T)acc[i];
+          const float r = (float)o[i];
+          psum[i] += r;
+          psq[i] = fmaf(r, r, psq[i]);
+        }
+        bufstore<RV>(o, rsy, vst, (unsigned)((outrow + oy) * a.Wo * a.C * sizeof(T)));
+        return;
+      }
+    }
+    store_round<T, CH>(y + ((size_t)oy * a.Wo + ox) * a.C, acc, psum, psq);
   };
 
   {
@@ -228,7 +284,7 @@ __global__ __launch_bounds__(256) void dw3_fwd_kernel(const Dw3Args a) {
                 }
             }
             const int oy = iy - 1;
-            if (oy >= oy0 && oy < oy1) store_round<T, CH>(y + ((size_t)oy * a.Wo + ox) * a.C, accA, psum, psq);
+            if (oy >= oy0 && oy < oy1) put(oy, accA);
 #pragma unroll
             for (int i = 0; i < CH; ++i) accA[i] = 0.f;   // becomes the "row iy+2" accumulator of the next row
           } else {
@@ -253,7 +309,7 @@ __global__ __launch_bounds__(256) void dw3_fwd_kernel(const Dw3Args a) {
 #pragma unroll
                   for (int i = 0; i < CH; ++i) accA[i] = fmaf(v[c][i], wk[6 + c][i], accA[i]);
                 const int oy = oy0 + (rel >> 1) - 1;
-                store_round<T, CH>(y + ((size_t)oy * a.Wo + ox) * a.C, accA, psum, psq);
+                put(oy, accA);
               }
 #pragma unroll
               for (int i = 0; i < CH; ++i) accA[i] = v[0][i] * wk[0][i];
@@ -319,7 +375,7 @@ __global__ __launch_bounds__(256) void dw3_fwd2_kernel(const Dw3Args a) {
     cg = blockIdx.y * 64 + (threadIdx.x & 63);
     on = cg < CG;
     if (!on) cg = 0;
-    q0 = blockIdx.x * 4 + (threadIdx.x >> 6);
+    q0 = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);      // wave-uniform: scalar item decode
     qstride = gridDim.x * 4;
   }
   const int c0 = cg * CH;
@@ -363,12 +419,14 @@ __global__ __launch_bounds__(256) void dw3_fwd2_kernel(const Dw3Args a) {
   }
   if (a.fold) __syncthreads();      // the scratch is zeroed again at the end of the kernel
 
-  for (int q = q0; q < a.nitems && on; q += qstride) {
+  const size_t xbytes = (size_t)a.B * a.H * a.W * a.C * sizeof(T), ybytes = (size_t)a.B * a.Ho * a.Wo * a.C * sizeof(T);
+  const __amdgpu_buffer_rsrc_t rsx = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.x), 0, (int)xbytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsy = __builtin_amdgcn_make_buffer_rsrc(a.y, 0, (int)ybytes, 0x00020000);
+  const unsigned OOB = 0x80000000u;         // beyond num_records of every tensor here (the launcher refuses >= 2 GB)
+  for (int q = q0; q < a.nitems; q += qstride) {
     int xp, rest;
     if (!a.slab) { xp = xp_fixed; rest = q; } else { xp = q % Wp; rest = q / Wp; }
-    const int chunk = rest % a.nchunks, b = rest / a.nchunks;
-    const T* __restrict__ x = reinterpret_cast<const T*>(a.x) + (size_t)b * a.H * a.W * a.C + c0;
-    T* __restrict__ y = reinterpret_cast<T*>(a.y) + (size_t)b * a.Ho * a.Wo * a.C + c0;
+    const int chunk = rest % a.nchunks, b = rest / a.nchunks;          // wave-uniform
     const int oy0 = chunk * a.rows_per_chunk, oy1 = min(a.Ho, oy0 + a.rows_per_chunk);
     const int x0 = 2 * xp;                  // output columns x0 (always valid) and x0+1
     const bool validB = x0 + 1 < a.W;
@@ -376,16 +434,20 @@ __global__ __launch_bounds__(256) void dw3_fwd2_kernel(const Dw3Args a) {
     const float m0 = x0 - 1 >= 0 ? 1.f : 0.f, m2 = validB ? 1.f : 0.f, m3 = x0 + 2 < a.W ? 1.f : 0.f;
     // (interior waves skip the mask multiplies altogether: wave-uniform)
     const bool edge = __any(x0 - 1 < 0 || x0 + 2 >= a.W);
-    int coff[4];
+    unsigned coff[4];                       // lane part of the load addresses (bytes)
 #pragma unroll
-    for (int c = 0; c < 4; ++c) coff[c] = min(max(x0 - 1 + c, 0), a.W - 1) * a.C;
+    for (int c = 0; c < 4; ++c) coff[c] = (unsigned)(min(max(x0 - 1 + c, 0), a.W - 1) * a.C + c0) * (unsigned)sizeof(T);
+    const unsigned stA = on ? (unsigned)(x0 * a.C + c0) * (unsigned)sizeof(T) : OOB;
+    const unsigned stB = (on && validB) ? stA + (unsigned)(a.C * sizeof(T)) : OOB;
+    const float mB = (on && validB) ? 1.f : 0.f;
     const int iy_first = oy0 - 1, iy_last = oy1;
+    const size_t imgrow = (size_t)b * a.H, outrow = (size_t)b * a.Ho;
 
     RV ring[PF][4];
     auto fetch = [&](int iy, RV* dst) {
-      const T* rp = x + (size_t)min(max(iy, 0), a.H - 1) * a.W * a.C;
+      const unsigned so = (unsigned)((imgrow + min(max(iy, 0), a.H - 1)) * a.W * a.C * sizeof(T));     // scalar
 #pragma unroll
-      for (int c = 0; c < 4; ++c) dst[c] = *reinterpret_cast<const RV*>(rp + coff[c]);
+      for (int c = 0; c < 4; ++c) dst[c] = bufload<RV>(rsx, coff[c], so);
     };
 #pragma unroll
     for (int u = 0; u < PF; ++u) {      // ring fill in slot order, pinned (see dw3_bwd2_kernel's row loop)
@@ -488,10 +550,10 @@ __global__ __launch_bounds__(256) void dw3_fwd2_kernel(const Dw3Args a) {
             }
           }
           const int oy = iy - 1;
-          if (oy >= oy0 && oy < oy1) {
-            T* yp = y + ((size_t)oy * a.Wo + x0) * a.C;
-            store_round2<T, CH>(yp, aA, psum, psq);
-            if (validB) store_round2<T, CH>(yp + a.C, aB, psum, psq);
+          if (oy >= oy0 && oy < oy1) {      // wave-uniform
+            const unsigned so = (unsigned)((outrow + oy) * a.Wo * a.C * sizeof(T));
+            bufstore<RV>(round_sums2<T, CH>(aA, psum, psq, 1.f), rsy, stA, so);      // (lanes that are off never flush their sums)
+            bufstore<RV>(round_sums2<T, CH>(aB, psum, psq, mB), rsy, stB, so);
           }
 #pragma unroll
           for (int h = 0; h < H2; ++h) aA[h] = aB[h] = f32x2{0.f, 0.f};
@@ -537,7 +599,8 @@ int launch_ch(Dw3Args& a, int s, hipStream_t st) {
   a.rows_per_chunk = cdiv(a.Ho, nchunks);
   a.nchunks = cdiv(a.Ho, a.rows_per_chunk);
   static const bool two_col = !getenv("T3D_DW_1COL");
-  const bool use2 = (s == 1 && CH == 4 && two_col);
+  // (the two-column kernel addresses through 32-bit buffer offsets: tensors below 2 GB)
+  const bool use2 = (s == 1 && CH == 4 && two_col && (size_t)a.B * a.H * a.W * a.C * sizeof(T) < (1ull << 31));
   const int Wcols = use2 ? (a.Wo + 1) / 2 : a.Wo;     // work items per row: column pairs or columns
   dim3 grid;
   // persistent blocks: enough to fill the chip, few enough that the per-block flush stays cheap (tools/sweep_dwf.sh)
