@@ -837,6 +837,8 @@ int launch_s1(Dw3BArgs& a, hipStream_t st) {
 template <typename T, int PF, int NTH, int ACT>
 __global__ __launch_bounds__(NTH) void dw3_bwd_s2_kernel(const Dw3BArgs a) {
   constexpr bool C6 = std::is_same<T, bf16_t>::value && ACT == T3D_ACT_RELU6;
+  // ACT < 0: the activation stays a runtime value (h-swish: its compile-time form needs 276 VGPRs -> one wave per SIMD)
+  const int act_rt = ACT >= 0 ? ACT : a.act;
   constexpr int CH = 4, H2 = 2;
   extern __shared__ float lred[];       // end of kernel: [11][Cb] fp64 accumulators
   using RV = rawvec<T, CH>;
@@ -854,11 +856,11 @@ __global__ __launch_bounds__(NTH) void dw3_bwd_s2_kernel(const Dw3BArgs a) {
     cg = blockIdx.y * 64 + (threadIdx.x & 63);
     on = cg < CG;
     if (!on) cg = 0;
-    q0 = blockIdx.x * (NTH / 64) + (threadIdx.x >> 6);
+    q0 = blockIdx.x * (NTH / 64) + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform: scalar item decode
     qstride = gridDim.x * (NTH / 64);
   }
   const int c0 = cg * CH;
-  const bool affine = a.scale != nullptr || ACT != T3D_ACT_NONE;
+  const bool affine = a.scale != nullptr || act_rt != T3D_ACT_NONE;
   const int cbase = a.slab ? blockIdx.y * 64 * CH : 0;
   const int Cb = a.slab ? min(64 * CH, a.C - cbase) : a.C;
   // requested BatchNorm-backward finalize of the gradient's coefficients, derived here (see dw3_bwd2_kernel)
@@ -905,6 +907,11 @@ __global__ __launch_bounds__(NTH) void dw3_bwd_s2_kernel(const Dw3BArgs a) {
 #pragma unroll
   for (int h = 0; h < H2; ++h) { sc6[h] = sc2[h] * f32x2{T3D_SIXTH, T3D_SIXTH}; sh6[h] = sh2[h] * f32x2{T3D_SIXTH, T3D_SIXTH}; }
 
+  const size_t obytes = (size_t)a.B * Ho * Wo * a.C * sizeof(T), ibytes = (size_t)a.B * a.H * a.W * a.C * sizeof(T);
+  const __amdgpu_buffer_rsrc_t rsz = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.dz), 0, (int)obytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsy = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.y), 0, (int)obytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsx = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.x), 0, (int)ibytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsd = __builtin_amdgcn_make_buffer_rsrc(a.dx, 0, (int)ibytes, 0x00020000);
   for (int q = q0; q < a.nitems && on; q += qstride) {
     int ow, rest;
     if (!a.slab) { ow = ow_fixed; rest = q; } else { ow = q % Wo; rest = q / Wo; }
@@ -929,6 +936,10 @@ __global__ __launch_bounds__(NTH) void dw3_bwd_s2_kernel(const Dw3BArgs a) {
     const float mo1 = ow + 1 < Wo ? 1.f : 0.f, mxB = colB ? 1.f : 0.f;
     const int ocoff[2] = {ow * a.C, min(ow + 1, Wo - 1) * a.C};
     const int icoff[2] = {ix * a.C, min(ix + 1, a.W - 1) * a.C};
+    // raw buffer addressing: scalar row offsets + 32-bit lane offsets (the launcher refuses tensors of 2 GB and more)
+    const unsigned ob[2] = {(unsigned)(ocoff[0] + c0) * (unsigned)sizeof(T), (unsigned)(ocoff[1] + c0) * (unsigned)sizeof(T)};
+    const unsigned ib[2] = {(unsigned)(icoff[0] + c0) * (unsigned)sizeof(T), (unsigned)(icoff[1] + c0) * (unsigned)sizeof(T)};
+    const size_t orow0 = (size_t)b * Ho, irow0 = (size_t)b * a.H;
 
     auto form_dy = [&](const RV& z, const RV& yy, float mask, f32x2* out) {
 #pragma unroll
@@ -948,14 +959,15 @@ __global__ __launch_bounds__(NTH) void dw3_bwd_s2_kernel(const Dw3BArgs a) {
     }
     RV rz[PF][2], ry[PF][2], rx[PF][4];
     auto fetch = [&](int o, int slot) {   // everything step `o` consumes: gradient row o+1, input rows 2o, 2o+1
-      const size_t ro = (size_t)min(o + 1, Ho - 1) * Wo * a.C;
-      const size_t ra = (size_t)min(2 * o, a.H - 1) * a.W * a.C, rb = (size_t)min(2 * o + 1, a.H - 1) * a.W * a.C;
+      const unsigned ro = (unsigned)((orow0 + min(o + 1, Ho - 1)) * Wo * a.C * sizeof(T));           // scalar row offsets
+      const unsigned ra = (unsigned)((irow0 + min(2 * o, a.H - 1)) * a.W * a.C * sizeof(T));
+      const unsigned rb = (unsigned)((irow0 + min(2 * o + 1, a.H - 1)) * a.W * a.C * sizeof(T));
 #pragma unroll
       for (int c = 0; c < 2; ++c) {
-        rz[slot][c] = *reinterpret_cast<const RV*>(zg + ro + ocoff[c]);
-        ry[slot][c] = *reinterpret_cast<const RV*>(yg + ro + ocoff[c]);
-        rx[slot][c] = *reinterpret_cast<const RV*>(xg + ra + icoff[c]);
-        rx[slot][2 + c] = *reinterpret_cast<const RV*>(xg + rb + icoff[c]);
+        rz[slot][c] = bufload<RV>(rsz, ob[c], ro);
+        ry[slot][c] = bufload<RV>(rsy, ob[c], ro);
+        rx[slot][c] = bufload<RV>(rsx, ib[c], ra);
+        rx[slot][2 + c] = bufload<RV>(rsx, ib[c], rb);
       }
     };
 #pragma unroll
@@ -991,7 +1003,7 @@ __global__ __launch_bounds__(NTH) void dw3_bwd_s2_kernel(const Dw3BArgs a) {
             for (int p = 0; p < 4; ++p)
 #pragma unroll
               for (int h = 0; h < H2; ++h) av[p][h] = pk_fma(av[p][h], sc2[h], sh2[h]);
-            switch (ACT) {
+            switch (act_rt) {
               case T3D_ACT_RELU:
 #pragma unroll
                 for (int p = 0; p < 4; ++p)
@@ -1063,7 +1075,7 @@ __global__ __launch_bounds__(NTH) void dw3_bwd_s2_kernel(const Dw3BArgs a) {
                 gv[2 * h + 1] = (ap[1] > 0.f && ap[1] < 1.f) ? gv[2 * h + 1] : 0.f;
               }
             } else if (affine) {
-              act_grad_affine_vec<CH>(gv, xv, scf, shf, ACT);
+              act_grad_affine_vec<CH>(gv, xv, scf, shf, act_rt);
             }
             const size_t off = ((size_t)(2 * o + (p >> 1)) * a.W + ix + (p & 1)) * a.C;
             if (rg) {
@@ -1079,7 +1091,7 @@ __global__ __launch_bounds__(NTH) void dw3_bwd_s2_kernel(const Dw3BArgs a) {
               psum[i] += v;
               psq[i] = fmaf(v, xv[i], psq[i]);
             }
-            *reinterpret_cast<RV*>(dxg + off) = ov;
+            bufstore<RV>(ov, rsd, ib[p & 1], (unsigned)((irow0 + 2 * o + (p >> 1)) * a.W * a.C * sizeof(T)));
           }
 #pragma unroll
           for (int h = 0; h < H2; ++h) {
@@ -1165,11 +1177,11 @@ int launch_s2(Dw3BArgs& a, hipStream_t st) {
     if (const int rc = t3d_fold_fallback(a.alpha, st)) return rc;
     a.fold = nullptr;
   }
-  // (a compile-time activation, as in the stride-1 kernel, pushes this one over 256 VGPRs -> 1 wave/SIMD: slower)
+  if ((size_t)a.B * a.H * a.W * a.C * sizeof(T) >= (1ull << 31)) return T3D_ERR_UNSUPPORTED;     // 32-bit buffer offsets
   switch (a.act) {
     case T3D_ACT_RELU: T3D_LAUNCH_TIMED((dw3_bwd_s2_kernel<T, PF, 256, T3D_ACT_RELU>), grid, dim3(256), lds, st, a); break;
     case T3D_ACT_RELU6: T3D_LAUNCH_TIMED((dw3_bwd_s2_kernel<T, PF, 256, T3D_ACT_RELU6>), grid, dim3(256), lds, st, a); break;
-    case T3D_ACT_HSWISH: T3D_LAUNCH_TIMED((dw3_bwd_s2_kernel<T, PF, 256, T3D_ACT_HSWISH>), grid, dim3(256), lds, st, a); break;
+    case T3D_ACT_HSWISH: T3D_LAUNCH_TIMED((dw3_bwd_s2_kernel<T, PF, 256, -1>), grid, dim3(256), lds, st, a); break;
     default: T3D_LAUNCH_TIMED((dw3_bwd_s2_kernel<T, PF, 256, T3D_ACT_NONE>), grid, dim3(256), lds, st, a); break;
   }
   T3D_CHECK_LAUNCH();
