@@ -415,9 +415,8 @@ def main():
             res['roofline'] = {'bound': 'hbm', 'kernel': top['kernel'], 'entry': top['entry'], 'achieved': top['achieved'],
                                'peak': HBM_PEAK / 1e9, 'unit': 'GB/s', 'frac': top['frac'], 'traffic': traffic,
                                'traffic_source': tsrc,
-                               'traffic_note': ("per launch, all tensors the kernel touches: 10 of the 13 stride-1 backward launches also read the "
-                                                "skip-connection gradient (a fifth tensor; the 2*(in+out) algorithmic figure counts four) and every "
-                                                "launch flushes 11*C partial sums") if traffic and top['kernel'] == 'dw3_bwd2_kernel' else None,
+                               'traffic_note': ("per launch, all tensors the kernel touches (gradient, raw output and raw input read, input gradient "
+                                                "written, halo columns / rows re-read) plus the flush of 11*C partial sums per workgroup") if traffic and top['kernel'] == 'dw3_bwd2_kernel' else None,
                                'launches_per_step': top['launches_per_step'],
                                'avg_launch_us': top['avg_launch_us'],
                                'algorithmic_MB_per_step': top['algorithmic_MB_per_step'],
