@@ -41,6 +41,13 @@ struct WgtArgs {
   t3d_pw::StemSrc stem;   // stem.img != null: the a side (K = 32) is gathered from the crops (pwconv_common.h)
   const T3dFold* fold;    // requested BatchNorm-backward finalize: (alpha, beta, gamma) derived per block, NOT published
                           // (the data-gradient kernel of the main stream publishes; common.h)
+  // fused y-free backward (DGF): the data gradient of the same layer from the staged [dz | x | 1] rows
+  const bf16_t* wd;       // [QB][PB]: row k = [alpha_n W[n][k] (n < Nz) | Q[k][.] (K) | c[k] | 0 ...], the P tile's column order
+  const void *e_res, *e_y;   // skip-connection gradient [M][K] or null; raw tensor of x's producer [M][K] or null (its sums)
+  void* dx;               // [M][K] bf16
+  double* stats;          // [2][K] replicas or null
+  int nrep;
+  long long rstride;
 };
 
 // one 16x16 tile row (transposed) fragment: pixels 8*lg .. 8*lg+7 of the step, channels ch0..ch0+15
@@ -60,8 +67,16 @@ __device__ __forceinline__ bf16x8 tr_frag(const bf16_t* tile, int rs, int ch0, i
 // SK: 32-pixel contraction sub-steps per barrier-separated step.  The narrow tiles of the wide, shallow layers (16 ... 144
 // channels on each side) stage only 4-12 KB per 32 pixels -- a quarter of the threads has a vector to move and the barrier
 // comes every few hundred bytes per thread; SK = 2 / 4 stages 64 / 128 pixels per step instead.
-template <int NTPW, int NTQ, bool SWAP, int G, int D, bool GEN, bool YF, bool STEM = false, int SK = 1>
+// DGF (y-free only, one output tile): ALSO the layer's data gradient  dx = [dz | x | 1] Wd^T (+ skip gradient), formed from
+// the SAME staged rows -- the pair t3d_pwconv_dgrad_yfree (main stream) + t3d_pwconv_wgrad_yfree (second stream) read the
+// wide gradient tensor twice, at the same time (each at half the bandwidth); here it is read once.  A step's pixels are
+// dealt to the pipeline's four waves as (16-pixel tile, 16-channel tile) units: A = Wd rows from LDS, B = the staged rows
+// read as they lie (pixel-major, 8 consecutive virtual channels per lane), D[k][pixel] -> a lane holds 4 consecutive
+// channels of one pixel: 8-byte stores; the skip gradient and the raw tensor of the producer (BatchNorm-backward sums of x's
+// producer, exactly as in the streaming kernel's epilogue) are fetched with the step's operands.
+template <int NTPW, int NTQ, bool SWAP, int G, int D, bool GEN, bool YF, bool STEM = false, int SK = 1, bool DGF = false>
 __global__ __launch_bounds__(256 * G) void pw_wgrad_tr_kernel(const WgtArgs a) {
+  static_assert(!DGF || (YF && !SWAP && !STEM), "the fused data gradient exists for the y-free layout only");
   constexpr int PB = 64 * NTPW, QB = 16 * NTQ;
   constexpr int RSP = PB + 8, RSQ = QB + 8;            // LDS row strides (elements): +16 B against bank conflicts
   constexpr int STEP = 32 * SK;
@@ -70,6 +85,10 @@ __global__ __launch_bounds__(256 * G) void pw_wgrad_tr_kernel(const WgtArgs a) {
   const int grp = threadIdx.x >> 8;
   bf16_t* const tiles = reinterpret_cast<bf16_t*>(smem) + grp * 2 * BUFE;  // this pipeline's two buffers
   float* coef = reinterpret_cast<float*>(reinterpret_cast<bf16_t*>(smem) + G * 2 * BUFE);   // dy side [3][nd] | a side [2][na]
+  constexpr int RSW = PB + 8;                           // Wd row stride in LDS (elements)
+  constexpr int NCOEF = 3 * (SWAP ? QB : PB) + 2 * (SWAP ? PB : QB);
+  bf16_t* const wdl = reinterpret_cast<bf16_t*>(coef + ((NCOEF + 3) & ~3));                  // DGF: [QB][RSW]
+  double* const dstat = reinterpret_cast<double*>(wdl + (DGF ? QB * RSW : 0));               // DGF: [QB][2]
 
   const int tid = threadIdx.x & 255, lane = tid & 63, wave = tid >> 6;
   const int P = SWAP ? a.K : a.N, Q = SWAP ? a.N : a.K;
@@ -118,6 +137,13 @@ __global__ __launch_bounds__(256 * G) void pw_wgrad_tr_kernel(const WgtArgs a) {
     ca[i] = (v && a.scale) ? a.scale[k] : 1.f;
     ca[aB + i] = (v && a.scale) ? a.shift[k] : 0.f;
   }
+  if constexpr (DGF) {
+    for (int i = threadIdx.x; i < QB * (PB / 8); i += 256 * G) {
+      const int r = i / (PB / 8), c = (i % (PB / 8)) * 8;
+      *reinterpret_cast<bf16x8*>(wdl + r * RSW + c) = *reinterpret_cast<const bf16x8*>(a.wd + (size_t)r * PB + c);
+    }
+    for (int i = threadIdx.x; i < 2 * QB; i += 256 * G) dstat[i] = 0.0;
+  }
   const bf16_t* __restrict__ dz = reinterpret_cast<const bf16_t*>(a.dz);
   const bf16_t* __restrict__ yy = reinterpret_cast<const bf16_t*>(a.y);
   const bf16_t* __restrict__ xx = reinterpret_cast<const bf16_t*>(a.x);
@@ -129,8 +155,15 @@ __global__ __launch_bounds__(256 * G) void pw_wgrad_tr_kernel(const WgtArgs a) {
   constexpr int VDY = (ndv + 255) / 256, VA = (nav + 255) / 256;   // vectors per thread and step
   // D register sets: the global loads of step s+D are issued while step s is being multiplied, so a load has D-1
   // whole iterations to land (one iteration ~= one MFMA burst, far shorter than the HBM round trip)
-  struct Regs { bf16x8 rz[VDY], ry[VDY], rx[VA]; };
+  // DGF units of a step: (16-pixel tile, 16-channel tile) pairs, dealt round-robin to the pipeline's four waves
+  constexpr int NU = DGF ? (STEP / 16) * NTQ : 1, UPW = (NU + 3) / 4;
+  struct Epi { bf16x4 res[UPW], xr[UPW]; };
+  struct Regs { bf16x8 rz[VDY], ry[VDY], rx[VA]; Epi e; };
   Regs rr[D];
+  Epi ecur;                     // epilogue operands of the step that is in LDS now
+  const int lgq = lane >> 4, lcq = lane & 15;
+  const bf16_t* __restrict__ eres = reinterpret_cast<const bf16_t*>(a.e_res);
+  const bf16_t* __restrict__ eyr = reinterpret_cast<const bf16_t*>(a.e_y);
 
   auto gload = [&](Regs& R, int m0) {
     // branch-free: out-of-range vectors read a clamped (valid) address and are zeroed when they are staged
@@ -156,6 +189,15 @@ __global__ __launch_bounds__(256 * G) void pw_wgrad_tr_kernel(const WgtArgs a) {
       const int row = v / aV, k = min(a0c + (v % aV) * 8, a.K - 8), m = min(m0 + row, a.M - 1);
       if constexpr (STEM) R.rx[i] = t3d_pw::stem_patch(a.stem, m, k);
       else R.rx[i] = *reinterpret_cast<const bf16x8*>(xx + (size_t)m * a.K + k);
+    }
+    if constexpr (DGF) {
+#pragma unroll
+      for (int i = 0; i < UPW; ++i) {
+        const int un = min(wave + 4 * i, NU - 1), pt = un / NTQ, kt = un % NTQ;
+        const size_t o = (size_t)min(m0 + pt * 16 + lcq, a.M - 1) * a.K + min(kt * 16 + 4 * lgq, a.K - 4);
+        if (eres) R.e.res[i] = *reinterpret_cast<const bf16x4*>(eres + o);
+        if (eyr) R.e.xr[i] = *reinterpret_cast<const bf16x4*>(eyr + o);
+      }
     }
   };
   auto ld8 = [](const float* p, float* o) {     // 8 consecutive LDS floats as two 16-B reads
@@ -252,6 +294,52 @@ __global__ __launch_bounds__(256 * G) void pw_wgrad_tr_kernel(const WgtArgs a) {
   for (int i = 0; i < NTPW; ++i)
 #pragma unroll
     for (int j = 0; j < NTQ; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float st1[UPW][4], st2[UPW][4];
+#pragma unroll
+  for (int i = 0; i < UPW; ++i)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) st1[i][r] = st2[i][r] = 0.f;
+  // data gradient of the step whose rows sit in `pcur` (first pixel m0)
+  auto dgrad_step = [&](const bf16_t* pcur, int m0) {
+    bf16_t* __restrict__ dxo = reinterpret_cast<bf16_t*>(a.dx);
+#pragma unroll
+    for (int i = 0; i < UPW; ++i) {
+      const int un = wave + 4 * i;
+      if (un < NU) {                       // wave-uniform
+        const int pt = un / NTQ, kt = un % NTQ;
+        f32x4 d = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int js = 0; js < PB / 32; ++js) {
+          const bf16x8 af = *reinterpret_cast<const bf16x8*>(wdl + (kt * 16 + lcq) * RSW + js * 32 + 8 * lgq);
+          const bf16x8 bfr = *reinterpret_cast<const bf16x8*>(pcur + (pt * 16 + lcq) * RSP + js * 32 + 8 * lgq);
+          d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bfr, d, 0, 0, 0);
+        }
+        // lane: channels kt*16 + 4*lg .. +3 of pixel m0 + pt*16 + lc
+        const int m = m0 + pt * 16 + lcq, k = kt * 16 + 4 * lgq;
+        const bool ok = m < mend && k < a.K;
+        float v[4] = {d[0], d[1], d[2], d[3]}, yv[4] = {0.f, 0.f, 0.f, 0.f};
+        if (eres) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] += (float)ecur.res[i][r];
+        }
+        bf16x4 o;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          o[r] = (bf16_t)v[r];
+          v[r] = ok ? (float)o[r] : 0.f;
+        }
+        if (ok) *reinterpret_cast<bf16x4*>(dxo + (size_t)m * a.K + k) = o;
+        if (a.stats) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            if (eyr) yv[r] = (float)ecur.xr[i][r];
+            st1[i][r] += v[r];
+            st2[i][r] = fmaf(v[r], eyr ? yv[r] : v[r], st2[i][r]);
+          }
+        }
+      }
+    }
+  };
 
   __syncthreads();   // coefficients visible
   const int nsteps = (mend - mbeg + STEP - 1) / STEP;
@@ -263,6 +351,7 @@ __global__ __launch_bounds__(256 * G) void pw_wgrad_tr_kernel(const WgtArgs a) {
 #pragma unroll
   for (int u = 0; u < D; ++u) gload(rr[u], step_m(u));
   lstore(rr[0], step_m(0), 0);
+  if constexpr (DGF) ecur = rr[0].e;
   __syncthreads();
   int buf = 0;
   for (int it0 = 0; it0 < niter; it0 += D) {
@@ -285,6 +374,10 @@ __global__ __launch_bounds__(256 * G) void pw_wgrad_tr_kernel(const WgtArgs a) {
             for (int j = 0; j < NTQ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pf, qf[j], acc[i][j], 0, 0, 0);
           }
         }
+        if constexpr (DGF) {
+          dgrad_step(pcur, step_m(it));
+          ecur = rr[(u + 1) % D].e;
+        }
         lstore(rr[(u + 1) % D], step_m(it + 1), buf ^ 1);
         __syncthreads();
         buf ^= 1;
@@ -292,6 +385,29 @@ __global__ __launch_bounds__(256 * G) void pw_wgrad_tr_kernel(const WgtArgs a) {
     }
   }
 
+  if constexpr (DGF) {
+    if (a.stats) {
+      // BatchNorm-backward sums of x's producer: lanes of one channel group meet by DPP, waves in fp64 LDS, blocks by fp64
+      // atomics into the replicas (exact adds in any order, as everywhere on the data-gradient path)
+#pragma unroll
+      for (int i = 0; i < UPW; ++i) {
+        const int un = wave + 4 * i;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float s1 = row16_sum(st1[i][r]), s2 = row16_sum(st2[i][r]);
+          const int k = (un % NTQ) * 16 + 4 * lgq + r;
+          if (un < NU && lcq == 0 && k < a.K) {
+            atomicAdd(dstat + 2 * k, (double)s1);
+            atomicAdd(dstat + 2 * k + 1, (double)s2);
+          }
+        }
+      }
+      __syncthreads();
+      for (int i = threadIdx.x; i < 2 * a.K; i += 256 * G)
+        atomicAdd(a.stats + (size_t)(blockIdx.x % a.nrep) * a.rstride + (size_t)(i & 1) * a.K + (i >> 1), dstat[i]);
+      __syncthreads();
+    }
+  }
   if constexpr (G == 2) {
     // pipeline 1 hands its accumulators to pipeline 0 through LDS, one row-tile group at a time (lane-private slots)
     f32x4* ex = reinterpret_cast<f32x4*>(smem);
@@ -564,6 +680,93 @@ int t3d_pw_wgrad_tr_stem(const void* dz, const void* y, const t3d_bnbwd* bb, con
   if (N == 32) { a.swap = 0; return launch_d<1, 2, false, 2, false, false, true, 4>(a, st); }     // P = N = 32, Q = K = 32
   if (N == 16) { a.swap = 1; return launch_d<1, 1, true, 2, false, false, true, 4>(a, st); }      // P = K = 32, Q = N = 16
   return T3D_ERR_UNSUPPORTED;
+}
+
+// ---- fused y-free backward (pwconv_yfree.hip: t3d_pwconv_bwd_yfree / _finish) ------------------------------------------
+// one configuration per layer shape, shared by the launch and by the later reduction of its partial tiles
+struct YfCfg { int ntpw, ntq, sk, S, rows_per_split, PB, QB; };
+static bool yf_cfg(int M, int K, int N, YfCfg& c) {
+  const int P = N + K + 8;
+  if (K > 32 || P > 256) return false;
+  c.ntq = K <= 16 ? 1 : 2;
+  c.ntpw = P <= 128 ? 2 : (P <= 192 ? 3 : 4);
+  c.sk = M >= (1 << 20) ? 2 : 1;
+  c.PB = 64 * c.ntpw; c.QB = 16 * c.ntq;
+  const int step = 32 * c.sk;
+  int S = 256;
+  const int maxs = cdiv(M, step * 4 * 2);
+  if (S > maxs) S = maxs;
+  if (S < 1) S = 1;
+  c.rows_per_split = cdiv(cdiv(M, S), step) * step;
+  c.S = cdiv(M, c.rows_per_split);
+  return true;
+}
+
+template <int NTPW, int NTQ, int SK>
+static int launch_fused(WgtArgs& a, const YfCfg& c, hipStream_t st) {
+  constexpr int G = 2, STEP = 32 * SK, PB = 64 * NTPW, QB = 16 * NTQ;
+  a.ptiles = a.qtiles = 1;
+  a.rows_per_split = c.rows_per_split;
+  a.nsplit = c.S;
+  const int ncoef = 3 * PB + 2 * QB;
+  const size_t lds = (size_t)G * 2 * STEP * ((PB + 8) + (QB + 8)) * 2 + (size_t)((ncoef + 3) & ~3) * 4 + (size_t)QB * (PB + 8) * 2 +
+                     (size_t)2 * QB * sizeof(double);
+  const void* fn = (const void*)pw_wgrad_tr_kernel<NTPW, NTQ, false, G, 2, false, true, false, SK, true>;
+  if (lds > 64 * 1024) (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipLaunchKernelGGL((pw_wgrad_tr_kernel<NTPW, NTQ, false, G, 2, false, true, false, SK, true>), dim3(c.S), dim3(256 * G), lds, st, a);
+  T3D_CHECK_LAUNCH();
+  return T3D_OK;
+}
+
+// bytes of scratch one fused launch needs: partial tiles [S][PB][QB] fp32 + the product matrix [(N + K + 8)][K] fp32
+size_t t3d_pw_bwd_yfree_scratch(int M, int K, int N) {
+  YfCfg c;
+  if (!yf_cfg(M, K, N, c)) return 0;
+  return (size_t)c.S * c.PB * c.QB * 4 + (((size_t)(N + K + 8) * K * 4 + 255) & ~(size_t)255);
+}
+
+// dx = [dz | x | 1] Wd^T (+ residual) AND the partial tiles of [dz | x | 1]^T x into `scratch` (main stream)
+int t3d_pw_bwd_yfree_launch(const void* dz, const void* x, const void* wd, const void* x_raw, const void* residual, void* dx,
+                            double* stats, void* scratch, int M, int HW, int K, int N, hipStream_t st) {
+  YfCfg c;
+  if (!yf_cfg(M, K, N, c)) return T3D_ERR_UNSUPPORTED;
+  WgtArgs a{};
+  a.dz = dz; a.x = x; a.y = dz;
+  a.M = M; a.HW = HW; a.K = K;
+  a.yfree = 1; a.Nz = N; a.N = N + K + 8;
+  a.ws = reinterpret_cast<float*>(scratch);
+  a.wd = reinterpret_cast<const bf16_t*>(wd);
+  a.e_res = residual; a.e_y = x_raw; a.dx = dx; a.stats = stats;
+  a.nrep = g_t3d_reduce.nrep; a.rstride = g_t3d_reduce.stats_stride;
+  if (a.stats && a.nrep < 1) { a.nrep = 1; a.rstride = 0; }
+#define T3D_YFL(P_, Q_, S_) return launch_fused<P_, Q_, S_>(a, c, st)
+  if (c.ntpw == 2 && c.ntq == 1) { if (c.sk == 2) T3D_YFL(2, 1, 2); else T3D_YFL(2, 1, 1); }
+  if (c.ntpw == 2 && c.ntq == 2) { if (c.sk == 2) T3D_YFL(2, 2, 2); else T3D_YFL(2, 2, 1); }
+  if (c.ntpw == 3 && c.ntq == 1) { if (c.sk == 2) T3D_YFL(3, 1, 2); else T3D_YFL(3, 1, 1); }
+  if (c.ntpw == 3 && c.ntq == 2) { if (c.sk == 2) T3D_YFL(3, 2, 2); else T3D_YFL(3, 2, 1); }
+  if (c.ntpw == 4 && c.ntq == 2) { if (c.sk == 2) T3D_YFL(4, 2, 2); else T3D_YFL(4, 2, 1); }
+  if (c.ntpw == 4 && c.ntq == 1) { if (c.sk == 2) T3D_YFL(4, 1, 2); else T3D_YFL(4, 1, 1); }
+#undef T3D_YFL
+  return T3D_ERR_UNSUPPORTED;
+}
+
+// partial tiles of a fused launch -> tmp [(N + K + 8)][K] (fixed-order sum; tmp lives behind the tiles in `scratch`)
+int t3d_pw_bwd_yfree_reduce(void* scratch, float** tmp_out, int M, int K, int N, hipStream_t st) {
+  YfCfg c;
+  if (!yf_cfg(M, K, N, c)) return T3D_ERR_UNSUPPORTED;
+  float* ws = reinterpret_cast<float*>(scratch);
+  float* tmp = ws + (size_t)c.S * c.PB * c.QB;
+  const size_t tmp_bytes = (size_t)(N + K + 8) * K * sizeof(float);
+  if (hipMemsetAsync(tmp, 0, tmp_bytes, st) != hipSuccess) return T3D_ERR_LAUNCH;
+  const int rows = N + K + 8;
+#define T3D_YFR(SPV) hipLaunchKernelGGL(wgrad_reduce_kernel<SPV>, dim3(cdiv(rows * c.QB, 256 / SPV)), dim3(256), 0, st, ws, tmp, rows, K, c.PB, c.QB, 1, 1, c.S)
+  if (c.S >= 64) T3D_YFR(16);
+  else if (c.S >= 8) T3D_YFR(4);
+  else T3D_YFR(1);
+#undef T3D_YFR
+  T3D_CHECK_LAUNCH();
+  *tmp_out = tmp;
+  return T3D_OK;
 }
 
 // y-free weight-gradient products (pwconv_yfree.hip):  tmp[(N + K + 8)][K] += [dz | x | 1]^T x   -- rows 0..N-1 = dz^T x,

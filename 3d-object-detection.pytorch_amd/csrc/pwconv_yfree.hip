@@ -18,6 +18,11 @@
 #include "pwconv_common.h"
 
 int t3d_pw_wgrad_tr_yfree(const void* dz, const void* x, float* tmp, int M, int HW, int K, int N, hipStream_t st);
+// fused y-free backward (pwconv_wgrad_tr.hip)
+size_t t3d_pw_bwd_yfree_scratch(int M, int K, int N);
+int t3d_pw_bwd_yfree_launch(const void* dz, const void* x, const void* wd, const void* x_raw, const void* residual, void* dx,
+                            double* stats, void* scratch, int M, int HW, int K, int N, hipStream_t st);
+int t3d_pw_bwd_yfree_reduce(void* scratch, float** tmp_out, int M, int K, int N, hipStream_t st);
 
 namespace {
 
@@ -31,7 +36,11 @@ namespace {
 __global__ __launch_bounds__(256) void yfree_prep_kernel(const bf16_t* __restrict__ wt, const float* __restrict__ alpha_g,
                                                          const float* __restrict__ beta_g, const float* __restrict__ gamma_g,
                                                          bf16_t* __restrict__ wcat, float* __restrict__ cvec, int K, int N,
-                                                         int NP, int KP, const T3dFold* __restrict__ fold) {
+                                                         int NP, int KP, const T3dFold* __restrict__ fold,
+                                                         bf16_t* __restrict__ wd, int PBw) {
+  // wd (optional, for the fused backward t3d_pwconv_bwd_yfree): the same numbers in the column order of the staged
+  // [dz | x | 1] rows -- row k = [alpha_n W[n][k] (N) | Q[k][.] (K) | c[k] | zeros to PBw]; the zero parts are never written
+  // (the caller clears the buffer once)
   extern __shared__ float fco[];      // [3][N] (alpha, beta, gamma): derived here when a finalize request rides on this launch
   __shared__ f32x4 red[3][64];
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6, lg = lane >> 4, lc = lane & 15;
@@ -80,6 +89,7 @@ __global__ __launch_bounds__(256) void yfree_prep_kernel(const bf16_t* __restric
     for (int r = 0; r < 4; ++r) {
       const int k = k0 + 4 * lg + r, k2 = q0 + lc;
       if (k < K) wcat[(size_t)k * tot + NP + k2] = (bf16_t)((k2 < K) ? acc[r] : 0.f);     // k2 in [K, KP): zero padding
+      if (wd && k < K && k2 < K) wd[(size_t)k * PBw + N + k2] = (bf16_t)acc[r];
     }
   }
   // ---- alpha . W part and c: the workgroups of tile column 0 own rows k0 .. k0+15 (row k = wt row k scaled by alpha)
@@ -97,6 +107,7 @@ __global__ __launch_bounds__(256) void yfree_prep_kernel(const bf16_t* __restric
         for (int j = 0; j < 8; ++j) o[j] = (bf16_t)0.f;
       }
       *reinterpret_cast<bf16x8*>(wcat + (size_t)k * tot + n) = o;
+      if (wd && n < N) *reinterpret_cast<bf16x8*>(wd + (size_t)k * PBw + n) = o;
     }
     // c[k] = sum_n gamma_n W[n][k]: 16 lanes per row
     const int row = t >> 4, sub = t & 15, k = k0 + row;
@@ -108,7 +119,10 @@ __global__ __launch_bounds__(256) void yfree_prep_kernel(const bf16_t* __restric
         for (int j = 0; j < 8; ++j) s2 = fmaf(gamma[n + j], (float)v[j], s2);
       }
     s2 = row16_sum(s2);
-    if (sub == 0 && k < K) cvec[k] = s2;
+    if (sub == 0 && k < K) {
+      cvec[k] = s2;
+      if (wd) wd[(size_t)k * PBw + N + K] = (bf16_t)s2;
+    }
   }
 }
 
@@ -140,8 +154,50 @@ __global__ __launch_bounds__(256) void yfree_combine_kernel(const float* __restr
 static inline int rup32(int v) { return (v + 31) / 32 * 32; }
 
 // include/t3d.h
+static int yfree_prep_impl(const void* wt, const t3d_bnbwd* bb, void* wcat, float* cvec, int K, int N, void* wd, int PBw,
+                           void* stream);
+
 extern "C" int t3d_pwconv_yfree_prep(const void* wt, const t3d_bnbwd* bb, void* wcat, float* cvec, int K, int N,
                                      void* stream) {
+  return yfree_prep_impl(wt, bb, wcat, cvec, K, N, nullptr, 0, stream);
+}
+
+// prep + the fused backward's weight layout wd [16 * ceil(K / 16)][PBw] (PBw = 64 * ceil((N + K + 8) / 64), cleared once by
+// the caller: only the non-zero entries are written)
+extern "C" int t3d_pwconv_yfree_prep2(const void* wt, const t3d_bnbwd* bb, void* wcat, float* cvec, void* wd, int K, int N,
+                                      void* stream) {
+  if (!wd) return T3D_ERR_ARG;
+  return yfree_prep_impl(wt, bb, wcat, cvec, K, N, wd, (N + K + 8 + 63) / 64 * 64, stream);
+}
+
+extern "C" int t3d_pwconv_bwd_yfree_scratch(int M, int K, int N) { return (int)t3d_pw_bwd_yfree_scratch(M, K, N); }
+
+// dx and the partial products of the weight gradient in ONE pass over [dz | x] (caller's MAIN stream); the weight gradient
+// is finished by t3d_pwconv_wgrad_yfree_finish (any stream ordered behind this launch)
+extern "C" int t3d_pwconv_bwd_yfree(const void* dz, const void* x, const void* wd, const void* x_raw, const t3d_prologue* pro_in,
+                                    const void* residual, void* dx, double* stats, void* scratch, long long scratch_bytes,
+                                    int M, int HW, int K, int N, void* stream) {
+  if (!dz || !x || !wd || !dx || !scratch || M <= 0 || HW <= 0 || K <= 0 || N <= 0 || (K % 8) || (N % 8)) return T3D_ERR_ARG;
+  if (pro_in && (pro_in->se || pro_in->act != T3D_ACT_NONE || pro_in->scale)) return T3D_ERR_UNSUPPORTED;   // (a linear block output)
+  const size_t need = t3d_pw_bwd_yfree_scratch(M, K, N);
+  if (!need || (size_t)scratch_bytes < need) return T3D_ERR_UNSUPPORTED;
+  return t3d_pw_bwd_yfree_launch(dz, x, wd, x_raw, residual, dx, stats, scratch, M, HW, K, N, reinterpret_cast<hipStream_t>(stream));
+}
+
+extern "C" int t3d_pwconv_wgrad_yfree_finish(void* scratch, const t3d_bnbwd* bb, const void* w, float* dw, int M, int K, int N,
+                                             void* stream) {
+  if (!scratch || !bb || !bb->alpha || !bb->beta || !bb->gamma || !w || !dw) return T3D_ERR_ARG;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  float* tmp = nullptr;
+  if (const int rc = t3d_pw_bwd_yfree_reduce(scratch, &tmp, M, K, N, st)) return rc;
+  hipLaunchKernelGGL(yfree_combine_kernel, dim3(cdiv(N * K, 256)), dim3(256), 0, st, tmp, reinterpret_cast<const bf16_t*>(w),
+                     bb->alpha, bb->beta, bb->gamma, dw, K, N);
+  T3D_CHECK_LAUNCH();
+  return T3D_OK;
+}
+
+static int yfree_prep_impl(const void* wt, const t3d_bnbwd* bb, void* wcat, float* cvec, int K, int N, void* wd, int PBw,
+                           void* stream) {
   const void* w = wt;
   if (!w || !bb || !bb->alpha || !bb->beta || !bb->gamma || !wcat || !cvec || K <= 0 || N <= 0 || (K % 8) || (N % 8))
     return T3D_ERR_ARG;
@@ -152,7 +208,7 @@ extern "C" int t3d_pwconv_yfree_prep(const void* wt, const t3d_bnbwd* bb, void* 
   else if (const int rc = t3d_fold_fallback(bb->alpha, reinterpret_cast<hipStream_t>(stream))) return rc;
   hipLaunchKernelGGL(yfree_prep_kernel, dim3(rup32(K) / 16, rup32(K) / 16), dim3(256), (size_t)3 * N * sizeof(float),
                      reinterpret_cast<hipStream_t>(stream), reinterpret_cast<const bf16_t*>(w), bb->alpha, bb->beta, bb->gamma,
-                     reinterpret_cast<bf16_t*>(wcat), cvec, K, N, rup32(N), rup32(K), fold);
+                     reinterpret_cast<bf16_t*>(wcat), cvec, K, N, rup32(N), rup32(K), fold, reinterpret_cast<bf16_t*>(wd), PBw);
   T3D_CHECK_LAUNCH();
   return T3D_OK;
 }

@@ -37,6 +37,7 @@ WORKSPACE_BYTES = 64 << 20      # partial weight-gradient tiles (include/t3d.h: 
 MAIN_WORKSPACE_BYTES = 16 << 20
 # y-free expand-layer backward (csrc/pwconv_yfree.hip): minimum M*N elements of the expanded tensor; 0 disables
 YFREE_MIN_ELEMS = int(os.environ.get('T3D_YFREE_MIN', 8 << 20))
+YFREE_FUSED = os.environ.get('T3D_YFREE_FUSED', '1') != '0'     # one-pass expand-layer backward (t3d_pwconv_bwd_yfree)
 HOOK_MIN = 1 << 20              # gradient-exchange granularity (elements): parallel.GradSync's bucket size
 HOOK_ON_SIDE = os.environ.get('T3D_HOOK_ON_SIDE', '1') != '0'
 
@@ -381,7 +382,8 @@ class Net:
     # ms per step on one box, 8.00 -> 7.97 on another (round 3b, forward half); with the atomics-free flush of round 3c the
     # backward half costs nothing either (7.64 ms both ways, 18 launches fewer), so both are on)
     _LAZY_DW = os.environ.get('T3D_LAZY_DW', '1')
-    DERIVING = frozenset(('t3d_pwconv_fwd', 't3d_pwconv_fwd_mat', 't3d_bn_apply', 't3d_pool_fwd', 't3d_pwconv_dgrad', 't3d_pwconv_yfree_prep')
+    DERIVING = frozenset(('t3d_pwconv_fwd', 't3d_pwconv_fwd_mat', 't3d_bn_apply', 't3d_pool_fwd', 't3d_pwconv_dgrad', 't3d_pwconv_yfree_prep',
+                          't3d_pwconv_yfree_prep2')
                          + (('t3d_dwconv_fwd',) if _LAZY_DW in ('1', 'fwd') else ())
                          + (('t3d_dwconv_bwd',) if _LAZY_DW in ('1', 'bwd') else ()))
 
@@ -1101,11 +1103,28 @@ class Net:
         wcat = self._buf(f'wcat:{i}', (K, tot))
         cvec = self._buf(f'cvec:{i}', (K,), torch.float32)
         HW = x.H * x.W
+        with_stats = x.bn is not None and not x.finished_act       # as _pw_dgrad
+        # ONE pass over the wide gradient for both products (csrc/pwconv_wgrad_tr.hip, DGF): the data gradient and the partial
+        # tiles of the weight-gradient products come out of the same staged rows on the main stream; the second stream only
+        # reduces and combines.  (The pair below reads d1 twice, from two streams at the same time.)
+        need = N.lib().t3d_pwconv_bwd_yfree_scratch(M, K, Nn) if (YFREE_FUSED and not (with_stats and x.gpro is not None)) else 0
+        if need > 0:
+            key = (f'wd:{i}', ((K + 15) // 16 * 16, (Nn + K + 8 + 63) // 64 * 64), self.dtype)
+            wd = self._bufs.get(key) if key in self._bufs else self._buf(key[0], key[1], zero=True)   # cleared ONCE: prep2 writes the non-zero entries
+            scratch = self._buf(f'yfscr:{i}', (need,), torch.uint8)
+            self._c('t3d_pwconv_yfree_prep2', N.ptr(self.wt[wname]), bb1, N.ptr(wcat), N.ptr(cvec), N.ptr(wd), K, Nn, st, bwd=bn1)
+            dx = self._buf(f'dzin:{i}', (M, K))
+            N.call('t3d_pwconv_bwd_yfree', N.ptr(d1), N.ptr(x.t), N.ptr(wd), N.ptr(x.raw) if with_stats else None, None,
+                   N.ptr(res) if res is not None else None, N.ptr(dx), self._bst(x.bn) if with_stats else None, N.ptr(scratch), need,
+                   M, HW, K, Nn, st, nbytes=M * (K + Nn) * self.esz)
+            self._wgrad(N.ptr(scratch), bb1, N.ptr(self.w[wname]), N.ptr(self.g[wname]), M, K, Nn, entry='t3d_pwconv_wgrad_yfree_finish')
+            if x.finished_act:
+                dx = self._act_bwd(dx, x, f'dzin:{i}:a')
+            return dx
         self._c('t3d_pwconv_yfree_prep', N.ptr(self.wt[wname]), bb1, N.ptr(wcat), N.ptr(cvec), K, Nn, st, bwd=bn1)
         self._wgrad(N.ptr(d1), N.ptr(x.t), bb1, N.ptr(self.w[wname]), N.ptr(self.g[wname]), M, HW, K, Nn,
                     entry='t3d_pwconv_wgrad_yfree', nbytes=M * (K + Nn) * self.esz)
         dx = self._buf(f'dzin:{i}', (M, K))
-        with_stats = x.bn is not None and not x.finished_act       # as _pw_dgrad
         N.call('t3d_pwconv_dgrad_yfree', N.ptr(d1), N.ptr(x.t), N.ptr(wcat), N.ptr(cvec),
                N.ptr(x.raw) if with_stats else None, x.gpro if with_stats else None,
                N.ptr(res) if res is not None else None, N.ptr(dx),

@@ -134,6 +134,23 @@ int t3d_pwconv_dgrad_yfree(const void* dz, const void* x, const void* wcat, cons
 int t3d_pwconv_wgrad_yfree(const void* dz, const void* x, const t3d_bnbwd* bb, const void* w, float* dw, int M, int HW,
                            int K, int N, void* stream);
 
+/* The same y-free backward with ONE pass over the wide gradient tensor (round 4): the pair above reads dz [M,N] twice, at the
+ * same time from two streams; t3d_pwconv_bwd_yfree forms dx AND the partial tiles of [dz | x | 1]^T x from the same staged rows.
+ *   _prep2: as _prep, plus wd -- the weights in the staged rows' column order, [16*ceil(K/16)][64*ceil((N+K+8)/64)] bf16,
+ *     cleared once by the caller (only the non-zero entries are written each step);
+ *   _bwd_yfree_scratch: RETURNS the bytes of `scratch` a launch of this shape needs (a query, not a status code; 0: shape not
+ *     supported -- K <= 32, N + K + 8 <= 256);
+ *   _bwd_yfree (the caller's main stream): dx [M,K] bf16 = [dz | x | 1] wd^T (+ residual), stats += sum(dx), sum(dx*x_raw)
+ *     (x_raw / pro_in as in t3d_pwconv_dgrad; only a linear producer -- no activation -- is supported), partial tiles -> scratch;
+ *   _wgrad_yfree_finish (any stream ordered behind it): dw [N,K] += the combined weight gradient, from `scratch`.
+ * Replaces the autograd of nn.Conv2d(K, N, 1) + nn.BatchNorm2d(N) (models/mobilenetv3.py:148-149), as the pair does. */
+int t3d_pwconv_yfree_prep2(const void* wt, const t3d_bnbwd* bb, void* wcat, float* cvec, void* wd, int K, int N, void* stream);
+int t3d_pwconv_bwd_yfree_scratch(int M, int K, int N);
+int t3d_pwconv_bwd_yfree(const void* dz, const void* x, const void* wd, const void* x_raw, const t3d_prologue* pro_in,
+                         const void* residual, void* dx, double* stats, void* scratch, long long scratch_bytes, int M, int HW,
+                         int K, int N, void* stream);
+int t3d_pwconv_wgrad_yfree_finish(void* scratch, const t3d_bnbwd* bb, const void* w, float* dw, int M, int K, int N, void* stream);
+
 /* Depthwise conv backward: data gradient and weight gradient in one pass.
  *   dz, y [B,Ho,Wo,C]: gradient at / raw input of the BatchNorm after the conv; bb its backward affine;
  *   w [C,k*k] fp32; x [B,H,W,C] + pro: tensor the forward conv read and how it was activated (no SE);

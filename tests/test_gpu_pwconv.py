@@ -257,6 +257,29 @@ def test_pw_yfree_backward(M, HW, K, N, res):
     ew, ew2 = (dw.double().cpu() - dw_ref).abs().max().item() / sw, (dw2.double().cpu() - dw_ref).abs().max().item() / sw
     assert ex < 1.5e-2 and ex < 2 * ex2 + 4e-3, (ex, ex2)          # bf16 output rounding dominates both
     assert ew < 1e-2 and ew < 2 * ew2 + 4e-3, (ew, ew2)
+    # ---- the one-pass form (round 4): data gradient + weight-gradient products from the same staged rows
+    need = N_.lib().t3d_pwconv_bwd_yfree_scratch(M, K, N)
+    if need > 0:
+        wdl = torch.zeros((K + 15) // 16 * 16, (N + K + 8 + 63) // 64 * 64, device=dev, dtype=bf)
+        N_.call('t3d_pwconv_yfree_prep2', N_.ptr(wtd), bb, N_.ptr(wcat), N_.ptr(cvec), N_.ptr(wdl), K, N, N_.stream())
+        scratch = torch.empty(need, device=dev, dtype=torch.uint8)
+        dx3 = torch.empty(M, K, device=dev, dtype=bf)
+        st3 = torch.zeros(2 * K, device=dev, dtype=torch.float64)
+        dw3 = torch.zeros(N, K, device=dev)
+        N_.call('t3d_set_reduction_replicas', 1, 0)
+        N_.call('t3d_pwconv_bwd_yfree', N_.ptr(dzd), N_.ptr(xd), N_.ptr(wdl), N_.ptr(yraw), None, N_.ptr(rd) if res else None,
+                N_.ptr(dx3), N_.ptr(st3), N_.ptr(scratch), need, M, HW, K, N, N_.stream())
+        N_.call('t3d_pwconv_wgrad_yfree_finish', N_.ptr(scratch), bb, N_.ptr(wd), N_.ptr(dw3), M, K, N, N_.stream())
+        torch.cuda.synchronize()
+        ex3 = (dx3.double().cpu() - dx_ref).abs().max().item() / sx
+        ew3 = (dw3.double().cpu() - dw_ref).abs().max().item() / sw
+        assert ex3 < 1.5e-2 and ex3 < 2 * ex2 + 4e-3, (ex3, ex2)
+        assert ew3 < 1e-2 and ew3 < 2 * ew2 + 4e-3, (ew3, ew2)
+        ref0, ref1 = dx3.double().sum(0), (dx3.double() * yraw.double()).sum(0)
+        np.testing.assert_allclose(st3[:K].cpu().numpy(), ref0.cpu().numpy(), rtol=1e-4, atol=1e-3 * M ** .5)
+        np.testing.assert_allclose(st3[K:].cpu().numpy(), ref1.cpu().numpy(), rtol=1e-4, atol=1e-3 * M ** .5)
+        # the same numbers as the pair up to the bf16 rounding of the bias c (it rides in the weight matrix here)
+        assert (dx3.float() - dx.float()).abs().max().item() <= 2e-2 * sx
 
 
 @pytest.mark.parametrize('dt', ['f32', 'bf16'])

@@ -61,13 +61,26 @@ else:
         stats = torch.zeros(nrep, 2 * max(K, Nn), device=dev, dtype=torch.float64)
         fn = lambda: N.call('t3d_pwconv_dgrad', N.dtype_code(x), N.ptr(dz), N.ptr(yy), bb, N.ptr(wt), N.ptr(x), pro, None,
                             N.ptr(dx), N.ptr(stats), None, M, HW, K, Nn, N.stream())
-    elif kind in ('pwdgrad_yf', 'pwwgrad_yf', 'yfprep'):
+    elif kind in ('pwdgrad_yf', 'pwwgrad_yf', 'yfprep', 'pwbwd_yf'):
         NP, KP = (Nn + 31) // 32 * 32, (K + 31) // 32 * 32
         wcat = torch.empty(K, NP + KP, device=dev, dtype=dt); cvec = torch.empty(K, device=dev)
         N.call('t3d_pwconv_yfree_prep', N.ptr(wt), bb, N.ptr(wcat), N.ptr(cvec), K, Nn, N.stream())
         stats = torch.zeros(nrep, 2 * max(K, Nn), device=dev, dtype=torch.float64)
         dw = torch.zeros(Nn, K, device=dev)
-        if kind == 'yfprep':
+        if kind == 'pwbwd_yf':      # the one-pass form: data gradient + partial products (main stream) + reduce / combine
+            need = N.lib().t3d_pwconv_bwd_yfree_scratch(M, K, Nn)
+            assert need > 0, 'shape not supported by the fused kernel'
+            wdl = torch.zeros((K + 15) // 16 * 16, (Nn + K + 8 + 63) // 64 * 64, device=dev, dtype=dt)
+            N.call('t3d_pwconv_yfree_prep2', N.ptr(wt), bb, N.ptr(wcat), N.ptr(cvec), N.ptr(wdl), K, Nn, N.stream())
+            scratch = torch.empty(need, device=dev, dtype=torch.uint8); dw = torch.zeros(Nn, K, device=dev)
+            both = '--with-finish' in sys.argv
+
+            def fn():
+                N.call('t3d_pwconv_bwd_yfree', N.ptr(dz), N.ptr(x), N.ptr(wdl), N.ptr(x), None, None, N.ptr(dx), N.ptr(stats),
+                       N.ptr(scratch), need, M, HW, K, Nn, N.stream())
+                if both:
+                    N.call('t3d_pwconv_wgrad_yfree_finish', N.ptr(scratch), bb, N.ptr(wq), N.ptr(dw), M, K, Nn, N.stream())
+        elif kind == 'yfprep':
             fn = lambda: N.call('t3d_pwconv_yfree_prep', N.ptr(wt), bb, N.ptr(wcat), N.ptr(cvec), K, Nn, N.stream())
         elif kind == 'pwdgrad_yf':
             fn = lambda: N.call('t3d_pwconv_dgrad_yfree', N.ptr(dz), N.ptr(x), N.ptr(wcat), N.ptr(cvec), N.ptr(x), None,
