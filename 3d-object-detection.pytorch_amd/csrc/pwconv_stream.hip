@@ -23,6 +23,14 @@
 #include "pwconv_common.h"
 
 namespace t3d_pw {
+// relu6(s x + t) = 6 clamp01((s/6) x + t/6): one v_pk_fma_f32 with the clamp modifier per channel pair (dwconv3_stream.hip has
+// the note); the 6 is applied to the accumulators in the epilogue (the product is linear in the operand)
+__device__ __forceinline__ f32x2 pk_fma_clamp01(f32x2 a, f32x2 b, f32x2 c) {
+  f32x2 d;
+  asm("v_pk_fma_f32 %0, %1, %2, %3 clamp" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+  return d;
+}
+
 namespace {
 
 
@@ -144,6 +152,13 @@ __global__ __launch_bounds__(512, KU > 2 ? 1 : 2) void pw_stream_kernel(const Ge
   }
   }
   __syncthreads();
+  // forward with a plain BatchNorm + ReLU6 prologue (every projection layer): the clamp form -- the staged (scale, shift) are
+  // divided by 6 (AFTER a derived finalize has published the true values) and the accumulators multiplied by 6 in the epilogue
+  const bool c6f = !DG && !ZM && !YF && !STEM && a.act == T3D_ACT_RELU6 && !(GEN && a.p2);
+  if (c6f) {
+    for (int i = tid; i < 2 * kpad; i += nthr) coef[i] *= T3D_SIXTH;
+    __syncthreads();
+  }
   PW_STAMP(1);
 
   const bool plainA = !ZM && (YF || (!DG && !a.p0 && !a.p2 && a.act == T3D_ACT_NONE));
@@ -287,6 +302,13 @@ __global__ __launch_bounds__(512, KU > 2 ? 1 : 2) void pw_stream_kernel(const Ge
 #pragma unroll
                     for (int j = 0; j < 8; ++j) x[j] *= sv[j];
                   }
+                } else if (c6f) {
+#pragma unroll
+                  for (int j = 0; j < 8; j += 2) {
+                    const f32x2 t = pk_fma_clamp01(f32x2{x[j], x[j + 1]}, f32x2{c0[j], c0[j + 1]}, f32x2{c1[j], c1[j + 1]});
+                    x[j] = t[0];
+                    x[j + 1] = t[1];
+                  }
                 } else {
                   act_affine_vec<8>(x, c0, c1, a.act);
                 }
@@ -381,6 +403,10 @@ __global__ __launch_bounds__(512, KU > 2 ? 1 : 2) void pw_stream_kernel(const Ge
         float v[8], yv[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) v[j] = acc[r][2 * q + (j >> 2)][j & 3];
+        if (c6f) {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) v[j] *= 6.f;
+        }
         if ((!DG || YF) && a.bias) {
 #pragma unroll
           for (int j = 0; j < 8; ++j) v[j] += a.bias[n + j];

@@ -24,6 +24,14 @@
 
 namespace {
 
+// relu6(s x + t) = 6 clamp01((s/6) x + t/6): one v_pk_fma_f32 with the clamp modifier per channel pair (dwconv3_stream.hip has the
+// note); the weight gradient is linear in the activated operand, so the 6 is applied once, to the accumulators at the flush
+__device__ __forceinline__ f32x2 pk_fma_clamp01(f32x2 a, f32x2 b, f32x2 c) {
+  f32x2 d;
+  asm("v_pk_fma_f32 %0, %1, %2, %3 clamp" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+  return d;
+}
+
 typedef __attribute__((ext_vector_type(4))) short s16x4;
 
 struct WgtArgs {
@@ -131,11 +139,13 @@ __global__ __launch_bounds__(256 * G) void pw_wgrad_tr_kernel(const WgtArgs a) {
     cdy[2 * dyB + i] = (v && !a.per_sample) ? a.gamma[n] : 0.f;
   }
   }
+  // ReLU6 on a plain BatchNorm affine (every projection layer's operand): the clamp form
+  const bool c6 = !GEN && !YF && !STEM && a.act == T3D_ACT_RELU6 && !a.se;
   for (int i = threadIdx.x; i < aB; i += 256 * G) {
     const int k = a0c + i;
     const bool v = k < a.K;
-    ca[i] = (v && a.scale) ? a.scale[k] : 1.f;
-    ca[aB + i] = (v && a.scale) ? a.shift[k] : 0.f;
+    ca[i] = ((v && a.scale) ? a.scale[k] : 1.f) * (c6 ? T3D_SIXTH : 1.f);
+    ca[aB + i] = ((v && a.scale) ? a.shift[k] : 0.f) * (c6 ? T3D_SIXTH : 1.f);
   }
   if constexpr (DGF) {
     for (int i = threadIdx.x; i < QB * (PB / 8); i += 256 * G) {
@@ -280,7 +290,14 @@ __global__ __launch_bounds__(256 * G) void pw_wgrad_tr_kernel(const WgtArgs a) {
               done = true;
             }
           }
-          if (!done) act_affine_vec<8>(u, sc, sh, a.act);
+          if (c6) {
+#pragma unroll
+            for (int j = 0; j < 8; j += 2) {
+              const f32x2 t = pk_fma_clamp01(f32x2{u[j], u[j + 1]}, f32x2{sc[j], sc[j + 1]}, f32x2{sh[j], sh[j + 1]});
+              u[j] = t[0];
+              u[j + 1] = t[1];
+            }
+          } else if (!done) act_affine_vec<8>(u, sc, sh, a.act);
 #pragma unroll
           for (int j = 0; j < 8; ++j) o[j] = (bf16_t)u[j];
         }
@@ -427,6 +444,12 @@ __global__ __launch_bounds__(256 * G) void pw_wgrad_tr_kernel(const WgtArgs a) {
     if (grp == 1) return;
   }
 
+  if (c6) {
+#pragma unroll
+    for (int i = 0; i < NTPW; ++i)
+#pragma unroll
+      for (int j = 0; j < NTQ; ++j) acc[i][j] = acc[i][j] * 6.f;
+  }
   // D[row = 4*(lane>>4) + reg -> p][col = lane&15 -> q]
   const int lg = lane >> 4, lc = lane & 15;
   if (a.ws) {

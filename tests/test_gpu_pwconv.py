@@ -176,7 +176,13 @@ def test_pwconv_wgrad(B, HW, K, N, dt, mode):
         a = _act(xq * scale + shift, 'relu6')
     else:
         a = _act((xq * scale + shift) * se.repeat_interleave(HW, 0), 'hswish')
-    a = _q(a, dtype)
+    if mode == 'bnact' and dt == 'bf16':
+        # the bf16 kernel forms ReLU6 as 6 * clamp01((s/6) x + t/6) (one packed instruction with the clamp modifier) and rounds
+        # THAT operand to bf16; the 6 is applied to the fp32 accumulators -- same accuracy, another rounding point
+        sixth = torch.tensor(0.16666667163372040, dtype=torch.float32)
+        a = _q((xq * (scale * sixth) + shift * sixth).clamp(0, 1), dtype) * 6
+    else:
+        a = _q(a, dtype)
     ref = dy.double().t() @ a.double()
     d = lambda t: t.to('cuda', dtype)
     dzd, yd, xd = d(dz), d(y), d(x)
