@@ -738,7 +738,7 @@ template <typename T, int CH>
 int launch_s1c(Dw3BArgs& a, hipStream_t st) {
   constexpr int PF = 3;
   const int CG = a.C / CH;
-  static const bool two_col = !getenv("T3D_DW_BWD_1COL");
+  const bool two_col = true;
   const int Wcols = two_col ? (a.W + 1) / 2 : a.W;
   const long long per_row_chunk = (long long)a.B * Wcols * CG;
   int nchunks = (int)((256LL * 64 * 24 + per_row_chunk - 1) / per_row_chunk);
@@ -751,7 +751,7 @@ int launch_s1c(Dw3BArgs& a, hipStream_t st) {
   dim3 grid;
   // tools/sweep_dwb.sh: the 4-channel variant needs AGPR spill space (1 wave/SIMD) and is best with one block per CU;
   // the 2-channel variant fits 2 waves/SIMD and is best with two (every extra block is one more flush)
-  static const int tb_env = getenv("T3D_DWB1_BLOCKS") ? atoi(getenv("T3D_DWB1_BLOCKS")) : 0;
+  const int tb_env = 0;
   const int target_blocks = tb_env ? tb_env : (CH == 2 && two_col ? 512 : 256);
   a.nrep = g_t3d_reduce.nrep;
   a.rstride = g_t3d_reduce.stats_stride;
@@ -759,7 +759,7 @@ int launch_s1c(Dw3BArgs& a, hipStream_t st) {
   // slab mapping (a wave = 64 consecutive channel groups of one column) only when it wastes < 12 % of the lanes
   // (12 %: 14x14x576 -- 288 channel pairs, 5 slabs -- is 5 % faster in slabs than flattened, where every workgroup flushes
   // sums of up to 512 channels instead of 128)
-  static const int waste_pct = getenv("T3D_DW_SLAB_WASTE") ? atoi(getenv("T3D_DW_SLAB_WASTE")) : 12;
+  const int waste_pct = 12;
   const bool flat = CG < 64 || (cdiv(CG, 64) * 64 - CG) * 100 > waste_pct * cdiv(CG, 64) * 64;
   if (flat) {
     a.slab = 0;
@@ -818,7 +818,7 @@ template <typename T>
 int launch_s1(Dw3BArgs& a, hipStream_t st) {
   // 2 channels per thread: half the live registers (no AGPR spills, twice the resident waves) beats the wider
   // loads of 4 channels per thread by 5-30 % on every layer
-  static const int ch = getenv("T3D_DWB_CH") ? atoi(getenv("T3D_DWB_CH")) : 2;
+  const int ch = 2;
   return (ch == 2 && a.C % 2 == 0) ? launch_s1c<T, 2>(a, st) : launch_s1c<T, 4>(a, st);
 }
 
@@ -1142,7 +1142,7 @@ int launch_s2(Dw3BArgs& a, hipStream_t st) {
   a.rows_per_chunk = cdiv(Ho, nchunks);
   a.nchunks = cdiv(Ho, a.rows_per_chunk);
   dim3 grid;
-  static const int tb_env = getenv("T3D_DWB2_BLOCKS") ? atoi(getenv("T3D_DWB2_BLOCKS")) : 0;
+  const int tb_env = 0;
   const int target_blocks = tb_env ? tb_env : (Ho >= 28 ? 512 : 384);   // tools/sweep_dwb.sh
   a.nrep = g_t3d_reduce.nrep;
   a.rstride = g_t3d_reduce.stats_stride;

@@ -598,13 +598,13 @@ int launch_ch(Dw3Args& a, int s, hipStream_t st) {
   if (nchunks < 1) nchunks = 1;
   a.rows_per_chunk = cdiv(a.Ho, nchunks);
   a.nchunks = cdiv(a.Ho, a.rows_per_chunk);
-  static const bool two_col = !getenv("T3D_DW_1COL");
+  const bool two_col = true;
   // (the two-column kernel addresses through 32-bit buffer offsets: tensors below 2 GB)
   const bool use2 = (s == 1 && CH == 4 && two_col && (size_t)a.B * a.H * a.W * a.C * sizeof(T) < (1ull << 31));
   const int Wcols = use2 ? (a.Wo + 1) / 2 : a.Wo;     // work items per row: column pairs or columns
   dim3 grid;
   // persistent blocks: enough to fill the chip, few enough that the per-block flush stays cheap (tools/sweep_dwf.sh)
-  static const int tb_env = getenv("T3D_DWF_BLOCKS") ? atoi(getenv("T3D_DWF_BLOCKS")) : 0;
+  const int tb_env = 0;
   const int target_blocks = tb_env ? tb_env : (s == 1 ? 512 : 768);
   a.nrep = g_t3d_reduce.nrep;
   a.rstride = g_t3d_reduce.stats_stride;
@@ -658,7 +658,7 @@ int launch_ch(Dw3Args& a, int s, hipStream_t st) {
 
 template <typename T>
 int launch(Dw3Args& a, int s, hipStream_t st) {
-  static const int ch = getenv("T3D_DW_CH") ? atoi(getenv("T3D_DW_CH")) : 4;
+  const int ch = 4;
   return ch == 8 ? launch_ch<T, 8>(a, s, st) : launch_ch<T, 4>(a, s, st);
 }
 

@@ -419,7 +419,7 @@ int launch5_s1(Dw5BArgs& a, hipStream_t st) {
   if (nchunks < 1) nchunks = 1;
   a.rows_per_chunk = cdiv(a.H, nchunks);
   a.nchunks = cdiv(a.H, a.rows_per_chunk);
-  static const int tb_env = getenv("T3D_DW5B_BLOCKS") ? atoi(getenv("T3D_DW5B_BLOCKS")) : 0;
+  const int tb_env = 0;
   const int target_blocks = tb_env ? tb_env : 512;
   a.nrep = g_t3d_reduce.nrep;
   a.rstride = g_t3d_reduce.stats_stride;
@@ -467,7 +467,7 @@ int launch5_s2(Dw5BArgs& a, hipStream_t st) {
   if (nchunks < 1) nchunks = 1;
   a.rows_per_chunk = cdiv(Ho, nchunks);
   a.nchunks = cdiv(Ho, a.rows_per_chunk);
-  static const int tb_env = getenv("T3D_DW5B_BLOCKS") ? atoi(getenv("T3D_DW5B_BLOCKS")) : 0;
+  const int tb_env = 0;
   const int target_blocks = tb_env ? tb_env : 512;
   a.nrep = g_t3d_reduce.nrep;
   a.rstride = g_t3d_reduce.stats_stride;

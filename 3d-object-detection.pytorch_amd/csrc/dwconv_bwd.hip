@@ -275,7 +275,7 @@ int launch(const DwBwdArgs& a0, int k, int s, hipStream_t st) {
   // interior input region = (TH*s) x (TW*s); aim at ~nslots strips of 4 input pixels
   a.TW = (a.Wo * s >= 16) ? 16 / s : ((a.Wo + 3) / 4) * 4;
   if (a.TW * s % 4) a.TW = ((a.TW + 3) / 4) * 4;
-  static const int th_mul = getenv("T3D_DWB_TH_MUL") ? atoi(getenv("T3D_DWB_TH_MUL")) : 1;
+  const int th_mul = 1;
   a.TH = th_mul * (nslots * 4) / (a.TW * s * s);
   if (a.TH < 1) a.TH = 1;
   if (a.TH > a.Ho) a.TH = a.Ho;

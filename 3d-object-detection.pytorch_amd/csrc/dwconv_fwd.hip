@@ -250,8 +250,6 @@ int launch(const DwFwdArgs& a0, int k, int s, hipStream_t st) {
 
 }  // namespace
 
-int t3d_dw3_plane_fwd(const void* x, const t3d_prologue* pro, const float* w, void* y, double* stats, int B, int H, int W,
-                      int C, hipStream_t st);
 int t3d_dw3_fwd_stream(int dtype, const void* x, const t3d_prologue* pro, const float* w, void* y, double* stats, int B,
                        int H, int W, int C, int stride, hipStream_t st);   // dwconv3_stream.hip
 
@@ -262,13 +260,6 @@ extern "C" int t3d_dwconv_fwd(int dtype, const void* x, const t3d_prologue* pro,
                               double* stats, float* gap_sum, int B, int H, int W, int C, int k, int stride,
                               void* stream) {
   if (!x || !w || !y || B <= 0 || H <= 0 || W <= 0 || C <= 0 || (C % 8)) return T3D_ERR_ARG;
-  static const bool plane = getenv("T3D_DW_PLANE") != nullptr;     // opt-in, measured slower (dwconv3_plane.hip)
-  if (plane && pro)
-    if (const int rc = t3d_fold_fallback(pro->scale, reinterpret_cast<hipStream_t>(stream))) return rc;
-  if (k == 3 && stride == 1 && dtype == T3D_BF16 && !gap_sum && H * W <= 196) {     // 14x14 / 7x7 stages: plane kernel
-    const int rc = t3d_dw3_plane_fwd(x, pro, w, y, stats, B, H, W, C, reinterpret_cast<hipStream_t>(stream));
-    if (rc != T3D_ERR_UNSUPPORTED) return rc;
-  }
   if (k == 3 && (stride == 1 || stride == 2) && !gap_sum && !(pro && pro->se) && !getenv("T3D_DW_TILED"))
     return t3d_dw3_fwd_stream(dtype, x, pro, w, y, stats, B, H, W, C, stride, reinterpret_cast<hipStream_t>(stream));
   // the kernels below read finished coefficients: a pending derive request for them becomes a launch of its own

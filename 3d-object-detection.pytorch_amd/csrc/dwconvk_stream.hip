@@ -188,7 +188,7 @@ int launch_ks(DwkArgs& a, hipStream_t st) {
   if (nchunks < 1) nchunks = 1;
   a.rows_per_chunk = cdiv(a.Ho, nchunks);
   a.nchunks = cdiv(a.Ho, a.rows_per_chunk);
-  static const int tb_env = getenv("T3D_DWK_BLOCKS") ? atoi(getenv("T3D_DWK_BLOCKS")) : 0;
+  const int tb_env = 0;
   const int target_blocks = tb_env ? tb_env : 768;
   a.nrep = g_t3d_reduce.nrep;
   a.rstride = g_t3d_reduce.stats_stride;

@@ -421,17 +421,3 @@ extern "C" int t3d_pwconv_dgrad(int dtype, const void* dz, const void* y, const 
   return dispatch(dtype, a, stream);
 }
 
-extern "C" int t3d_stem_fwd(int dtype, const void* imgs, int fmt, const float* mean, const float* inv_std, const void* w32,
-                            void* y, double* stats, int B, int H, int W, int C, void* stream) {
-  if (!imgs || !w32 || !y || B <= 0 || H <= 0 || W <= 0 || C <= 0 || (C % 8) || C > 32) return T3D_ERR_ARG;
-  if (fmt != 0 && fmt != 1) return T3D_ERR_ARG;
-  if (fmt == 1 && (!mean || !inv_std)) return T3D_ERR_ARG;
-  if (dtype != T3D_BF16) return T3D_ERR_UNSUPPORTED;      // fp32 parity mode: t3d_stem_im2col + t3d_pwconv_fwd
-  GemmArgs a{};
-  const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
-  a.stem.img = imgs; a.stem.fmt = fmt; a.stem.mean = mean; a.stem.istd = inv_std;
-  a.stem.H = H; a.stem.W = W; a.stem.Ho = Ho; a.stem.Wo = Wo;
-  a.a0 = imgs; a.w = w32; a.out = y; a.stats = stats;
-  a.M = B * Ho * Wo; a.HW = Ho * Wo; a.Kin = 32; a.Nout = C;
-  return stream_launch(a, reinterpret_cast<hipStream_t>(stream));
-}

@@ -5,41 +5,6 @@
 
 namespace t3d_pw {
 
-// Direct stem (nn.Conv2d(3, C, 3, 2, 1), models/mobilenetv3.py:110-115): the 3x3 / stride-2 patches are gathered from the
-// crops on the fly as the GEMM's K = 32 operand (27 taps in (ci, ky, kx) order + 5 zero columns), so no im2col pass and
-// no patch matrix in HBM.  fmt 0: fp32 NCHW, already normalised (the reference's input contract,
-// dataloaders/objectron_main.py:51-96); fmt 1: uint8 NHWC pixels, normalised here as (u/255 - mean[ci]) / std[ci]
-// (configs/default_config.py:9-10).
-struct StemSrc {
-  const void* img;
-  const float *mean, *istd;
-  int fmt, H, W, Ho, Wo;
-};
-
-// patch taps k0 .. k0+7 (k0 a multiple of 8) of output pixel m, as the bf16 MFMA operand
-__device__ __forceinline__ bf16x8 stem_patch(const StemSrc& s, int m, int k0) {
-  const int hw = s.Ho * s.Wo;
-  const int b = m / hw, rem = m - b * hw, oy = rem / s.Wo, ox = rem - oy * s.Wo;
-  bf16x8 o;
-#pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    const int k = k0 + j, kc = k < 27 ? k : 26;
-    const int ci = kc / 9, ky = (kc - ci * 9) / 3, kx = kc - ci * 9 - ky * 3;
-    const int iy = 2 * oy - 1 + ky, ix = 2 * ox - 1 + kx;
-    const bool ok = k < 27 && iy >= 0 && iy < s.H && ix >= 0 && ix < s.W;
-    const int iyc = min(max(iy, 0), s.H - 1), ixc = min(max(ix, 0), s.W - 1);
-    float v;
-    if (s.fmt == 0) {
-      v = reinterpret_cast<const float*>(s.img)[(((size_t)b * 3 + ci) * s.H + iyc) * s.W + ixc];
-    } else {
-      const unsigned char u = reinterpret_cast<const unsigned char*>(s.img)[(((size_t)b * s.H + iyc) * s.W + ixc) * 3 + ci];
-      v = ((float)u * (1.f / 255.f) - s.mean[ci]) * s.istd[ci];
-    }
-    o[j] = (bf16_t)(ok ? v : 0.f);
-  }
-  return o;
-}
-
 struct GemmArgs {
   const void* a0;   // FWD: x (raw or finished); DGRAD: dz
   const void* a1;   // DGRAD: y (raw output of the differentiated conv), else null
@@ -68,7 +33,6 @@ struct GemmArgs {
   const void* z_res;
   void* z_out;
   T3dQuant quant;        // forward BatchNorm sums snapped onto a fixed grid (order-independent, common.h); q == 0: off
-  StemSrc stem;          // stem.img != null: a0 is not a tensor, the K = 32 operand is gathered from the crops
 };
 
 template <typename T> __device__ __forceinline__ void ldvec(const T* p, float* v);

@@ -52,7 +52,7 @@ __device__ unsigned long long g_pw_trace[16];
 
 // ZM (forward only): materialising operand -- z = bf16(affine(a0) + residual) is formed on load, used as the operand and
 // written out once (what a t3d_bn_apply launch in front of this kernel would have done: one launch and one pass less)
-template <int NT, int R, bool DG, bool GEN, bool YF = false, int KU = 2, bool STEM = false, bool ZM = false>
+template <int NT, int R, bool DG, bool GEN, bool YF = false, int KU = 2, bool ZM = false>
 __global__ __launch_bounds__(512, KU > 2 ? 1 : 2) void pw_stream_kernel(const GemmArgs a, const int nchunks, const int KS, const int nrep, const long long rstride) {
   constexpr int BN = NT * 16;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -154,7 +154,7 @@ __global__ __launch_bounds__(512, KU > 2 ? 1 : 2) void pw_stream_kernel(const Ge
   __syncthreads();
   // forward with a plain BatchNorm + ReLU6 prologue (every projection layer): the clamp form -- the staged (scale, shift) are
   // divided by 6 (AFTER a derived finalize has published the true values) and the accumulators multiplied by 6 in the epilogue
-  const bool c6f = !DG && !ZM && !YF && !STEM && a.act == T3D_ACT_RELU6 && !(GEN && a.p2);
+  const bool c6f = !DG && !ZM && !YF && a.act == T3D_ACT_RELU6 && !(GEN && a.p2);
   if (c6f) {
     for (int i = tid; i < 2 * kpad; i += nthr) coef[i] *= T3D_SIXTH;
     __syncthreads();
@@ -242,9 +242,7 @@ __global__ __launch_bounds__(512, KU > 2 ? 1 : 2) void pw_stream_kernel(const Ge
           const int k = min(ks * 32 + lg * 8, a.row0 - 8);
 #pragma unroll
           for (int r = 0; r < R; ++r) {
-            if constexpr (STEM) {
-              fa[u][r] = stem_patch(a.stem, mld[r], lg * 8);
-            } else {
+            {
               fa[u][r] = *reinterpret_cast<const bf16x8*>(A0 + (size_t)mld[r] * a.row0 + k);
               if (DGL) fb[u][r] = *reinterpret_cast<const bf16x8*>(A1 + (size_t)mld[r] * a.row0 + k);
               if constexpr (ZM) {
@@ -519,7 +517,7 @@ __global__ __launch_bounds__(512, KU > 2 ? 1 : 2) void pw_stream_kernel(const Ge
   PW_STAMP(4);
 }
 
-template <int NT, int R, bool DG, bool GEN, bool YF = false, int KU = 2, bool STEM = false, bool ZM = false>
+template <int NT, int R, bool DG, bool GEN, bool YF = false, int KU = 2, bool ZM = false>
 int launch_v(GemmArgs& a, int KS, hipStream_t st) {
   constexpr int BN = NT * 16;
   const int kpad = KS * 32;
@@ -532,7 +530,7 @@ int launch_v(GemmArgs& a, int KS, hipStream_t st) {
   const bool ps = GEN && a.ps_stats != nullptr;          // per-sample sums: a block owns whole samples (kernel)
   const int gps = cdiv(a.HW, 16 * R);
   const int threads = (lds <= 48 * 1024 || (ps && gps <= 4)) ? 256 : 512;
-  const void* fn = (const void*)pw_stream_kernel<NT, R, DG, GEN, YF, KU, STEM, ZM>;
+  const void* fn = (const void*)pw_stream_kernel<NT, R, DG, GEN, YF, KU, ZM>;
   if (lds > 64 * 1024) (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   static int occ_cache[2] = {0, 0};   // per instantiation (function-local static of the template), per block size
   int& occ = occ_cache[threads == 512];
@@ -554,15 +552,15 @@ int launch_v(GemmArgs& a, int KS, hipStream_t st) {
     nxb = (up * nchunks <= 256 * per_cu) ? up : (nxb & ~7);
   }
   // a pending BatchNorm-finalize request belongs to this launch when it names the coefficients of its operand
-  // (per-sample coefficients and the y-free / stem variants have none to derive)
+  // (per-sample coefficients and the y-free variant have none to derive)
   a.quant = (!DG && a.stats && !getenv("T3D_NO_SNAP")) ? t3d_quant_for(a.M) : T3dQuant{0.0, 0.0};
-  if (YF || STEM || a.per_sample) {
+  if (YF || a.per_sample) {
     if (const int rc = t3d_fold_fallback(a.p0, st)) return rc;
     a.fold = nullptr;
   } else {
     a.fold = t3d_take_fold(a.p0);
   }
-  hipLaunchKernelGGL((pw_stream_kernel<NT, R, DG, GEN, YF, KU, STEM, ZM>), dim3(nxb * nchunks), dim3(threads), lds, st, a, nchunks, KS,
+  hipLaunchKernelGGL((pw_stream_kernel<NT, R, DG, GEN, YF, KU, ZM>), dim3(nxb * nchunks), dim3(threads), lds, st, a, nchunks, KS,
                      g_t3d_reduce.nrep, g_t3d_reduce.stats_stride);
   T3D_CHECK_LAUNCH();
   return T3D_OK;
@@ -580,7 +578,7 @@ int launch_nt(GemmArgs& a, int KS, hipStream_t st, int deep_ku = 0) {
   if (a.dgrad && !gen && deep_ku == 3) return launch_v<NT, R, true, false, false, 3>(a, KS, st);
   if (a.dgrad && !gen && deep_ku == 5) return launch_v<NT, R, true, false, false, 5>(a, KS, st);
   if (a.dgrad) return gen ? launch_v<NT, R, true, true>(a, KS, st) : launch_v<NT, R, true, false>(a, KS, st);
-  if (a.z_out) return gen ? T3D_ERR_UNSUPPORTED : launch_v<NT, R, false, false, false, 2, false, true>(a, KS, st);
+  if (a.z_out) return gen ? T3D_ERR_UNSUPPORTED : launch_v<NT, R, false, false, false, 2, true>(a, KS, st);
   return gen ? launch_v<NT, R, false, true>(a, KS, st) : launch_v<NT, R, false, false>(a, KS, st);
 }
 
@@ -594,10 +592,6 @@ extern "C" int t3d_debug_pw_trace(unsigned long long* out) {
 
 int stream_launch(GemmArgs& a, hipStream_t st) {
   if (!a.row0) a.row0 = a.Kin;
-  if (a.stem.img) {     // direct stem: K = 32 gathered patch taps, N = stem channels (16 / 32): one narrow instantiation
-    if (a.Kin != 32 || a.Nout > 32 || a.dgrad || a.p0 || a.p2) return T3D_ERR_UNSUPPORTED;
-    return launch_v<2, 2, false, false, false, 2, true>(a, 1, st);
-  }
 
   if (a.ps_stats && (a.stats || a.M % a.HW)) return T3D_ERR_UNSUPPORTED;   // the block-level per-sample reduction uses the statistics scratch
   const int KS = cdiv(a.Kin, 32);
@@ -606,17 +600,17 @@ int stream_launch(GemmArgs& a, hipStream_t st) {
   if (nt_cap > 10) nt_cap = 10;
   // narrow contraction (K <= 64): re-reading the activation per output chunk costs almost nothing, so trade chunks for
   // registers / occupancy
-  static const int small_k_cap = getenv("T3D_PW_NTCAP") ? atoi(getenv("T3D_PW_NTCAP")) : 10;
+  const int small_k_cap = 10;
   if (a.Kin <= 64 && nt_cap > small_k_cap) nt_cap = small_k_cap;
   // squeeze-excite data gradient (per-sample sums / gates in registers): wider tiles spill (NT = 8: 216 B, 10: 412 B)
-  static const int gen_cap = getenv("T3D_PW_GEN_NTCAP") ? atoi(getenv("T3D_PW_GEN_NTCAP")) : 6;
+  const int gen_cap = 6;
   if (a.dgrad && (a.per_sample || a.ps_stats || a.e_se) && nt_cap > gen_cap) nt_cap = gen_cap;
   // small-stage data gradients of the projection convs (contraction over 96 / 160 / 320 bottleneck channels, <= 28x28
   // pixels): all k-steps of a round in flight + hoisted epilogue loads (kernel: HOIST), at a tile width that leaves the
   // registers for it.  OPT-IN (T3D_PW_DEEP_DG=1): the launches themselves get 3-8 % faster alone (576 <- 96 @14x14: 46.2 ->
   // 45.0 us, 960 <- 160 @7x7: 31.7 -> 29.1), but the STEP gets slower (8.46 -> 8.54 ms, three A/B pairs): it is bound by the
   // two streams' combined HBM traffic, and what these launches stop waiting for, the depthwise backward beside them loses
-  static const int deep_dg = getenv("T3D_PW_DEEP_DG") ? atoi(getenv("T3D_PW_DEEP_DG")) : 0;
+  const int deep_dg = 0;
   int deep_ku = 0;
   if (deep_dg && a.dgrad && !a.a2 && !(a.per_sample || a.ps_stats || a.e_se) && a.e_y && !a.e_res && a.M <= 256 * 28 * 28 &&
       (KS == 3 || KS % 5 == 0) && a.Nout >= 96) {

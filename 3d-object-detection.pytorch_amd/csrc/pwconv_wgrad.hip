@@ -231,18 +231,3 @@ extern "C" int t3d_pwconv_wgrad(int dtype, const void* dz, const void* y, const 
   return T3D_OK;
 }
 
-int t3d_pw_wgrad_tr_stem(const void* dz, const void* y, const t3d_bnbwd* bb, const t3d_pw::StemSrc& src, float* dw, int M,
-                         int HW, int N, hipStream_t st);
-
-extern "C" int t3d_stem_wgrad(int dtype, const void* dz, const void* y, const t3d_bnbwd* bb, const void* imgs, int fmt,
-                              const float* mean, const float* inv_std, float* dw32, int B, int H, int W, int C,
-                              void* stream) {
-  if (!dz || !y || !bb || !bb->beta || !imgs || !dw32 || B <= 0 || H <= 0 || W <= 0) return T3D_ERR_ARG;
-  if (fmt != 0 && fmt != 1) return T3D_ERR_ARG;
-  if (fmt == 1 && (!mean || !inv_std)) return T3D_ERR_ARG;
-  if (dtype != T3D_BF16) return T3D_ERR_UNSUPPORTED;      // fp32 parity mode: the patch matrix + t3d_pwconv_wgrad
-  t3d_pw::StemSrc s{};
-  s.img = imgs; s.fmt = fmt; s.mean = mean; s.istd = inv_std; s.H = H; s.W = W;
-  s.Ho = (H + 2 - 3) / 2 + 1; s.Wo = (W + 2 - 3) / 2 + 1;
-  return t3d_pw_wgrad_tr_stem(dz, y, bb, s, dw32, B * s.Ho * s.Wo, s.Ho * s.Wo, C, reinterpret_cast<hipStream_t>(stream));
-}

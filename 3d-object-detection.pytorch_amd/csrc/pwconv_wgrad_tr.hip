@@ -46,7 +46,6 @@ struct WgtArgs {
   int swap;          // 0: P = N (dy side), Q = K (a side); 1: P = K, Q = N
   int ptiles, qtiles, rows_per_split, nsplit;
   float* ws;         // partial tiles [split][tile][PB][QB] (plain stores) or null (atomics into dw)
-  t3d_pw::StemSrc stem;   // stem.img != null: the a side (K = 32) is gathered from the crops (pwconv_common.h)
   const T3dFold* fold;    // requested BatchNorm-backward finalize: (alpha, beta, gamma) derived per block, NOT published
                           // (the data-gradient kernel of the main stream publishes; common.h)
   // fused y-free backward (DGF): the data gradient of the same layer from the staged [dz | x | 1] rows
@@ -82,9 +81,9 @@ __device__ __forceinline__ bf16x8 tr_frag(const bf16_t* tile, int rs, int ch0, i
 // read as they lie (pixel-major, 8 consecutive virtual channels per lane), D[k][pixel] -> a lane holds 4 consecutive
 // channels of one pixel: 8-byte stores; the skip gradient and the raw tensor of the producer (BatchNorm-backward sums of x's
 // producer, exactly as in the streaming kernel's epilogue) are fetched with the step's operands.
-template <int NTPW, int NTQ, bool SWAP, int G, int D, bool GEN, bool YF, bool STEM = false, int SK = 1, bool DGF = false>
+template <int NTPW, int NTQ, bool SWAP, int G, int D, bool GEN, bool YF, int SK = 1, bool DGF = false>
 __global__ __launch_bounds__(256 * G) void pw_wgrad_tr_kernel(const WgtArgs a) {
-  static_assert(!DGF || (YF && !SWAP && !STEM), "the fused data gradient exists for the y-free layout only");
+  static_assert(!DGF || (YF && !SWAP), "the fused data gradient exists for the y-free layout only");
   constexpr int PB = 64 * NTPW, QB = 16 * NTQ;
   constexpr int RSP = PB + 8, RSQ = QB + 8;            // LDS row strides (elements): +16 B against bank conflicts
   constexpr int STEP = 32 * SK;
@@ -140,7 +139,7 @@ __global__ __launch_bounds__(256 * G) void pw_wgrad_tr_kernel(const WgtArgs a) {
   }
   }
   // ReLU6 on a plain BatchNorm affine (every projection layer's operand): the clamp form
-  const bool c6 = !GEN && !YF && !STEM && a.act == T3D_ACT_RELU6 && !a.se;
+  const bool c6 = !GEN && !YF && a.act == T3D_ACT_RELU6 && !a.se;
   for (int i = threadIdx.x; i < aB; i += 256 * G) {
     const int k = a0c + i;
     const bool v = k < a.K;
@@ -197,8 +196,7 @@ __global__ __launch_bounds__(256 * G) void pw_wgrad_tr_kernel(const WgtArgs a) {
     for (int i = 0; i < VA; ++i) {
       const int v = min(tid + 256 * i, nav - 1);
       const int row = v / aV, k = min(a0c + (v % aV) * 8, a.K - 8), m = min(m0 + row, a.M - 1);
-      if constexpr (STEM) R.rx[i] = t3d_pw::stem_patch(a.stem, m, k);
-      else R.rx[i] = *reinterpret_cast<const bf16x8*>(xx + (size_t)m * a.K + k);
+      R.rx[i] = *reinterpret_cast<const bf16x8*>(xx + (size_t)m * a.K + k);
     }
     if constexpr (DGF) {
 #pragma unroll
@@ -548,7 +546,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_tr_kernel(const float* __res
   }
 }
 
-template <int NTPW, int NTQ, bool SWAP, int D, bool GEN, bool YF = false, bool STEM = false, int SK = 1>
+template <int NTPW, int NTQ, bool SWAP, int D, bool GEN, bool YF = false, int SK = 1>
 int launch_d(WgtArgs& a, hipStream_t st) {
   constexpr int G = 2;
   constexpr int STEP = 32 * SK;
@@ -560,8 +558,8 @@ int launch_d(WgtArgs& a, hipStream_t st) {
   const int dyB = a.swap ? QB : PB, aB = a.swap ? PB : QB;
   const size_t lds = (size_t)G * 2 * STEP * ((PB + 8) + (QB + 8)) * 2 + (size_t)(3 * dyB + 2 * aB) * 4;
   // pixel splits: fill the chip (2 blocks per CU), but keep the partial-dW flush (S * N*K atomics) below ~8 MB
-  static const int tgt_blocks = getenv("T3D_WG_BLOCKS") ? atoi(getenv("T3D_WG_BLOCKS")) : 256;
-  static const long long cap_mb = getenv("T3D_WG_FLUSH_MB") ? atoi(getenv("T3D_WG_FLUSH_MB")) : 8;
+  const int tgt_blocks = 256;
+  const long long cap_mb = 8;
   int S = (tgt_blocks + tiles - 1) / tiles;
   const long long tile_bytes = (long long)tiles * PB * QB * 4;
   const bool use_ws = g_t3d_ws.ptr && g_t3d_ws.bytes >= tile_bytes && !getenv("T3D_WG_ATOMIC");
@@ -579,9 +577,9 @@ int launch_d(WgtArgs& a, hipStream_t st) {
   S = cdiv(a.M, a.rows_per_split);
   a.ws = use_ws ? reinterpret_cast<float*>(g_t3d_ws.ptr) : nullptr;
   if (lds > 64 * 1024)
-    (void)hipFuncSetAttribute((const void*)pw_wgrad_tr_kernel<NTPW, NTQ, SWAP, G, D, GEN, YF, STEM, SK>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute((const void*)pw_wgrad_tr_kernel<NTPW, NTQ, SWAP, G, D, GEN, YF, SK>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   a.nsplit = S;
-  hipLaunchKernelGGL((pw_wgrad_tr_kernel<NTPW, NTQ, SWAP, G, D, GEN, YF, STEM, SK>), dim3(tiles * S), dim3(256 * G), lds, st, a);
+  hipLaunchKernelGGL((pw_wgrad_tr_kernel<NTPW, NTQ, SWAP, G, D, GEN, YF, SK>), dim3(tiles * S), dim3(256 * G), lds, st, a);
   if (use_ws) {
     // split groups inside the workgroup: enough parallelism for a small dW with hundreds of splits
 #define T3D_WGR(SPV)                                                                                                              \
@@ -604,14 +602,14 @@ int launch_d(WgtArgs& a, hipStream_t st) {
 
 template <int NTPW, int NTQ, bool SWAP>
 int launch_sw(WgtArgs& a, hipStream_t st) {
-  static const int depth = getenv("T3D_WG_DEPTH") ? atoi(getenv("T3D_WG_DEPTH")) : 2;   // 2 measured best (1: -12 %, 3: -2 %)
+  const int depth = 2;   // 2 measured best (1: -12 %, 3: -2 %)
   if (a.yfree) {
     if constexpr (!SWAP) {
-      static const int sk_env = getenv("T3D_WG_SK") ? atoi(getenv("T3D_WG_SK")) : 0;
+      const int sk_env = 0;
       constexpr int width = 64 * NTPW + 16 * NTQ;
       if constexpr (width <= 288) {
         const int sk = sk_env ? sk_env : (a.M >= (1 << 20) ? 2 : 1);
-        if (sk >= 2) return launch_d<NTPW, NTQ, false, 2, false, true, false, 2>(a, st);
+        if (sk >= 2) return launch_d<NTPW, NTQ, false, 2, false, true, 2>(a, st);
       }
       return launch_d<NTPW, NTQ, false, 2, false, true>(a, st);
     }
@@ -620,13 +618,13 @@ int launch_sw(WgtArgs& a, hipStream_t st) {
   if (a.per_sample || a.se) return launch_d<NTPW, NTQ, SWAP, 1, true>(a, st);   // SE layers: per-sample coefficients / gates
   if (depth == 1) return launch_d<NTPW, NTQ, SWAP, 1, false>(a, st);
   // pixels per step (see the kernel): wider steps for the narrow tiles of the layers with many pixels per workgroup
-  static const int sk_env = getenv("T3D_WG_SK") ? atoi(getenv("T3D_WG_SK")) : 0;
+  const int sk_env = 0;
   constexpr int width = 64 * NTPW + 16 * NTQ;
   // (isolated, B = 256: 112x112 32 -> 16: 181 -> 141 us, 32 -> 32: 174 -> 138 us; the 56x56 / 28x28 layers do not move or lose)
   if constexpr (width <= 288) {
     const int sk = sk_env ? sk_env : (a.M >= (1 << 20) ? 2 : 1);
-    if (sk >= 4 && width <= 128) return launch_d<NTPW, NTQ, SWAP, 2, false, false, false, 4>(a, st);
-    if (sk >= 2) return launch_d<NTPW, NTQ, SWAP, 2, false, false, false, 2>(a, st);
+    if (sk >= 4 && width <= 128) return launch_d<NTPW, NTQ, SWAP, 2, false, false, 4>(a, st);
+    if (sk >= 2) return launch_d<NTPW, NTQ, SWAP, 2, false, false, 2>(a, st);
   }
   return launch_d<NTPW, NTQ, SWAP, 2, false>(a, st);
 }
@@ -646,7 +644,7 @@ static int choose_and_launch(WgtArgs& a, hipStream_t st) {
   // every pipeline >= ~12 steps of 32 pixels when the chip is filled -- a wide tile reads each operand once but, on the
   // small-pixel-count layers, degenerates into a handful of steps followed by a large partial flush; a narrow tile
   // re-reads the (small) Q-side operand through L2 instead.
-  static const int min_steps = getenv("T3D_WG_MIN_STEPS") ? atoi(getenv("T3D_WG_MIN_STEPS")) : 12;
+  const int min_steps = 12;
   auto steps_with = [&](int ntpw, int qb) {
     const int tiles = cdiv(P, 64 * ntpw) * cdiv(Q, qb);
     int S = cdiv(256, tiles);
@@ -692,19 +690,6 @@ int t3d_pw_wgrad_tr_entry(const void* dz, const void* y, const t3d_bnbwd* bb, co
   return choose_and_launch(a, st);
 }
 
-// stem weight gradient: dW32 [C][32] += dy^T * patches, the patches gathered from the crops (no saved patch matrix)
-int t3d_pw_wgrad_tr_stem(const void* dz, const void* y, const t3d_bnbwd* bb, const t3d_pw::StemSrc& src, float* dw, int M,
-                         int HW, int N, hipStream_t st) {
-  WgtArgs a{};
-  a.dz = dz; a.y = y; a.x = dz;
-  a.alpha = bb->alpha; a.beta = bb->beta; a.gamma = bb->gamma; a.per_sample = bb->per_sample;
-  a.dw = dw; a.M = M; a.HW = HW; a.K = 32; a.N = N;
-  a.stem = src;
-  if (N == 32) { a.swap = 0; return launch_d<1, 2, false, 2, false, false, true, 4>(a, st); }     // P = N = 32, Q = K = 32
-  if (N == 16) { a.swap = 1; return launch_d<1, 1, true, 2, false, false, true, 4>(a, st); }      // P = K = 32, Q = N = 16
-  return T3D_ERR_UNSUPPORTED;
-}
-
 // ---- fused y-free backward (pwconv_yfree.hip: t3d_pwconv_bwd_yfree / _finish) ------------------------------------------
 // one configuration per layer shape, shared by the launch and by the later reduction of its partial tiles
 struct YfCfg { int ntpw, ntq, sk, S, rows_per_split, PB, QB; };
@@ -734,9 +719,9 @@ static int launch_fused(WgtArgs& a, const YfCfg& c, hipStream_t st) {
   const int ncoef = 3 * PB + 2 * QB;
   const size_t lds = (size_t)G * 2 * STEP * ((PB + 8) + (QB + 8)) * 2 + (size_t)((ncoef + 3) & ~3) * 4 + (size_t)QB * (PB + 8) * 2 +
                      (size_t)2 * QB * sizeof(double);
-  const void* fn = (const void*)pw_wgrad_tr_kernel<NTPW, NTQ, false, G, 2, false, true, false, SK, true>;
+  const void* fn = (const void*)pw_wgrad_tr_kernel<NTPW, NTQ, false, G, 2, false, true, SK, true>;
   if (lds > 64 * 1024) (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  hipLaunchKernelGGL((pw_wgrad_tr_kernel<NTPW, NTQ, false, G, 2, false, true, false, SK, true>), dim3(c.S), dim3(256 * G), lds, st, a);
+  hipLaunchKernelGGL((pw_wgrad_tr_kernel<NTPW, NTQ, false, G, 2, false, true, SK, true>), dim3(c.S), dim3(256 * G), lds, st, a);
   T3D_CHECK_LAUNCH();
   return T3D_OK;
 }

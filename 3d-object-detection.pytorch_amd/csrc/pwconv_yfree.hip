@@ -202,7 +202,7 @@ static int yfree_prep_impl(const void* wt, const t3d_bnbwd* bb, void* wcat, floa
   if (!w || !bb || !bb->alpha || !bb->beta || !bb->gamma || !wcat || !cvec || K <= 0 || N <= 0 || (K % 8) || (N % 8))
     return T3D_ERR_ARG;
   if (bb->per_sample) return T3D_ERR_UNSUPPORTED;
-  static const bool derive = !getenv("T3D_YFREE_PREP_NO_DERIVE");
+  const bool derive = true;
   const T3dFold* fold = nullptr;
   if (derive) fold = t3d_take_fold(bb->alpha);
   else if (const int rc = t3d_fold_fallback(bb->alpha, reinterpret_cast<hipStream_t>(stream))) return rc;

@@ -81,10 +81,7 @@ SIGNATURES = {
     't3d_res_relu_fwd': [_I, _P, _PP, _P, _PP, _P, _I, _I, _P],
     't3d_res_relu_bwd': [_I, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P],
     't3d_subsample': [_I, _P, _P, _I, _I, _I, _I, _I, _I, _P],
-    't3d_expdw_fwd': [_P, _P, _P, _P, _I, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
     't3d_ir_block_eval': [_P, _P, _P, _P, _I, _P, _P, _P, _I, _P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _I, _P],
-    't3d_stem_fwd': [_I, _P, _I, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
-    't3d_stem_wgrad': [_I, _P, _P, _BP, _P, _I, _P, _P, _P, _I, _I, _I, _I, _P],
     't3d_bn_apply': [_I, _P, _PP, _P, _P, _I, _I, _P],
     't3d_bn_act_bwd': [_I, _P, _P, _PP, _P, _P, _I, _I, _P],
     't3d_gap_fwd': [_I, _P, _PP, _P, _I, _I, _I, _P],

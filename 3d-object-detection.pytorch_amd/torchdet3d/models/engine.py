@@ -39,7 +39,7 @@ MAIN_WORKSPACE_BYTES = 16 << 20
 YFREE_MIN_ELEMS = int(os.environ.get('T3D_YFREE_MIN', 8 << 20))
 YFREE_FUSED = os.environ.get('T3D_YFREE_FUSED', '1') != '0'     # one-pass expand-layer backward (t3d_pwconv_bwd_yfree)
 HOOK_MIN = 1 << 20              # gradient-exchange granularity (elements): parallel.GradSync's bucket size
-HOOK_ON_SIDE = os.environ.get('T3D_HOOK_ON_SIDE', '1') != '0'
+HOOK_ON_SIDE = True              # (round 3: the gradient exchange is issued from the second stream; the other order stalled the main one)
 
 
 class _BN:
@@ -49,9 +49,6 @@ class _BN:
 
 
 def _nrep_for(C):
-    fixed = os.environ.get('T3D_NREP')
-    if fixed:
-        return int(fixed)
     return 16 if C <= 160 else (8 if C <= 640 else 4)
 
 
@@ -66,7 +63,7 @@ def _concurrent_stream(device, tries=8):
     with torch.cuda.device(device):
         probe = torch.zeros(1, device=device)
         for _ in range(tries):
-            st = torch.cuda.Stream(device=device, priority=int(os.environ.get('T3D_SIDE_PRIO', '0')))
+            st = torch.cuda.Stream(device=device, priority=0)
             cands.append(st)
             e0, e_side, e_main = (torch.cuda.Event(enable_timing=True) for _ in range(3))
             torch.cuda.synchronize(device)
@@ -134,13 +131,7 @@ class Net:
         self._side_busy = False
         # uint8 input path (include/t3d.h: t3d_stem_fwd, fmt 1): normalisation of configs/default_config.py:9-10
         self.set_input_normalization([0.5931, 0.4690, 0.4229], [0.2471, 0.2214, 0.2157])
-        self._direct_stem = bool(os.environ.get('T3D_STEM_DIRECT'))
         self._fused_eval = not os.environ.get('T3D_NO_FUSED_EVAL')   # 14x14 / 7x7 blocks as one launch in inference mode
-        # expand + depthwise as one launch in training mode (csrc/expdw_fwd.hip): OPT-IN (T3D_EXPDW=1).  First version, correct
-        # but latency-bound (112x112x16->96: 516 us against 400 for the two launches it replaces) and it needs a
-        # statistics-only pass of the 1x1 conv in front (94 us there) -- DESIGN.md section 7 has the measurements and what
-        # the fused forward + backward pair would remove (the expanded tensor's 6 HBM passes per block)
-        self._fuse_expdw = bool(os.environ.get('T3D_EXPDW'))
 
     def set_input_normalization(self, mean, std):
         """Per-channel mean / std applied to uint8 crops inside the stem kernel ((u/255 - mean) / std)."""
@@ -222,9 +213,7 @@ class Net:
         self._cur_nrep = None
         # T3D_NO_LAZY_BN=1: every BatchNorm finalize as a launch of its own (the round-2 behaviour)
         self._lazy = not os.environ.get('T3D_NO_LAZY_BN')
-        self._zfuse = not os.environ.get('T3D_NO_ZFUSE')        # block outputs materialised by the consuming 1x1 conv
-        if os.environ.get('T3D_LAZY_SKIP'):     # measurement aid: entry points that get the standalone finalize instead
-            self.DERIVING = self.DERIVING - frozenset(os.environ['T3D_LAZY_SKIP'].split(','))
+        self._zfuse = True              # block outputs materialised by the consuming 1x1 conv (t3d_pwconv_fwd_mat)
         if sh is None:
             self.reset_parameters()
 
@@ -381,7 +370,7 @@ class Net:
     # with the ~3-us round trip to the sums, but the 5-us finalize launch and the ~6-us dispatch gap behind it go: 7.90 -> 7.83
     # ms per step on one box, 8.00 -> 7.97 on another (round 3b, forward half); with the atomics-free flush of round 3c the
     # backward half costs nothing either (7.64 ms both ways, 18 launches fewer), so both are on)
-    _LAZY_DW = os.environ.get('T3D_LAZY_DW', '1')
+    _LAZY_DW = '1'
     DERIVING = frozenset(('t3d_pwconv_fwd', 't3d_pwconv_fwd_mat', 't3d_bn_apply', 't3d_pool_fwd', 't3d_pwconv_dgrad', 't3d_pwconv_yfree_prep',
                           't3d_pwconv_yfree_prep2')
                          + (('t3d_dwconv_fwd',) if _LAZY_DW in ('1', 'fwd') else ())
@@ -620,25 +609,19 @@ class Net:
         sv = dict(B=B, imgs=imgs, blocks=[])
         self.saved_blocks = sv['blocks']
 
-        # ---- stem (mobilenetv3.py:110-115,178): patch gather + GEMM.  T3D_STEM_DIRECT=1 (bf16 storage) gathers the patches
-        # inside the GEMM kernels instead (no patch matrix; measured slower, DESIGN.md finding 13)
+        # ---- stem (mobilenetv3.py:110-115,178): patch gather + GEMM (a direct stem that gathers the patches inside the GEMM
+        # kernels was measured slower, DESIGN.md finding 13; tools/scratch/pruned_r4 has what is left of it)
         Ho, Wo = (H + 2 - 3) // 2 + 1, (W + 2 - 3) // 2 + 1
         M = B * Ho * Wo
         bn0 = self.bns['features.0.1']
         y0 = self._buf('y:stem', (M, a.stem_c))
-        direct = self._direct_stem and dt == N.BF16
-        if direct:
-            col = None
-            N.call('t3d_stem_fwd', dt, N.ptr(imgs), int(u8), N.ptr(self.in_mean), N.ptr(self.in_istd), N.ptr(self.w['stem']),
-                   N.ptr(y0), self._st(bn0), B, H, W, a.stem_c, st, nbytes=imgs.numel() * imgs.element_size() + M * a.stem_c * 2)
+        col = self._buf('col', (M, 32))
+        if u8:
+            N.call('t3d_stem_im2col_u8', dt, N.ptr(imgs), N.ptr(self.in_mean), N.ptr(self.in_istd), N.ptr(col), B, H, W, st)
         else:
-            col = self._buf('col', (M, 32))
-            if u8:
-                N.call('t3d_stem_im2col_u8', dt, N.ptr(imgs), N.ptr(self.in_mean), N.ptr(self.in_istd), N.ptr(col), B, H, W, st)
-            else:
-                N.call('t3d_stem_im2col', dt, N.ptr(imgs), N.ptr(col), B, H, W, st)
-            N.call('t3d_pwconv_fwd', dt, N.ptr(col), None, N.ptr(self.w['stem']), None, N.ptr(y0), self._st(bn0),
-                   M, Ho * Wo, 32, a.stem_c, st, nbytes=M * (32 + a.stem_c) * self.esz)
+            N.call('t3d_stem_im2col', dt, N.ptr(imgs), N.ptr(col), B, H, W, st)
+        N.call('t3d_pwconv_fwd', dt, N.ptr(col), None, N.ptr(self.w['stem']), None, N.ptr(y0), self._st(bn0),
+               M, Ho * Wo, 32, a.stem_c, st, nbytes=M * (32 + a.stem_c) * self.esz)
         pro0 = self._bn_fwd(bn0, M, a.stem_act)
         cur = _Src(y0, pro0, B, Ho, Wo, a.stem_c, raw=y0, bn=bn0, gpro=pro0)
         sv['col'], sv['stem'] = col, cur
@@ -707,46 +690,6 @@ class Net:
         lds = mt * 16 * (blk.cin + 8) * 2 + P * 68 * 4 + mt * 16 * 72 * 2 + 64 * (blk.cin + 8) * 2 + blk.cout * 72 * 2 + 64 * 9 * 4 + 4 * 64 * 4
         return lds <= 160 * 1024
 
-    def _fuse_expdw_ok(self, blk, x):
-        """Training, bf16: expand 1x1 + BatchNorm + activation + depthwise 3x3 as ONE launch (csrc/expdw_fwd.hip) -- the
-        expanded tensor is consumed out of LDS instead of being read back from HBM."""
-        return (self.training and self._fuse_expdw and self.dt == N.BF16 and blk.expand and blk.k == 3 and not blk.se
-                and blk.act in ('relu', 'relu6') and x.pro is None and blk.cin % 8 == 0 and blk.cin <= 160)
-
-    def _block_fwd_fused(self, i, blk, x, rec):
-        st, dt = N.stream(), self.dt
-        p = f'features.{i + 1}.conv'
-        B, H, W = x.B, x.H, x.W
-        bn1, bn2, bn3 = self.bns[p + '.1'], self.bns[p + '.4'], self.bns[p + '.8']
-        dwn, pwn = p + '.3.weight', p + '.7.weight'
-        M = B * H * W
-        # the expansion's batch statistics: the 1x1 conv as a statistics-only pass over the narrow input (nothing stored)
-        N.call('t3d_pwconv_fwd', dt, N.ptr(x.t), None, N.ptr(self.w[p + '.0.weight']), None, None, self._st(bn1),
-               M, H * W, blk.cin, blk.cexp, st, nbytes=M * blk.cin * self.esz)
-        pro1 = self._bn_fwd(bn1, M, blk.act)
-        self._settle_f(bn1)
-        Ho, Wo = (H + 2 - 3) // blk.s + 1, (W + 2 - 3) // blk.s + 1
-        M2 = B * Ho * Wo
-        y1 = self._buf(f'y1:{i}', (M, blk.cexp))
-        y2 = self._buf(f'y2:{i}', (M2, blk.cexp))
-        N.call('t3d_expdw_fwd', N.ptr(x.t), N.ptr(self.w[p + '.0.weight']), N.ptr(bn1.scale), N.ptr(bn1.shift),
-               N.ACT[blk.act], N.ptr(self.p[dwn]), N.ptr(y1), N.ptr(y2), self._st(bn2), B, H, W, blk.cin, blk.cexp, blk.s, st,
-               nbytes=(M * (blk.cin + 2 * blk.cexp) + M2 * blk.cexp) * self.esz)
-        src = _Src(y1, pro1, B, H, W, blk.cexp, raw=y1, bn=bn1, gpro=pro1)
-        rec['s1'] = src
-        pro2 = self._bn_fwd(bn2, M2, blk.act)
-        s2 = _Src(y2, pro2, B, Ho, Wo, blk.cexp, raw=y2, bn=bn2, gpro=pro2)
-        y3 = self._buf(f'y3:{i}', (M2, blk.cout))
-        self._c('t3d_pwconv_fwd', dt, N.ptr(y2), pro2, N.ptr(self.w[pwn]), None, N.ptr(y3), self._st(bn3),
-                M2, Ho * Wo, blk.cexp, blk.cout, st, nbytes=M2 * (blk.cexp + blk.cout) * self.esz, fwd=bn2)
-        pro3 = self._bn_fwd(bn3, M2, 'none')
-        z = self._buf(f'z:{i}', (M2, blk.cout))
-        self._c('t3d_bn_apply', dt, N.ptr(y3), pro3, N.ptr(x.t) if blk.res else None, N.ptr(z), M2, blk.cout, st, fwd=bn3)
-        out = _Src(z, None, B, Ho, Wo, blk.cout, raw=y3, bn=bn3, gpro=None)
-        rec.update(src=src, s2=s2, y3=y3, bn3=bn3, out=out, names=(dwn, pwn), blk=blk, idx=i)
-        self.saved_blocks.append(rec)
-        return out
-
     def _block_fwd(self, i, blk, x, sv):
         st, dt = N.stream(), self.dt
         p = f'features.{i + 1}.conv'
@@ -763,14 +706,10 @@ class Net:
             return _Src(z, None, B, H, W, blk.cout, raw=None, bn=bn3, gpro=None)
         if x.zbuf is not None and not blk.expand:
             self._resolve(x)                   # (the depthwise conv of a no-expand block reads the finished tensor)
-        if x.zbuf is not None and self._fuse_expdw:
-            self._resolve(x)
         if blk.res and x.pro is not None and x.zbuf is None:
             x = self._finish(x, f'z:in{i}')
         rec = dict(x=x)
         src = x
-        if self._fuse_expdw_ok(blk, x):
-            return self._block_fwd_fused(i, blk, x, rec)
         if blk.expand:                                                    # mobilenetv3.py:146-150
             bn1 = self.bns[p + '.1']
             M = B * H * W
@@ -1001,16 +940,8 @@ class Net:
         bb = self._bn_bwd(bn0)
         self._settle_b(bn0)
         M = s0.B * s0.H * s0.W
-        if sv['col'] is None:       # direct stem: the patches are gathered from the crops again
-            im = sv['imgs']
-            u8 = im.dtype == torch.uint8
-            H, W = (im.shape[1], im.shape[2]) if u8 else (im.shape[2], im.shape[3])
-            self._wgrad(dt, N.ptr(dz), N.ptr(s0.raw), bb, N.ptr(im), int(u8), N.ptr(self.in_mean), N.ptr(self.in_istd),
-                        N.ptr(dw32), s0.B, H, W, a.stem_c, entry='t3d_stem_wgrad',
-                        nbytes=im.numel() * im.element_size() + M * a.stem_c * 2)
-        else:
-            self._wgrad(dt, N.ptr(dz), N.ptr(s0.raw), bb, N.ptr(sv['col']), None, N.ptr(dw32),
-                        M, s0.H * s0.W, 32, a.stem_c, nbytes=M * (32 + a.stem_c) * self.esz)
+        self._wgrad(dt, N.ptr(dz), N.ptr(s0.raw), bb, N.ptr(sv['col']), None, N.ptr(dw32),
+                    M, s0.H * s0.W, 32, a.stem_c, nbytes=M * (32 + a.stem_c) * self.esz)
         self._flush_dw()
         self._join_side()
         N.call('t3d_copy_cols', N.ptr(dw32), N.ptr(self.g['features.0.0.weight']), a.stem_c, 32, 27, st)

@@ -275,13 +275,6 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    # the step's main (critical-path) stream; T3D_MAIN_PRIO=-1: a high-priority stream, so that the weight-gradient
-    # kernels of the second stream only fill what the main chain leaves idle
-    main_stream = None
-    if os.environ.get('T3D_MAIN_PRIO'):
-        main_stream = torch.cuda.Stream(device=dev, priority=int(os.environ['T3D_MAIN_PRIO']))
-        main_stream.wait_stream(torch.cuda.current_stream())
-        torch.cuda.set_stream(main_stream)
     # ---- warm-up (untimed).  With --profile-all the second half of it times every kernel family, the weight gradients
     # on the main stream for those steps (event pairs on the second stream would also count the time a launch waits
     # for the main stream's persistent kernels to free registers, not just the kernel)

@@ -202,20 +202,6 @@ int t3d_ir_block_eval(const void* x, const void* w1, const float* scale1, const 
 int t3d_crop_resize_u8(const unsigned char* frame, const int* rects, unsigned char* out, int n, int H, int W, int oh, int ow,
                        void* stream);
 
-/* Direct stem (bf16 storage, opt-in: T3D_STEM_DIRECT=1): the same convolution WITHOUT the patch matrix -- the 3x3 /
- * stride-2 taps are gathered from the crops inside the GEMM kernels (forward and weight gradient), so t3d_stem_im2col, its
- * 205 MB matrix (B = 256 @224^2) and the passes over it disappear.  Measured SLOWER than the patch matrix on MI355X (the
- * per-lane gathers run at the GEMM kernel's occupancy: step 9.4 vs 8.66 ms), hence not the default; DESIGN.md finding 13.  imgs: fmt 0 = fp32 NCHW [B,3,H,W], normalised (the reference's input contract);
- * fmt 1 = uint8 NHWC [B,H,W,3] raw pixels, normalised in the kernel as (u/255 - mean[c]) * inv_std[c]
- * (configs/default_config.py:9-10: the crops can then stay uint8 from the decoder to the GPU, 4x less PCIe / HBM).
- * w32 [C,32] storage dtype (t3d_copy_cols + t3d_pack_weight of the [C,3,3,3] weight), y [B*Ho*Wo, C] raw output,
- * stats as t3d_pwconv_fwd; _wgrad: dz, y, bb as t3d_pwconv_wgrad, dw32 [C,32] fp32 += (caller zeroes).
- * fp32 storage returns T3D_ERR_UNSUPPORTED (parity mode keeps the patch matrix). */
-int t3d_stem_fwd(int dtype, const void* imgs, int fmt, const float* mean, const float* inv_std, const void* w32, void* y,
-                 double* stats, int B, int H, int W, int C, void* stream);
-int t3d_stem_wgrad(int dtype, const void* dz, const void* y, const t3d_bnbwd* bb, const void* imgs, int fmt,
-                   const float* mean, const float* inv_std, float* dw32, int B, int H, int W, int C, void* stream);
-
 /* Materialise a block output:  z = act(scale*y + shift) + residual   (residual may be NULL; scale NULL = identity).
  * Replaces the BatchNorm normalise pass + `x + self.conv(x)` (mobilenetv3.py:159,162-164). y,z,residual [M,C]. */
 int t3d_bn_apply(int dtype, const void* y, const t3d_prologue* pro, const void* residual, void* z, int M, int C,
@@ -367,19 +353,6 @@ int t3d_se_bwd_weights(const float* m, const float* h, const float* dq, const fl
  *   w [N,K], y [M,N] raw output, stats as in t3d_pwconv_fwd. */
 int t3d_pwconv_fwd_mat(int dtype, const void* y_in, const t3d_prologue* pro_in, const void* residual, void* z_out,
                        const void* w, void* y, double* stats, int M, int HW, int K, int N, void* stream);
-
-/* Fused expand 1x1 conv + BatchNorm + activation + depthwise 3x3 conv forward of an inverted-residual block, training
- * mode, bf16 storage (models/mobilenetv3.py:146-153: nn.Conv2d(K, C, 1) -> BatchNorm2d -> act -> nn.Conv2d(C, C, 3, s, 1,
- * groups=C) + the statistics pass of the BatchNorm that follows).  The expanded tensor is recomputed per tile on the
- * matrix cores and consumed out of LDS, so it costs no HBM read (and, with y1 == NULL, no write).
- *   z [B,H,W,K] finished block input, w1 [C,K] bf16, scale1 / shift1 [C]: the FINALIZED affine of the expansion's
- *   BatchNorm (its batch sums come from a statistics-only pass: t3d_pwconv_fwd with y = NULL), act: T3D_ACT_*,
- *   wdw [C,9] fp32, y1 [B,H,W,C] raw expansion or NULL (stored for a backward that reads it; the stored, rounded value is
- *   then the one that is normalised, exactly as layer by layer), y2 [B,Ho,Wo,C] raw depthwise output,
- *   stats2 [2*C] fp64 or NULL: += sum(y2), sum(y2^2) (replicas as in t3d_set_reduction_replicas).
- * K <= 160, K % 8 == 0, C % 8 == 0, stride 1 or 2; T3D_ERR_UNSUPPORTED otherwise. */
-int t3d_expdw_fwd(const void* z, const void* w1, const float* scale1, const float* shift1, int act, const float* wdw,
-                  void* y1, void* y2, double* stats2, int B, int H, int W, int K, int C, int stride, void* stream);
 
 /* SSD detector post-processing (configs/detection/mnv2_ssd_300_2_heads.py:15-39,65-69: SSDHead outputs of <= 2 feature
  * maps -> DeltaXYWH decode -> softmax -> per-class greedy NMS), one launch per frame batch.  The implementing mmdetection

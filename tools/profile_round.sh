@@ -1,17 +1,17 @@
 #!/bin/bash
 # everything the round's profiles/ are made of, in one GPU call.  usage: tools/profile_round.sh <tag> <commit>
 cd $GRAFT_REPO_ROOT; export TMPDIR=/tmp
-tag=${1:-r3}; commit=${2:-?}; o=gpurun_out/$tag; mkdir -p $o
+tag=${1:-r4}; commit=${2:-?}; o=gpurun_out/$tag; mkdir -p $o
 python3 bench.py --steps 30 --warmup 8 > $o/bench_bf16.json 2> $o/bench_bf16.err
 python3 bench.py --steps 30 --warmup 8 --no-cpu-baseline --profile-all > /dev/null 2> $o/bench_bf16_families.txt
 python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline --per-launch > /dev/null 2> $o/bench_bf16_per_launch.txt
 python3 bench.py --steps 10 --warmup 3 --dtype f32 --no-cpu-baseline > $o/bench_f32.json 2> /dev/null
 python3 bench.py --steps 30 --warmup 8 --eval --no-cpu-baseline > $o/bench_eval.json 2> /dev/null
+python3 bench.py --steps 30 --warmup 8 --eval --eval-dtype bf16 --no-cpu-baseline > $o/bench_eval_bf16_optin.json 2> /dev/null
 python3 bench.py --steps 20 --warmup 5 --model mobilenetv3_large --no-cpu-baseline > $o/bench_mnv3_large.json 2> /dev/null
 python3 bench.py --steps 20 --warmup 5 --model mobilenetv3_small --no-cpu-baseline > $o/bench_mnv3_small.json 2> /dev/null
 python3 bench.py --steps 30 --warmup 8 --engine --no-cpu-baseline > $o/bench_bf16_engine_loop.json 2> /dev/null
 bash tools/time_kernels.sh > $o/isolated_kernel_timings.txt 2>&1
-python3 tools/time_expdw.py 2>&1 | grep -v amdgpu.ids > $o/expdw_fused_forward_timings.txt
 python3 tools/bench_two_stage.py --detector 2> /dev/null | tail -1 > $o/two_stage_pipeline_bench.jsonl
 python3 tools/bench_two_stage.py --dets 64 2> /dev/null | tail -1 >> $o/two_stage_pipeline_bench.jsonl
 # rocprofv3 kernel trace + stats of the default bench (the program itself after `--`)
