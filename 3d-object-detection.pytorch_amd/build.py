@@ -31,7 +31,9 @@ def build(force=False, verbose=True):
     jobs = []
     for s in srcs:
         src, obj = os.path.join(CSRC, s), os.path.join(OBJ, s[:-4] + '.o')
-        if force or _newer(src, obj) or any(_newer(h, obj) for h in hdrs):
+        # (a unit that is another unit compiled for a second storage type -- `#include "x.hip"` -- follows that source too)
+        incs = [os.path.join(CSRC, m) for m in __import__('re').findall(r'#include "(\w+\.hip)"', open(src).read())]
+        if force or _newer(src, obj) or any(_newer(h, obj) for h in hdrs + incs):
             jobs.append((src, obj))
 
     def cc(job):

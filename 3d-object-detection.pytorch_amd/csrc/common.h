@@ -9,6 +9,8 @@
 typedef __bf16 bf16_t;
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef _Float16 f16_t;       // fp16 activation storage: inference forward only (3 more mantissa bits than bf16 at every MFMA operand)
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(2))) float f32x2;
 // packed fp32 FMA: one v_pk_fma_f32 does two lanes' worth of fused multiply-adds per issue slot (the fp32 VALU peak
@@ -223,6 +225,21 @@ template <> struct Vec8<bf16_t> {
     *reinterpret_cast<bf16x8*>(p) = a;
   }
   static __device__ __forceinline__ float round(float x) { return (float)(bf16_t)x; }
+};
+
+template <> struct Vec8<f16_t> {
+  static __device__ __forceinline__ void load(const f16_t* p, float v[8]) {
+    const f16x8 a = *reinterpret_cast<const f16x8*>(p);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = (float)a[i];
+  }
+  static __device__ __forceinline__ void store(f16_t* p, const float v[8]) {
+    f16x8 a;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) a[i] = (f16_t)v[i];
+    *reinterpret_cast<f16x8*>(p) = a;
+  }
+  static __device__ __forceinline__ float round(float x) { return (float)(f16_t)x; }
 };
 
 // ---- activations (reference: torchdet3d/models/mobilenetv3.py:74-89) ------

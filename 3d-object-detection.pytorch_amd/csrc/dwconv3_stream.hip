@@ -109,7 +109,7 @@ __device__ __forceinline__ void store_round(T* p, const float* acc, float* psum,
 // stencil math -- a.act is only read by the launcher
 template <typename T, int S, int CH, int PF, int ACT>
 __global__ __launch_bounds__(256) void dw3_fwd_kernel(const Dw3Args a) {
-  constexpr bool C6 = std::is_same<T, bf16_t>::value && ACT == T3D_ACT_RELU6 && S == 2;
+  constexpr bool C6 = !std::is_same<T, float>::value && ACT == T3D_ACT_RELU6 && S == 2;
   constexpr int H2 = CH / 2;
   extern __shared__ __attribute__((aligned(16))) float lstat[];  // [2][C] doubles at the end of the kernel (sums); floats for a derived finalize
   using RV = rawvec<T, CH>;
@@ -358,7 +358,7 @@ __global__ __launch_bounds__(256) void dw3_fwd_kernel(const Dw3Args a) {
 template <typename T, int PF, int ACT>
 __global__ __launch_bounds__(256) void dw3_fwd2_kernel(const Dw3Args a) {
   constexpr int CH = 4, H2 = CH / 2;
-  constexpr bool C6 = std::is_same<T, bf16_t>::value && ACT == T3D_ACT_RELU6;
+  constexpr bool C6 = !std::is_same<T, float>::value && ACT == T3D_ACT_RELU6;
   extern __shared__ __attribute__((aligned(16))) float lstat[];  // [2][C] doubles at the end of the kernel (sums); floats for a derived finalize
   using RV = rawvec<T, CH>;
   const int CG = a.C / CH, Wp = (a.Wo + 1) / 2;
@@ -675,5 +675,6 @@ int t3d_dw3_fwd_stream(int dtype, const void* x, const t3d_prologue* pro, const 
   a.Wo = (W + 2 - 3) / stride + 1;
   if (dtype == T3D_F32) return launch<float>(a, stride, st);
   if (dtype == T3D_BF16) return launch<bf16_t>(a, stride, st);
+  if (dtype == T3D_F16) return launch<f16_t>(a, stride, st);       // inference forward
   return T3D_ERR_ARG;
 }

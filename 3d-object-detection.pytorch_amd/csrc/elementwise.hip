@@ -397,6 +397,8 @@ static int im2col_launch(int dtype, const void* x, bool u8, const float* mean, c
     if (u8) T3D_IM2COL(float, true); else T3D_IM2COL(float, false);
   } else if (dtype == T3D_BF16) {
     if (u8) T3D_IM2COL(bf16_t, true); else T3D_IM2COL(bf16_t, false);
+  } else if (dtype == T3D_F16) {
+    if (u8) T3D_IM2COL(f16_t, true); else T3D_IM2COL(f16_t, false);
   } else {
     return T3D_ERR_ARG;
   }
@@ -428,6 +430,7 @@ extern "C" int t3d_bn_apply(int dtype, const void* y, const t3d_prologue* pro, c
   const size_t lds = a.fold ? (size_t)2 * C * sizeof(float) : 0;
   if (dtype == T3D_F32) hipLaunchKernelGGL(bn_apply_kernel<float>, dim3(grid), dim3(256), lds, st, a);
   else if (dtype == T3D_BF16) hipLaunchKernelGGL(bn_apply_kernel<bf16_t>, dim3(grid), dim3(256), lds, st, a);
+  else if (dtype == T3D_F16) hipLaunchKernelGGL(bn_apply_kernel<f16_t>, dim3(grid), dim3(256), lds, st, a);
   else return T3D_ERR_ARG;
   T3D_CHECK_LAUNCH();
   return T3D_OK;
@@ -501,6 +504,7 @@ extern "C" int t3d_pool_fwd(int dtype, const void* y, const t3d_prologue* pro, i
   if (const int rc = t3d_fold_fallback(a.scale, st)) return rc;      // no derive prologue here: finalize as its own launch
   if (dtype == T3D_F32) hipLaunchKernelGGL(gap_fwd_kernel<float>, grid, dim3(256), 0, st, a);
   else if (dtype == T3D_BF16) hipLaunchKernelGGL(gap_fwd_kernel<bf16_t>, grid, dim3(256), 0, st, a);
+  else if (dtype == T3D_F16) hipLaunchKernelGGL(gap_fwd_kernel<f16_t>, grid, dim3(256), 0, st, a);
   else return T3D_ERR_ARG;
   T3D_CHECK_LAUNCH();
   return T3D_OK;

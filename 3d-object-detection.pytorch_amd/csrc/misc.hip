@@ -268,6 +268,7 @@ extern "C" int t3d_pack_weights_batched(int dtype, const long long* desc, int n,
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   if (dtype == T3D_F32) hipLaunchKernelGGL(pack_batched_kernel<float>, dim3(n, 48), dim3(256), 0, st, desc);
   else if (dtype == T3D_BF16) hipLaunchKernelGGL(pack_batched_kernel<bf16_t>, dim3(n, 48), dim3(256), 0, st, desc);
+  else if (dtype == T3D_F16) hipLaunchKernelGGL(pack_batched_kernel<f16_t>, dim3(n, 48), dim3(256), 0, st, desc);
   else return T3D_ERR_ARG;
   T3D_CHECK_LAUNCH();
   return T3D_OK;
@@ -283,6 +284,8 @@ extern "C" int t3d_pack_weight(int dtype, const float* w, void* out, int rows, i
     hipLaunchKernelGGL(pack_kernel<float>, dim3(grid), dim3(256), 0, st, w, (float*)out, rows, cols, transpose);
   else if (dtype == T3D_BF16)
     hipLaunchKernelGGL(pack_kernel<bf16_t>, dim3(grid), dim3(256), 0, st, w, (bf16_t*)out, rows, cols, transpose);
+  else if (dtype == T3D_F16)
+    hipLaunchKernelGGL(pack_kernel<f16_t>, dim3(grid), dim3(256), 0, st, w, (f16_t*)out, rows, cols, transpose);
   else
     return T3D_ERR_ARG;
   T3D_CHECK_LAUNCH();

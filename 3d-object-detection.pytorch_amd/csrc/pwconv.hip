@@ -352,6 +352,10 @@ int dispatch(int dtype, GemmArgs& a, void* stream) {
     const int rc = stream_launch(a, st);
     if (rc != T3D_ERR_UNSUPPORTED) return rc;
   }
+  if (dtype == T3D_F16) {                    // inference forward in fp16 storage: the streaming kernel or nothing
+    if (const int rc = t3d_fold_fallback(a.p0, st)) return rc;
+    return stream_launch_f16(a, st);
+  }
   // the LDS-tiled kernel reads finished coefficients: a pending derive request for them becomes a launch of its own
   if (const int rc = t3d_fold_fallback(a.p0, st)) return rc;
   if (dtype == T3D_F32) return launch<float>(a, st);

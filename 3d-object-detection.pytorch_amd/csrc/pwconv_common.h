@@ -50,5 +50,7 @@ template <> __device__ __forceinline__ void stvec<bf16_t>(bf16_t* p, const float
 
 // bf16 streaming kernel (pwconv_stream.hip); returns T3D_ERR_UNSUPPORTED when the shape does not fit it
 int stream_launch(GemmArgs& a, hipStream_t st);
+// the same kernel in fp16 storage, inference forward only (pwconv_stream_f16.hip)
+int stream_launch_f16(GemmArgs& a, hipStream_t st);
 
 }  // namespace t3d_pw

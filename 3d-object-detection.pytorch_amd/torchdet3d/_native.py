@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # T3D_LIB: another build of the same library (A/B timing of one kernel file: tools/ab_lib.sh); the product loads the in-tree one
 LIB_PATH = os.environ.get('T3D_LIB') or os.path.join(os.path.dirname(_HERE), 'libt3d_hip.so')
 
-F32, BF16 = 0, 1
+F32, BF16, F16 = 0, 1, 2        # include/t3d.h: T3D_F32 / T3D_BF16 / T3D_F16 (fp16: inference forward only)
 ACT = {'none': 0, 'relu': 1, 'relu6': 2, 'hswish': 3}
 POOL = {'avg': 0, 'max': 1, 'avg+max': 2}
 _P, _I, _F, _D, _L = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_double, ctypes.c_longlong
@@ -148,6 +148,8 @@ def dtype_code(t):
         return F32
     if t.dtype == torch.bfloat16:
         return BF16
+    if t.dtype == torch.float16:
+        return F16
     raise RuntimeError(f'unsupported storage dtype {t.dtype}')
 
 

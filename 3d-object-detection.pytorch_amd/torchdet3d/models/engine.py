@@ -109,9 +109,11 @@ class Net:
         self.arch = Arch(name)
         self.name, self.num_classes = name, num_classes
         self.device = torch.device(device)
-        assert dtype in (torch.float32, torch.bfloat16)
+        # torch.float16: INFERENCE storage only (the forward kernels exist in fp16, csrc/pwconv_stream_f16.hip etc.; gradients
+        # keep bf16's range) -- three more mantissa bits than bf16 at every MFMA operand, same bytes
+        assert dtype in (torch.float32, torch.bfloat16, torch.float16)
         self.dtype = dtype
-        self.dt = N.F32 if dtype == torch.float32 else N.BF16
+        self.dt = {torch.float32: N.F32, torch.bfloat16: N.BF16, torch.float16: N.F16}[dtype]
         self.esz = 4 if dtype == torch.float32 else 2      # bytes per stored activation element
         self._share = share
         self._layout()
@@ -498,6 +500,8 @@ class Net:
         kp [B,9,2] fp32 in (0,1), logits [B,num_classes] fp32 (None when num_classes == 1).
         all_heads (export mode, model_builder.py:112-124): kp [9,B,9,2], every regressor on every sample."""
         a, st = self.arch, N.stream()
+        if train and self.dt == N.F16:
+            raise RuntimeError('fp16 storage is an inference-only mode (build the model with storage_dtype bf16 or f32 to train)')
         sv = self._features(imgs, train)
         B = sv['B']
         pooled, cur, yl, prol = sv['pooled'], sv['last_in'], sv['yl'], sv['prol']

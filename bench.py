@@ -120,7 +120,7 @@ def parse():
     ap.add_argument('--eval', action='store_true', help='time the validation step instead of the train step: `Evaluator.val_step` '
                     'of a model built by build_model (eval-mode forward on the engine `model.eval_storage_dtype` selects -- fp32 '
                     'storage by default, also for a bf16 model -- + ADD / SADD / accuracy / 3-D IoU per class)')
-    ap.add_argument('--eval-dtype', default='', choices=['', 'bf16', 'f32'], help="model.eval_storage_dtype for --eval; 'bf16' is "
+    ap.add_argument('--eval-dtype', default='', choices=['', 'bf16', 'f16', 'f32'], help="model.eval_storage_dtype for --eval; 'bf16' is "
                     'the OPT-IN throughput inference, outside the 1e-3 3-D-IoU bound for MobileNetV2 (labelled in the output)')
     ap.add_argument('--engine', action='store_true', help='drive models.engine.Net + the loss / optimizer kernels directly '
                     'instead of going through the reference-shaped API (build_model / build_optimizer / LossManager / '
@@ -351,7 +351,7 @@ def main():
 
     eval_dt = None
     if args.eval:
-        eval_dt = ('bf16' if model.net_eval.dtype == torch.bfloat16 else 'f32') if use_api else args.dtype
+        eval_dt = {torch.bfloat16: 'bf16', torch.float16: 'f16', torch.float32: 'f32'}[model.net_eval.dtype] if use_api else args.dtype
     if rank == 0:
         crops = B * world * args.steps / dt
         res = {

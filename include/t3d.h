@@ -26,7 +26,8 @@
 extern "C" {
 #endif
 
-enum { T3D_F32 = 0, T3D_BF16 = 1 };
+enum { T3D_F32 = 0, T3D_BF16 = 1, T3D_F16 = 2 };    /* T3D_F16: INFERENCE forward only (round 4): t3d_stem_im2col[_u8], t3d_pwconv_fwd,
+                                                         t3d_dwconv_fwd (k = 3), t3d_bn_apply, t3d_pool_fwd, t3d_pack_weight[s_batched] */
 enum { T3D_ACT_NONE = 0, T3D_ACT_RELU = 1, T3D_ACT_RELU6 = 2, T3D_ACT_HSWISH = 3 };
 enum { T3D_OK = 0, T3D_ERR_ARG = -1, T3D_ERR_LAUNCH = -2, T3D_ERR_UNSUPPORTED = -3 };
 

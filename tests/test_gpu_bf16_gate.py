@@ -152,6 +152,41 @@ def test_bf16_mnv2_b256_224_eval_metrics_vs_cpu_oracle():
     _iou_gate(ref_kp, kp.cpu(), 'oracle', kp32.cpu(), tol=5e-3)
 
 
+def test_fp16_inference_storage_of_the_headline_model_is_inside_the_iou_bound():
+    """MobileNetV2's bf16 INFERENCE misses the north-star's 3-D-IoU bound (2e-3 .. 4e-3
+    against 1e-3, the test above); fp16 activation storage -- the same bytes, three more mantissa bits at every MFMA operand
+    and stored layer -- is inside it at BASELINE config 2's shape, at every sigma, with ADD / SADD / accuracy as tight as
+    before.  `model.eval_storage_dtype = 'f16'` selects it (inference only; training stays bf16)."""
+    from oracle import model as OMod
+    from oracle.weights import make_inputs, make_state_dict
+    from torchdet3d.models.engine import Net
+    B, HW, nc = 256, 224, 9
+    imgs, gt_kp, cats = make_inputs(B, HW, HW, nc)
+    sd = make_state_dict('mobilenetv2', nc)
+    torch.set_num_threads(min(os.cpu_count() or 1, 32))
+    with torch.no_grad():
+        outs = [OMod.forward(sd, 'mobilenetv2', imgs[i:i + 64], cats[i:i + 64], train=False, num_classes=nc)
+                for i in range(0, B, 64)]
+    ref_kp, ref_lg = torch.cat([o[0] for o in outs]), torch.cat([o[1] for o in outs])
+    net = Net('mobilenetv2', nc, 'cuda', torch.float16)
+    net.load_state_dict(sd)
+    kp, lg = net.forward(imgs.cuda(), cats.cuda(), train=False)
+    kp, lg = kp.clone(), lg.clone()
+    with pytest.raises(RuntimeError, match='inference-only'):
+        net.forward(imgs.cuda()[:8], cats.cuda()[:8], train=True)
+    a, s, acc = _metrics(kp, gt_kp.cuda(), lg, cats.cuda())
+    ar, sr, accr = _metrics(ref_kp.cuda(), gt_kp.cuda(), ref_lg.cuda(), cats.cuda())
+    d = kp.cpu() - ref_kp
+    print(f'fp16 mnv2 b256@224: dADD {a - ar:+.2e} dSADD {s - sr:+.2e} acc {acc} (oracle {accr}) keypoint deviation rms '
+          f'{d.pow(2).mean().sqrt().item():.2e} max {d.abs().max().item():.2e}')
+    assert abs(a - ar) < TOL and abs(s - sr) < TOL and abs(acc - accr) <= 2.0 / B + 1e-9
+    for sigma in (0.003, 0.01, 0.024, 0.05):
+        gts = _gt_star(ref_kp.numpy(), sigma)
+        iou_ref, iou_16 = _iou(ref_kp, gts), _iou(kp.cpu(), gts)
+        print(f'   sigma {sigma}: IoU(oracle, gt*) {iou_ref:.5f}  IoU(fp16, gt*) {iou_16:.5f}  diff {iou_16 - iou_ref:+.2e}')
+        assert abs(iou_16 - iou_ref) < TOL, (sigma, iou_16, iou_ref)
+
+
 def test_bf16_training_mode_model_returns_fp32_inference_within_the_iou_bound():
     """The benchmarked configuration through the API: `build_model` with storage_dtype = 'bf16' trains in bf16 storage and
     answers eval-mode forwards from the fp32-storage engine over the same parameters (the default; 'bf16' inference is an
