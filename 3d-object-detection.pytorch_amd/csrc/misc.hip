@@ -16,19 +16,27 @@ __global__ void pack_kernel(const float* __restrict__ w, T* __restrict__ out, in
   }
 }
 
-// one launch for every weight matrix of the model: desc[t] = {src, out (or 0), out_t (or 0), rows, cols} as int64
+// one launch for every weight matrix of the model: desc[t] = {src, out (or 0), out_t (or 0), rows, cols, frag (or 0), frag_t (or 0)}
+// as int64.  frag / frag_t: fragment-order copies of the matrix / its transpose for the deep-contraction pointwise kernel
+// (t3d_pwconv_pack_frag in include/t3d.h has the layout; the zero padding is the caller's, the buffers are cleared once)
 template <typename T>
 __global__ void pack_batched_kernel(const long long* __restrict__ desc) {
-  const long long* d = desc + (size_t)blockIdx.x * 5;
+  const long long* d = desc + (size_t)blockIdx.x * 7;
   const float* __restrict__ w = reinterpret_cast<const float*>(d[0]);
   T* __restrict__ out = reinterpret_cast<T*>(d[1]);
   T* __restrict__ out_t = reinterpret_cast<T*>(d[2]);
   const int rows = (int)d[3], cols = (int)d[4];
+  T* __restrict__ frag = reinterpret_cast<T*>(d[5]);
+  T* __restrict__ frag_t = reinterpret_cast<T*>(d[6]);
+  const int KS = (cols + 31) / 32, KSt = (rows + 31) / 32;
   const size_t n = (size_t)rows * cols;
   for (size_t i = blockIdx.y * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.y * blockDim.x) {
     const T v = (T)w[i];
+    const int r = (int)(i / cols), c = (int)(i % cols);
     if (out) out[i] = v;
-    if (out_t) out_t[(i % cols) * rows + i / cols] = v;
+    if (out_t) out_t[(size_t)c * rows + r] = v;
+    if (frag) frag[((((size_t)(r >> 4) * KS + (c >> 5)) * 4 + ((c >> 3) & 3)) * 16 + (r & 15)) * 8 + (c & 7)] = v;
+    if (frag_t) frag_t[((((size_t)(c >> 4) * KSt + (r >> 5)) * 4 + ((r >> 3) & 3)) * 16 + (c & 15)) * 8 + (r & 7)] = v;
   }
 }
 

@@ -18,6 +18,7 @@
 //     sits in between).  Sums are reduced over the 16 pixels of a DPP row, parked in
 //     LDS across the block's persistent tile loop and leave as one fp64 atomic per
 //     channel per block.
+#include <cstdlib>
 #include <type_traits>
 #include "pwconv_common.h"
 
@@ -348,6 +349,9 @@ int launch(GemmArgs& a, hipStream_t st) {
 int dispatch(int dtype, GemmArgs& a, void* stream) {
   if (a.M <= 0 || a.Kin <= 0 || a.Nout <= 0 || (a.Kin % 8) || (a.Nout % 8) || a.HW <= 0) return T3D_ERR_ARG;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const bool wfrag = (dtype & T3D_W_FRAG) != 0;     // `w` is the fragment-order copy (include/t3d.h): the deep-contraction kernel only
+  dtype &= ~T3D_W_FRAG;
+  if (wfrag) return dtype == T3D_BF16 ? ((a.M > 0 && deep_shape(a.Kin, a.Nout)) ? deep_launch(a, st) : T3D_ERR_ARG) : T3D_ERR_ARG;
   if (dtype == T3D_BF16) {
     const int rc = stream_launch(a, st);
     if (rc != T3D_ERR_UNSUPPORTED) return rc;

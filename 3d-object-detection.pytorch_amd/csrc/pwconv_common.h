@@ -50,6 +50,10 @@ template <> __device__ __forceinline__ void stvec<bf16_t>(bf16_t* p, const float
 
 // bf16 streaming kernel (pwconv_stream.hip); returns T3D_ERR_UNSUPPORTED when the shape does not fit it
 int stream_launch(GemmArgs& a, hipStream_t st);
+// bf16 kernel for deep contractions with wide outputs (pwconv_deep.hip: operand staged once, fragment-order weights streamed
+// from L2); returns T3D_ERR_UNSUPPORTED for every other shape.  deep_shape: the shapes it takes (t3d_pwconv_wants_frag)
+int deep_launch(GemmArgs& a, hipStream_t st);
+bool deep_shape(int Kin, int Nout);
 // the same kernel in fp16 storage, inference forward only (pwconv_stream_f16.hip)
 int stream_launch_f16(GemmArgs& a, hipStream_t st);
 

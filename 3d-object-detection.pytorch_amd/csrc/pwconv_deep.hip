@@ -1,0 +1,390 @@
+// Pointwise (1x1) convolution forward / data-gradient for DEEP contractions (K >= 512 with an output wider than the streaming
+// kernel's LDS weight chunk), bf16 storage, weights in FRAGMENT ORDER (t3d_pwconv_pack_frag, T3D_W_FRAG), gfx950.
+//
+//   out[m][n] = epilogue( sum_k  pro(A)[m][k] * W[n][k] )
+//
+// pwconv_stream.hip keeps a weight chunk W[n0 : n0+16 NT][all K] in LDS and streams the activations past it.  At K = 960 /
+// 1280 (the 7x7 stage: projection forward, expansion data gradient, the last conv's data gradient) 120 KB of LDS hold only
+// 64 / 32 output channels, so the launch splits into 3 - 10 output chunks and every chunk reads AND TRANSFORMS the whole
+// operand again (BatchNorm affine + activation, or the two-tensor BatchNorm-backward affine): 320 <- 1280 at 7x7 ran 126 us
+// for 10 GFLOP.  Here the roles are swapped:
+//   * a workgroup (4 waves, ONE per SIMD: the whole 512-register budget each) owns 64 pixels and all output channels of its
+//     chunk (<= 192); the operand is read and transformed ONCE, in phases of 8 k-steps, into a double-buffered LDS tile in
+//     MFMA-fragment order ([row tile][k-step][lane] x 16 B: linear, conflict-free writes and reads);
+//   * the WEIGHTS are streamed from L2 straight into registers, a whole phase ahead.  They have to be in fragment order in
+//     memory ([16-channel tile][k-step][lane] x 16 B, zero padded): a wave's fragment is then 1 KB contiguous.  Loading
+//     fragments out of the row-major matrix (16 rows x 64 B per instruction, one 16-B request per lane) ran at ~20 KB/us per
+//     CU -- the same rate the streaming kernel's weight staging shows -- and WAS the kernel (k-loop 22 us of 36);
+//   * loads return IN ORDER per wave (vmcnt), so a weight fragment (L2 hit) issued behind an operand row (HBM) is not usable
+//     before that row has arrived.  Issue order per phase p: the weights of the WHOLE phase p + 1, then the operand rows of
+//     phase p + 2 -- a multiply never waits on anything younger than its own weights, and both kinds of loads have a full
+//     phase / two phases (64 - 128 KB per workgroup in flight) to arrive;
+//   * everything inside the phase loop is branch-free (k-steps / tiles past the end are zero fragments or repeats against
+//     clamped loads), so the compiler counts vmcnt down instead of draining it at control-flow joins;
+//   * epilogue and statistics as in the streaming kernel (a lane holds 4 consecutive channels of one pixel per tile; sums per
+//     lane in registers, one owner per channel in the block, one fp64 atomic per channel per block).
+// No squeeze-excite / per-sample coefficients, no bias, no materialising operand: those shapes stay with the streaming kernel.
+#include <cstdlib>
+#include <type_traits>
+#include "pwconv_common.h"
+
+namespace t3d_pw {
+namespace {
+
+__device__ __forceinline__ f32x2 deep_fma_clamp01(f32x2 a, f32x2 b, f32x2 c) {
+  f32x2 d;
+  asm("v_pk_fma_f32 %0, %1, %2, %3 clamp" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+  return d;
+}
+
+#ifdef T3D_PW_TRACE
+// debug build only (tools/pw_trace.sh): wall-clock stamps (10 ns units) of the first and the last block's wave 0
+__device__ unsigned long long g_deep_trace[16];
+#define DEEP_STAMP(i)                                                                                     \
+  do {                                                                                                    \
+    if (threadIdx.x == 0 && blockIdx.y == 0 && (blockIdx.x == 0 || blockIdx.x == gridDim.x - 1))         \
+      g_deep_trace[(blockIdx.x == 0 ? 0 : 8) + (i)] = wall_clock64();                                     \
+  } while (0)
+#else
+#define DEEP_STAMP(i)
+#endif
+
+constexpr int RT = 4;        // row tiles (16 pixels) per block
+constexpr int KSP = 8;       // k-steps per phase (one LDS buffer = RT * KSP KB)
+constexpr int NW = 4;        // waves per block
+constexpr int NTW = 3;       // 16-channel tiles per wave: tiles wave, wave + 4, wave + 8 of the chunk (<= 12 tiles = 192 channels)
+constexpr int IT = RT * KSP / NW;   // staging items (16 rows x 32 k) per wave per phase: row tile `wave`, every k-step
+
+template <bool DG>
+__global__ __launch_bounds__(64 * NW, 1) void pw_deep_kernel(const GemmArgs a, const int KS, const int ntiles, const int nrep,
+                                                             const long long rstride) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  bf16x8* Af = reinterpret_cast<bf16x8*>(smem);                                   // [2][RT][KSP][64]
+  const int kpad = KS * 32;
+  float* coef = reinterpret_cast<float*>(smem + (size_t)2 * RT * KSP * 1024);     // [3][kpad]
+  const int BN = ntiles * 16;
+  float* ecoef = coef + 3 * kpad;                                                 // [2][BN]
+  double* dstat = reinterpret_cast<double*>(ecoef + 2 * BN);                      // [BN][2]
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lg = lane >> 4, lc = lane & 15;
+  const int m0 = blockIdx.x * (16 * RT), n0 = blockIdx.y * BN;
+  const bf16_t* __restrict__ A0 = reinterpret_cast<const bf16_t*>(a.a0);
+  const bf16_t* __restrict__ A1 = reinterpret_cast<const bf16_t*>(a.a1);
+  bf16_t* __restrict__ out = reinterpret_cast<bf16_t*>(a.out);
+  const int nph = (KS + KSP - 1) / KSP;
+  DEEP_STAMP(0);
+
+  // the wave's tiles; a slot past the chunk's (or the layer's) last tile repeats it (same instructions in every wave, the
+  // repeats' results are dropped)
+  int tix[NTW];
+  bool tok[NTW];
+  const int tlast = min(ntiles, (a.Nout - n0 + 15) / 16) - 1;
+  const bf16x8* wt_[NTW];        // fragment-order weights of the tile: [k-step][lane]
+#pragma unroll
+  for (int i = 0; i < NTW; ++i) {
+    const int t = wave + NW * i;
+    tok[i] = t <= tlast;
+    tix[i] = min(t, tlast);
+    wt_[i] = reinterpret_cast<const bf16x8*>(a.w) + ((size_t)(n0 / 16 + tix[i]) * KS) * 64 + lane;
+  }
+  bf16x8 wf[2][KSP][NTW];
+  auto w_issue = [&](auto slot_tag, const int ph) {        // weight fragments of phase ph
+    constexpr int SL = decltype(slot_tag)::value;
+#pragma unroll
+    for (int u = 0; u < KSP; ++u) {
+      const int ks = min(ph * KSP + u, KS - 1);
+#pragma unroll
+      for (int t = 0; t < NTW; ++t) wf[SL][u][t] = wt_[t][(size_t)ks * 64];
+    }
+  };
+  // operand rows of this wave's staging items
+  const size_t arow = (size_t)min(m0 + wave * 16 + lc, a.M - 1) * a.Kin + lg * 8;
+  const bool rok = m0 + wave * 16 + lc < a.M;
+  bf16x8 pa[2][IT], pb[DG ? 2 : 1][DG ? IT : 1];
+  auto a_issue = [&](auto slot_tag, const int ph) {
+    constexpr int SL = decltype(slot_tag)::value;
+#pragma unroll
+    for (int j = 0; j < IT; ++j) {
+      const int k = min((ph * KSP + j) * 32, a.Kin - 8 - lg * 8);
+      pa[SL][j] = *reinterpret_cast<const bf16x8*>(A0 + arow + k);
+      if (DG) pb[DG ? SL : 0][DG ? j : 0] = *reinterpret_cast<const bf16x8*>(A1 + arow + k);
+    }
+  };
+  w_issue(std::integral_constant<int, 0>{}, 0);
+  a_issue(std::integral_constant<int, 0>{}, 0);
+  a_issue(std::integral_constant<int, 1>{}, 1);
+
+  // ---- coefficients of the operand transform (derived from the replica sums when a finalize request rides on this launch)
+  for (int i = tid; i < BN * 2; i += 64 * NW) dstat[i] = 0.0;
+  for (int i = tid; i < BN; i += 64 * NW) {
+    const int n = n0 + i;
+    const bool v = DG && a.e_scale && n < a.Nout;
+    ecoef[i] = v ? a.e_scale[n] : 1.f;
+    ecoef[BN + i] = v ? a.e_shift[n] : 0.f;
+  }
+  if (a.fold) {
+    for (int i = a.Kin + tid; i < kpad; i += 64 * NW) {
+      coef[i] = DG ? 0.f : 1.f; coef[kpad + i] = 0.f; coef[2 * kpad + i] = 0.f;
+    }
+    t3d_fold_block(a.fold, 0, a.Kin, coef, kpad, blockIdx.x == 0 && blockIdx.y == 0);
+  } else {
+    for (int i = tid; i < kpad; i += 64 * NW) {
+      const bool v = i < a.Kin;
+      if (!DG) {
+        coef[i] = (v && a.p0) ? a.p0[i] : 1.f;
+        coef[kpad + i] = (v && a.p0) ? a.p1[i] : 0.f;
+      } else {
+        coef[i] = v ? a.p0[i] : 0.f;
+        coef[kpad + i] = v ? a.p1[i] : 0.f;
+        coef[2 * kpad + i] = v ? a.p2[i] : 0.f;
+      }
+    }
+    __syncthreads();
+  }
+  // forward, BatchNorm + ReLU6 prologue: relu6(s x + t) = 6 clamp01((s/6) x + t/6) (pwconv_stream.hip), the 6 in the epilogue
+  const bool c6f = !DG && a.p0 && a.act == T3D_ACT_RELU6;
+  if (c6f) {
+    for (int i = tid; i < 2 * kpad; i += 64 * NW) coef[i] *= T3D_SIXTH;
+    __syncthreads();
+  }
+  const int fact = c6f ? -1 : a.act;      // forward transform: -1 = clamp form
+  DEEP_STAMP(1);
+
+  f32x4 acc[RT][NTW];
+#pragma unroll
+  for (int r = 0; r < RT; ++r)
+#pragma unroll
+    for (int t = 0; t < NTW; ++t) acc[r][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // one phase; SL = ph & 1 selects the LDS buffer, the weight slot in use and the operand-row slot
+  auto phase = [&](auto slot_tag, const int ph) {
+    constexpr int SL = decltype(slot_tag)::value;
+    bf16x8* Ab = Af + (size_t)SL * RT * KSP * 64;
+    // ---- transform + store this phase's operand rows (issued two phases ago)
+#pragma unroll
+    for (int j = 0; j < IT; ++j) {
+      const int k = (ph * KSP + j) * 32 + lg * 8;
+      const bool ok = rok && (k < a.Kin);
+      const int kc = min(k, kpad - 8);
+      const float4 c0a = *reinterpret_cast<const float4*>(coef + kc), c0b = *reinterpret_cast<const float4*>(coef + kc + 4);
+      const float4 c1a = *reinterpret_cast<const float4*>(coef + kpad + kc),
+                   c1b = *reinterpret_cast<const float4*>(coef + kpad + kc + 4);
+      const float c0[8] = {c0a.x, c0a.y, c0a.z, c0a.w, c0b.x, c0b.y, c0b.z, c0b.w};
+      const float c1[8] = {c1a.x, c1a.y, c1a.z, c1a.w, c1b.x, c1b.y, c1b.z, c1b.w};
+      float x[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) x[e] = (float)pa[SL][j][e];
+      if (!DG) {
+        if (fact == -1) {
+#pragma unroll
+          for (int e = 0; e < 8; e += 2) {
+            const f32x2 t = deep_fma_clamp01(f32x2{x[e], x[e + 1]}, f32x2{c0[e], c0[e + 1]}, f32x2{c1[e], c1[e + 1]});
+            x[e] = t[0];
+            x[e + 1] = t[1];
+          }
+        } else {
+          act_affine_vec<8>(x, c0, c1, fact);      // (no prologue: scale 1, shift 0, no activation)
+        }
+      } else {
+        const float4 c2a = *reinterpret_cast<const float4*>(coef + 2 * kpad + kc),
+                     c2b = *reinterpret_cast<const float4*>(coef + 2 * kpad + kc + 4);
+        const float c2[8] = {c2a.x, c2a.y, c2a.z, c2a.w, c2b.x, c2b.y, c2b.z, c2b.w};
+#pragma unroll
+        for (int e = 0; e < 8; ++e) x[e] = c0[e] * x[e] + c1[e] * (float)pb[DG ? SL : 0][DG ? j : 0][e] + c2[e];
+      }
+      bf16x8 b;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) b[e] = ok ? (bf16_t)x[e] : (bf16_t)0.f;
+      Ab[(wave * KSP + j) * 64 + lane] = b;
+    }
+    __syncthreads();
+    if (ph == 0) DEEP_STAMP(2);
+    // (sched_barrier: the machine scheduler otherwise sinks the prefetch loads down between the MFMAs, to where their
+    //  registers are free)
+    __builtin_amdgcn_sched_barrier(0);
+    w_issue(std::integral_constant<int, 1 - SL>{}, ph + 1);       // (past the last phase: clamped re-reads, never used)
+    a_issue(std::integral_constant<int, SL>{}, ph + 2);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int u = 0; u < KSP; ++u) {
+      bf16x8 b[RT];
+#pragma unroll
+      for (int r = 0; r < RT; ++r) b[r] = Ab[(r * KSP + u) * 64 + lane];
+#pragma unroll
+      for (int t = 0; t < NTW; ++t)
+#pragma unroll
+        for (int r = 0; r < RT; ++r) acc[r][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[SL][u][t], b[r], acc[r][t], 0, 0, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  for (int ph = 0; ph < nph; ph += 2) {
+    phase(std::integral_constant<int, 0>{}, ph);
+    if (ph + 1 < nph) phase(std::integral_constant<int, 1>{}, ph + 1);
+  }
+
+  DEEP_STAMP(3);
+  // ---------------- epilogue: lane holds channels n0 + 16 T + 4 lg .. +3 of pixel m0 + 16 r + lc ----------
+  const bool keep_stats = a.stats != nullptr;
+  float st1[NTW][4], st2[NTW][4];
+#pragma unroll
+  for (int i = 0; i < NTW; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) st1[i][j] = st2[i][j] = 0.f;
+  // all epilogue loads first (the data gradient's activation input and skip gradient: RT x NTW 8-byte loads each)
+  bf16x4 eyr[DG ? RT : 1][NTW], err[DG ? RT : 1][NTW];
+  if (DG) {
+#pragma unroll
+    for (int r = 0; r < RT; ++r) {
+      const size_t mo = (size_t)min(m0 + r * 16 + lc, a.M - 1) * a.Nout;
+#pragma unroll
+      for (int i = 0; i < NTW; ++i) {
+        const int n = min(n0 + tix[i] * 16 + lg * 4, a.Nout - 4);
+        if (a.e_y) eyr[DG ? r : 0][i] = *reinterpret_cast<const bf16x4*>(reinterpret_cast<const bf16_t*>(a.e_y) + mo + n);
+        if (a.e_res) err[DG ? r : 0][i] = *reinterpret_cast<const bf16x4*>(reinterpret_cast<const bf16_t*>(a.e_res) + mo + n);
+      }
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < RT; ++r) {
+    const int m = m0 + r * 16 + lc;
+    const bool ok = m < a.M;
+#pragma unroll
+    for (int i = 0; i < NTW; ++i) {
+      const int nl = tix[i] * 16 + lg * 4, n = n0 + nl;
+      if (!tok[i] || n >= a.Nout) continue;     // (whole 4-channel groups are in or out: Nout % 8 == 0)
+      float v[4], yv[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) v[j] = acc[r][i][j];
+      if (c6f) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] *= 6.f;
+      }
+      if (DG && a.e_y) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) yv[j] = (float)eyr[DG ? r : 0][i][j];
+        if (a.e_act != T3D_ACT_NONE) {
+          const float4 s0 = *reinterpret_cast<const float4*>(ecoef + nl), h0 = *reinterpret_cast<const float4*>(ecoef + BN + nl);
+          const float es[4] = {s0.x, s0.y, s0.z, s0.w}, eh[4] = {h0.x, h0.y, h0.z, h0.w};
+          act_grad_affine_vec<4>(v, yv, es, eh, a.e_act);
+        }
+      }
+      if (DG && a.e_res) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] += (float)err[DG ? r : 0][i][j];
+      }
+      bf16x4 o;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        o[j] = (bf16_t)v[j];
+        v[j] = ok ? (float)o[j] : 0.f;
+      }
+      if (ok) *reinterpret_cast<bf16x4*>(out + (size_t)m * a.Nout + n) = o;
+      if (keep_stats) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          st1[i][j] += v[j];
+          st2[i][j] = fmaf(v[j], (DG && a.e_y) ? yv[j] : v[j], st2[i][j]);
+        }
+      }
+    }
+  }
+  DEEP_STAMP(4);
+  if (keep_stats) {
+#pragma unroll
+    for (int i = 0; i < NTW; ++i) {
+      const int nl = tix[i] * 16 + lg * 4;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float s1 = row16_sum(st1[i][j]), s2 = row16_sum(st2[i][j]);
+        if (lc == 0 && tok[i] && n0 + nl < a.Nout) {
+          dstat[(nl + j) * 2] = t3d_snap(s1, a.quant, false);           // one owner per channel in the block: plain stores
+          dstat[(nl + j) * 2 + 1] = t3d_snap(s2, a.quant, !DG);
+        }
+      }
+    }
+    __syncthreads();
+    for (int i = tid; i < BN * 2; i += 64 * NW) {
+      const int n = n0 + (i >> 1);
+      if (n < a.Nout) atomicAdd(a.stats + (size_t)(blockIdx.x % nrep) * rstride + (size_t)(i & 1) * a.Nout + n, dstat[i]);
+    }
+  }
+  DEEP_STAMP(5);
+}
+
+template <bool DG>
+int launch_deep(GemmArgs& a, int KS, int ntiles, int nchunks, hipStream_t st) {
+  const size_t lds = (size_t)2 * RT * KSP * 1024 + (size_t)3 * KS * 32 * 4 + (size_t)ntiles * 16 * (2 * 4 + 2 * 8);
+  if (lds > 150 * 1024) return T3D_ERR_UNSUPPORTED;
+  const void* fn = (const void*)pw_deep_kernel<DG>;
+  if (lds > 64 * 1024) (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  a.quant = (!DG && a.stats && !getenv("T3D_NO_SNAP")) ? t3d_quant_for(a.M) : T3dQuant{0.0, 0.0};
+  a.fold = t3d_take_fold(a.p0);
+  hipLaunchKernelGGL((pw_deep_kernel<DG>), dim3(cdiv(a.M, 16 * RT), nchunks), dim3(64 * NW), lds, st, a, KS, ntiles,
+                     g_t3d_reduce.nrep, g_t3d_reduce.stats_stride);
+  T3D_CHECK_LAUNCH();
+  return T3D_OK;
+}
+
+// fragment order: out[((T * KS + ks) * 64 + lg * 16 + lc) * 8 + j] = w[T * 16 + lc][ks * 32 + lg * 8 + j], zero past rows / cols
+__global__ void pack_frag_kernel(const bf16_t* __restrict__ w, bf16_t* __restrict__ out, int rows, int cols, int KS, size_t total) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int j = i & 7, lc = (i >> 3) & 15, lg = (i >> 7) & 3;
+    const size_t tk = i >> 9;
+    const int ks = (int)(tk % KS), T = (int)(tk / KS);
+    const int n = T * 16 + lc, k = ks * 32 + lg * 8 + j;
+    out[i] = (n < rows && k < cols) ? w[(size_t)n * cols + k] : (bf16_t)0.f;
+  }
+}
+
+}  // namespace
+
+#ifdef T3D_PW_TRACE
+extern "C" int t3d_debug_deep_trace(unsigned long long* out) {
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_deep_trace), sizeof(unsigned long long) * 16) == hipSuccess ? 0 : -1;
+}
+#endif
+
+// is (contraction Kin -> Nout) a shape for this kernel?  Only where the streaming kernel needs more than one output chunk
+// (its chunk: <= 120 KB of weights, <= 10 tiles)
+bool deep_shape(int Kin, int Nout) {
+  if (Kin < 512 || (Kin % 8) || (Nout % 8)) return false;
+  const int KS = cdiv(Kin, 32);
+  int nt_cap = 120 / KS;
+  if (nt_cap > 10) nt_cap = 10;
+  nt_cap &= ~1;
+  return !(nt_cap >= 2 && Nout <= nt_cap * 16);
+}
+
+// bf16, a.w in fragment order; T3D_ERR_UNSUPPORTED = "not a launch for this kernel"
+int deep_launch(GemmArgs& a, hipStream_t st) {
+  if (a.a2 || a.z_out || a.per_sample || a.ps_stats || a.e_se || a.bias || (!a.dgrad && a.p2)) return T3D_ERR_UNSUPPORTED;
+  if (a.row0 && a.row0 != a.Kin) return T3D_ERR_UNSUPPORTED;
+  if (a.dgrad && (!a.a1 || !a.p0 || !a.p1 || !a.p2)) return T3D_ERR_UNSUPPORTED;
+  if (!deep_shape(a.Kin, a.Nout)) return T3D_ERR_UNSUPPORTED;
+  const int KS = cdiv(a.Kin, 32);
+  const int tiles = cdiv(a.Nout, 16);
+  // chunks of <= 12 tiles (192 channels), evenly sized; every chunk stages the operand again (from L2)
+  const int nchunks = cdiv(tiles, NW * NTW), ntiles = cdiv(tiles, nchunks);
+  return a.dgrad ? launch_deep<true>(a, KS, ntiles, nchunks, st) : launch_deep<false>(a, KS, ntiles, nchunks, st);
+}
+
+}  // namespace t3d_pw
+
+// include/t3d.h
+extern "C" int t3d_pwconv_frag_bytes(int rows, int cols) {
+  if (rows <= 0 || cols <= 0) return 0;
+  return cdiv(rows, 16) * cdiv(cols, 32) * 1024;
+}
+
+extern "C" int t3d_pwconv_wants_frag(int K, int N) { return t3d_pw::deep_shape(K, N) ? 1 : 0; }
+
+extern "C" int t3d_pwconv_pack_frag(const void* w, void* out, int rows, int cols, void* stream) {
+  if (!w || !out || rows <= 0 || cols <= 0) return T3D_ERR_ARG;
+  const size_t total = (size_t)t3d_pwconv_frag_bytes(rows, cols) / 2;
+  hipLaunchKernelGGL(t3d_pw::pack_frag_kernel, dim3((unsigned)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048)), dim3(256), 0,
+                     reinterpret_cast<hipStream_t>(stream), reinterpret_cast<const bf16_t*>(w), reinterpret_cast<bf16_t*>(out), rows,
+                     cols, cdiv(cols, 32), total);
+  T3D_CHECK_LAUNCH();
+  return T3D_OK;
+}

@@ -605,7 +605,7 @@ int launch_nt(GemmArgs& a, int KS, hipStream_t st, int deep_ku = 0) {
 
 }  // namespace
 
-#ifdef T3D_PW_TRACE
+#if defined(T3D_PW_TRACE) && !defined(T3D_PW_F16)
 extern "C" int t3d_debug_pw_trace(unsigned long long* out) {
   return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_pw_trace), sizeof(unsigned long long) * 16) == hipSuccess ? 0 : -1;
 }

@@ -12,6 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # T3D_LIB: another build of the same library (A/B timing of one kernel file: tools/ab_lib.sh); the product loads the in-tree one
 LIB_PATH = os.environ.get('T3D_LIB') or os.path.join(os.path.dirname(_HERE), 'libt3d_hip.so')
 
+W_FRAG = 0x100                  # include/t3d.h: T3D_W_FRAG (weights in fragment order, bf16 pointwise convs)
 F32, BF16, F16 = 0, 1, 2        # include/t3d.h: T3D_F32 / T3D_BF16 / T3D_F16 (fp16: inference forward only)
 ACT = {'none': 0, 'relu': 1, 'relu6': 2, 'hswish': 3}
 POOL = {'avg': 0, 'max': 1, 'avg+max': 2}
@@ -106,6 +107,9 @@ SIGNATURES = {
     't3d_fold_request': [_P, _P],
     't3d_fold_pending': [],
     't3d_pack_weights_batched': [_I, _P, _I, _P],
+    't3d_pwconv_pack_frag': [_P, _P, _I, _I, _P],
+    't3d_pwconv_frag_bytes': [_I, _I],
+    't3d_pwconv_wants_frag': [_I, _I],
     't3d_iou3d': [_P, _P, _I, _I, _P, _P, _P, _P, _P],
     't3d_box_iou3d': [_P, _I, _P, _P, _P],
     't3d_adamw_step': [_P, _P, _P, _P, _L, _D, _D, _D, _D, _D, _L, _D, _P],

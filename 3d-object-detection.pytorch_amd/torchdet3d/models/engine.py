@@ -33,6 +33,7 @@ BN_EPS, BN_MOM = 1e-5, 0.1      # PyTorch defaults the reference relies on (SURV
 NREP = 16                       # reduction replicas (include/t3d.h: t3d_set_reduction_replicas)
 FUSED_EVAL_MIN_B = int(os.environ.get('T3D_FUSED_EVAL_MIN_B', '96'))
 DW_SLOTS = int(os.environ.get('T3D_DW_SLOTS', '512'))   # depthwise weight-gradient slots per layer (>= the workgroups of a t3d_dwconv_bwd launch)
+PW_DEEP = os.environ.get('T3D_PW_DEEP', '1') != '0'      # deep-contraction pointwise kernel + fragment-order weights (A/B switch)
 WORKSPACE_BYTES = 64 << 20      # partial weight-gradient tiles (include/t3d.h: t3d_set_workspace)
 MAIN_WORKSPACE_BYTES = 16 << 20
 # y-free expand-layer backward (csrc/pwconv_yfree.hip): minimum M*N elements of the expanded tensor; 0 disables
@@ -293,6 +294,10 @@ class Net:
         if getattr(self, '_pack_desc', None) is None:
             # one descriptor table for every 1x1 weight: a single launch re-packs them all each step
             self.w, self.wt, rows = {}, {}, []
+            # fragment-order copies for the deep-contraction kernel (csrc/pwconv_deep.hip), keyed by the plain copy's address:
+            # forward of a layer whose (K, N) the kernel takes, data gradient of one whose (N, K) it takes
+            self._frag = {}
+            lib = N.lib()
             for k, (s, kind) in self.shapes.items():
                 if kind != 'param' or len(s) != 4 or s[2] != 1:
                     continue
@@ -304,7 +309,15 @@ class Net:
                     self.w[k] = self._buf('w:' + k, (n, kk))
                     out = self.w[k].data_ptr()
                 self.wt[k] = self._buf('wt:' + k, (kk, n))
-                rows.append([src.data_ptr(), out, self.wt[k].data_ptr(), n, kk])
+                fr = frt = 0
+                if self.dt == N.BF16 and PW_DEEP:
+                    if lib.t3d_pwconv_wants_frag(kk, n):
+                        f = self._buf('wf:' + k, (lib.t3d_pwconv_frag_bytes(n, kk) // 2,), zero=True)
+                        self._frag[self.w[k].data_ptr()], fr = f, f.data_ptr()
+                    if lib.t3d_pwconv_wants_frag(n, kk):
+                        f = self._buf('wtf:' + k, (lib.t3d_pwconv_frag_bytes(kk, n) // 2,), zero=True)
+                        self._frag[self.wt[k].data_ptr()], frt = f, f.data_ptr()
+                rows.append([src.data_ptr(), out, self.wt[k].data_ptr(), n, kk, fr, frt])
             self._pack_desc = torch.tensor(rows, dtype=torch.int64, device=self.device)
         N.call('t3d_pack_weights_batched', self.dt, N.ptr(self._pack_desc), self._pack_desc.shape[0], st)
         # squeeze-excite FCs (nn.Linear, fp32): transposed copies for the one-launch forward (t3d_se_fwd_fused)
@@ -313,7 +326,7 @@ class Net:
             for k, (s, kind) in self.shapes.items():
                 if kind == 'param' and len(s) == 2 and ('.fc.0.weight' in k or '.fc.2.weight' in k):
                     self.wt[k] = self._buf('wt:' + k, (s[1], s[0]), torch.float32)
-                    rows.append([self.p[k].data_ptr(), 0, self.wt[k].data_ptr(), s[0], s[1]])
+                    rows.append([self.p[k].data_ptr(), 0, self.wt[k].data_ptr(), s[0], s[1], 0, 0])
             self._se_pack_desc = torch.tensor(rows, dtype=torch.int64, device=self.device) if rows else False
         if self._se_pack_desc is not False:
             N.call('t3d_pack_weights_batched', N.F32, N.ptr(self._se_pack_desc), self._se_pack_desc.shape[0], st)
@@ -647,6 +660,12 @@ class Net:
         sv.update(last_in=cur, yl=yl, prol=prol, pooled=pooled, HWl=cur.H * cur.W, bnl=bnl)
         return sv
 
+    def _wsel(self, w, plain=True):
+        """(dtype argument, weight pointer) of a pointwise launch: the fragment-order copy where the layer has one and the launch
+        is one the deep-contraction kernel takes (`plain`: no squeeze-excite gates / per-sample coefficients)."""
+        f = self._frag.get(w.data_ptr()) if plain and self.dt == N.BF16 else None
+        return (self.dt | N.W_FRAG, N.ptr(f)) if f is not None else (self.dt, N.ptr(w))
+
     def _resolve(self, src):
         """Materialise a pending block output (z = BN(y3) + skip) as a launch of its own -- for the consumers that are not
         a 1x1 conv (a 1x1 conv forms z while it loads its operand: `_pw_from`)."""
@@ -665,7 +684,8 @@ class Net:
                     self._st(bn_out), M, HW, K, Nn, st, nbytes=nb, fwd=x.bn)
             x.t, x.pro, x.zres, x.zbuf = x.zbuf, None, None, None
         else:
-            self._c('t3d_pwconv_fwd', self.dt, N.ptr(x.t), x.pro, N.ptr(w), None, N.ptr(y), self._st(bn_out), M, HW, K, Nn,
+            wd, wp = self._wsel(w, x.pro is None or not x.pro.se)
+            self._c('t3d_pwconv_fwd', wd, N.ptr(x.t), x.pro, wp, None, N.ptr(y), self._st(bn_out), M, HW, K, Nn,
                     st, nbytes=nb, fwd=x.bn if x.pro is not None else None)
 
     def _finish(self, src, tag):
@@ -776,7 +796,8 @@ class Net:
         # linear 1x1 projection (mobilenetv3.py:142-143,158-159)
         bn3 = self.bns[bn3n]
         y3 = self._buf(f'y3:{i}', (M2, blk.cout))
-        self._c('t3d_pwconv_fwd', dt, N.ptr(y2), pro2, N.ptr(self.w[pwn]), None, N.ptr(y3), self._st(bn3),
+        wd, wp = self._wsel(self.w[pwn], not pro2.se)
+        self._c('t3d_pwconv_fwd', wd, N.ptr(y2), pro2, wp, None, N.ptr(y3), self._st(bn3),
                 M2, Ho * Wo, blk.cexp, blk.cout, st, nbytes=M2 * (blk.cexp + blk.cout) * self.esz, fwd=bn2)
         pro3 = self._bn_fwd(bn3, M2, 'none')
         z = self._buf(f'z:{i}', (M2, blk.cout))
@@ -955,7 +976,8 @@ class Net:
         of x's producer, with that BatchNorm's backward sums accumulated."""
         dx = self._buf(tag, (M, K))
         with_stats = x.bn is not None and not x.finished_act
-        self._c('t3d_pwconv_dgrad', self.dt, N.ptr(dz), N.ptr(y), bb, N.ptr(wt),
+        wd, wp = self._wsel(wt, not bb.per_sample and not (with_stats and x.gpro is not None and x.gpro.se))
+        self._c('t3d_pwconv_dgrad', wd, N.ptr(dz), N.ptr(y), bb, wp,
                 N.ptr(x.raw) if with_stats else None, x.gpro if with_stats else None,
                 N.ptr(residual) if residual is not None else None, N.ptr(dx),
                 self._bst(x.bn) if with_stats else None, None, M, HW, K, Nn, N.stream(),

@@ -32,12 +32,26 @@ class ResNetEngine(Net):
                     w32 = self._buf('wc32:' + k, (n, kp), torch.float32)
                     self.w[k] = w32 if self.dt == N.F32 else self._buf('wc:' + k, (n, kp))
                     self.wt[k] = self._buf('wct:' + k, (kp, n))
-                    self._conv_pack.append((k, n, c, kk, kp, w32))
-        for k, n, c, kk, kp, w32 in self._conv_pack:
+                    # fragment-order copies for the deep-contraction kernel (engine.py: `_frag`, `_wsel`)
+                    fr = frt = None
+                    if self.dt == N.BF16 and hasattr(self, '_frag'):
+                        lib = N.lib()
+                        if lib.t3d_pwconv_wants_frag(kp, n):
+                            fr = self._buf('wcf:' + k, (lib.t3d_pwconv_frag_bytes(n, kp) // 2,), zero=True)
+                            self._frag[self.w[k].data_ptr()] = fr
+                        if lib.t3d_pwconv_wants_frag(n, kp):
+                            frt = self._buf('wctf:' + k, (lib.t3d_pwconv_frag_bytes(kp, n) // 2,), zero=True)
+                            self._frag[self.wt[k].data_ptr()] = frt
+                    self._conv_pack.append((k, n, c, kk, kp, w32, fr, frt))
+        for k, n, c, kk, kp, w32, fr, frt in self._conv_pack:
             N.call('t3d_pack_conv_weight', N.F32, N.ptr(self.p[k]), N.ptr(w32), n, c, kk, kp, st)
             if self.dt != N.F32:
                 N.call('t3d_pack_weight', self.dt, N.ptr(w32), N.ptr(self.w[k]), n, kp, 0, st)
             N.call('t3d_pack_weight', self.dt, N.ptr(w32), N.ptr(self.wt[k]), n, kp, 1, st)
+            if fr is not None:
+                N.call('t3d_pwconv_pack_frag', N.ptr(self.w[k]), N.ptr(fr), n, kp, st)
+            if frt is not None:
+                N.call('t3d_pwconv_pack_frag', N.ptr(self.wt[k]), N.ptr(frt), kp, n, st)
 
     def _kp(self, key):
         return self.w[key].shape[1]
@@ -55,7 +69,8 @@ class ResNetEngine(Net):
         return bb
 
     def _pw(self, x, pro, w, y, bn, M, HW, K, Nn):
-        N.call('t3d_pwconv_fwd', self.dt, N.ptr(x), pro, N.ptr(w), None, N.ptr(y), self._st(bn), M, HW, K, Nn, N.stream(),
+        wd, wp = self._wsel(w, pro is None or not pro.se)
+        N.call('t3d_pwconv_fwd', wd, N.ptr(x), pro, wp, None, N.ptr(y), self._st(bn), M, HW, K, Nn, N.stream(),
                nbytes=M * (K + Nn) * self.esz)
 
     # ------------------------------------------------------------------ forward
@@ -140,7 +155,8 @@ class ResNetEngine(Net):
         """dx [M,K] = (BN-backward of dz through y) W ; with x_raw / gpro: times act'(.) + the producer's backward sums.
         bn: the BatchNorm behind `bb` while its backward finalize is still pending -- the launch derives the coefficients in
         its prologue and publishes them (engine.py `_c`)."""
-        self._c('t3d_pwconv_dgrad', self.dt, N.ptr(dz), N.ptr(y), bb, N.ptr(wt), N.ptr(x_raw) if x_raw is not None else None,
+        wd, wp = self._wsel(wt, not bb.per_sample and not (gpro is not None and gpro.se))
+        self._c('t3d_pwconv_dgrad', wd, N.ptr(dz), N.ptr(y), bb, wp, N.ptr(x_raw) if x_raw is not None else None,
                 gpro, N.ptr(residual) if residual is not None else None, N.ptr(dx),
                 self._bst(bn_in) if bn_in is not None else None, None, M, HW, K, Nn, N.stream(), bwd=bn,
                 nbytes=M * (K + Nn) * self.esz)

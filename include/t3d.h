@@ -28,6 +28,11 @@ extern "C" {
 
 enum { T3D_F32 = 0, T3D_BF16 = 1, T3D_F16 = 2 };    /* T3D_F16: INFERENCE forward only (round 4): t3d_stem_im2col[_u8], t3d_pwconv_fwd,
                                                          t3d_dwconv_fwd (k = 3), t3d_bn_apply, t3d_pool_fwd, t3d_pack_weight[s_batched] */
+/* Weight layout flag of the bf16 pointwise convolutions (round 4): `T3D_BF16 | T3D_W_FRAG` as the dtype argument of
+ * t3d_pwconv_fwd / t3d_pwconv_dgrad says that `w` / `wt` is the FRAGMENT-ORDER copy made by t3d_pwconv_pack_frag (or by
+ * t3d_pack_weights_batched's `frag` / `frag_t` outputs) of the matrix the plain call takes.  Only for shapes for which
+ * t3d_pwconv_wants_frag returns 1 (deep contractions: csrc/pwconv_deep.hip); any other use returns T3D_ERR_ARG. */
+enum { T3D_W_FRAG = 0x100 };
 enum { T3D_ACT_NONE = 0, T3D_ACT_RELU = 1, T3D_ACT_RELU6 = 2, T3D_ACT_HSWISH = 3 };
 enum { T3D_OK = 0, T3D_ERR_ARG = -1, T3D_ERR_LAUNCH = -2, T3D_ERR_UNSUPPORTED = -3 };
 
@@ -93,6 +98,17 @@ typedef struct {
  *   stats [2*N] fp64 or NULL: += sum(y), sum(y^2) per output channel (caller zeroes). */
 int t3d_pwconv_fwd(int dtype, const void* x, const t3d_prologue* pro, const void* w, const float* bias,
                    void* y, double* stats, int M, int HW, int K, int N, void* stream);
+
+/* Fragment-order weights for the deep-contraction kernel (csrc/pwconv_deep.hip; no reference counterpart: a layout of the
+ * weights nn.Conv2d holds, mobilenetv3.py:142-159).  `w` [rows, cols] bf16 row-major -> out[((T*KS + ks)*64 + lg*16 + lc)*8 + j]
+ * = w[16 T + lc][32 ks + 8 lg + j] (KS = ceil(cols / 32), zero past rows / cols): the A operand of
+ * v_mfma_f32_16x16x32_bf16 for 16 output channels x 32 contraction elements is 1 KB contiguous, so a wave loads it with
+ * one fully coalesced instruction instead of 64 separate 16-byte requests.  t3d_pwconv_frag_bytes: size of `out`.
+ * t3d_pwconv_wants_frag(K, N): 1 if the bf16 pointwise kernels take the fragment-order layout for a contraction over K
+ * into N output channels (forward: (K, N) of the layer with `w`; data gradient: (N, K) with the copy of `wt`). */
+int t3d_pwconv_frag_bytes(int rows, int cols);
+int t3d_pwconv_wants_frag(int K, int N);
+int t3d_pwconv_pack_frag(const void* w, void* out, int rows, int cols, void* stream);
 
 /* Pointwise conv data gradient (autograd of the conv above + the surrounding BN/activation).
  *   dz [M,N], y [M,N]: gradient at / raw input of the BatchNorm after the conv, bb its backward affine;
@@ -482,8 +498,10 @@ int t3d_set_workspace(void* ptr, long long bytes);
  * (classifier Linear(960, 1280) on 256 samples: 16 workgroups x 40 serial rounds otherwise).  NULL / 0 = unsplit. */
 int t3d_set_main_workspace(void* ptr, long long bytes);
 
-/* All weight matrices of a model in ONE launch: desc is a DEVICE array of n records of 5 int64
- * {src fp32 [rows,cols], out [rows,cols] or 0, out_t [cols,rows] or 0, rows, cols} (outputs in `dtype`). */
+/* All weight matrices of a model in ONE launch: desc is a DEVICE array of n records of 7 int64
+ * {src fp32 [rows,cols], out [rows,cols] or 0, out_t [cols,rows] or 0, rows, cols, frag or 0, frag_t or 0} (outputs in `dtype`);
+ * frag / frag_t: fragment-order copies of the matrix / of its transpose (t3d_pwconv_pack_frag; t3d_pwconv_frag_bytes(rows, cols)
+ * / (cols, rows) bytes, cleared once by the caller: only the elements of the matrix are written). */
 int t3d_pack_weights_batched(int dtype, const long long* desc, int n, void* stream);
 
 /* Optimizer step: torch.optim.AdamW as build_optimizer(name='adam') constructs it

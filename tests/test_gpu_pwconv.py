@@ -34,12 +34,61 @@ def _pack(w, dtype, transpose=False):
     return out
 
 
+def _frag(wd):
+    """Fragment-order copy of a packed bf16 weight matrix (t3d_pwconv_pack_frag)."""
+    from torchdet3d import _native as N
+    r, c = wd.shape
+    out = torch.zeros(N.lib().t3d_pwconv_frag_bytes(r, c) // 2, device='cuda', dtype=torch.bfloat16)
+    N.call('t3d_pwconv_pack_frag', N.ptr(wd), N.ptr(out), r, c, N.stream())
+    return out
+
+
+def test_fragment_order_weight_layout():
+    """t3d_pwconv_pack_frag and the frag / frag_t outputs of t3d_pack_weights_batched against the definition in include/t3d.h,
+    ragged rows and columns included; the flag is refused where the deep-contraction kernel does not apply."""
+    from torchdet3d import _native as N
+    g = torch.Generator().manual_seed(5)
+    for r, c in [(160, 960), (40, 72), (520, 1032)]:
+        w = torch.randn(r, c, generator=g)
+        wq = w.to('cuda', torch.bfloat16)
+        KS = (c + 31) // 32
+        ref = torch.zeros((r + 15) // 16, KS, 4, 16, 8, dtype=torch.bfloat16)
+        wp = torch.zeros((r + 15) // 16 * 16, KS * 32, dtype=torch.bfloat16)
+        wp[:r, :c] = wq.cpu()
+        ref = wp.view(-1, 16, KS, 4, 8).permute(0, 2, 3, 1, 4).contiguous().view(-1)
+        got = _frag(wq)
+        torch.cuda.synchronize()
+        assert torch.equal(got.cpu(), ref)
+        # batched form: plain, transposed and both fragment-order copies in one launch
+        wf = w.cuda()
+        out, out_t = torch.empty(r, c, device='cuda', dtype=torch.bfloat16), torch.empty(c, r, device='cuda', dtype=torch.bfloat16)
+        fr = torch.zeros_like(got)
+        frt = torch.zeros(N.lib().t3d_pwconv_frag_bytes(c, r) // 2, device='cuda', dtype=torch.bfloat16)
+        desc = torch.tensor([[wf.data_ptr(), out.data_ptr(), out_t.data_ptr(), r, c, fr.data_ptr(), frt.data_ptr()]],
+                            dtype=torch.int64, device='cuda')
+        N.call('t3d_pack_weights_batched', N.BF16, N.ptr(desc), 1, N.stream())
+        torch.cuda.synchronize()
+        assert torch.equal(out, wq) and torch.equal(out_t, wq.t().contiguous())
+        assert torch.equal(fr.cpu(), ref) and torch.equal(frt, _frag(out_t))
+    x = torch.zeros(64, 96, device='cuda', dtype=torch.bfloat16)
+    y = torch.zeros(64, 24, device='cuda', dtype=torch.bfloat16)
+    assert N.lib().t3d_pwconv_wants_frag(96, 24) == 0 and N.lib().t3d_pwconv_wants_frag(960, 160) == 1
+    rc = N.lib().t3d_pwconv_fwd(N.BF16 | N.W_FRAG, N.ptr(x), None, N.ptr(y), None, N.ptr(y), None, 64, 64, 96, 24, N.stream())
+    assert rc == -1          # T3D_ERR_ARG
+
+
 SHAPES = [  # B, HW, K, N
     (2, 36, 16, 96), (3, 49, 96, 24), (2, 100, 24, 144), (5, 9, 160, 960), (2, 144, 672, 112),
     (7, 1, 960, 1280), (2, 333, 72, 40), (1, 130, 200, 80), (2, 64, 320, 1280), (2, 200, 8, 8)]
 
 
-@pytest.mark.parametrize('B,HW,K,N', SHAPES)
+# deep contractions with outputs wider than the streaming kernel's LDS weight chunk: pwconv_deep.hip (operand resident in LDS,
+# weights streamed), incl. ragged K (not a multiple of 32), a ragged last 32-channel block and several output chunks
+DEEP_FWD = [(8, 49, 960, 160), (3, 49, 960, 320), (5, 49, 576, 160), (2, 37, 1032, 520), (1, 70, 2048, 512)]
+DEEP_BWD = [(8, 49, 160, 960), (3, 49, 320, 1280), (2, 37, 520, 1032), (1, 70, 512, 2048)]
+
+
+@pytest.mark.parametrize('B,HW,K,N', SHAPES + DEEP_FWD)
 @pytest.mark.parametrize('dt', ['f32', 'bf16'])
 @pytest.mark.parametrize('mode', ['plain', 'bnact', 'se_pre', 'se_post'])
 def test_pwconv_fwd(B, HW, K, N, dt, mode):
@@ -72,15 +121,22 @@ def test_pwconv_fwd(B, HW, K, N, dt, mode):
     bd = bias.cuda() if bias is not None else None
     p = None if mode == 'plain' else Nt.prologue(keep[0], keep[1], keep[2] if mode.startswith('se') else None, act,
                                                  mode == 'se_post')
-    Nt.call('t3d_pwconv_fwd', Nt.dtype_code(xd), Nt.ptr(xd), p, Nt.ptr(wd), Nt.ptr(bd), Nt.ptr(y), Nt.ptr(stats),
-            M, HW, K, N, Nt.stream())
-    torch.cuda.synchronize()
-    got = y.float().cpu()
-    tol = 1e-5 if dt == 'f32' else 1e-2
-    np.testing.assert_allclose(got.numpy(), ref.float().numpy(), atol=tol * max(1., ref.abs().max().item()), rtol=tol)
-    st = stats.cpu().view(2, N)
-    np.testing.assert_allclose(st[0].numpy(), got.double().sum(0).numpy(), rtol=1e-5, atol=1e-4 * M ** .5)
-    np.testing.assert_allclose(st[1].numpy(), (got.double() ** 2).sum(0).numpy(), rtol=1e-5, atol=1e-4)
+    # second pass for the shapes of the deep-contraction kernel (csrc/pwconv_deep.hip): the same call with the fragment-order copy
+    # of the weights and T3D_W_FRAG (no bias, no gates there)
+    variants = [(Nt.dtype_code(xd), wd)]
+    if dt == 'bf16' and mode == 'bnact' and Nt.lib().t3d_pwconv_wants_frag(K, N):
+        variants.append((Nt.BF16 | Nt.W_FRAG, _frag(wd)))
+    for code, wv in variants:
+        y.zero_(); stats.zero_()
+        Nt.call('t3d_pwconv_fwd', code, Nt.ptr(xd), p, Nt.ptr(wv), Nt.ptr(bd), Nt.ptr(y), Nt.ptr(stats),
+                M, HW, K, N, Nt.stream())
+        torch.cuda.synchronize()
+        got = y.float().cpu()
+        tol = 1e-5 if dt == 'f32' else 1e-2
+        np.testing.assert_allclose(got.numpy(), ref.float().numpy(), atol=tol * max(1., ref.abs().max().item()), rtol=tol)
+        st = stats.cpu().view(2, N)
+        np.testing.assert_allclose(st[0].numpy(), got.double().sum(0).numpy(), rtol=1e-5, atol=1e-4 * M ** .5)
+        np.testing.assert_allclose(st[1].numpy(), (got.double() ** 2).sum(0).numpy(), rtol=1e-5, atol=1e-4)
 
 
 # projection-conv data gradients of the 14x14 / 7x7 stages: contraction over 96 / 160 / 320 channels -> the deep-round
@@ -88,7 +144,7 @@ def test_pwconv_fwd(B, HW, K, N, dt, mode):
 DEEP_DG = [(16, 196, 576, 96), (8, 49, 960, 160), (3, 49, 960, 320), (5, 100, 384, 96), (7, 33, 200, 88), (2, 49, 104, 152)]
 
 
-@pytest.mark.parametrize('B,HW,K,N', SHAPES + DEEP_DG)
+@pytest.mark.parametrize('B,HW,K,N', SHAPES + DEEP_DG + DEEP_BWD)
 @pytest.mark.parametrize('dt', ['f32', 'bf16'])
 @pytest.mark.parametrize('mode', ['input', 'input_res', 'bnact', 'se_pre', 'persample'])
 def test_pwconv_dgrad(B, HW, K, N, dt, mode):
@@ -131,19 +187,24 @@ def test_pwconv_dgrad(B, HW, K, N, dt, mode):
     has_act = mode in ('bnact', 'se_pre', 'persample')
     pin = Nt.prologue(keep[3], keep[4], keep[5] if mode == 'se_pre' else None, act, False) if has_act else None
     use_ps = mode == 'se_pre'
-    Nt.call('t3d_pwconv_dgrad', Nt.dtype_code(dzd), Nt.ptr(dzd), Nt.ptr(yd), bb, Nt.ptr(wt),
-            Nt.ptr(xd) if has_act else None, pin, Nt.ptr(rd) if mode == 'input_res' else None, Nt.ptr(dx),
-            Nt.ptr(stats) if (has_act and not use_ps) else None, Nt.ptr(psst) if use_ps else None,
-            M, HW, K, N, Nt.stream())
-    torch.cuda.synchronize()
-    got = dx.float().cpu()
-    tol = 2e-5 if dt == 'f32' else 1.5e-2
-    np.testing.assert_allclose(got.numpy(), gref.float().numpy(), atol=tol * max(1., gref.abs().max().item()), rtol=tol)
-    if has_act and not use_ps:
-        st = stats.cpu().view(2, K)
-        np.testing.assert_allclose(st[0].numpy(), got.double().sum(0).numpy(), rtol=1e-5, atol=1e-4 * M ** .5)
-        np.testing.assert_allclose(st[1].numpy(), (got.double() * xq.double()).sum(0).numpy(), rtol=1e-5,
-                                   atol=1e-4 * M ** .5)
+    variants = [(Nt.dtype_code(dzd), wt)]
+    if dt == 'bf16' and mode in ('input', 'input_res', 'bnact') and Nt.lib().t3d_pwconv_wants_frag(N, K):
+        variants.append((Nt.BF16 | Nt.W_FRAG, _frag(wt)))      # deep-contraction kernel: fragment-order copy of wt
+    for code, wv in variants:
+        dx.zero_(); stats.zero_()
+        Nt.call('t3d_pwconv_dgrad', code, Nt.ptr(dzd), Nt.ptr(yd), bb, Nt.ptr(wv),
+                Nt.ptr(xd) if has_act else None, pin, Nt.ptr(rd) if mode == 'input_res' else None, Nt.ptr(dx),
+                Nt.ptr(stats) if (has_act and not use_ps) else None, Nt.ptr(psst) if use_ps else None,
+                M, HW, K, N, Nt.stream())
+        torch.cuda.synchronize()
+        got = dx.float().cpu()
+        tol = 2e-5 if dt == 'f32' else 1.5e-2
+        np.testing.assert_allclose(got.numpy(), gref.float().numpy(), atol=tol * max(1., gref.abs().max().item()), rtol=tol)
+        if has_act and not use_ps:
+            st = stats.cpu().view(2, K)
+            np.testing.assert_allclose(st[0].numpy(), got.double().sum(0).numpy(), rtol=1e-5, atol=1e-4 * M ** .5)
+            np.testing.assert_allclose(st[1].numpy(), (got.double() * xq.double()).sum(0).numpy(), rtol=1e-5,
+                                       atol=1e-4 * M ** .5)
     if use_ps:
         p1 = got.double().view(B, HW, K).sum(1)
         p2 = (got.double() * xq.double()).view(B, HW, K).sum(1)

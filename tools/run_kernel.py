@@ -53,13 +53,21 @@ else:
     ws = torch.empty(64 << 20, device=dev, dtype=torch.uint8)
     N.call('t3d_set_workspace', N.ptr(ws), ws.numel())
     N.call('t3d_set_reduction_replicas', nrep, 2 * max(K, Nn))
+    def frag(wm, kk, nn):       # --frag: the fragment-order copy + T3D_W_FRAG where the deep-contraction kernel takes the shape
+        if '--frag' not in sys.argv or dt != torch.bfloat16 or not N.lib().t3d_pwconv_wants_frag(kk, nn):
+            return N.dtype_code(x), wm
+        out = torch.zeros(N.lib().t3d_pwconv_frag_bytes(*wm.shape) // 2, device=dev, dtype=dt)
+        N.call('t3d_pwconv_pack_frag', N.ptr(wm), N.ptr(out), wm.shape[0], wm.shape[1], N.stream())
+        return N.BF16 | N.W_FRAG, out
     if kind == 'pwfwd':
         stats = torch.zeros(nrep, 2 * max(K, Nn), device=dev, dtype=torch.float64)
-        fn = lambda: N.call('t3d_pwconv_fwd', N.dtype_code(x), N.ptr(x), pro, N.ptr(wq), None, N.ptr(y), N.ptr(stats),
+        code, wv = frag(wq, K, Nn)
+        fn = lambda: N.call('t3d_pwconv_fwd', code, N.ptr(x), pro, N.ptr(wv), None, N.ptr(y), N.ptr(stats),
                             M, HW, K, Nn, N.stream())
     elif kind == 'pwdgrad':
         stats = torch.zeros(nrep, 2 * max(K, Nn), device=dev, dtype=torch.float64)
-        fn = lambda: N.call('t3d_pwconv_dgrad', N.dtype_code(x), N.ptr(dz), N.ptr(yy), bb, N.ptr(wt), N.ptr(x), pro, None,
+        code, wv = frag(wt, Nn, K)
+        fn = lambda: N.call('t3d_pwconv_dgrad', code, N.ptr(dz), N.ptr(yy), bb, N.ptr(wv), N.ptr(x), pro, None,
                             N.ptr(dx), N.ptr(stats), None, M, HW, K, Nn, N.stream())
     elif kind in ('pwdgrad_yf', 'pwwgrad_yf', 'yfprep', 'pwbwd_yf'):
         NP, KP = (Nn + 31) // 32 * 32, (K + 31) // 32 * 32
@@ -104,6 +112,14 @@ if os.environ.get('T3D_TRACE'):      # library built with -DT3D_PW_TRACE (tools/
     lib = ctypes.CDLL(N.LIB_PATH)
     e0.record(); fn(); e1.record(); torch.cuda.synchronize()
     buf = (ctypes.c_ulonglong * 16)()
+    if os.environ['T3D_TRACE'] == 'deep':      # pwconv_deep.hip
+        assert lib.t3d_debug_deep_trace(buf) == 0
+        t = [v * 0.01 for v in buf]
+        base = min(t[0], t[8])
+        for nm, o in (('first block', 0), ('last block', 8)):
+            print(f'  {nm}: start {t[o] - base:.2f} | coefficients {t[o + 1] - base:.2f} | phase 0 staged {t[o + 2] - base:.2f} | '
+                  f'k-loop done {t[o + 3] - base:.2f} | stored {t[o + 4] - base:.2f} | stats done {t[o + 5] - base:.2f}')
+        sys.exit(0)
     assert lib.t3d_debug_pw_trace(buf) == 0
     t = [v * 0.01 for v in buf]      # 100 MHz -> us
     base = min(t[0], t[8])
