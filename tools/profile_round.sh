@@ -10,6 +10,8 @@ python3 bench.py --steps 30 --warmup 8 --eval --no-cpu-baseline > $o/bench_eval.
 python3 bench.py --steps 30 --warmup 8 --eval --eval-dtype bf16 --no-cpu-baseline > $o/bench_eval_bf16_optin.json 2> /dev/null
 python3 bench.py --steps 20 --warmup 5 --model mobilenetv3_large --no-cpu-baseline > $o/bench_mnv3_large.json 2> /dev/null
 python3 bench.py --steps 20 --warmup 5 --model mobilenetv3_small --no-cpu-baseline > $o/bench_mnv3_small.json 2> /dev/null
+python3 bench.py --steps 30 --warmup 8 --eval --eval-dtype f16 --no-cpu-baseline > $o/bench_eval_f16.json 2> /dev/null
+python3 bench.py --steps 20 --warmup 5 --model resnet50 --batch 64 --no-cpu-baseline > $o/bench_resnet50.json 2> /dev/null
 python3 bench.py --steps 30 --warmup 8 --engine --no-cpu-baseline > $o/bench_bf16_engine_loop.json 2> /dev/null
 bash tools/time_kernels.sh > $o/isolated_kernel_timings.txt 2>&1
 python3 tools/bench_two_stage.py --detector 2> /dev/null | tail -1 > $o/two_stage_pipeline_bench.jsonl

@@ -1,0 +1,8 @@
+#!/bin/bash
+# usage: ab_env_step.sh VAR   (A/B of the headline step with VAR=0 / VAR=1)
+cd $GRAFT_REPO_ROOT; export TMPDIR=/tmp
+for i in 1 2; do
+  for v in 0 1; do
+    echo -n "$1=$v  "; env $1=$v python bench.py --steps 60 --warmup 10 --no-cpu-baseline 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(d['value'], d['ms_per_step'], d['config'].get('final_loss'))"
+  done
+done
