@@ -16,9 +16,21 @@ __global__ void pack_kernel(const float* __restrict__ w, T* __restrict__ out, in
   }
 }
 
+// Fragment order of a [rows][cols] matrix (include/t3d.h: t3d_pwconv_pack_frag): 16-B piece index of elements
+// (r, 8 c8 .. 8 c8 + 7).  Rows are grouped in pairs of 16-row tiles with the streaming kernel's permutation (MFMA row lc of tile
+// T  <->  row (T >> 1) * 32 + (lc >> 2) * 8 + (T & 1) * 4 + (lc & 3)), so that a lane ends up with 8 consecutive output
+// channels of a 32-channel block.
+__device__ __forceinline__ size_t t3d_frag_piece(int r, int c8, int KS) {
+  const int rr = r & 31, T = (r >> 5) * 2 + ((rr >> 2) & 1), lc = (rr >> 3) * 4 + (rr & 3);
+  return ((size_t)T * KS + (c8 >> 2)) * 64 + (c8 & 3) * 16 + lc;
+}
+
 // one launch for every weight matrix of the model: desc[t] = {src, out (or 0), out_t (or 0), rows, cols, frag (or 0), frag_t (or 0)}
-// as int64.  frag / frag_t: fragment-order copies of the matrix / its transpose for the deep-contraction pointwise kernel
-// (t3d_pwconv_pack_frag in include/t3d.h has the layout; the zero padding is the caller's, the buffers are cleared once)
+// as int64.  frag / frag_t: fragment-order copies of the matrix / its transpose for the bf16 / fp16 pointwise kernels (the
+// zero padding is the caller's, the buffers are cleared once).  A thread converts 8 consecutive elements of a row (one 16-B
+// piece of `out` and of `frag`), then 8 consecutive elements of a COLUMN (one piece of `out_t` and `frag_t`: strided 4-byte
+// reads of the fp32 master, L2 hits) -- every write is 16 B; the element-per-thread form wrote three of the four copies as
+// scattered 2-byte stores.
 template <typename T>
 __global__ void pack_batched_kernel(const long long* __restrict__ desc) {
   const long long* d = desc + (size_t)blockIdx.x * 7;
@@ -30,13 +42,41 @@ __global__ void pack_batched_kernel(const long long* __restrict__ desc) {
   T* __restrict__ frag_t = reinterpret_cast<T*>(d[6]);
   const int KS = (cols + 31) / 32, KSt = (rows + 31) / 32;
   const size_t n = (size_t)rows * cols;
+  if constexpr (sizeof(T) == 2) {
+    if (!(rows & 7) && !(cols & 7)) {
+      typedef T V8 __attribute__((ext_vector_type(8)));
+      const int c8n = cols >> 3, r8n = rows >> 3;
+      const size_t n1 = (size_t)rows * c8n, n2 = (out_t || frag_t) ? (size_t)cols * r8n : 0;
+      for (size_t i = blockIdx.y * (size_t)blockDim.x + threadIdx.x; i < n1 + n2; i += (size_t)gridDim.y * blockDim.x) {
+        V8 v;
+        if (i < n1) {
+          const int r = (int)(i / c8n), c8 = (int)(i - (size_t)r * c8n);
+          const float4 a = *reinterpret_cast<const float4*>(w + (size_t)r * cols + c8 * 8);
+          const float4 b = *reinterpret_cast<const float4*>(w + (size_t)r * cols + c8 * 8 + 4);
+          v[0] = (T)a.x; v[1] = (T)a.y; v[2] = (T)a.z; v[3] = (T)a.w; v[4] = (T)b.x; v[5] = (T)b.y; v[6] = (T)b.z; v[7] = (T)b.w;
+          if (out) *reinterpret_cast<V8*>(out + (size_t)r * cols + c8 * 8) = v;
+          if (frag) *reinterpret_cast<V8*>(frag + t3d_frag_piece(r, c8, KS) * 8) = v;
+        } else {
+          const size_t k = i - n1;
+          const int c = (int)(k / r8n), r8 = (int)(k - (size_t)c * r8n);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] = (T)w[(size_t)(r8 * 8 + e) * cols + c];
+          if (out_t) *reinterpret_cast<V8*>(out_t + (size_t)c * rows + r8 * 8) = v;
+          if (frag_t) *reinterpret_cast<V8*>(frag_t + t3d_frag_piece(c, r8, KSt) * 8) = v;
+        }
+      }
+      return;
+    }
+  }
   for (size_t i = blockIdx.y * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.y * blockDim.x) {
     const T v = (T)w[i];
     const int r = (int)(i / cols), c = (int)(i % cols);
     if (out) out[i] = v;
     if (out_t) out_t[(size_t)c * rows + r] = v;
-    if (frag) frag[((((size_t)(r >> 4) * KS + (c >> 5)) * 4 + ((c >> 3) & 3)) * 16 + (r & 15)) * 8 + (c & 7)] = v;
-    if (frag_t) frag_t[((((size_t)(c >> 4) * KSt + (r >> 5)) * 4 + ((r >> 3) & 3)) * 16 + (c & 15)) * 8 + (r & 7)] = v;
+    if constexpr (sizeof(T) == 2) {
+      if (frag) frag[t3d_frag_piece(r, c >> 3, KS) * 8 + (c & 7)] = v;
+      if (frag_t) frag_t[t3d_frag_piece(c, r >> 3, KSt) * 8 + (r & 7)] = v;
+    }
   }
 }
 

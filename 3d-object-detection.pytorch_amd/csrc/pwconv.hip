@@ -349,12 +349,15 @@ int launch(GemmArgs& a, hipStream_t st) {
 int dispatch(int dtype, GemmArgs& a, void* stream) {
   if (a.M <= 0 || a.Kin <= 0 || a.Nout <= 0 || (a.Kin % 8) || (a.Nout % 8) || a.HW <= 0) return T3D_ERR_ARG;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-  const bool wfrag = (dtype & T3D_W_FRAG) != 0;     // `w` is the fragment-order copy (include/t3d.h): the deep-contraction kernel only
+  // `w` is the fragment-order copy (include/t3d.h: T3D_W_FRAG): the deep-contraction kernel where it takes the shape, else the
+  // streaming kernel; the LDS-tiled fallback below cannot read it
+  a.wfrag = (dtype & T3D_W_FRAG) ? 1 : 0;
   dtype &= ~T3D_W_FRAG;
-  if (wfrag) return dtype == T3D_BF16 ? ((a.M > 0 && deep_shape(a.Kin, a.Nout)) ? deep_launch(a, st) : T3D_ERR_ARG) : T3D_ERR_ARG;
+  if (a.wfrag && dtype != T3D_BF16 && dtype != T3D_F16) return T3D_ERR_ARG;
   if (dtype == T3D_BF16) {
-    const int rc = stream_launch(a, st);
-    if (rc != T3D_ERR_UNSUPPORTED) return rc;
+    int rc = (a.wfrag && deep_shape(a.Kin, a.Nout)) ? deep_launch(a, st) : T3D_ERR_UNSUPPORTED;
+    if (rc == T3D_ERR_UNSUPPORTED) rc = stream_launch(a, st);
+    if (rc != T3D_ERR_UNSUPPORTED || a.wfrag) return rc;
   }
   if (dtype == T3D_F16) {                    // inference forward in fp16 storage: the streaming kernel or nothing
     if (const int rc = t3d_fold_fallback(a.p0, st)) return rc;
@@ -380,7 +383,8 @@ extern "C" int t3d_pwconv_fwd(int dtype, const void* x, const t3d_prologue* pro,
   if (!y) {
     // statistics-only pass (the BatchNorm sums of a conv whose output is never stored: t3d_expdw_fwd recomputes it in
     // LDS): bf16 streaming kernel only
-    if (dtype != T3D_BF16 || (K % 8) || (N % 8) || M <= 0 || HW <= 0) return T3D_ERR_UNSUPPORTED;
+    a.wfrag = (dtype & T3D_W_FRAG) ? 1 : 0;
+    if ((dtype & ~T3D_W_FRAG) != T3D_BF16 || (K % 8) || (N % 8) || M <= 0 || HW <= 0) return T3D_ERR_UNSUPPORTED;
     return stream_launch(a, reinterpret_cast<hipStream_t>(stream));
   }
   return dispatch(dtype, a, stream);
@@ -393,16 +397,20 @@ extern "C" int t3d_pwconv_fwd_mat(int dtype, const void* y_in, const t3d_prologu
                                   const void* w, void* y, double* stats, int M, int HW, int K, int N, void* stream) {
   if (!y_in || !pro_in || !z_out || !w || !y) return T3D_ERR_ARG;
   if (pro_in->se || M <= 0 || K <= 0 || N <= 0 || (K % 8) || (N % 8) || HW <= 0) return T3D_ERR_ARG;
+  const bool wfrag = (dtype & T3D_W_FRAG) != 0;
+  dtype &= ~T3D_W_FRAG;
   if (dtype == T3D_BF16) {
     GemmArgs a{};
+    a.wfrag = wfrag ? 1 : 0;
     a.a0 = y_in;
     a.p0 = pro_in->scale; a.p1 = pro_in->shift; a.act = pro_in->act;
     a.z_res = residual; a.z_out = z_out;
     a.w = w; a.out = y; a.stats = stats;
     a.M = M; a.HW = HW; a.Kin = K; a.Nout = N;
     const int rc = stream_launch(a, reinterpret_cast<hipStream_t>(stream));
-    if (rc != T3D_ERR_UNSUPPORTED) return rc;
+    if (rc != T3D_ERR_UNSUPPORTED || wfrag) return rc;
   }
+  if (wfrag) return T3D_ERR_ARG;
   // no materialising kernel for this case (fp32 storage, shapes outside the streaming kernel): the two launches it fuses
   if (const int rc = t3d_bn_apply(dtype, y_in, pro_in, residual, z_out, M, K, stream)) return rc;
   return t3d_pwconv_fwd(dtype, z_out, nullptr, w, nullptr, y, stats, M, HW, K, N, stream);

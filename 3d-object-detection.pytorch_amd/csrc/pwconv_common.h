@@ -32,6 +32,7 @@ struct GemmArgs {
   // the finished block output that t3d_bn_apply would have written; the blocks of output chunk 0 also STORE it to z_out
   const void* z_res;
   void* z_out;
+  int wfrag;             // `w` is the fragment-order copy (include/t3d.h: T3D_W_FRAG; streaming and deep-contraction kernels)
   T3dQuant quant;        // forward BatchNorm sums snapped onto a fixed grid (order-independent, common.h); q == 0: off
 };
 

@@ -12,7 +12,8 @@
 //     chunk (<= 192); the operand is read and transformed ONCE, in phases of 8 k-steps, into a double-buffered LDS tile in
 //     MFMA-fragment order ([row tile][k-step][lane] x 16 B: linear, conflict-free writes and reads);
 //   * the WEIGHTS are streamed from L2 straight into registers, a whole phase ahead.  They have to be in fragment order in
-//     memory ([16-channel tile][k-step][lane] x 16 B, zero padded): a wave's fragment is then 1 KB contiguous.  Loading
+//     memory ([16-row tile][k-step][lane] x 16 B, rows in the streaming kernel's pair permutation, zero padded: include/t3d.h):
+//     a wave's fragment is then 1 KB contiguous.  Loading
 //     fragments out of the row-major matrix (16 rows x 64 B per instruction, one 16-B request per lane) ran at ~20 KB/us per
 //     CU -- the same rate the streaming kernel's weight staging shows -- and WAS the kernel (k-loop 22 us of 36);
 //   * loads return IN ORDER per wave (vmcnt), so a weight fragment (L2 hit) issued behind an operand row (HBM) is not usable
@@ -21,7 +22,8 @@
 //     phase / two phases (64 - 128 KB per workgroup in flight) to arrive;
 //   * everything inside the phase loop is branch-free (k-steps / tiles past the end are zero fragments or repeats against
 //     clamped loads), so the compiler counts vmcnt down instead of draining it at control-flow joins;
-//   * epilogue and statistics as in the streaming kernel (a lane holds 4 consecutive channels of one pixel per tile; sums per
+//   * epilogue and statistics as in the streaming kernel (a lane holds channels 32 (T >> 1) + 8 lg + 4 (T & 1) .. +3 of one
+//     pixel for tile T; sums per
 //     lane in registers, one owner per channel in the block, one fp64 atomic per channel per block).
 // No squeeze-excite / per-sample coefficients, no bias, no materialising operand: those shapes stay with the streaming kernel.
 #include <cstdlib>
@@ -52,7 +54,7 @@ __device__ unsigned long long g_deep_trace[16];
 constexpr int RT = 4;        // row tiles (16 pixels) per block
 constexpr int KSP = 8;       // k-steps per phase (one LDS buffer = RT * KSP KB)
 constexpr int NW = 4;        // waves per block
-constexpr int NTW = 3;       // 16-channel tiles per wave: tiles wave, wave + 4, wave + 8 of the chunk (<= 12 tiles = 192 channels)
+constexpr int NTW = 3;       // 16-row tiles per wave: tiles wave, wave + 4, wave + 8 of the chunk (<= 12 tiles = 192 channels)
 constexpr int IT = RT * KSP / NW;   // staging items (16 rows x 32 k) per wave per phase: row tile `wave`, every k-step
 
 template <bool DG>
@@ -79,7 +81,7 @@ __global__ __launch_bounds__(64 * NW, 1) void pw_deep_kernel(const GemmArgs a, c
   // repeats' results are dropped)
   int tix[NTW];
   bool tok[NTW];
-  const int tlast = min(ntiles, (a.Nout - n0 + 15) / 16) - 1;
+  const int tlast = min(ntiles, (a.Nout - n0 + 31) / 32 * 2) - 1;      // (whole pairs: a layer's last pair may be half padding)
   const bf16x8* wt_[NTW];        // fragment-order weights of the tile: [k-step][lane]
 #pragma unroll
   for (int i = 0; i < NTW; ++i) {
@@ -224,7 +226,7 @@ __global__ __launch_bounds__(64 * NW, 1) void pw_deep_kernel(const GemmArgs a, c
   }
 
   DEEP_STAMP(3);
-  // ---------------- epilogue: lane holds channels n0 + 16 T + 4 lg .. +3 of pixel m0 + 16 r + lc ----------
+  // ---------------- epilogue: lane holds channels n0 + 32 (T >> 1) + 8 lg + 4 (T & 1) .. +3 of pixel m0 + 16 r + lc ----------
   const bool keep_stats = a.stats != nullptr;
   float st1[NTW][4], st2[NTW][4];
 #pragma unroll
@@ -239,7 +241,7 @@ __global__ __launch_bounds__(64 * NW, 1) void pw_deep_kernel(const GemmArgs a, c
       const size_t mo = (size_t)min(m0 + r * 16 + lc, a.M - 1) * a.Nout;
 #pragma unroll
       for (int i = 0; i < NTW; ++i) {
-        const int n = min(n0 + tix[i] * 16 + lg * 4, a.Nout - 4);
+        const int n = min(n0 + (tix[i] >> 1) * 32 + lg * 8 + (tix[i] & 1) * 4, a.Nout - 4);
         if (a.e_y) eyr[DG ? r : 0][i] = *reinterpret_cast<const bf16x4*>(reinterpret_cast<const bf16_t*>(a.e_y) + mo + n);
         if (a.e_res) err[DG ? r : 0][i] = *reinterpret_cast<const bf16x4*>(reinterpret_cast<const bf16_t*>(a.e_res) + mo + n);
       }
@@ -251,7 +253,7 @@ __global__ __launch_bounds__(64 * NW, 1) void pw_deep_kernel(const GemmArgs a, c
     const bool ok = m < a.M;
 #pragma unroll
     for (int i = 0; i < NTW; ++i) {
-      const int nl = tix[i] * 16 + lg * 4, n = n0 + nl;
+      const int nl = (tix[i] >> 1) * 32 + lg * 8 + (tix[i] & 1) * 4, n = n0 + nl;      // (n0 is a multiple of 32)
       if (!tok[i] || n >= a.Nout) continue;     // (whole 4-channel groups are in or out: Nout % 8 == 0)
       float v[4], yv[4];
 #pragma unroll
@@ -293,7 +295,7 @@ __global__ __launch_bounds__(64 * NW, 1) void pw_deep_kernel(const GemmArgs a, c
   if (keep_stats) {
 #pragma unroll
     for (int i = 0; i < NTW; ++i) {
-      const int nl = tix[i] * 16 + lg * 4;
+      const int nl = (tix[i] >> 1) * 32 + lg * 8 + (tix[i] & 1) * 4;
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const float s1 = row16_sum(st1[i][j]), s2 = row16_sum(st2[i][j]);
@@ -326,14 +328,16 @@ int launch_deep(GemmArgs& a, int KS, int ntiles, int nchunks, hipStream_t st) {
   return T3D_OK;
 }
 
-// fragment order: out[((T * KS + ks) * 64 + lg * 16 + lc) * 8 + j] = w[T * 16 + lc][ks * 32 + lg * 8 + j], zero past rows / cols
-__global__ void pack_frag_kernel(const bf16_t* __restrict__ w, bf16_t* __restrict__ out, int rows, int cols, int KS, size_t total) {
+// fragment order (include/t3d.h): out[((T * KS + ks) * 64 + lg * 16 + lc) * 8 + j] = w[row(T, lc)][ks * 32 + lg * 8 + j],
+// row(T, lc) = (T >> 1) * 32 + (lc >> 2) * 8 + (T & 1) * 4 + (lc & 3), zero past rows / cols; any 16-bit storage type
+__global__ void pack_frag_kernel(const unsigned short* __restrict__ w, unsigned short* __restrict__ out, int rows, int cols, int KS,
+                                 size_t total) {
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
     const int j = i & 7, lc = (i >> 3) & 15, lg = (i >> 7) & 3;
     const size_t tk = i >> 9;
     const int ks = (int)(tk % KS), T = (int)(tk / KS);
-    const int n = T * 16 + lc, k = ks * 32 + lg * 8 + j;
-    out[i] = (n < rows && k < cols) ? w[(size_t)n * cols + k] : (bf16_t)0.f;
+    const int n = (T >> 1) * 32 + (lc >> 2) * 8 + (T & 1) * 4 + (lc & 3), k = ks * 32 + lg * 8 + j;
+    out[i] = (n < rows && k < cols) ? w[(size_t)n * cols + k] : (unsigned short)0;
   }
 }
 
@@ -363,9 +367,9 @@ int deep_launch(GemmArgs& a, hipStream_t st) {
   if (a.dgrad && (!a.a1 || !a.p0 || !a.p1 || !a.p2)) return T3D_ERR_UNSUPPORTED;
   if (!deep_shape(a.Kin, a.Nout)) return T3D_ERR_UNSUPPORTED;
   const int KS = cdiv(a.Kin, 32);
-  const int tiles = cdiv(a.Nout, 16);
-  // chunks of <= 12 tiles (192 channels), evenly sized; every chunk stages the operand again (from L2)
-  const int nchunks = cdiv(tiles, NW * NTW), ntiles = cdiv(tiles, nchunks);
+  const int pairs = cdiv(a.Nout, 32);
+  // chunks of <= 6 pairs of tiles (192 channels), evenly sized; every chunk stages the operand again (from L2)
+  const int nchunks = cdiv(pairs, NW * NTW / 2), ntiles = 2 * cdiv(pairs, nchunks);
   return a.dgrad ? launch_deep<true>(a, KS, ntiles, nchunks, st) : launch_deep<false>(a, KS, ntiles, nchunks, st);
 }
 
@@ -374,16 +378,19 @@ int deep_launch(GemmArgs& a, hipStream_t st) {
 // include/t3d.h
 extern "C" int t3d_pwconv_frag_bytes(int rows, int cols) {
   if (rows <= 0 || cols <= 0) return 0;
-  return cdiv(rows, 16) * cdiv(cols, 32) * 1024;
+  return 2 * cdiv(rows, 32) * cdiv(cols, 32) * 1024;
 }
 
+// where the fragment-order copy PAYS: the deep-contraction kernel's shapes.  (The streaming kernel takes the layout for every
+// shape of its own -- its weight staging becomes one linear copy -- but that is worth ~1 us per launch alone and nothing in
+// the step, less than packing a second copy of every layer costs: DESIGN finding 34.)
 extern "C" int t3d_pwconv_wants_frag(int K, int N) { return t3d_pw::deep_shape(K, N) ? 1 : 0; }
 
 extern "C" int t3d_pwconv_pack_frag(const void* w, void* out, int rows, int cols, void* stream) {
   if (!w || !out || rows <= 0 || cols <= 0) return T3D_ERR_ARG;
   const size_t total = (size_t)t3d_pwconv_frag_bytes(rows, cols) / 2;
   hipLaunchKernelGGL(t3d_pw::pack_frag_kernel, dim3((unsigned)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048)), dim3(256), 0,
-                     reinterpret_cast<hipStream_t>(stream), reinterpret_cast<const bf16_t*>(w), reinterpret_cast<bf16_t*>(out), rows,
+                     reinterpret_cast<hipStream_t>(stream), reinterpret_cast<const unsigned short*>(w), reinterpret_cast<unsigned short*>(out), rows,
                      cols, cdiv(cols, 32), total);
   T3D_CHECK_LAUNCH();
   return T3D_OK;

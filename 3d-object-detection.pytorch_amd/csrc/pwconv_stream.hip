@@ -109,7 +109,29 @@ __global__ __launch_bounds__(512, KU > 2 ? 1 : 2) void pw_stream_kernel(const Ge
   // ---- stage the weight chunk in fragment order: MFMA row lc of tile t <-> n_local = (t>>1)*32 + (lc>>2)*8 + (t&1)*4 + (lc&3)
   // (eight independent loads in flight per thread, branch-free: a block of the 7x7 stage stages up to 120 KB before it
   // can start, and with one dependent load -> store round per 8 KB that prologue WAS most of those launches)
-  {
+  if (a.wfrag) {
+    // fragment-order weights (include/t3d.h: T3D_W_FRAG): the chunk is NT * KS KB contiguous, in exactly the order of Wf -- a
+    // linear 16-B copy, fully coalesced (tiles past the matrix's last pair: zero).  Gathering the fragments out of the
+    // row-major matrix (below) runs at ~20 KB/us per CU: 2-6 us of every launch, 0.13 ms of the step (DESIGN finding 34)
+    constexpr int SU = 8;
+    const int total = NT * KS * 64, tiles = (a.Nout + 31) / 32 * 2, t0 = n0 / 16;
+    const ST8* __restrict__ P = reinterpret_cast<const ST8*>(a.w) + (size_t)t0 * KS * 64;
+    const int valid = max(0, min(NT, tiles - t0)) * KS * 64;
+    for (int i0 = tid; i0 < total; i0 += nthr * SU) {
+      ST8 v[SU];
+#pragma unroll
+      for (int u = 0; u < SU; ++u) v[u] = P[min(i0 + u * nthr, valid - 1)];
+#pragma unroll
+      for (int u = 0; u < SU; ++u) {
+        const int i = i0 + u * nthr;
+        if (i >= valid) {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) v[u][j] = (ST)0.f;
+        }
+        if (i < total) Wf[i] = v[u];
+      }
+    }
+  } else {
     constexpr int SU = 8;
     const int total = NT * KS * 64;
     for (int i0 = tid; i0 < total; i0 += nthr * SU) {

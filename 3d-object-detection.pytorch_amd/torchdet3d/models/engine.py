@@ -33,7 +33,7 @@ BN_EPS, BN_MOM = 1e-5, 0.1      # PyTorch defaults the reference relies on (SURV
 NREP = 16                       # reduction replicas (include/t3d.h: t3d_set_reduction_replicas)
 FUSED_EVAL_MIN_B = int(os.environ.get('T3D_FUSED_EVAL_MIN_B', '96'))
 DW_SLOTS = int(os.environ.get('T3D_DW_SLOTS', '512'))   # depthwise weight-gradient slots per layer (>= the workgroups of a t3d_dwconv_bwd launch)
-PW_DEEP = os.environ.get('T3D_PW_DEEP', '1') != '0'      # deep-contraction pointwise kernel + fragment-order weights (A/B switch)
+PW_FRAG = os.environ.get('T3D_PW_FRAG', '1') != '0'      # fragment-order weights for the 16-bit pointwise kernels (A/B switch)
 WORKSPACE_BYTES = 64 << 20      # partial weight-gradient tiles (include/t3d.h: t3d_set_workspace)
 MAIN_WORKSPACE_BYTES = 16 << 20
 # y-free expand-layer backward (csrc/pwconv_yfree.hip): minimum M*N elements of the expanded tensor; 0 disables
@@ -294,8 +294,8 @@ class Net:
         if getattr(self, '_pack_desc', None) is None:
             # one descriptor table for every 1x1 weight: a single launch re-packs them all each step
             self.w, self.wt, rows = {}, {}, []
-            # fragment-order copies for the deep-contraction kernel (csrc/pwconv_deep.hip), keyed by the plain copy's address:
-            # forward of a layer whose (K, N) the kernel takes, data gradient of one whose (N, K) it takes
+            # fragment-order copies (include/t3d.h: T3D_W_FRAG; the streaming kernel stages them with a linear copy, the
+            # deep-contraction kernel streams them), keyed by the plain copy's address: forward (K, N), data gradient (N, K)
             self._frag = {}
             lib = N.lib()
             for k, (s, kind) in self.shapes.items():
@@ -310,7 +310,7 @@ class Net:
                     out = self.w[k].data_ptr()
                 self.wt[k] = self._buf('wt:' + k, (kk, n))
                 fr = frt = 0
-                if self.dt == N.BF16 and PW_DEEP:
+                if self.dt in (N.BF16, N.F16) and PW_FRAG:
                     if lib.t3d_pwconv_wants_frag(kk, n):
                         f = self._buf('wf:' + k, (lib.t3d_pwconv_frag_bytes(n, kk) // 2,), zero=True)
                         self._frag[self.w[k].data_ptr()], fr = f, f.data_ptr()
@@ -661,9 +661,8 @@ class Net:
         return sv
 
     def _wsel(self, w, plain=True):
-        """(dtype argument, weight pointer) of a pointwise launch: the fragment-order copy where the layer has one and the launch
-        is one the deep-contraction kernel takes (`plain`: no squeeze-excite gates / per-sample coefficients)."""
-        f = self._frag.get(w.data_ptr()) if plain and self.dt == N.BF16 else None
+        """(dtype argument, weight pointer) of a pointwise launch: the fragment-order copy where the layer has one."""
+        f = self._frag.get(w.data_ptr()) if self.dt in (N.BF16, N.F16) else None
         return (self.dt | N.W_FRAG, N.ptr(f)) if f is not None else (self.dt, N.ptr(w))
 
     def _resolve(self, src):
@@ -680,7 +679,8 @@ class Net:
         """1x1 conv forward reading `x`; a pending block output is materialised by the conv itself (t3d_pwconv_fwd_mat)."""
         st, nb = N.stream(), M * (K + Nn) * self.esz
         if x.zbuf is not None:
-            self._c('t3d_pwconv_fwd_mat', self.dt, N.ptr(x.t), x.pro, N.ptr(x.zres), N.ptr(x.zbuf), N.ptr(w), N.ptr(y),
+            wd, wp = self._wsel(w)
+            self._c('t3d_pwconv_fwd_mat', wd, N.ptr(x.t), x.pro, N.ptr(x.zres), N.ptr(x.zbuf), wp, N.ptr(y),
                     self._st(bn_out), M, HW, K, Nn, st, nbytes=nb, fwd=x.bn)
             x.t, x.pro, x.zres, x.zbuf = x.zbuf, None, None, None
         else:
@@ -1124,7 +1124,8 @@ class Net:
             bn2 = s2.bn
             proj_wgrad()
             dv = self._buf(f'dv2g:{i}', (M2, C))
-            N.call('t3d_pwconv_dgrad', dt, N.ptr(dz), N.ptr(rec['y3']), bb3, N.ptr(self.wt[pwn]), None, None, None,
+            wd, wp = self._wsel(self.wt[pwn])
+            N.call('t3d_pwconv_dgrad', wd, N.ptr(dz), N.ptr(rec['y3']), bb3, wp, None, None, None,
                    N.ptr(dv), None, None, M2, HW2, C, blk.cout, st, nbytes=M2 * (C + blk.cout) * self.esz)
             ps = self._buf(f'se_ps:{i}', (B, C, 2), torch.float32)
             N.call('t3d_se_after_sums', dt, N.ptr(dv), N.ptr(s2.raw), se['pro2n'], N.ptr(ps), B, HW2, C, st)
@@ -1149,7 +1150,8 @@ class Net:
             proj_wgrad()
             ps = self._buf(f'se_ps:{i}', (B, C, 2), torch.float32, zero=True)
             dv2 = self._buf(f'dv2:{i}', (M2, C))
-            N.call('t3d_pwconv_dgrad', dt, N.ptr(dz), N.ptr(rec['y3']), bb3, N.ptr(self.wt[pwn]), N.ptr(s2.raw), s2.gpro,
+            wd, wp = self._wsel(self.wt[pwn])
+            N.call('t3d_pwconv_dgrad', wd, N.ptr(dz), N.ptr(rec['y3']), bb3, wp, N.ptr(s2.raw), s2.gpro,
                    None, N.ptr(dv2), None, N.ptr(ps), M2, HW2, C, blk.cout, st, nbytes=M2 * (C + blk.cout) * self.esz)
             g = self._buf(f'se_g:{i}', (B, C), torch.float32)
             dq = self._buf(f'se_dq:{i}', (B, C), torch.float32)

@@ -34,7 +34,7 @@ class ResNetEngine(Net):
                     self.wt[k] = self._buf('wct:' + k, (kp, n))
                     # fragment-order copies for the deep-contraction kernel (engine.py: `_frag`, `_wsel`)
                     fr = frt = None
-                    if self.dt == N.BF16 and hasattr(self, '_frag'):
+                    if self.dt in (N.BF16, N.F16) and hasattr(self, '_frag') and self._frag is not None:
                         lib = N.lib()
                         if lib.t3d_pwconv_wants_frag(kp, n):
                             fr = self._buf('wcf:' + k, (lib.t3d_pwconv_frag_bytes(n, kp) // 2,), zero=True)

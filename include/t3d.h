@@ -28,10 +28,12 @@ extern "C" {
 
 enum { T3D_F32 = 0, T3D_BF16 = 1, T3D_F16 = 2 };    /* T3D_F16: INFERENCE forward only (round 4): t3d_stem_im2col[_u8], t3d_pwconv_fwd,
                                                          t3d_dwconv_fwd (k = 3), t3d_bn_apply, t3d_pool_fwd, t3d_pack_weight[s_batched] */
-/* Weight layout flag of the bf16 pointwise convolutions (round 4): `T3D_BF16 | T3D_W_FRAG` as the dtype argument of
- * t3d_pwconv_fwd / t3d_pwconv_dgrad says that `w` / `wt` is the FRAGMENT-ORDER copy made by t3d_pwconv_pack_frag (or by
- * t3d_pack_weights_batched's `frag` / `frag_t` outputs) of the matrix the plain call takes.  Only for shapes for which
- * t3d_pwconv_wants_frag returns 1 (deep contractions: csrc/pwconv_deep.hip); any other use returns T3D_ERR_ARG. */
+/* Weight layout flag of the 16-bit pointwise convolutions (round 4): `T3D_BF16 | T3D_W_FRAG` (or `T3D_F16 | ...`) as the dtype
+ * argument of t3d_pwconv_fwd / t3d_pwconv_fwd_mat / t3d_pwconv_dgrad says that `w` / `wt` is the FRAGMENT-ORDER copy made by
+ * t3d_pwconv_pack_frag (or by t3d_pack_weights_batched's `frag` / `frag_t` outputs) of the matrix the plain call takes.  The
+ * deep-contraction kernel streams the fragments from L2 (csrc/pwconv_deep.hip; t3d_pwconv_wants_frag names its shapes), the
+ * streaming kernel stages its weight chunk with one linear copy (csrc/pwconv_stream.hip); shapes neither of them takes return
+ * T3D_ERR_UNSUPPORTED / T3D_ERR_ARG (the LDS-tiled fallback kernel reads the row-major matrix only). */
 enum { T3D_W_FRAG = 0x100 };
 enum { T3D_ACT_NONE = 0, T3D_ACT_RELU = 1, T3D_ACT_RELU6 = 2, T3D_ACT_HSWISH = 3 };
 enum { T3D_OK = 0, T3D_ERR_ARG = -1, T3D_ERR_LAUNCH = -2, T3D_ERR_UNSUPPORTED = -3 };
@@ -99,13 +101,16 @@ typedef struct {
 int t3d_pwconv_fwd(int dtype, const void* x, const t3d_prologue* pro, const void* w, const float* bias,
                    void* y, double* stats, int M, int HW, int K, int N, void* stream);
 
-/* Fragment-order weights for the deep-contraction kernel (csrc/pwconv_deep.hip; no reference counterpart: a layout of the
- * weights nn.Conv2d holds, mobilenetv3.py:142-159).  `w` [rows, cols] bf16 row-major -> out[((T*KS + ks)*64 + lg*16 + lc)*8 + j]
- * = w[16 T + lc][32 ks + 8 lg + j] (KS = ceil(cols / 32), zero past rows / cols): the A operand of
- * v_mfma_f32_16x16x32_bf16 for 16 output channels x 32 contraction elements is 1 KB contiguous, so a wave loads it with
- * one fully coalesced instruction instead of 64 separate 16-byte requests.  t3d_pwconv_frag_bytes: size of `out`.
- * t3d_pwconv_wants_frag(K, N): 1 if the bf16 pointwise kernels take the fragment-order layout for a contraction over K
- * into N output channels (forward: (K, N) of the layer with `w`; data gradient: (N, K) with the copy of `wt`). */
+/* Fragment-order weights (no reference counterpart: a layout of the weights nn.Conv2d holds, mobilenetv3.py:142-159).
+ * `w` [rows, cols] in a 16-bit storage type, row-major -> out[((T*KS + ks)*64 + lg*16 + lc)*8 + j] = w[row(T, lc)][32 ks + 8 lg + j],
+ * row(T, lc) = 32 (T >> 1) + 8 (lc >> 2) + 4 (T & 1) + (lc & 3), T < 2 ceil(rows / 32), KS = ceil(cols / 32), zero past rows / cols:
+ * the A operand of v_mfma_f32_16x16x32_{bf16,f16} for 16 output channels x 32 contraction elements is 1 KB contiguous (a wave
+ * loads it with one fully coalesced instruction instead of 64 separate 16-byte requests), and the row permutation inside a
+ * pair of tiles leaves every lane with 8 consecutive output channels of a 32-channel block.  t3d_pwconv_frag_bytes: size of
+ * `out`.  t3d_pwconv_wants_frag(K, N): 1 where the layout pays -- the deep-contraction kernel's shapes (K >= 512 and an output
+ * wider than the streaming kernel's LDS chunk) -- for a contraction over K into N output channels (forward: (K, N) of the
+ * layer with `w`; data gradient: (N, K) with the copy of `wt`).  The flag itself is accepted for every shape the streaming
+ * kernel takes as well (K, N multiples of 8, K <= 1920). */
 int t3d_pwconv_frag_bytes(int rows, int cols);
 int t3d_pwconv_wants_frag(int K, int N);
 int t3d_pwconv_pack_frag(const void* w, void* out, int rows, int cols, void* stream);

@@ -34,6 +34,14 @@ def _pack(w, dtype, transpose=False):
     return out
 
 
+def _takes_frag(K, N, plain=True):
+    """Shapes for which the 16-bit pointwise entry points accept T3D_W_FRAG (include/t3d.h): the streaming kernel's (its LDS chunk
+    holds >= 2 tiles of every k-step) and, for launches without bias / gates / per-sample coefficients, the deep-contraction
+    kernel's."""
+    from torchdet3d import _native as Nt
+    return K % 8 == 0 and N % 8 == 0 and ((K + 31) // 32 <= 60 or (plain and bool(Nt.lib().t3d_pwconv_wants_frag(K, N))))
+
+
 def _frag(wd):
     """Fragment-order copy of a packed bf16 weight matrix (t3d_pwconv_pack_frag)."""
     from torchdet3d import _native as N
@@ -51,11 +59,12 @@ def test_fragment_order_weight_layout():
     for r, c in [(160, 960), (40, 72), (520, 1032)]:
         w = torch.randn(r, c, generator=g)
         wq = w.to('cuda', torch.bfloat16)
-        KS = (c + 31) // 32
-        ref = torch.zeros((r + 15) // 16, KS, 4, 16, 8, dtype=torch.bfloat16)
-        wp = torch.zeros((r + 15) // 16 * 16, KS * 32, dtype=torch.bfloat16)
+        KS, NP = (c + 31) // 32, (r + 31) // 32
+        wp = torch.zeros(NP * 32, KS * 32, dtype=torch.bfloat16)
         wp[:r, :c] = wq.cpu()
-        ref = wp.view(-1, 16, KS, 4, 8).permute(0, 2, 3, 1, 4).contiguous().view(-1)
+        # row(T, lc) = 32 (T >> 1) + 8 (lc >> 2) + 4 (T & 1) + (lc & 3): [pair][lc >> 2][T & 1][lc & 3] -> [pair][T & 1][lc >> 2][lc & 3]
+        rows = wp.view(NP, 4, 2, 4, KS * 32).permute(0, 2, 1, 3, 4).reshape(NP * 2, 16, KS, 4, 8)      # [T][lc][ks][lg][j]
+        ref = rows.permute(0, 2, 3, 1, 4).contiguous().view(-1)                                         # [T][ks][lg][lc][j]
         got = _frag(wq)
         torch.cuda.synchronize()
         assert torch.equal(got.cpu(), ref)
@@ -73,8 +82,9 @@ def test_fragment_order_weight_layout():
     x = torch.zeros(64, 96, device='cuda', dtype=torch.bfloat16)
     y = torch.zeros(64, 24, device='cuda', dtype=torch.bfloat16)
     assert N.lib().t3d_pwconv_wants_frag(96, 24) == 0 and N.lib().t3d_pwconv_wants_frag(960, 160) == 1
-    rc = N.lib().t3d_pwconv_fwd(N.BF16 | N.W_FRAG, N.ptr(x), None, N.ptr(y), None, N.ptr(y), None, 64, 64, 96, 24, N.stream())
-    assert rc == -1          # T3D_ERR_ARG
+    assert N.lib().t3d_pwconv_wants_frag(2048, 8) == 1 and N.lib().t3d_pwconv_wants_frag(960, 64) == 0
+    rc = N.lib().t3d_pwconv_fwd(N.F32 | N.W_FRAG, N.ptr(x), None, N.ptr(y), None, N.ptr(y), None, 64, 64, 96, 24, N.stream())
+    assert rc == -1          # T3D_ERR_ARG: 16-bit storage only
 
 
 SHAPES = [  # B, HW, K, N
@@ -121,10 +131,10 @@ def test_pwconv_fwd(B, HW, K, N, dt, mode):
     bd = bias.cuda() if bias is not None else None
     p = None if mode == 'plain' else Nt.prologue(keep[0], keep[1], keep[2] if mode.startswith('se') else None, act,
                                                  mode == 'se_post')
-    # second pass for the shapes of the deep-contraction kernel (csrc/pwconv_deep.hip): the same call with the fragment-order copy
-    # of the weights and T3D_W_FRAG (no bias, no gates there)
+    # second pass: the same call with the fragment-order copy of the weights and T3D_W_FRAG (streaming kernel: linear weight
+    # staging; deep-contraction kernel, csrc/pwconv_deep.hip, for its shapes when there are no gates)
     variants = [(Nt.dtype_code(xd), wd)]
-    if dt == 'bf16' and mode == 'bnact' and Nt.lib().t3d_pwconv_wants_frag(K, N):
+    if dt == 'bf16' and _takes_frag(K, N, mode == 'bnact'):
         variants.append((Nt.BF16 | Nt.W_FRAG, _frag(wd)))
     for code, wv in variants:
         y.zero_(); stats.zero_()
@@ -188,8 +198,8 @@ def test_pwconv_dgrad(B, HW, K, N, dt, mode):
     pin = Nt.prologue(keep[3], keep[4], keep[5] if mode == 'se_pre' else None, act, False) if has_act else None
     use_ps = mode == 'se_pre'
     variants = [(Nt.dtype_code(dzd), wt)]
-    if dt == 'bf16' and mode in ('input', 'input_res', 'bnact') and Nt.lib().t3d_pwconv_wants_frag(N, K):
-        variants.append((Nt.BF16 | Nt.W_FRAG, _frag(wt)))      # deep-contraction kernel: fragment-order copy of wt
+    if dt == 'bf16' and _takes_frag(N, K, mode in ('input', 'input_res', 'bnact')):
+        variants.append((Nt.BF16 | Nt.W_FRAG, _frag(wt)))      # fragment-order copy of wt
     for code, wv in variants:
         dx.zero_(); stats.zero_()
         Nt.call('t3d_pwconv_dgrad', code, Nt.ptr(dzd), Nt.ptr(yd), bb, Nt.ptr(wv),

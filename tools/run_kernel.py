@@ -54,7 +54,7 @@ else:
     N.call('t3d_set_workspace', N.ptr(ws), ws.numel())
     N.call('t3d_set_reduction_replicas', nrep, 2 * max(K, Nn))
     def frag(wm, kk, nn):       # --frag: the fragment-order copy + T3D_W_FRAG where the deep-contraction kernel takes the shape
-        if '--frag' not in sys.argv or dt != torch.bfloat16 or not N.lib().t3d_pwconv_wants_frag(kk, nn):
+        if '--frag' not in sys.argv or dt != torch.bfloat16:
             return N.dtype_code(x), wm
         out = torch.zeros(N.lib().t3d_pwconv_frag_bytes(*wm.shape) // 2, device=dev, dtype=dt)
         N.call('t3d_pwconv_pack_frag', N.ptr(wm), N.ptr(out), wm.shape[0], wm.shape[1], N.stream())

@@ -2,6 +2,6 @@
 cd $GRAFT_REPO_ROOT; export TMPDIR=/tmp
 for i in 1 2; do
   for v in 0 1; do
-    echo -n "T3D_PW_DEEP=$v  "; T3D_PW_DEEP=$v python bench.py --steps 60 --warmup 10 --no-cpu-baseline 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(d['value'], d['ms_per_step'], d['config'].get('final_loss'))"
+    echo -n "T3D_PW_FRAG=$v  "; T3D_PW_FRAG=$v python bench.py --steps 60 --warmup 10 --no-cpu-baseline 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(d['value'], d['ms_per_step'], d['config'].get('final_loss'))"
   done
 done
