@@ -751,7 +751,7 @@ int launch_s1c(Dw3BArgs& a, hipStream_t st) {
   dim3 grid;
   // tools/sweep_dwb.sh: the 4-channel variant needs AGPR spill space (1 wave/SIMD) and is best with one block per CU;
   // the 2-channel variant fits 2 waves/SIMD and is best with two (every extra block is one more flush)
-  const int tb_env = 0;
+  static const int tb_env = getenv("T3D_DW_TB") ? atoi(getenv("T3D_DW_TB")) : 0;      // (sweep knob, tools/scratch/sweep_tb.sh)
   const int target_blocks = tb_env ? tb_env : (CH == 2 && two_col ? 512 : 256);
   a.nrep = g_t3d_reduce.nrep;
   a.rstride = g_t3d_reduce.stats_stride;
@@ -1142,8 +1142,8 @@ int launch_s2(Dw3BArgs& a, hipStream_t st) {
   a.rows_per_chunk = cdiv(Ho, nchunks);
   a.nchunks = cdiv(Ho, a.rows_per_chunk);
   dim3 grid;
-  const int tb_env = 0;
-  const int target_blocks = tb_env ? tb_env : (Ho >= 28 ? 512 : 384);   // tools/sweep_dwb.sh
+  static const int tb_env = getenv("T3D_DW_TB") ? atoi(getenv("T3D_DW_TB")) : 0;      // (sweep knob, tools/scratch/sweep_tb.sh)
+  const int target_blocks = tb_env ? tb_env : 512;   // (round 4 sweep, tools/scratch/sweep_tb.sh: 14x14x576 46.6 -> 41.4 us, 28x28x192 54.3 -> 51.5 against 384)
   a.nrep = g_t3d_reduce.nrep;
   a.rstride = g_t3d_reduce.stats_stride;
   const int nth = 256;

@@ -604,8 +604,9 @@ int launch_ch(Dw3Args& a, int s, hipStream_t st) {
   const int Wcols = use2 ? (a.Wo + 1) / 2 : a.Wo;     // work items per row: column pairs or columns
   dim3 grid;
   // persistent blocks: enough to fill the chip, few enough that the per-block flush stays cheap (tools/sweep_dwf.sh)
-  const int tb_env = 0;
-  const int target_blocks = tb_env ? tb_env : (s == 1 ? 512 : 768);
+  static const int tb_env = getenv("T3D_DW_TB") ? atoi(getenv("T3D_DW_TB")) : 0;      // (sweep knob, tools/scratch/sweep_tb.sh)
+  // (round 4, tools/scratch/sweep_tb.sh: the small-spatial s=1 layers gain 4-5 % at 768: 28x28x192 38.0 -> 35.7 us, 14x14x384 24.8 -> 23.7)
+  const int target_blocks = tb_env ? tb_env : ((s == 1 && a.H > 28) ? 512 : 768);
   a.nrep = g_t3d_reduce.nrep;
   a.rstride = g_t3d_reduce.stats_stride;
   if (CG < 64) {
