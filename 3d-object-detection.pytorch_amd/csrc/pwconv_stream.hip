@@ -673,9 +673,14 @@ int T3D_PW_LAUNCH(GemmArgs& a, hipStream_t st) {
   }
   switch (NT) {
     case 2: return launch_nt<2, 2>(a, KS, st, deep_ku);
-    case 4: return launch_nt<4, 2>(a, KS, st, deep_ku);
-    case 6: return launch_nt<6, 1>(a, KS, st, deep_ku);
-    case 8: return launch_nt<8, 1>(a, KS, st, deep_ku);
+    case 4: return launch_nt<4, 2>(a, KS, st, deep_ku);     // (R = 4 for NT = 2 / 4: 5-40 % slower, measured)
+    case 6:
+      // two 16-pixel groups per iteration (round 4): twice the loads in flight per wave and two MFMAs per weight fragment read --
+      // 16 -> 96 @112x112 216 -> 209 us, 96 <- 24 390 -> 366, 576 -> 96 @14x14 30.0 -> 26.7, step 6.997 -> 6.904 ms (three A/B
+      // pairs).  Not for the squeeze-excite / per-sample variants: their extra registers spill at R = 2 (72 VGPRs to scratch)
+      if (a.per_sample || a.ps_stats || a.e_se || (!a.dgrad && a.p2)) return launch_nt<6, 1>(a, KS, st, deep_ku);
+      return launch_nt<6, 2>(a, KS, st, deep_ku);
+    case 8: return launch_nt<8, 1>(a, KS, st, deep_ku);     // (R = 2: forward 64 -> 384 @14x14 -8 %, data gradient spills 32 VGPRs)
     default: return launch_nt<10, 1>(a, KS, st, deep_ku);
   }
 }
