@@ -671,6 +671,12 @@ int T3D_PW_LAUNCH(GemmArgs& a, hipStream_t st) {
       if (ch < best_chunks || (ch == best_chunks && pad < best_pad)) { best_chunks = ch; best_pad = pad; NT = nt; }
     }
   }
+  // wide outputs that are a whole number of 96-channel tiles (384, 576, 960 of the 14x14 / 7x7 stages) and need several chunks
+  // anyway: the 96-channel tile with two pixel groups per iteration beats fewer, wider chunks with one (round 4: 96 -> 576 31.6 ->
+  // 28.7 us, 160 -> 960 23.4 -> 21.6, 64 -> 384 22.4 -> 20.8; 144 channels in ONE 160-wide chunk stays: 72 vs 79 us)
+  if (NT > 6 && nt_cap >= 6 && cdiv(a.Nout, NT * 16) > 1 && a.Nout % 96 == 0 &&
+      !(a.per_sample || a.ps_stats || a.e_se || (!a.dgrad && a.p2)))
+    NT = 6;
   switch (NT) {
     case 2: return launch_nt<2, 2>(a, KS, st, deep_ku);
     case 4: return launch_nt<4, 2>(a, KS, st, deep_ku);     // (R = 4 for NT = 2 / 4: 5-40 % slower, measured)
