@@ -778,7 +778,9 @@ int launch_s1c(Dw3BArgs& a, hipStream_t st) {
     if (gx < 1) gx = 1;
     grid = dim3(gx, ns);
   }
-  if (two_col && (size_t)a.B * a.H * a.W * a.C * sizeof(T) >= (1ull << 32)) return T3D_ERR_UNSUPPORTED;   // 32-bit buffer offsets
+  // 32-bit buffer offsets, and the dropped-lane sentinel 0x80000000 has to stay out of range.  This return sits in front
+  // of t3d_take_fold below: a refused launch must leave a pending finalize request for the tiled fallback to honour.
+  if (two_col && (size_t)a.B * a.H * a.W * a.C * sizeof(T) >= (1ull << 31)) return T3D_ERR_UNSUPPORTED;
   {   // depthwise weight gradient: one slot per workgroup when the caller provides enough of them (t3d_set_dw_slots)
     const int needed = (two_col && a.slab) ? (int)grid.x : (int)(grid.x * grid.y);
     a.dw_slots = (a.dw && g_t3d_reduce.dw_slots >= needed) ? needed : 0;
@@ -1171,13 +1173,14 @@ int launch_s2(Dw3BArgs& a, hipStream_t st) {
   }
   const size_t lds = (size_t)22 * (a.slab ? 64 * CH : a.C) * sizeof(float);   // [11][Cb] fp64
   a.noflush = getenv("T3D_DEBUG_NOFLUSH") ? 1 : 0;
+  // (in front of t3d_take_fold: a refused launch leaves the pending finalize request to the tiled fallback)
+  if ((size_t)a.B * a.H * a.W * a.C * sizeof(T) >= (1ull << 31)) return T3D_ERR_UNSUPPORTED;     // 32-bit buffer offsets
   if (!a.per_sample) {
     a.fold = t3d_take_fold(a.alpha);
   } else {
     if (const int rc = t3d_fold_fallback(a.alpha, st)) return rc;
     a.fold = nullptr;
   }
-  if ((size_t)a.B * a.H * a.W * a.C * sizeof(T) >= (1ull << 31)) return T3D_ERR_UNSUPPORTED;     // 32-bit buffer offsets
   switch (a.act) {
     case T3D_ACT_RELU: T3D_LAUNCH_TIMED((dw3_bwd_s2_kernel<T, PF, 256, T3D_ACT_RELU>), grid, dim3(256), lds, st, a); break;
     case T3D_ACT_RELU6: T3D_LAUNCH_TIMED((dw3_bwd_s2_kernel<T, PF, 256, T3D_ACT_RELU6>), grid, dim3(256), lds, st, a); break;

@@ -55,6 +55,7 @@ struct WgtArgs {
   double* stats;          // [2][K] replicas or null
   int nrep;
   long long rstride;
+  int assign;             // dw is WRITTEN, not accumulated into (the y-free product matrix: no clear needed ahead of the launch)
 };
 
 // one 16x16 tile row (transposed) fragment: pixels 8*lg .. 8*lg+7 of the step, channels ch0..ch0+15
@@ -481,7 +482,7 @@ __global__ __launch_bounds__(256 * G) void pw_wgrad_tr_kernel(const WgtArgs a) {
 // meet in LDS in index order.  Every element has one owner, so the final add into dW is a plain read-modify-write.
 template <int SP>
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw, int N, int K,
-                                                           int PB, int QB, int qtiles, int tiles, int S) {
+                                                           int PB, int QB, int qtiles, int tiles, int S, int assign) {
   // straight orientation (P = N, Q = K): threads run along q = k, the contiguous axis of both the partial tiles and dW
   constexpr int EL = 256 / SP;
   __shared__ float red[SP][EL];
@@ -505,7 +506,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
       for (int j = 1; j < SP; ++j) s += red[j][el];
     }
   }
-  if (sp == 0 && live) dw[(size_t)p * K + q] += s;
+  if (sp == 0 && live) dw[(size_t)p * K + q] = assign ? s : dw[(size_t)p * K + q] + s;
 }
 
 // the transposed orientation (dW [N][K] with the partial tiles' contiguous axis q = n): a 32 x 32 patch per workgroup goes
@@ -514,7 +515,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
 // 47 us, now a few).  1024 threads = 32 (q) x 32 / SP (p rows, SP of them per thread) x SP split groups.
 template <int SG>
 __global__ __launch_bounds__(256) void wgrad_reduce_tr_kernel(const float* __restrict__ ws, float* __restrict__ dw, int N, int K,
-                                                               int PB, int QB, int qtiles, int tiles, int S) {
+                                                               int PB, int QB, int qtiles, int tiles, int S, int assign) {
   // 256 threads = 32 (q) x PT (p rows) x SG (split groups), PT * SG = 8: one row and S / SG partials per thread.  Many
   // splits mean a small dW (a 112x112 layer's 96 x 24): narrow patches (PT = 1 for SG = 8) give it enough workgroups --
   // with 32 x 32 patches three workgroups walked 256 partials per thread, 83 us of pure load latency.  (256 threads, not
@@ -541,7 +542,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_tr_kernel(const float* __res
       float t = part[pl2][ql];
 #pragma unroll
       for (int g = 1; g < SG; ++g) t += part[g * PT + pl2][ql];
-      dw[(size_t)n * K + k] += t;
+      dw[(size_t)n * K + k] = assign ? t : dw[(size_t)n * K + k] + t;
     }
   }
 }
@@ -576,6 +577,8 @@ int launch_d(WgtArgs& a, hipStream_t st) {
   a.rows_per_split = cdiv(cdiv(a.M, S), STEP) * STEP;
   S = cdiv(a.M, a.rows_per_split);
   a.ws = use_ws ? reinterpret_cast<float*>(g_t3d_ws.ptr) : nullptr;
+  // (atomics into dw: an assigned-to dw is cleared first; with partial tiles the reduction writes it)
+  if (a.assign && !use_ws && hipMemsetAsync(a.dw, 0, (size_t)a.N * a.K * sizeof(float), st) != hipSuccess) return T3D_ERR_LAUNCH;
   if (lds > 64 * 1024)
     (void)hipFuncSetAttribute((const void*)pw_wgrad_tr_kernel<NTPW, NTQ, SWAP, G, D, GEN, YF, SK>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   a.nsplit = S;
@@ -586,10 +589,10 @@ int launch_d(WgtArgs& a, hipStream_t st) {
   do {                                                                                                                            \
     if (SWAP)                                                                                                                     \
       hipLaunchKernelGGL(wgrad_reduce_tr_kernel<(SPV == 16 ? 8 : SPV)>, dim3(cdiv(a.K, 8 / (SPV == 16 ? 8 : SPV)) * cdiv(a.qtiles * QB, 32)), dim3(256), 0, st, \
-                         a.ws, a.dw, a.N, a.K, PB, QB, a.qtiles, tiles, S);                                                       \
+                         a.ws, a.dw, a.N, a.K, PB, QB, a.qtiles, tiles, S, a.assign);                                             \
     else                                                                                                                          \
       hipLaunchKernelGGL(wgrad_reduce_kernel<SPV>, dim3(cdiv(a.N * a.qtiles * QB, 256 / SPV)), dim3(256), 0, st, a.ws, a.dw, a.N, \
-                         a.K, PB, QB, a.qtiles, tiles, S);                                                                        \
+                         a.K, PB, QB, a.qtiles, tiles, S, a.assign);                                                              \
   } while (0)
     if (S >= 64) T3D_WGR(16);
     else if (S >= 8) T3D_WGR(4);
@@ -667,9 +670,9 @@ static int choose_and_launch(WgtArgs& a, hipStream_t st) {
 // fixed-order sum of partial tiles (straight orientation) for the fp32 parity kernel of pwconv_wgrad.hip
 int t3d_pw_wgrad_reduce(const float* ws, float* dw, int N, int K, int PB, int QB, int qtiles, int tiles, int S, hipStream_t st) {
   const int blocks = [&](int sp) { return cdiv(N * qtiles * QB, 256 / sp); }(S >= 64 ? 16 : (S >= 8 ? 4 : 1));
-  if (S >= 64) hipLaunchKernelGGL(wgrad_reduce_kernel<16>, dim3(blocks), dim3(256), 0, st, ws, dw, N, K, PB, QB, qtiles, tiles, S);
-  else if (S >= 8) hipLaunchKernelGGL(wgrad_reduce_kernel<4>, dim3(blocks), dim3(256), 0, st, ws, dw, N, K, PB, QB, qtiles, tiles, S);
-  else hipLaunchKernelGGL(wgrad_reduce_kernel<1>, dim3(blocks), dim3(256), 0, st, ws, dw, N, K, PB, QB, qtiles, tiles, S);
+  if (S >= 64) hipLaunchKernelGGL(wgrad_reduce_kernel<16>, dim3(blocks), dim3(256), 0, st, ws, dw, N, K, PB, QB, qtiles, tiles, S, 0);
+  else if (S >= 8) hipLaunchKernelGGL(wgrad_reduce_kernel<4>, dim3(blocks), dim3(256), 0, st, ws, dw, N, K, PB, QB, qtiles, tiles, S, 0);
+  else hipLaunchKernelGGL(wgrad_reduce_kernel<1>, dim3(blocks), dim3(256), 0, st, ws, dw, N, K, PB, QB, qtiles, tiles, S, 0);
   T3D_CHECK_LAUNCH();
   return T3D_OK;
 }
@@ -695,7 +698,9 @@ int t3d_pw_wgrad_tr_entry(const void* dz, const void* y, const t3d_bnbwd* bb, co
 struct YfCfg { int ntpw, ntq, sk, S, rows_per_split, PB, QB; };
 static bool yf_cfg(int M, int K, int N, YfCfg& c) {
   const int P = N + K + 8;
-  if (K > 32 || P > 256) return false;
+  // P <= 64: t3d_pwconv_yfree_prep2 lays wd out with 64-column rows there, the kernel's narrowest tile (ntpw = 2) stages
+  // 128-column rows -- such shapes take the two-launch pair
+  if (K > 32 || P > 256 || P <= 64) return false;
   c.ntq = K <= 16 ? 1 : 2;
   c.ntpw = P <= 128 ? 2 : (P <= 192 ? 3 : 4);
   c.sk = M >= (1 << 20) ? 2 : 1;
@@ -764,10 +769,9 @@ int t3d_pw_bwd_yfree_reduce(void* scratch, float** tmp_out, int M, int K, int N,
   if (!yf_cfg(M, K, N, c)) return T3D_ERR_UNSUPPORTED;
   float* ws = reinterpret_cast<float*>(scratch);
   float* tmp = ws + (size_t)c.S * c.PB * c.QB;
-  const size_t tmp_bytes = (size_t)(N + K + 8) * K * sizeof(float);
-  if (hipMemsetAsync(tmp, 0, tmp_bytes, st) != hipSuccess) return T3D_ERR_LAUNCH;
   const int rows = N + K + 8;
-#define T3D_YFR(SPV) hipLaunchKernelGGL(wgrad_reduce_kernel<SPV>, dim3(cdiv(rows * c.QB, 256 / SPV)), dim3(256), 0, st, ws, tmp, rows, K, c.PB, c.QB, 1, 1, c.S)
+  // (every entry of tmp has one owner thread that WRITES it: no clear ahead of the launch)
+#define T3D_YFR(SPV) hipLaunchKernelGGL(wgrad_reduce_kernel<SPV>, dim3(cdiv(rows * c.QB, 256 / SPV)), dim3(256), 0, st, ws, tmp, rows, K, c.PB, c.QB, 1, 1, c.S, 1)
   if (c.S >= 64) T3D_YFR(16);
   else if (c.S >= 8) T3D_YFR(4);
   else T3D_YFR(1);
@@ -784,5 +788,6 @@ int t3d_pw_wgrad_tr_yfree(const void* dz, const void* x, float* tmp, int M, int 
   a.dz = dz; a.x = x; a.y = dz;
   a.dw = tmp; a.M = M; a.HW = HW; a.K = K;
   a.yfree = 1; a.Nz = N; a.N = N + K + 8;
+  a.assign = 1;
   return choose_and_launch(a, st);
 }

@@ -242,7 +242,7 @@ extern "C" int t3d_pwconv_wgrad_yfree(const void* dz, const void* x, const t3d_b
   if (!g_t3d_ws.ptr || (size_t)g_t3d_ws.bytes < 2 * tmp_bytes + (1 << 20)) return T3D_ERR_UNSUPPORTED;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   float* tmp = reinterpret_cast<float*>(reinterpret_cast<char*>(g_t3d_ws.ptr) + ((g_t3d_ws.bytes - tmp_bytes) & ~(size_t)255));
-  if (hipMemsetAsync(tmp, 0, tmp_bytes, st) != hipSuccess) return T3D_ERR_LAUNCH;
+  // (tmp is written, not accumulated into: t3d_pw_wgrad_tr_yfree's reduction assigns every entry, or clears it first)
   const T3dWorkspace saved = g_t3d_ws;
   g_t3d_ws.bytes = reinterpret_cast<char*>(tmp) - reinterpret_cast<char*>(g_t3d_ws.ptr);   // keep the tiles off the tail
   const int rc = t3d_pw_wgrad_tr_yfree(dz, x, tmp, M, HW, K, N, st);

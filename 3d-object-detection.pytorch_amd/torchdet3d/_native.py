@@ -120,6 +120,18 @@ SIGNATURES = {
     't3d_dropout_mask': [_P, _L, ctypes.c_ulonglong, ctypes.c_ulonglong, _F, _P],
     't3d_loss_fwd_bwd': [_LP, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P],
     't3d_metrics_per_sample': [_P, _P, _P, _P, _P, _I, _I, _P],
+    # step plans (csrc/plan.hip): record once, replay with one call
+    't3d_plan_create': [ctypes.POINTER(_P)],
+    't3d_plan_destroy': [_P],
+    't3d_plan_add_call': [_P, ctypes.c_char_p, _I, ctypes.POINTER(_I), ctypes.POINTER(ctypes.c_ulonglong), ctypes.POINTER(_I)],
+    't3d_plan_add_fork': [_P, _P, _P],
+    't3d_plan_add_copy_d2h': [_P, _I, _P, _L, _P],
+    't3d_plan_add_event_record': [_P, _I, _P],
+    't3d_plan_end_segment': [_P],
+    't3d_plan_num_ops': [_P, _I],
+    't3d_plan_time_entry': [_P, ctypes.c_char_p, _I],
+    't3d_plan_failed_op': [_P, ctypes.POINTER(_I)],
+    't3d_plan_run': [_P, _I, ctypes.POINTER(ctypes.c_ulonglong), _I, ctypes.POINTER(_P), _I],
 }
 
 _lib = None
@@ -205,12 +217,20 @@ _KERNEL_TIMED = frozenset(('t3d_dwconv_fwd', 't3d_dwconv_bwd'))     # entry poin
 _ABLATE = frozenset(x for x in os.environ.get('T3D_ABLATE', '').split(',') if x)
 
 
-def call(name, *args, nbytes=None):
+# plan slots (values that change from step to step): see trainer/step_plan.py
+SLOT_IMGS, SLOT_GT, SLOT_CATS, SLOT_DROPOUT, SLOT_STEP, SLOT_LR, SLOT_RB_DST, SLOT_RB_EVENT, NSLOTS = range(9)
+recorder = None    # set to a PlanRecorder while a step is being recorded (torchdet3d/trainer/step_plan.py)
+
+
+def call(name, *args, nbytes=None, slots=None):
     """Enqueue one C-ABI entry point on the current stream; `nbytes` = algorithmic HBM bytes of the launch
-    (bookkeeping for the roofline report only)."""
+    (bookkeeping for the roofline report only); `slots` = {argument index: plan slot} for the arguments that change
+    from step to step (only looked at while a plan is being recorded)."""
     if _ABLATE and name in _ABLATE:
         return
     fn = getattr(lib(), name)
+    if recorder is not None:
+        recorder.add_call(name, args, nbytes, slots)
     t = timer
     if t is not None and (t.only is None or name in t.only):
         e0, e1 = t.event(), t.event()
@@ -242,3 +262,84 @@ def bnbwd(alpha, beta, gamma, per_sample=False):
     b = BnBwd(ptr(alpha), ptr(beta), ptr(gamma), int(per_sample))
     b._keep = (alpha, beta, gamma)
     return b
+
+
+# ---- step plans (include/t3d.h: t3d_plan_*) ---------------------------------------------------------------------------
+_U64 = (1 << 64) - 1
+
+
+def _word(argtype, v):
+    """One argument as the 64-bit word t3d_plan_add_call takes (kind 0)."""
+    import struct
+    if argtype is _F:
+        return struct.unpack('<I', struct.pack('<f', float(v)))[0]
+    if argtype is _D:
+        return struct.unpack('<Q', struct.pack('<d', float(v)))[0]
+    if v is None:
+        return 0
+    return int(v) & _U64
+
+
+def double_bits(x):
+    import struct
+    return struct.unpack('<Q', struct.pack('<d', float(x)))[0]
+
+
+class PlanRecorder:
+    """Builds a t3d_plan while the engine issues a step through `call` (which still executes every call).  `ptr_slots`:
+    {device address: slot} -- any pointer argument equal to one of these addresses is bound to the slot (the batch's
+    input tensors); scalar slots are named by the call site (`call(..., slots={index: slot})`)."""
+
+    def __init__(self, ptr_slots=None):
+        self.plan = _P()
+        rc = lib().t3d_plan_create(ctypes.byref(self.plan))
+        if rc != 0:
+            raise RuntimeError(f't3d_plan_create failed with code {rc}')
+        self.ptr_slots = dict(ptr_slots or {})
+        self.calls = []          # (name, int-args signature, nbytes) per call op, in order: what a timed replay reports against
+        self.keep = []           # objects whose device memory the plan points into
+        self.breaks = []         # host callbacks between segment i and i + 1
+
+    def add_call(self, name, args, nbytes, slots):
+        types = SIGNATURES[name]
+        n = len(types)
+        if len(args) != n:
+            raise RuntimeError(f'{name}: {len(args)} arguments for a {n}-argument entry point')
+        kinds, words, sizes = (_I * n)(), (ctypes.c_ulonglong * n)(), (_I * n)()
+        for i, (t, v) in enumerate(zip(types, args)):
+            if slots and i in slots:
+                kinds[i], words[i] = 2, slots[i]
+            elif isinstance(v, ctypes.Structure):
+                kinds[i], words[i], sizes[i] = 1, ctypes.addressof(v), ctypes.sizeof(v)
+                self.keep.append(getattr(v, '_keep', None))
+            elif t is _P and v is not None and int(v) in self.ptr_slots:
+                kinds[i], words[i] = 2, self.ptr_slots[int(v)]
+            elif t in (_PP, _BP, _LP):
+                if v is not None:
+                    raise RuntimeError(f'{name}: argument {i} is not a ctypes structure')
+                kinds[i], words[i] = 0, 0
+            else:
+                kinds[i], words[i] = 0, _word(t, v)
+        rc = lib().t3d_plan_add_call(self.plan, name.encode(), n, kinds, words, sizes)
+        if rc != 0:
+            raise RuntimeError(f't3d_plan_add_call({name}) failed with code {rc}')
+        self.calls.append((name, tuple(a for a in args[:-1] if isinstance(a, int) and not isinstance(a, bool) and 0 <= a < (1 << 31)),
+                           nbytes))
+
+    def add_fork(self, from_stream, to_stream):
+        rc = lib().t3d_plan_add_fork(self.plan, from_stream, to_stream)
+        if rc != 0:
+            raise RuntimeError(f't3d_plan_add_fork failed with code {rc}')
+
+    def add_readback(self, dst_slot, src, nbytes, event_slot, stream_):
+        lib().t3d_plan_add_copy_d2h(self.plan, dst_slot, src.data_ptr(), nbytes, stream_)
+        lib().t3d_plan_add_event_record(self.plan, event_slot, stream_)
+        self.keep.append(src)
+
+    def end_segment(self):
+        return lib().t3d_plan_end_segment(self.plan)
+
+    def host_break(self, what):
+        """Host code runs here in the eager step (a gradient-exchange callback): close the segment, remember what to call."""
+        self.end_segment()
+        self.breaks.append(what)

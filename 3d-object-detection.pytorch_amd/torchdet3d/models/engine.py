@@ -132,6 +132,7 @@ class Net:
         if self.device.type == 'cuda' and not os.environ.get('T3D_NO_SIDE_STREAM'):
             self._side = _concurrent_stream(self.device)
         self._side_busy = False
+        self.persistent_outputs = False
         # uint8 input path (include/t3d.h: t3d_stem_fwd, fmt 1): normalisation of configs/default_config.py:9-10
         self.set_input_normalization([0.5931, 0.4690, 0.4229], [0.2471, 0.2214, 0.2157])
         self._fused_eval = not os.environ.get('T3D_NO_FUSED_EVAL')   # 14x14 / 7x7 blocks as one launch in inference mode
@@ -541,7 +542,10 @@ class Net:
             f = yc
         # ---- heads (model_builder.py:137-144)
         ncls = self.num_classes
-        logits = torch.empty(B, ncls, device=self.device) if ncls > 1 else None
+        keep = self.persistent_outputs and not all_heads
+        # (persistent_outputs: the step plan's mode -- kp / logits live in engine buffers whose addresses do not change from
+        # step to step; a caller of the plain API gets fresh tensors it may hold on to)
+        logits = (self._buf('out:logits', (B, ncls), torch.float32) if keep else torch.empty(B, ncls, device=self.device)) if ncls > 1 else None
         if all_heads:
             kp = torch.empty(9, B, 18, device=self.device)
             N.call('t3d_head_fwd_all', N.ptr(f), fpro, N.ptr(self.wreg), N.ptr(self.breg),
@@ -557,10 +561,10 @@ class Net:
                 self._dropout_calls = getattr(self, '_dropout_calls', 0) + 1
                 # (one process per GPU: main.py seeds every rank alike -- the rank term keeps the ranks' masks independent)
                 seed = (torch.initial_seed() + 0x9E3779B97F4A7C15 * getattr(self, 'seed_rank', 0)) & ((1 << 64) - 1)
-                N.call('t3d_dropout_mask', N.ptr(mask), B * a.feat_c, seed, self._dropout_calls, 0.5, st)
+                N.call('t3d_dropout_mask', N.ptr(mask), B * a.feat_c, seed, self._dropout_calls, 0.5, st, slots={3: N.SLOT_DROPOUT})
             else:
                 mask = mask.to(self.device, torch.float32).contiguous()
-        kp = torch.empty(B, 18, device=self.device)
+        kp = self._buf('out:kp', (B, 18), torch.float32) if keep else torch.empty(B, 18, device=self.device)
         N.call('t3d_head_fwd', N.ptr(f), fpro, N.ptr(cats), N.ptr(self.wreg), N.ptr(self.breg),
                N.ptr(self.p['cls_fc.1.weight']), N.ptr(self.p['cls_fc.1.bias']), N.ptr(mask), N.ptr(kp),
                N.ptr(logits), B, a.feat_c, ncls, st)
@@ -620,7 +624,12 @@ class Net:
         else:
             B, _, H, W = imgs.shape
         if train:
-            self._statbuf.zero_()
+            # the BatchNorm sum replicas of the step, cleared by the library's own kernel (no framework launch in the step)
+            if getattr(self, '_stat_zero_desc', None) is None:
+                nb = self._statbuf.numel() * 8
+                assert nb % 16 == 0
+                self._stat_zero_desc = torch.tensor([[self._statbuf.data_ptr(), nb]], dtype=torch.int64, device=self.device)
+            N.call('t3d_zero_batched', N.ptr(self._stat_zero_desc), 1, st)
         else:
             self._eval_affines()
         sv = dict(B=B, imgs=imgs, blocks=[])
@@ -661,8 +670,10 @@ class Net:
         return sv
 
     def _wsel(self, w, plain=True):
-        """(dtype argument, weight pointer) of a pointwise launch: the fragment-order copy where the layer has one."""
-        f = self._frag.get(w.data_ptr()) if self.dt in (N.BF16, N.F16) else None
+        """(dtype argument, weight pointer) of a pointwise launch: the fragment-order copy where the layer has one and the
+        launch is a `plain` one (no squeeze-excite gate / per-sample coefficients: the gated variants of a deep layer have no
+        fragment-order path in the deep-contraction kernel, csrc/pwconv_deep.hip, and take the row-major copy)."""
+        f = self._frag.get(w.data_ptr()) if (plain and self.dt in (N.BF16, N.F16)) else None
         return (self.dt | N.W_FRAG, N.ptr(f)) if f is not None else (self.dt, N.ptr(w))
 
     def _resolve(self, src):
@@ -841,8 +852,7 @@ class Net:
         if self._side is None:
             N.call(entry, *args, N.stream(), **kw)
             return
-        main = torch.cuda.current_stream()
-        self._side.wait_stream(main)
+        self._fork_side()
         if N.timer is None:
             N.call(entry, *args, self._side.cuda_stream, **kw)     # the ABI takes the stream: no context switch needed
         else:
@@ -856,9 +866,20 @@ class Net:
                     N.ptr(self.g[sen + '.fc.0.bias']), N.ptr(self.g[sen + '.fc.2.weight']), N.ptr(self.g[sen + '.fc.2.bias']),
                     B, C, R, entry='t3d_se_bwd_weights')
 
+    def _fork_side(self):
+        """The second stream waits for everything enqueued on the main stream so far (an event record + a stream wait; noted in
+        the step plan being recorded, if any)."""
+        main = torch.cuda.current_stream()
+        self._side.wait_stream(main)
+        if N.recorder is not None:
+            N.recorder.add_fork(main.cuda_stream, self._side.cuda_stream)
+
     def _join_side(self):
         if self._side is not None and self._side_busy:
-            torch.cuda.current_stream().wait_stream(self._side)
+            main = torch.cuda.current_stream()
+            main.wait_stream(self._side)
+            if N.recorder is not None:
+                N.recorder.add_fork(self._side.cuda_stream, main.cuda_stream)
             self._side_busy = False
 
     def backward(self, dkp, dlogits=None):
@@ -1037,14 +1058,25 @@ class Net:
                 # one -- the collective's own stream then waits for both, and the main stream waits for nobody (joining the
                 # streams here, as rounds 1-3a did, stalled the data-gradient chain three or four times per step until the
                 # weight-gradient backlog had drained)
-                self._side.wait_stream(torch.cuda.current_stream())
-                with torch.cuda.stream(self._side):
-                    self.grad_hook(lo)
+                self._fork_side()
+                self._hook(lo, True)
                 self._side_busy = True
             else:
                 self._join_side()
-                self.grad_hook(lo)
+                self._hook(lo, False)
             self._hook_hi = lo
+
+    def _hook(self, lo, on_side):
+        """Gradient-exchange callback (host code: an RCCL collective issued through torch.distributed) with the second or
+        the main stream current.  A step plan being recorded is cut into segments here: the replay runs a segment, makes
+        this call, runs the next."""
+        if N.recorder is not None:
+            N.recorder.host_break(('hook', lo, on_side))
+        if on_side:
+            with torch.cuda.stream(self._side):
+                self.grad_hook(lo)
+        else:
+            self.grad_hook(lo)
 
     def _yfree_ok(self, x, M, K, Nn):
         """Expand layer on a finished bf16 input, wide enough that skipping the two extra passes over the M x N tensors

@@ -23,10 +23,12 @@ class _Pending(Mapping):
     _FIELDS = (('loss', 0), ('ADD', 3), ('SADD', 4), ('acc', 5))
     __slots__ = ('_slot', '_vals')
 
-    def __init__(self, dev_vec, slot):
+    def __init__(self, dev_vec, slot, enqueued=False):
+        # enqueued: the copy into the slot and its event record are already in the stream (a replayed step plan issues them)
         self._slot, self._vals = slot, None
-        slot[0][:dev_vec.numel()].copy_(dev_vec, non_blocking=True)
-        slot[1].record()
+        if not enqueued:
+            slot[0][:dev_vec.numel()].copy_(dev_vec, non_blocking=True)
+            slot[1].record()
         slot[2] = self
 
     def _resolve(self):
@@ -71,6 +73,14 @@ class Trainer:
         `print_freq` iterations (as `train` does) never stalls the launch queue (the reference's loop has six `.item()`
         syncs per iteration, train.py:57-62 + metrics.py:29,35)."""
         imgs, gt_kp, gt_cats = put_on_device([imgs, gt_kp, gt_cats], self.device)
+        # the same iteration without the per-launch host loop (trainer/step_plan.py: the entry points in step order without
+        # autograd glue for the first iterations, then ONE t3d_plan_run call per step); what it does not cover -- user
+        # criterions, ALWA, a framework optimizer, host-side or non-contiguous inputs -- takes the sequence below
+        sp = self._step_plan()
+        if sp is not None and sp.accepts(imgs, gt_kp, gt_cats):
+            slot = self._slot()
+            out, enqueued = sp.run(imgs, gt_kp, gt_cats, slot)
+            return _Pending(out, slot, enqueued)
         pred_kp, pred_cats = self.model(imgs, gt_cats)
         loss = self.loss_manager.parse_losses(pred_kp, gt_kp, pred_cats, gt_cats, it)
         self.optimizer.zero_grad()
@@ -85,6 +95,14 @@ class Trainer:
         ADD, SADD = compute_average_distance(pred_kp, gt_kp)
         return dict(loss=loss.item(), ADD=ADD, SADD=SADD, acc=compute_accuracy(pred_cats, gt_cats))
 
+    def _step_plan(self):
+        sp = self.__dict__.get('_sp', False)
+        if sp is False or (sp is not None and (sp.model is not self.model or sp.lm is not self.loss_manager or sp.opt is not self.optimizer)):
+            from .step_plan import StepPlan
+            sp = self._sp = (StepPlan(self.model, self.loss_manager, self.optimizer)
+                             if StepPlan.usable(self.model, self.loss_manager, self.optimizer) else None)
+        return sp
+
     RING = 64      # read-back slots in rotation; a slot is reused RING iterations later (its mapping is resolved first)
 
     def _slot(self):
@@ -94,6 +112,7 @@ class Trainer:
         if len(ring) < self.RING:
             import torch
             ring.append([torch.empty(16, dtype=torch.float32).pin_memory(), torch.cuda.Event(), None])
+            ring[-1][1].record()                   # (creates the HIP event: a replayed step plan records it by handle)
             return ring[-1]
         slot = ring[turn]
         if slot[2] is not None:

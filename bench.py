@@ -322,6 +322,13 @@ def main():
     # reports it), not recorded around the launch call (which adds 5-9 us of event packets and dispatch latency)
     rtimer = N.KernelTimer(set(DW_ENTRIES), prealloc=2 * 40 * ((args.steps + every - 1) // every), kernel_exact=not os.environ.get('T3D_EVENTS_AROUND'))
     N.timer = None
+    # the API path replays a recorded step plan (trainer/step_plan.py: one t3d_plan_run per step): the event pairs are then
+    # attached by the replay itself, to the same launches through the same t3d_set_launch_events
+    sp = trainer._step_plan() if (use_api and not args.eval) else None
+    ptimer = None
+    if sp is not None and sp.rec is not None:
+        from torchdet3d.trainer.step_plan import PlanTiming
+        ptimer = sp.timing = PlanTiming(sp, DW_ENTRIES, (args.steps + every - 1) // every)
     # no cyclic-GC pass inside the timed region: one in three fresh processes had a single 36-44 ms step in it
     # (config.step_ms_min_med_max), i.e. +12 % on the 30-step average, from a collection over the freshly imported heap
     import gc
@@ -332,15 +339,20 @@ def main():
     t0 = time.perf_counter()
     marks[0].record()
     for i in range(args.steps):
-        N.timer = rtimer if i % every == 0 else None
+        if ptimer is not None:
+            ptimer.active = i % every == 0
+        else:
+            N.timer = rtimer if i % every == 0 else None
         step(i)
         marks[i + 1].record()
     N.timer = None
     barrier()
     dt = time.perf_counter() - t0
     gc.enable()
+    if ptimer is not None:
+        sp.timing = None
     per_step = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps))
-    launches = rtimer.per_launch()
+    launches = ptimer.per_launch() if ptimer is not None else rtimer.per_launch()
     nsampled = (args.steps + every - 1) // every
     if world > 1:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
@@ -369,6 +381,9 @@ def main():
                        'driven_through': (('torchdet3d.builders.build_model / Evaluator.val_step' if args.eval else
                                            'torchdet3d.builders.build_model / build_optimizer / LossManager / Trainer.train_step')
                                           if use_api else 'models.engine.Net + loss / optimizer entry points'),
+                       'step_form': (('one t3d_plan_run call per step (recorded step plan: %d launches, %d stream forks)'
+                                      % (N.lib().t3d_plan_num_ops(sp.rec.plan, 0), N.lib().t3d_plan_num_ops(sp.rec.plan, 1)))
+                                     if ptimer is not None else 'one host call per launch'),
                        'roofline_sampled_steps': nsampled,
                        'device_warmup_s': device_warmup_s, 'step_ms_min_med_max': [round(per_step[0], 3), round(per_step[len(per_step) // 2], 3), round(per_step[-1], 3)], 'side_stream_probe': list(__import__('torchdet3d.models.engine', fromlist=['x'])._concurrent_stream.log), 'rccl_ranks': world if dist.is_initialized() else 0},
         }

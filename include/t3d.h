@@ -161,7 +161,7 @@ int t3d_pwconv_wgrad_yfree(const void* dz, const void* x, const t3d_bnbwd* bb, c
  *   _prep2: as _prep, plus wd -- the weights in the staged rows' column order, [16*ceil(K/16)][64*ceil((N+K+8)/64)] bf16,
  *     cleared once by the caller (only the non-zero entries are written each step);
  *   _bwd_yfree_scratch: RETURNS the bytes of `scratch` a launch of this shape needs (a query, not a status code; 0: shape not
- *     supported -- K <= 32, N + K + 8 <= 256);
+ *     supported -- K <= 32, 64 < N + K + 8 <= 256);
  *   _bwd_yfree (the caller's main stream): dx [M,K] bf16 = [dz | x | 1] wd^T (+ residual), stats += sum(dx), sum(dx*x_raw)
  *     (x_raw / pro_in as in t3d_pwconv_dgrad; only a linear producer -- no activation -- is supported), partial tiles -> scratch;
  *   _wgrad_yfree_finish (any stream ordered behind it): dw [N,K] += the combined weight gradient, from `scratch`.
@@ -536,6 +536,42 @@ int t3d_dropout_mask(float* mask, long long n, unsigned long long seed, unsigned
 /* Zero fill of several device buffers in one launch: desc = n rows of int64 {ptr, bytes}, bytes % 16 == 0, DEVICE array
  * (the per-step clears of the gradient buffer, the BatchNorm sum replicas and the depthwise weight-gradient replicas). */
 int t3d_zero_batched(const long long* desc, int n, void* stream);
+
+/* Step plans (round 5; csrc/plan.hip): the whole train iteration as ONE host call.
+ * Replaces the per-launch host loop of torchdet3d/trainer/train.py:44-55 + builders/optim_builder.py:10-12 (model forward,
+ * losses, loss.backward(), optimizer.step()): ~230 enqueue-only calls of this header that are the same from step to step
+ * except for a few values.  A plan is a recorded list of
+ *   calls        any enqueue entry point of this header by NAME with its arguments as 64-bit words (pointers and integers
+ *                as they are, float / double as their bit patterns), the three by-pointer structs (t3d_prologue, t3d_bnbwd,
+ *                t3d_loss_cfg) COPIED into the plan;
+ *   forks        hipEventRecord on one stream + hipStreamWaitEvent on another (the weight-gradient stream's dependencies);
+ *   read-backs   an asynchronous device-to-host copy and an event record (the step's metrics on their way to the host),
+ * and t3d_plan_run replays a segment of it through the same exported entry points (same host-side state, same launches:
+ * bit-identical to issuing the calls one by one).  What changes per step goes through SLOTS: an argument recorded with
+ * kind 2 takes its value from slots[index] at run time (input pointers of the batch, dropout counter, optimizer step
+ * count, learning rate bits, pinned read-back address, event handle).
+ *   kinds[i]: 0 literal word, 1 struct (words[i] = HOST address of the struct, struct_bytes[i] its size; copied), 2 slot
+ *             (words[i] = slot index);
+ *   _end_segment closes the current segment and RETURNS its index (segments let a caller interleave work of its own, e.g.
+ *             an RCCL all-reduce of a gradient bucket, between two runs); _num_ops RETURNS the op count (kind -1: all, 0 calls,
+ *             1 forks, 2 copies, 3 event records);
+ *   _time_entry switches kernel-exact event timing (t3d_set_launch_events) on / off for one entry point; _run then attaches
+ *             consecutive pairs of `events` (hipEvent_t, timing enabled) to that entry point's launches in op order;
+ *   _run      segment >= 0, or -1 for the whole plan; RETURNS the number of events consumed (>= 0) or T3D_ERR_*;
+ *             _failed_op RETURNS the index of the op that failed (-1: none) and its return code. */
+typedef struct t3d_plan t3d_plan;
+int t3d_plan_create(t3d_plan** out);
+int t3d_plan_destroy(t3d_plan* plan);
+int t3d_plan_add_call(t3d_plan* plan, const char* entry, int nargs, const int* kinds, const unsigned long long* words,
+                      const int* struct_bytes);
+int t3d_plan_add_fork(t3d_plan* plan, void* from_stream, void* to_stream);
+int t3d_plan_add_copy_d2h(t3d_plan* plan, int dst_slot, const void* src, long long bytes, void* stream);
+int t3d_plan_add_event_record(t3d_plan* plan, int event_slot, void* stream);
+int t3d_plan_end_segment(t3d_plan* plan);
+int t3d_plan_num_ops(const t3d_plan* plan, int kind);
+int t3d_plan_time_entry(t3d_plan* plan, const char* entry, int on);
+int t3d_plan_failed_op(const t3d_plan* plan, int* rc_out);
+int t3d_plan_run(t3d_plan* plan, int segment, const unsigned long long* slots, int nslots, void** events, int nevents);
 
 #ifdef __cplusplus
 }

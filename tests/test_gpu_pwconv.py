@@ -271,7 +271,7 @@ def test_pwconv_wgrad(B, HW, K, N, dt, mode):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize('M,HW,K,N', [(4096, 64, 16, 96), (3000, 100, 24, 144), (2048, 64, 32, 192), (1024, 16, 64, 384),
-                                      (520, 8, 16, 96)])
+                                      (520, 8, 16, 96), (2048, 64, 8, 48)])     # K=8, N=48: N+K+8 = 64, the pair only
 @pytest.mark.parametrize('res', [False, True])
 def test_pw_yfree_backward(M, HW, K, N, res):
     """y-free expand-layer backward (t3d_pwconv_*_yfree) vs fp64 autograd of conv1x1 + the BatchNorm-backward affine,
@@ -336,6 +336,8 @@ def test_pw_yfree_backward(M, HW, K, N, res):
     assert ew < 1e-2 and ew < 2 * ew2 + 4e-3, (ew, ew2)
     # ---- the one-pass form (round 4): data gradient + weight-gradient products from the same staged rows
     need = N_.lib().t3d_pwconv_bwd_yfree_scratch(M, K, N)
+    if N + K + 8 <= 64:
+        assert need == 0      # prep2's 64-column rows are narrower than the kernel's narrowest staged tile: refused
     if need > 0:
         wdl = torch.zeros((K + 15) // 16 * 16, (N + K + 8 + 63) // 64 * 64, device=dev, dtype=bf)
         N_.call('t3d_pwconv_yfree_prep2', N_.ptr(wtd), bb, N_.ptr(wcat), N_.ptr(cvec), N_.ptr(wdl), K, N, N_.stream())
