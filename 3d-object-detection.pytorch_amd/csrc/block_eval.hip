@@ -312,10 +312,10 @@ int launch_blk(const BlkArgs& a, int B, size_t lds, hipStream_t st) {
   const void* fn = (const void*)ir_block_eval_kernel<MTW, NT2>;
   static bool attr = false;
   if (!attr) {
-    if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return T3D_ERR_UNSUPPORTED;
+    if (t3d_max_lds(fn, 160 * 1024) != hipSuccess) return T3D_ERR_UNSUPPORTED;
     attr = true;
   }
-  hipLaunchKernelGGL((ir_block_eval_kernel<MTW, NT2>), dim3(B), dim3(NTHR), lds, st, a);
+  T3D_LAUNCH((ir_block_eval_kernel<MTW, NT2>), dim3(B), dim3(NTHR), lds, st, a);
   T3D_CHECK_LAUNCH();
   return T3D_OK;
 }

@@ -114,7 +114,7 @@ __global__ __launch_bounds__(256) void bn_fold_kernel(const T3dFold* __restrict_
 int t3d_fold_fallback(const void* key, hipStream_t st) {
   const T3dFold* d = t3d_take_fold(key);
   if (!d) return T3D_OK;
-  hipLaunchKernelGGL(bn_fold_kernel, dim3(32), dim3(256), 0, st, d);      // up to 2048 channels
+  T3D_LAUNCH(bn_fold_kernel, dim3(32), dim3(256), 0, st, d);      // up to 2048 channels
   T3D_CHECK_LAUNCH();
   return T3D_OK;
 }
@@ -124,7 +124,7 @@ extern "C" int t3d_bn_finalize(const double* stats, int C, double count, const f
                                float momentum, float eps, float* scale, float* shift, float* mean, float* invstd,
                                void* stream) {
   if (!stats || !scale || !shift || C <= 0 || count <= 0) return T3D_ERR_ARG;
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, 16)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+  T3D_LAUNCH(bn_finalize_kernel, dim3(cdiv(C, 16)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
                      stats, g_t3d_reduce.nrep, g_t3d_reduce.stats_stride, C, count, gamma, beta, running_mean, running_var, num_batches_tracked, momentum, eps,
                      scale, shift, mean, invstd);
   T3D_CHECK_LAUNCH();
@@ -134,7 +134,7 @@ extern "C" int t3d_bn_finalize(const double* stats, int C, double count, const f
 extern "C" int t3d_bn_eval_affine(int C, const float* gamma, const float* beta, const float* running_mean,
                                   const float* running_var, float eps, float* scale, float* shift, void* stream) {
   if (!running_mean || !running_var || !scale || !shift || C <= 0) return T3D_ERR_ARG;
-  hipLaunchKernelGGL(bn_eval_affine_kernel, dim3(cdiv(C, 256)), dim3(256), 0,
+  T3D_LAUNCH(bn_eval_affine_kernel, dim3(cdiv(C, 256)), dim3(256), 0,
                      reinterpret_cast<hipStream_t>(stream), C, gamma, beta, running_mean, running_var, eps, scale,
                      shift);
   T3D_CHECK_LAUNCH();
@@ -143,7 +143,7 @@ extern "C" int t3d_bn_eval_affine(int C, const float* gamma, const float* beta, 
 
 extern "C" int t3d_bn_eval_affine_batched(const long long* desc, int n, float eps, void* stream) {
   if (!desc || n <= 0) return T3D_ERR_ARG;
-  hipLaunchKernelGGL(bn_eval_affine_batched_kernel, dim3(n, 2), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), desc, eps);
+  T3D_LAUNCH(bn_eval_affine_batched_kernel, dim3(n, 2), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), desc, eps);
   T3D_CHECK_LAUNCH();
   return T3D_OK;
 }
@@ -154,7 +154,7 @@ extern "C" int t3d_bn_bwd_finalize(const double* stats, int C, double count, con
                                    const float* invstd, float* alpha, float* beta, float* gammac, float* dgamma,
                                    float* dbeta, void* stream) {
   if (!stats || !mean || !invstd || !alpha || !beta || !gammac || C <= 0 || count <= 0) return T3D_ERR_ARG;
-  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(C, 16)), dim3(256), 0,
+  T3D_LAUNCH(bn_bwd_finalize_kernel, dim3(cdiv(C, 16)), dim3(256), 0,
                      reinterpret_cast<hipStream_t>(stream), stats, g_t3d_reduce.nrep, g_t3d_reduce.stats_stride, C, count, gamma, mean, invstd, alpha, beta,
                      gammac, dgamma, dbeta);
   T3D_CHECK_LAUNCH();

@@ -25,6 +25,10 @@ __device__ __forceinline__ f32x2 pk_fma(f32x2 a, f32x2 b, f32x2 c) { return __bu
 
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 
+// hipFuncAttributeMaxDynamicSharedMemorySize, raised at most once per (kernel, size): the launch paths used to make this
+// runtime call in front of every launch with more than 64 KB of LDS (~70 per training step; misc.hip)
+hipError_t t3d_max_lds(const void* fn, int bytes);
+
 // Reduction replicas (t3d_set_reduction_replicas, misc.hip): contended atomics into one small array run an order of
 // magnitude below the chip's atomic rate, so block b adds its BatchNorm sums / depthwise weight gradient into
 // replica b % nrep; the finalize kernels (and the caller, for dw) sum the replicas.
@@ -41,13 +45,38 @@ extern T3dReduceCfg g_t3d_reduce;
 // call measures (bench.py's roofline block; the depthwise launches are 50-200 us long).
 struct T3dLaunchEvents { hipEvent_t start, stop; };
 extern T3dLaunchEvents g_t3d_time;
+
+// Device-side hand-off to another stream (t3d_plan_run, plan.hip): while `ev` is set, every kernel launched on `stream`
+// carries `ev` as the STOP event of its own dispatch packet (hipExtLaunchKernelGGL), so that a hipStreamWaitEvent(other, ev)
+// issued afterwards waits for the completion signal of the last such kernel -- the producing queue gets NO event-record
+// packet (an event recorded behind a kernel is a barrier packet of its own, and the kernel behind it started 6-30 us late:
+// ~35 of them per training step were most of the main queue's 0.3 ms of gaps).  Also counts launches, so that a plan being
+// recorded knows which calls launched a kernel and on which stream.
+struct T3dSignal { hipEvent_t ev; hipStream_t stream; };
+extern T3dSignal g_t3d_signal;
+extern unsigned long long g_t3d_launches;
+extern hipStream_t g_t3d_last_stream;
+#define T3D_LAUNCH(kernel, grid, block, lds, st, ...)                                                                    \
+  do {                                                                                                                   \
+    ++g_t3d_launches;                                                                                                    \
+    g_t3d_last_stream = (st);                                                                                            \
+    if (g_t3d_signal.ev && g_t3d_signal.stream == (st)) {                                                                \
+      hipExtLaunchKernelGGL(kernel, grid, block, lds, st, nullptr, g_t3d_signal.ev, 0, __VA_ARGS__);                     \
+    } else {                                                                                                             \
+      hipLaunchKernelGGL(kernel, grid, block, lds, st, __VA_ARGS__);                                                     \
+    }                                                                                                                    \
+  } while (0)
 #define T3D_LAUNCH_TIMED(kernel, grid, block, lds, st, ...)                                                              \
   do {                                                                                                                   \
     if (g_t3d_time.start) {                                                                                              \
+      ++g_t3d_launches;                                                                                                  \
+      g_t3d_last_stream = (st);                                                                                          \
       hipExtLaunchKernelGGL(kernel, grid, block, lds, st, g_t3d_time.start, g_t3d_time.stop, 0, __VA_ARGS__);            \
       g_t3d_time.start = g_t3d_time.stop = nullptr;                                                                      \
+      /* (a timed launch that also has to signal: a plain event record behind it) */                                     \
+      if (g_t3d_signal.ev && g_t3d_signal.stream == (st)) (void)hipEventRecord(g_t3d_signal.ev, st);                     \
     } else {                                                                                                             \
-      hipLaunchKernelGGL(kernel, grid, block, lds, st, __VA_ARGS__);                                                     \
+      T3D_LAUNCH(kernel, grid, block, lds, st, __VA_ARGS__);                                                             \
     }                                                                                                                    \
   } while (0)
 

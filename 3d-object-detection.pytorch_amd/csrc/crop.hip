@@ -76,7 +76,7 @@ extern "C" int t3d_crop_resize_u8(const unsigned char* frame, const int* rects, 
   if (n == 0) return T3D_OK;
   const size_t total = (size_t)n * oh * ow;
   const int grid = (int)((total + 255) / 256 > 16384 ? 16384 : (total + 255) / 256);
-  hipLaunchKernelGGL(crop_resize_kernel, dim3(grid), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), frame, rects, out, n, H,
+  T3D_LAUNCH(crop_resize_kernel, dim3(grid), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), frame, rects, out, n, H,
                      W, oh, ow);
   T3D_CHECK_LAUNCH();
   return T3D_OK;

@@ -435,7 +435,7 @@ static int im2col_launch(int dtype, const void* x, bool u8, const float* mean, c
   if (lds > 64 * 1024) return T3D_ERR_UNSUPPORTED;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
 #define T3D_IM2COL(T, U) \
-  hipLaunchKernelGGL((im2col_kernel<T, U>), dim3(grid), dim3(256), lds, st, x, mean, istd, (T*)col, B, H, W, Ho, Wo)
+  T3D_LAUNCH((im2col_kernel<T, U>), dim3(grid), dim3(256), lds, st, x, mean, istd, (T*)col, B, H, W, Ho, Wo)
   if (dtype == T3D_F32) {
     if (u8) T3D_IM2COL(float, true); else T3D_IM2COL(float, false);
   } else if (dtype == T3D_BF16) {
@@ -471,9 +471,9 @@ extern "C" int t3d_bn_apply(int dtype, const void* y, const t3d_prologue* pro, c
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   a.fold = t3d_take_fold(a.scale);      // a requested finalize of this BatchNorm is derived inside the kernel
   const size_t lds = a.fold ? (size_t)2 * C * sizeof(float) : 0;
-  if (dtype == T3D_F32) hipLaunchKernelGGL(bn_apply_kernel<float>, dim3(grid), dim3(256), lds, st, a);
-  else if (dtype == T3D_BF16) hipLaunchKernelGGL(bn_apply_kernel<bf16_t>, dim3(grid), dim3(256), lds, st, a);
-  else if (dtype == T3D_F16) hipLaunchKernelGGL(bn_apply_kernel<f16_t>, dim3(grid), dim3(256), lds, st, a);
+  if (dtype == T3D_F32) T3D_LAUNCH(bn_apply_kernel<float>, dim3(grid), dim3(256), lds, st, a);
+  else if (dtype == T3D_BF16) T3D_LAUNCH(bn_apply_kernel<bf16_t>, dim3(grid), dim3(256), lds, st, a);
+  else if (dtype == T3D_F16) T3D_LAUNCH(bn_apply_kernel<f16_t>, dim3(grid), dim3(256), lds, st, a);
   else return T3D_ERR_ARG;
   T3D_CHECK_LAUNCH();
   return T3D_OK;
@@ -491,8 +491,8 @@ extern "C" int t3d_bn_act_bwd(int dtype, const void* dz, const void* y, const t3
   if ((size_t)grid * 256 < (size_t)(C / 8)) return T3D_ERR_UNSUPPORTED;
   const size_t lds = (size_t)2 * C * sizeof(double);
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-  if (dtype == T3D_F32) hipLaunchKernelGGL(bn_act_bwd_kernel<float>, dim3(grid), dim3(256), lds, st, a);
-  else if (dtype == T3D_BF16) hipLaunchKernelGGL(bn_act_bwd_kernel<bf16_t>, dim3(grid), dim3(256), lds, st, a);
+  if (dtype == T3D_F32) T3D_LAUNCH(bn_act_bwd_kernel<float>, dim3(grid), dim3(256), lds, st, a);
+  else if (dtype == T3D_BF16) T3D_LAUNCH(bn_act_bwd_kernel<bf16_t>, dim3(grid), dim3(256), lds, st, a);
   else return T3D_ERR_ARG;
   T3D_CHECK_LAUNCH();
   return T3D_OK;
@@ -508,8 +508,8 @@ extern "C" int t3d_se_after_sums(int dtype, const void* dv, const void* y, const
   dim3 grid(B, cdiv(C / 8, 32));
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   if (const int rc = t3d_fold_fallback(a.scale, st)) return rc;      // no derive prologue here: finalize as its own launch
-  if (dtype == T3D_F32) hipLaunchKernelGGL(se_after_sums_kernel<float>, grid, dim3(256), 0, st, a);
-  else if (dtype == T3D_BF16) hipLaunchKernelGGL(se_after_sums_kernel<bf16_t>, grid, dim3(256), 0, st, a);
+  if (dtype == T3D_F32) T3D_LAUNCH(se_after_sums_kernel<float>, grid, dim3(256), 0, st, a);
+  else if (dtype == T3D_BF16) T3D_LAUNCH(se_after_sums_kernel<bf16_t>, grid, dim3(256), 0, st, a);
   else return T3D_ERR_ARG;
   T3D_CHECK_LAUNCH();
   return T3D_OK;
@@ -527,8 +527,8 @@ extern "C" int t3d_se_after_apply(int dtype, const void* dv, const void* y, cons
   if ((size_t)grid * 256 < (size_t)(C / 8)) return T3D_ERR_UNSUPPORTED;
   const size_t lds = (size_t)2 * C * sizeof(double);
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-  if (dtype == T3D_F32) hipLaunchKernelGGL(se_after_apply_kernel<float>, dim3(grid), dim3(256), lds, st, a);
-  else if (dtype == T3D_BF16) hipLaunchKernelGGL(se_after_apply_kernel<bf16_t>, dim3(grid), dim3(256), lds, st, a);
+  if (dtype == T3D_F32) T3D_LAUNCH(se_after_apply_kernel<float>, dim3(grid), dim3(256), lds, st, a);
+  else if (dtype == T3D_BF16) T3D_LAUNCH(se_after_apply_kernel<bf16_t>, dim3(grid), dim3(256), lds, st, a);
   else return T3D_ERR_ARG;
   T3D_CHECK_LAUNCH();
   return T3D_OK;
@@ -545,9 +545,9 @@ extern "C" int t3d_pool_fwd(int dtype, const void* y, const t3d_prologue* pro, i
   dim3 grid(B, cdiv(C / 8, 32));
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   if (const int rc = t3d_fold_fallback(a.scale, st)) return rc;      // no derive prologue here: finalize as its own launch
-  if (dtype == T3D_F32) hipLaunchKernelGGL(gap_fwd_kernel<float>, grid, dim3(256), 0, st, a);
-  else if (dtype == T3D_BF16) hipLaunchKernelGGL(gap_fwd_kernel<bf16_t>, grid, dim3(256), 0, st, a);
-  else if (dtype == T3D_F16) hipLaunchKernelGGL(gap_fwd_kernel<f16_t>, grid, dim3(256), 0, st, a);
+  if (dtype == T3D_F32) T3D_LAUNCH(gap_fwd_kernel<float>, grid, dim3(256), 0, st, a);
+  else if (dtype == T3D_BF16) T3D_LAUNCH(gap_fwd_kernel<bf16_t>, grid, dim3(256), 0, st, a);
+  else if (dtype == T3D_F16) T3D_LAUNCH(gap_fwd_kernel<f16_t>, grid, dim3(256), 0, st, a);
   else return T3D_ERR_ARG;
   T3D_CHECK_LAUNCH();
   return T3D_OK;
@@ -570,8 +570,8 @@ extern "C" int t3d_pool_bwd(int dtype, const float* dpooled, const void* y, cons
   fill_pro(a, pro);
   dim3 grid(B < 256 ? B : 256, cdiv(C / 8, 32));
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-  if (dtype == T3D_F32) hipLaunchKernelGGL(gap_bwd_kernel<float>, grid, dim3(256), 0, st, a, B, g_t3d_reduce.nrep, g_t3d_reduce.stats_stride);
-  else if (dtype == T3D_BF16) hipLaunchKernelGGL(gap_bwd_kernel<bf16_t>, grid, dim3(256), 0, st, a, B, g_t3d_reduce.nrep, g_t3d_reduce.stats_stride);
+  if (dtype == T3D_F32) T3D_LAUNCH(gap_bwd_kernel<float>, grid, dim3(256), 0, st, a, B, g_t3d_reduce.nrep, g_t3d_reduce.stats_stride);
+  else if (dtype == T3D_BF16) T3D_LAUNCH(gap_bwd_kernel<bf16_t>, grid, dim3(256), 0, st, a, B, g_t3d_reduce.nrep, g_t3d_reduce.stats_stride);
   else return T3D_ERR_ARG;
   T3D_CHECK_LAUNCH();
   return T3D_OK;

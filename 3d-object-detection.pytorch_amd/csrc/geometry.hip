@@ -324,7 +324,7 @@ extern "C" int t3d_iou3d(const float* pred_kp, const float* gt_kp, int B, int po
   // NDC camera of geometry.py:29-37 applied to the default matrix (:16-19): fx = fy = 2, cx = cy = 0
   double fx = 2.0, fy = 2.0, cx = 0.0, cy = 0.0;
   if (camera_ndc) { fx = camera_ndc[0]; fy = camera_ndc[1]; cx = camera_ndc[2]; cy = camera_ndc[3]; }
-  hipLaunchKernelGGL(iou3d_kernel, dim3(B), dim3(128), 0, reinterpret_cast<hipStream_t>(stream), pred_kp, gt_kp, portrait,
+  T3D_LAUNCH(iou3d_kernel, dim3(B), dim3(128), 0, reinterpret_cast<hipStream_t>(stream), pred_kp, gt_kp, portrait,
                      fx, fy, cx, cy, iou, total, lifted, nullptr);
   T3D_CHECK_LAUNCH();
   return T3D_OK;
@@ -332,7 +332,7 @@ extern "C" int t3d_iou3d(const float* pred_kp, const float* gt_kp, int B, int po
 
 extern "C" int t3d_box_iou3d(const double* verts, int B, double* iou, double* total, void* stream) {
   if (!verts || !iou || B <= 0) return T3D_ERR_ARG;
-  hipLaunchKernelGGL(iou3d_kernel, dim3(B), dim3(128), 0, reinterpret_cast<hipStream_t>(stream), nullptr, nullptr, 0, 2.0,
+  T3D_LAUNCH(iou3d_kernel, dim3(B), dim3(128), 0, reinterpret_cast<hipStream_t>(stream), nullptr, nullptr, 0, 2.0,
                      2.0, 0.0, 0.0, iou, total, nullptr, verts);
   T3D_CHECK_LAUNCH();
   return T3D_OK;

@@ -295,7 +295,7 @@ extern "C" int t3d_head_fwd(const float* f, const t3d_prologue* pro, const int64
   a.f = f; a.cats = cats; a.wreg = wreg; a.breg = breg; a.wcls = wcls; a.bcls = bcls; a.mask = mask;
   a.kp = kp; a.logits = logits; a.B = B; a.F = F; a.ncls = ncls;
   fill(a, pro);
-  hipLaunchKernelGGL(head_fwd_kernel, dim3(B), dim3(256), (size_t)2 * F * sizeof(float),
+  T3D_LAUNCH(head_fwd_kernel, dim3(B), dim3(256), (size_t)2 * F * sizeof(float),
                      reinterpret_cast<hipStream_t>(stream), a);
   T3D_CHECK_LAUNCH();
   return T3D_OK;
@@ -306,7 +306,7 @@ extern "C" int t3d_linear_fwd(const float* x, const float* w, const float* bias,
   if (!x || !w || !y || M <= 0 || K <= 0 || N <= 0) return T3D_ERR_ARG;
   const long long total = (long long)M * N;
   const int grid = (int)((total + 3) / 4 < 4096 ? (total + 3) / 4 : 4096);
-  hipLaunchKernelGGL(linear_fwd_kernel, dim3(grid), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), x, w, bias, y,
+  T3D_LAUNCH(linear_fwd_kernel, dim3(grid), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), x, w, bias, y,
                      M, K, N);
   T3D_CHECK_LAUNCH();
   return T3D_OK;
@@ -322,7 +322,7 @@ extern "C" int t3d_head_fwd_all(const float* f, const t3d_prologue* pro, const f
   a.f = f; a.wreg = wreg; a.breg = breg; a.wcls = wcls; a.bcls = bcls;
   a.kp = kp_all; a.logits = logits; a.B = B; a.F = F; a.ncls = ncls; a.all_heads = 1;
   fill(a, pro);
-  hipLaunchKernelGGL(head_fwd_kernel, dim3(B), dim3(256), (size_t)2 * F * sizeof(float),
+  T3D_LAUNCH(head_fwd_kernel, dim3(B), dim3(256), (size_t)2 * F * sizeof(float),
                      reinterpret_cast<hipStream_t>(stream), a);
   T3D_CHECK_LAUNCH();
   return T3D_OK;
@@ -342,9 +342,9 @@ extern "C" int t3d_head_bwd(const float* f, const t3d_prologue* pro, const int64
   a.dwcls = dwcls; a.dbcls = dbcls; a.B = B; a.F = F; a.ncls = ncls;
   fill(a, pro);
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-  hipLaunchKernelGGL(head_bwd_data_kernel, dim3(B), dim3(256), 0, st, a);
+  T3D_LAUNCH(head_bwd_data_kernel, dim3(B), dim3(256), 0, st, a);
   if (dwreg)        // NULL: data gradient only, the weight gradients follow through t3d_head_bwd_weights
-    hipLaunchKernelGGL(head_bwd_weight_kernel, dim3(10, cdiv(F, 256), 1), dim3(256), 0, st, a);
+    T3D_LAUNCH(head_bwd_weight_kernel, dim3(10, cdiv(F, 256), 1), dim3(256), 0, st, a);
   T3D_CHECK_LAUNCH();
   return T3D_OK;
 }
@@ -361,7 +361,7 @@ extern "C" int t3d_head_bwd_weights(const float* f, const t3d_prologue* pro, con
   a.f = f; a.cats = cats; a.mask = mask; a.dlogits = dlogits; a.dpre = const_cast<float*>(dpre);
   a.dwreg = dwreg; a.dbreg = dbreg; a.dwcls = dwcls; a.dbcls = dbcls; a.B = B; a.F = F; a.ncls = ncls;
   fill(a, pro);
-  hipLaunchKernelGGL(head_bwd_weight_kernel, dim3(10, cdiv(F, 256), 1), dim3(256), 0,
+  T3D_LAUNCH(head_bwd_weight_kernel, dim3(10, cdiv(F, 256), 1), dim3(256), 0,
                      reinterpret_cast<hipStream_t>(stream), a);
   T3D_CHECK_LAUNCH();
   return T3D_OK;

@@ -246,7 +246,7 @@ extern "C" int t3d_metrics_per_sample(const float* kp, const float* gt_kp, const
                                       float* out, int B, int ncls, void* stream) {
   if (!kp || !gt_kp || !cats || !out || B <= 0) return T3D_ERR_ARG;
   if (logits && (ncls <= 0 || ncls > 64)) return T3D_ERR_ARG;
-  hipLaunchKernelGGL(metrics_per_sample_kernel, dim3(cdiv(B, 256)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+  T3D_LAUNCH(metrics_per_sample_kernel, dim3(cdiv(B, 256)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
                      kp, gt_kp, logits, cats, out, B, ncls);
   T3D_CHECK_LAUNCH();
   return T3D_OK;
@@ -257,7 +257,7 @@ extern "C" int t3d_loss_fwd_bwd(const t3d_loss_cfg* cfg, const float* kp, const 
                                 void* stream) {
   if (!cfg || !kp || !gt_kp || !cats || !out || B <= 0) return T3D_ERR_ARG;
   if (logits && (ncls <= 0 || ncls > 64)) return T3D_ERR_ARG;
-  hipLaunchKernelGGL(loss_kernel, dim3(1), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), *cfg, kp, gt_kp,
+  T3D_LAUNCH(loss_kernel, dim3(1), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), *cfg, kp, gt_kp,
                      logits, cats, out, dkp, dlogits, B, ncls);
   T3D_CHECK_LAUNCH();
   return T3D_OK;

@@ -245,7 +245,7 @@ extern "C" int t3d_adamw_step(float* p, const float* g, float* m, float* v, long
   const double bc1 = 1.0 - pow(b1d, (double)step), bc2 = 1.0 - pow(b2d, (double)step);
   const long long n4 = n / 4;
   const int grid = (int)((n4 + 255) / 256 < 2048 ? (n4 + 255) / 256 : 2048);
-  hipLaunchKernelGGL(adamw_kernel, dim3(grid), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), p, g, m, v, n4,
+  T3D_LAUNCH(adamw_kernel, dim3(grid), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), p, g, m, v, n4,
                      (float)(1.0 - lr * weight_decay), (float)(1.0 - b1d), (float)beta2, (float)(1.0 - b2d),
                      (float)(lr / bc1), (float)(1.0 / sqrt(bc2)), (float)eps, (float)grad_scale);
   T3D_CHECK_LAUNCH();
@@ -254,7 +254,7 @@ extern "C" int t3d_adamw_step(float* p, const float* g, float* m, float* v, long
 
 extern "C" int t3d_copy_cols(const float* src, float* dst, int rows, int cols_src, int cols_dst, void* stream) {
   if (!src || !dst || rows <= 0 || cols_src <= 0 || cols_dst <= 0) return T3D_ERR_ARG;
-  hipLaunchKernelGGL(copy_cols_kernel, dim3(cdiv(rows * cols_dst, 256) < 256 ? cdiv(rows * cols_dst, 256) : 256),
+  T3D_LAUNCH(copy_cols_kernel, dim3(cdiv(rows * cols_dst, 256) < 256 ? cdiv(rows * cols_dst, 256) : 256),
                      dim3(256), 0, reinterpret_cast<hipStream_t>(stream), src, dst, rows, cols_src, cols_dst);
   T3D_CHECK_LAUNCH();
   return T3D_OK;
@@ -264,7 +264,7 @@ extern "C" int t3d_bn_bias_grad(const double* fwd_stats, const double* bwd_stats
                                 const float* alpha, const float* beta, const float* gammac, float* dbias,
                                 void* stream) {
   if (!fwd_stats || !bwd_stats || !alpha || !beta || !gammac || !dbias || C <= 0) return T3D_ERR_ARG;
-  hipLaunchKernelGGL(bn_bias_grad_kernel, dim3(cdiv(C, 256)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+  T3D_LAUNCH(bn_bias_grad_kernel, dim3(cdiv(C, 256)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
                      fwd_stats, bwd_stats, g_t3d_reduce.nrep, g_t3d_reduce.stats_stride, C, count, alpha, beta, gammac,
                      dbias);
   T3D_CHECK_LAUNCH();
@@ -274,7 +274,7 @@ extern "C" int t3d_bn_bias_grad(const double* fwd_stats, const double* bwd_stats
 extern "C" int t3d_se_bwd_affine(const float* s, const float* g, const float* alpha, const float* gammac, float* aps,
                                  float* gps, int B, int C, void* stream) {
   if (!s || !g || !alpha || !gammac || !aps || !gps || B <= 0 || C <= 0) return T3D_ERR_ARG;
-  hipLaunchKernelGGL(se_bwd_affine_kernel, dim3(cdiv(B * C, 256) < 512 ? cdiv(B * C, 256) : 512), dim3(256), 0,
+  T3D_LAUNCH(se_bwd_affine_kernel, dim3(cdiv(B * C, 256) < 512 ? cdiv(B * C, 256) : 512), dim3(256), 0,
                      reinterpret_cast<hipStream_t>(stream), s, g, alpha, gammac, aps, gps, B, C);
   T3D_CHECK_LAUNCH();
   return T3D_OK;
@@ -284,7 +284,7 @@ extern "C" int t3d_dropout_mask(float* mask, long long n, unsigned long long see
                                 void* stream) {
   if (!mask || n <= 0 || !(p >= 0.f && p < 1.f)) return T3D_ERR_ARG;
   const long long n4 = (n + 3) / 4;
-  hipLaunchKernelGGL(dropout_mask_kernel, dim3((int)((n4 + 255) / 256 < 1024 ? (n4 + 255) / 256 : 1024)), dim3(256), 0,
+  T3D_LAUNCH(dropout_mask_kernel, dim3((int)((n4 + 255) / 256 < 1024 ? (n4 + 255) / 256 : 1024)), dim3(256), 0,
                      reinterpret_cast<hipStream_t>(stream), mask, n, seed, offset, 1.f - p, 1.f / (1.f - p));
   T3D_CHECK_LAUNCH();
   return T3D_OK;
@@ -292,21 +292,21 @@ extern "C" int t3d_dropout_mask(float* mask, long long n, unsigned long long see
 
 extern "C" int t3d_zero_batched(const long long* desc, int n, void* stream) {
   if (!desc || n <= 0) return T3D_ERR_ARG;
-  hipLaunchKernelGGL(zero_batched_kernel, dim3(n, 64), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), desc);
+  T3D_LAUNCH(zero_batched_kernel, dim3(n, 64), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), desc);
   T3D_CHECK_LAUNCH();
   return T3D_OK;
 }
 
 extern "C" int t3d_sum_slots_batched(const long long* desc, int n, void* stream) {
   if (!desc || n <= 0) return T3D_ERR_ARG;
-  hipLaunchKernelGGL(sum_slots_batched_kernel, dim3(n, 32), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), desc);
+  T3D_LAUNCH(sum_slots_batched_kernel, dim3(n, 32), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), desc);
   T3D_CHECK_LAUNCH();
   return T3D_OK;
 }
 
 extern "C" int t3d_sum_replicas_batched(const long long* desc, int n, int nrep, void* stream) {
   if (!desc || n <= 0 || nrep < 1) return T3D_ERR_ARG;
-  hipLaunchKernelGGL(sum_replicas_batched_kernel, dim3(n, 8), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), desc, nrep);
+  T3D_LAUNCH(sum_replicas_batched_kernel, dim3(n, 8), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), desc, nrep);
   T3D_CHECK_LAUNCH();
   return T3D_OK;
 }
@@ -314,9 +314,9 @@ extern "C" int t3d_sum_replicas_batched(const long long* desc, int n, int nrep, 
 extern "C" int t3d_pack_weights_batched(int dtype, const long long* desc, int n, void* stream) {
   if (!desc || n <= 0) return T3D_ERR_ARG;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-  if (dtype == T3D_F32) hipLaunchKernelGGL(pack_batched_kernel<float>, dim3(n, 48), dim3(256), 0, st, desc);
-  else if (dtype == T3D_BF16) hipLaunchKernelGGL(pack_batched_kernel<bf16_t>, dim3(n, 48), dim3(256), 0, st, desc);
-  else if (dtype == T3D_F16) hipLaunchKernelGGL(pack_batched_kernel<f16_t>, dim3(n, 48), dim3(256), 0, st, desc);
+  if (dtype == T3D_F32) T3D_LAUNCH(pack_batched_kernel<float>, dim3(n, 48), dim3(256), 0, st, desc);
+  else if (dtype == T3D_BF16) T3D_LAUNCH(pack_batched_kernel<bf16_t>, dim3(n, 48), dim3(256), 0, st, desc);
+  else if (dtype == T3D_F16) T3D_LAUNCH(pack_batched_kernel<f16_t>, dim3(n, 48), dim3(256), 0, st, desc);
   else return T3D_ERR_ARG;
   T3D_CHECK_LAUNCH();
   return T3D_OK;
@@ -329,11 +329,11 @@ extern "C" int t3d_pack_weight(int dtype, const float* w, void* out, int rows, i
   const int grid = (int)((n + 255) / 256 < 1024 ? (n + 255) / 256 : 1024);
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   if (dtype == T3D_F32)
-    hipLaunchKernelGGL(pack_kernel<float>, dim3(grid), dim3(256), 0, st, w, (float*)out, rows, cols, transpose);
+    T3D_LAUNCH(pack_kernel<float>, dim3(grid), dim3(256), 0, st, w, (float*)out, rows, cols, transpose);
   else if (dtype == T3D_BF16)
-    hipLaunchKernelGGL(pack_kernel<bf16_t>, dim3(grid), dim3(256), 0, st, w, (bf16_t*)out, rows, cols, transpose);
+    T3D_LAUNCH(pack_kernel<bf16_t>, dim3(grid), dim3(256), 0, st, w, (bf16_t*)out, rows, cols, transpose);
   else if (dtype == T3D_F16)
-    hipLaunchKernelGGL(pack_kernel<f16_t>, dim3(grid), dim3(256), 0, st, w, (f16_t*)out, rows, cols, transpose);
+    T3D_LAUNCH(pack_kernel<f16_t>, dim3(grid), dim3(256), 0, st, w, (f16_t*)out, rows, cols, transpose);
   else
     return T3D_ERR_ARG;
   T3D_CHECK_LAUNCH();
@@ -348,6 +348,15 @@ extern "C" int t3d_set_exact_pool(int on) {
 }
 
 T3dLaunchEvents g_t3d_time = {nullptr, nullptr};
+T3dSignal g_t3d_signal = {nullptr, nullptr};
+unsigned long long g_t3d_launches = 0;
+hipStream_t g_t3d_last_stream = nullptr;
+
+extern "C" int t3d_launch_count(unsigned long long* count, void** last_stream) {
+  if (count) *count = g_t3d_launches;
+  if (last_stream) *last_stream = g_t3d_last_stream;
+  return T3D_OK;
+}
 
 extern "C" int t3d_set_launch_events(void* start_event, void* stop_event) {
   if ((start_event == nullptr) != (stop_event == nullptr)) return T3D_ERR_ARG;
@@ -402,3 +411,18 @@ extern "C" int t3d_set_workspace(void* ptr, long long bytes) {
   g_t3d_ws.bytes = ptr ? bytes : 0;
   return T3D_OK;
 }
+
+// see common.h: the attribute only ever has to grow, so remember the largest value set per kernel
+#include <mutex>
+#include <unordered_map>
+hipError_t t3d_max_lds(const void* fn, int bytes) {
+  static std::mutex mu;
+  static std::unordered_map<const void*, int> seen;
+  std::lock_guard<std::mutex> lock(mu);
+  int& cur = seen[fn];
+  if (bytes <= cur) return hipSuccess;
+  const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+  if (e == hipSuccess) cur = bytes;
+  return e;
+}
+

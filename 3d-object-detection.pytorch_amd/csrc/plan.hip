@@ -90,8 +90,12 @@ struct Op {
   int nargs;
   uint64_t w[kMaxArgs];         // literal words (ARG_STRUCT: offset into the plan's struct arena, fixed up to a pointer at run time)
   uint8_t ak[kMaxArgs];         // ArgKind per argument
-  // OP_FORK: w[0] = stream recorded on, w[1] = stream that waits;  OP_COPY_D2H: dst, src, bytes, stream;  OP_EVENT_RECORD: event, stream
+  // OP_FORK: w[0] = stream recorded on, w[1] = stream that waits, w[2] = 1: wait only (`ev` is the stop event of an earlier
+  // call's last kernel, owned by that op);  OP_COPY_D2H: dst, src, bytes, stream;  OP_EVENT_RECORD: event, stream
+  // OP_CALL: ev != null: the kernels this call launches on stream `sig_stream` carry `ev` as their stop event (common.h:
+  // T3dSignal) -- the hand-off of t3d_plan_add_fork_after
   hipEvent_t ev;
+  hipStream_t sig_stream;
 };
 
 }  // namespace
@@ -120,7 +124,7 @@ extern "C" int t3d_plan_create(t3d_plan** out) {
 extern "C" int t3d_plan_destroy(t3d_plan* p) {
   if (!p) return T3D_OK;
   for (Op& o : p->ops)
-    if (o.kind == OP_FORK && o.ev) (void)hipEventDestroy(o.ev);
+    if (o.ev && !(o.kind == OP_FORK && o.w[2])) (void)hipEventDestroy(o.ev);
   delete p;
   return T3D_OK;
 }
@@ -159,6 +163,27 @@ extern "C" int t3d_plan_add_fork(t3d_plan* p, void* from_stream, void* to_stream
   o.w[0] = reinterpret_cast<uintptr_t>(from_stream);
   o.w[1] = reinterpret_cast<uintptr_t>(to_stream);
   if (hipEventCreateWithFlags(&o.ev, hipEventDisableTiming) != hipSuccess) return T3D_ERR_LAUNCH;
+  p->ops.push_back(o);
+  return T3D_OK;
+}
+
+// The stream `to_stream` waits for the LAST kernel that call op `producer_op` launches on `from_stream` -- through the stop
+// event of that kernel's own dispatch packet: nothing is enqueued on `from_stream` (include/t3d.h).
+extern "C" int t3d_plan_add_fork_after(t3d_plan* p, int producer_op, void* from_stream, void* to_stream) {
+  if (!p || producer_op < 0 || producer_op >= (int)p->ops.size() || p->ops[producer_op].kind != OP_CALL) return T3D_ERR_ARG;
+  Op& prod = p->ops[producer_op];
+  hipStream_t from = reinterpret_cast<hipStream_t>(from_stream);
+  if (prod.ev && prod.sig_stream != from) return T3D_ERR_ARG;
+  if (!prod.ev) {
+    if (hipEventCreateWithFlags(&prod.ev, hipEventDisableTiming) != hipSuccess) return T3D_ERR_LAUNCH;
+    prod.sig_stream = from;
+  }
+  Op o{};
+  o.kind = OP_FORK;
+  o.w[0] = reinterpret_cast<uintptr_t>(from_stream);
+  o.w[1] = reinterpret_cast<uintptr_t>(to_stream);
+  o.w[2] = 1;
+  o.ev = prod.ev;
   p->ops.push_back(o);
   return T3D_OK;
 }
@@ -242,7 +267,9 @@ extern "C" int t3d_plan_run(t3d_plan* p, int segment, const unsigned long long* 
         if (rc) break;
         const bool timed = events && p->timed[o.entry] && used + 2 <= nevents;
         if (timed) (void)t3d_set_launch_events(events[used], events[used + 1]);
+        if (o.ev) g_t3d_signal = {o.ev, o.sig_stream};
         rc = kEntries[o.entry].run(w);
+        if (o.ev) g_t3d_signal = {nullptr, nullptr};
         if (timed) {
           (void)t3d_set_launch_events(nullptr, nullptr);
           used += 2;
@@ -252,7 +279,8 @@ extern "C" int t3d_plan_run(t3d_plan* p, int segment, const unsigned long long* 
       case OP_FORK: {
         hipStream_t from = reinterpret_cast<hipStream_t>(static_cast<uintptr_t>(o.w[0]));
         hipStream_t to = reinterpret_cast<hipStream_t>(static_cast<uintptr_t>(o.w[1]));
-        if (hipEventRecord(o.ev, from) != hipSuccess || hipStreamWaitEvent(to, o.ev, 0) != hipSuccess) rc = T3D_ERR_LAUNCH;
+        if (!o.w[2] && hipEventRecord(o.ev, from) != hipSuccess) rc = T3D_ERR_LAUNCH;
+        if (rc == T3D_OK && hipStreamWaitEvent(to, o.ev, 0) != hipSuccess) rc = T3D_ERR_LAUNCH;
         break;
       }
       case OP_COPY_D2H: {

@@ -320,7 +320,7 @@ int launch_nt(GemmArgs& a, hipStream_t st) {
   int gx = a.mtiles < 2048 / ny ? a.mtiles : 2048 / ny;
   if (gx < 1) gx = 1;
   if (lds > 64 * 1024)
-    (void)hipFuncSetAttribute((const void*)pw_gemm_kernel<T, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)t3d_max_lds((const void*)pw_gemm_kernel<T, NT>, (int)lds);
   a.kz = 1;
   const int nk = kpad / MM<T>::BK;
   if (std::is_same<T, float>::value && gx * ny <= 64 && nk >= 16 && !a.e_y && !a.e_res && !a.ps_stats) {
@@ -331,9 +331,9 @@ int launch_nt(GemmArgs& a, hipStream_t st) {
       a.part = reinterpret_cast<float*>(g_t3d_ws_main.ptr);
     }
   }
-  hipLaunchKernelGGL((pw_gemm_kernel<T, NT>), dim3(gx, ny, a.kz), dim3(256), lds, st, a);
+  T3D_LAUNCH((pw_gemm_kernel<T, NT>), dim3(gx, ny, a.kz), dim3(256), lds, st, a);
   if (a.kz > 1)
-    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(cdiv(a.Nout, 64), cdiv(a.M, 64)), dim3(256), 0, st, a.part, a.bias,
+    T3D_LAUNCH(splitk_reduce_kernel, dim3(cdiv(a.Nout, 64), cdiv(a.M, 64)), dim3(256), 0, st, a.part, a.bias,
                        reinterpret_cast<float*>(a.out), a.stats, a.kz, a.M, a.Nout);
   T3D_CHECK_LAUNCH();
   return T3D_OK;

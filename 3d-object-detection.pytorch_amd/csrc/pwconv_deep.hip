@@ -319,10 +319,10 @@ int launch_deep(GemmArgs& a, int KS, int ntiles, int nchunks, hipStream_t st) {
   const size_t lds = (size_t)2 * RT * KSP * 1024 + (size_t)3 * KS * 32 * 4 + (size_t)ntiles * 16 * (2 * 4 + 2 * 8);
   if (lds > 150 * 1024) return T3D_ERR_UNSUPPORTED;
   const void* fn = (const void*)pw_deep_kernel<DG>;
-  if (lds > 64 * 1024) (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (lds > 64 * 1024) (void)t3d_max_lds(fn, (int)lds);
   a.quant = (!DG && a.stats && !getenv("T3D_NO_SNAP")) ? t3d_quant_for(a.M) : T3dQuant{0.0, 0.0};
   a.fold = t3d_take_fold(a.p0);
-  hipLaunchKernelGGL((pw_deep_kernel<DG>), dim3(cdiv(a.M, 16 * RT), nchunks), dim3(64 * NW), lds, st, a, KS, ntiles,
+  T3D_LAUNCH((pw_deep_kernel<DG>), dim3(cdiv(a.M, 16 * RT), nchunks), dim3(64 * NW), lds, st, a, KS, ntiles,
                      g_t3d_reduce.nrep, g_t3d_reduce.stats_stride);
   T3D_CHECK_LAUNCH();
   return T3D_OK;
@@ -389,7 +389,7 @@ extern "C" int t3d_pwconv_wants_frag(int K, int N) { return t3d_pw::deep_shape(K
 extern "C" int t3d_pwconv_pack_frag(const void* w, void* out, int rows, int cols, void* stream) {
   if (!w || !out || rows <= 0 || cols <= 0) return T3D_ERR_ARG;
   const size_t total = (size_t)t3d_pwconv_frag_bytes(rows, cols) / 2;
-  hipLaunchKernelGGL(t3d_pw::pack_frag_kernel, dim3((unsigned)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048)), dim3(256), 0,
+  T3D_LAUNCH(t3d_pw::pack_frag_kernel, dim3((unsigned)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048)), dim3(256), 0,
                      reinterpret_cast<hipStream_t>(stream), reinterpret_cast<const unsigned short*>(w), reinterpret_cast<unsigned short*>(out), rows,
                      cols, cdiv(cols, 32), total);
   T3D_CHECK_LAUNCH();

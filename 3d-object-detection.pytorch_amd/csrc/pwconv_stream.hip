@@ -568,7 +568,7 @@ int launch_v(GemmArgs& a, int KS, hipStream_t st) {
   const int gps = cdiv(a.HW, 16 * R);
   const int threads = (lds <= 48 * 1024 || (ps && gps <= 4)) ? 256 : 512;
   const void* fn = (const void*)pw_stream_kernel<NT, R, DG, GEN, YF, KU, ZM>;
-  if (lds > 64 * 1024) (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (lds > 64 * 1024) (void)t3d_max_lds(fn, (int)lds);
   static int occ_cache[2] = {0, 0};   // per instantiation (function-local static of the template), per block size
   int& occ = occ_cache[threads == 512];
   if (occ == 0) {
@@ -597,7 +597,7 @@ int launch_v(GemmArgs& a, int KS, hipStream_t st) {
   } else {
     a.fold = t3d_take_fold(a.p0);
   }
-  hipLaunchKernelGGL((pw_stream_kernel<NT, R, DG, GEN, YF, KU, ZM>), dim3(nxb * nchunks), dim3(threads), lds, st, a, nchunks, KS,
+  T3D_LAUNCH((pw_stream_kernel<NT, R, DG, GEN, YF, KU, ZM>), dim3(nxb * nchunks), dim3(threads), lds, st, a, nchunks, KS,
                      g_t3d_reduce.nrep, g_t3d_reduce.stats_stride);
   T3D_CHECK_LAUNCH();
   return T3D_OK;

@@ -580,18 +580,18 @@ int launch_d(WgtArgs& a, hipStream_t st) {
   // (atomics into dw: an assigned-to dw is cleared first; with partial tiles the reduction writes it)
   if (a.assign && !use_ws && hipMemsetAsync(a.dw, 0, (size_t)a.N * a.K * sizeof(float), st) != hipSuccess) return T3D_ERR_LAUNCH;
   if (lds > 64 * 1024)
-    (void)hipFuncSetAttribute((const void*)pw_wgrad_tr_kernel<NTPW, NTQ, SWAP, G, D, GEN, YF, SK>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)t3d_max_lds((const void*)pw_wgrad_tr_kernel<NTPW, NTQ, SWAP, G, D, GEN, YF, SK>, (int)lds);
   a.nsplit = S;
-  hipLaunchKernelGGL((pw_wgrad_tr_kernel<NTPW, NTQ, SWAP, G, D, GEN, YF, SK>), dim3(tiles * S), dim3(256 * G), lds, st, a);
+  T3D_LAUNCH((pw_wgrad_tr_kernel<NTPW, NTQ, SWAP, G, D, GEN, YF, SK>), dim3(tiles * S), dim3(256 * G), lds, st, a);
   if (use_ws) {
     // split groups inside the workgroup: enough parallelism for a small dW with hundreds of splits
 #define T3D_WGR(SPV)                                                                                                              \
   do {                                                                                                                            \
     if (SWAP)                                                                                                                     \
-      hipLaunchKernelGGL(wgrad_reduce_tr_kernel<(SPV == 16 ? 8 : SPV)>, dim3(cdiv(a.K, 8 / (SPV == 16 ? 8 : SPV)) * cdiv(a.qtiles * QB, 32)), dim3(256), 0, st, \
+      T3D_LAUNCH(wgrad_reduce_tr_kernel<(SPV == 16 ? 8 : SPV)>, dim3(cdiv(a.K, 8 / (SPV == 16 ? 8 : SPV)) * cdiv(a.qtiles * QB, 32)), dim3(256), 0, st, \
                          a.ws, a.dw, a.N, a.K, PB, QB, a.qtiles, tiles, S, a.assign);                                             \
     else                                                                                                                          \
-      hipLaunchKernelGGL(wgrad_reduce_kernel<SPV>, dim3(cdiv(a.N * a.qtiles * QB, 256 / SPV)), dim3(256), 0, st, a.ws, a.dw, a.N, \
+      T3D_LAUNCH(wgrad_reduce_kernel<SPV>, dim3(cdiv(a.N * a.qtiles * QB, 256 / SPV)), dim3(256), 0, st, a.ws, a.dw, a.N, \
                          a.K, PB, QB, a.qtiles, tiles, S, a.assign);                                                              \
   } while (0)
     if (S >= 64) T3D_WGR(16);
@@ -670,9 +670,9 @@ static int choose_and_launch(WgtArgs& a, hipStream_t st) {
 // fixed-order sum of partial tiles (straight orientation) for the fp32 parity kernel of pwconv_wgrad.hip
 int t3d_pw_wgrad_reduce(const float* ws, float* dw, int N, int K, int PB, int QB, int qtiles, int tiles, int S, hipStream_t st) {
   const int blocks = [&](int sp) { return cdiv(N * qtiles * QB, 256 / sp); }(S >= 64 ? 16 : (S >= 8 ? 4 : 1));
-  if (S >= 64) hipLaunchKernelGGL(wgrad_reduce_kernel<16>, dim3(blocks), dim3(256), 0, st, ws, dw, N, K, PB, QB, qtiles, tiles, S, 0);
-  else if (S >= 8) hipLaunchKernelGGL(wgrad_reduce_kernel<4>, dim3(blocks), dim3(256), 0, st, ws, dw, N, K, PB, QB, qtiles, tiles, S, 0);
-  else hipLaunchKernelGGL(wgrad_reduce_kernel<1>, dim3(blocks), dim3(256), 0, st, ws, dw, N, K, PB, QB, qtiles, tiles, S, 0);
+  if (S >= 64) T3D_LAUNCH(wgrad_reduce_kernel<16>, dim3(blocks), dim3(256), 0, st, ws, dw, N, K, PB, QB, qtiles, tiles, S, 0);
+  else if (S >= 8) T3D_LAUNCH(wgrad_reduce_kernel<4>, dim3(blocks), dim3(256), 0, st, ws, dw, N, K, PB, QB, qtiles, tiles, S, 0);
+  else T3D_LAUNCH(wgrad_reduce_kernel<1>, dim3(blocks), dim3(256), 0, st, ws, dw, N, K, PB, QB, qtiles, tiles, S, 0);
   T3D_CHECK_LAUNCH();
   return T3D_OK;
 }
@@ -725,8 +725,8 @@ static int launch_fused(WgtArgs& a, const YfCfg& c, hipStream_t st) {
   const size_t lds = (size_t)G * 2 * STEP * ((PB + 8) + (QB + 8)) * 2 + (size_t)((ncoef + 3) & ~3) * 4 + (size_t)QB * (PB + 8) * 2 +
                      (size_t)2 * QB * sizeof(double);
   const void* fn = (const void*)pw_wgrad_tr_kernel<NTPW, NTQ, false, G, 2, false, true, SK, true>;
-  if (lds > 64 * 1024) (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  hipLaunchKernelGGL((pw_wgrad_tr_kernel<NTPW, NTQ, false, G, 2, false, true, SK, true>), dim3(c.S), dim3(256 * G), lds, st, a);
+  if (lds > 64 * 1024) (void)t3d_max_lds(fn, (int)lds);
+  T3D_LAUNCH((pw_wgrad_tr_kernel<NTPW, NTQ, false, G, 2, false, true, SK, true>), dim3(c.S), dim3(256 * G), lds, st, a);
   T3D_CHECK_LAUNCH();
   return T3D_OK;
 }
@@ -771,7 +771,7 @@ int t3d_pw_bwd_yfree_reduce(void* scratch, float** tmp_out, int M, int K, int N,
   float* tmp = ws + (size_t)c.S * c.PB * c.QB;
   const int rows = N + K + 8;
   // (every entry of tmp has one owner thread that WRITES it: no clear ahead of the launch)
-#define T3D_YFR(SPV) hipLaunchKernelGGL(wgrad_reduce_kernel<SPV>, dim3(cdiv(rows * c.QB, 256 / SPV)), dim3(256), 0, st, ws, tmp, rows, K, c.PB, c.QB, 1, 1, c.S, 1)
+#define T3D_YFR(SPV) T3D_LAUNCH(wgrad_reduce_kernel<SPV>, dim3(cdiv(rows * c.QB, 256 / SPV)), dim3(256), 0, st, ws, tmp, rows, K, c.PB, c.QB, 1, 1, c.S, 1)
   if (c.S >= 64) T3D_YFR(16);
   else if (c.S >= 8) T3D_YFR(4);
   else T3D_YFR(1);

@@ -190,7 +190,7 @@ extern "C" int t3d_pwconv_wgrad_yfree_finish(void* scratch, const t3d_bnbwd* bb,
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   float* tmp = nullptr;
   if (const int rc = t3d_pw_bwd_yfree_reduce(scratch, &tmp, M, K, N, st)) return rc;
-  hipLaunchKernelGGL(yfree_combine_kernel, dim3(cdiv(N * K, 256)), dim3(256), 0, st, tmp, reinterpret_cast<const bf16_t*>(w),
+  T3D_LAUNCH(yfree_combine_kernel, dim3(cdiv(N * K, 256)), dim3(256), 0, st, tmp, reinterpret_cast<const bf16_t*>(w),
                      bb->alpha, bb->beta, bb->gamma, dw, K, N);
   T3D_CHECK_LAUNCH();
   return T3D_OK;
@@ -206,7 +206,7 @@ static int yfree_prep_impl(const void* wt, const t3d_bnbwd* bb, void* wcat, floa
   const T3dFold* fold = nullptr;
   if (derive) fold = t3d_take_fold(bb->alpha);
   else if (const int rc = t3d_fold_fallback(bb->alpha, reinterpret_cast<hipStream_t>(stream))) return rc;
-  hipLaunchKernelGGL(yfree_prep_kernel, dim3(rup32(K) / 16, rup32(K) / 16), dim3(256), (size_t)3 * N * sizeof(float),
+  T3D_LAUNCH(yfree_prep_kernel, dim3(rup32(K) / 16, rup32(K) / 16), dim3(256), (size_t)3 * N * sizeof(float),
                      reinterpret_cast<hipStream_t>(stream), reinterpret_cast<const bf16_t*>(w), bb->alpha, bb->beta, bb->gamma,
                      reinterpret_cast<bf16_t*>(wcat), cvec, K, N, rup32(N), rup32(K), fold, reinterpret_cast<bf16_t*>(wd), PBw);
   T3D_CHECK_LAUNCH();
@@ -248,7 +248,7 @@ extern "C" int t3d_pwconv_wgrad_yfree(const void* dz, const void* x, const t3d_b
   const int rc = t3d_pw_wgrad_tr_yfree(dz, x, tmp, M, HW, K, N, st);
   g_t3d_ws = saved;
   if (rc != T3D_OK) return rc;
-  hipLaunchKernelGGL(yfree_combine_kernel, dim3(cdiv(N * K, 256)), dim3(256), 0, st, tmp, reinterpret_cast<const bf16_t*>(w),
+  T3D_LAUNCH(yfree_combine_kernel, dim3(cdiv(N * K, 256)), dim3(256), 0, st, tmp, reinterpret_cast<const bf16_t*>(w),
                      bb->alpha, bb->beta, bb->gamma, dw, K, N);
   T3D_CHECK_LAUNCH();
   return T3D_OK;

@@ -730,15 +730,15 @@ extern "C" int t3d_im2col(int dtype, const void* x, const t3d_prologue* pro, voi
     const int g = runs_for(M, 8192, &rpw), cs = log2_exact(C), kinv = 65536 / k + 1;
     const size_t lds = sc ? (size_t)2 * C * sizeof(float) : 0;
     T3D_DISPATCH(dtype,
-                 hipLaunchKernelGGL(im2col_v_kernel<float>, dim3(g), dim3(256), lds, st, (const float*)x, sc, sh, act, (float*)col, B, H, W, C, k, stride, pad, Ho, Wo, Kp, cs, kinv, rpw),
-                 hipLaunchKernelGGL(im2col_v_kernel<bf16_t>, dim3(g), dim3(256), lds, st, (const bf16_t*)x, sc, sh, act, (bf16_t*)col, B, H, W, C, k, stride, pad, Ho, Wo, Kp, cs, kinv, rpw));
+                 T3D_LAUNCH(im2col_v_kernel<float>, dim3(g), dim3(256), lds, st, (const float*)x, sc, sh, act, (float*)col, B, H, W, C, k, stride, pad, Ho, Wo, Kp, cs, kinv, rpw),
+                 T3D_LAUNCH(im2col_v_kernel<bf16_t>, dim3(g), dim3(256), lds, st, (const bf16_t*)x, sc, sh, act, (bf16_t*)col, B, H, W, C, k, stride, pad, Ho, Wo, Kp, cs, kinv, rpw));
     T3D_CHECK_LAUNCH();
     return T3D_OK;
   }
   const int g = grid_for((long long)B * Ho * Wo * Kp);
   T3D_DISPATCH(dtype,
-               hipLaunchKernelGGL(im2col_kernel<float>, dim3(g), dim3(256), 0, st, (const float*)x, sc, sh, act, (float*)col, B, H, W, C, k, stride, pad, Ho, Wo, Kp),
-               hipLaunchKernelGGL(im2col_kernel<bf16_t>, dim3(g), dim3(256), 0, st, (const bf16_t*)x, sc, sh, act, (bf16_t*)col, B, H, W, C, k, stride, pad, Ho, Wo, Kp));
+               T3D_LAUNCH(im2col_kernel<float>, dim3(g), dim3(256), 0, st, (const float*)x, sc, sh, act, (float*)col, B, H, W, C, k, stride, pad, Ho, Wo, Kp),
+               T3D_LAUNCH(im2col_kernel<bf16_t>, dim3(g), dim3(256), 0, st, (const bf16_t*)x, sc, sh, act, (bf16_t*)col, B, H, W, C, k, stride, pad, Ho, Wo, Kp));
   T3D_CHECK_LAUNCH();
   return T3D_OK;
 }
@@ -753,15 +753,15 @@ extern "C" int t3d_im2col_nchw(int dtype, const float* x, void* col, int B, int 
     int rpw;
     const int g = runs_for(M, 8192, &rpw), cinv = 65536 / C + 1, kinv = 65536 / k + 1;
     T3D_DISPATCH(dtype,
-                 hipLaunchKernelGGL(im2col_nchw_v_kernel<float>, dim3(g), dim3(256), 0, st, x, (float*)col, B, H, W, C, k, stride, pad, Ho, Wo, Kp, cinv, kinv, rpw),
-                 hipLaunchKernelGGL(im2col_nchw_v_kernel<bf16_t>, dim3(g), dim3(256), 0, st, x, (bf16_t*)col, B, H, W, C, k, stride, pad, Ho, Wo, Kp, cinv, kinv, rpw));
+                 T3D_LAUNCH(im2col_nchw_v_kernel<float>, dim3(g), dim3(256), 0, st, x, (float*)col, B, H, W, C, k, stride, pad, Ho, Wo, Kp, cinv, kinv, rpw),
+                 T3D_LAUNCH(im2col_nchw_v_kernel<bf16_t>, dim3(g), dim3(256), 0, st, x, (bf16_t*)col, B, H, W, C, k, stride, pad, Ho, Wo, Kp, cinv, kinv, rpw));
     T3D_CHECK_LAUNCH();
     return T3D_OK;
   }
   const int g = grid_for((long long)B * Ho * Wo * Kp);
   T3D_DISPATCH(dtype,
-               hipLaunchKernelGGL(im2col_nchw_kernel<float>, dim3(g), dim3(256), 0, st, x, (float*)col, B, H, W, C, k, stride, pad, Ho, Wo, Kp),
-               hipLaunchKernelGGL(im2col_nchw_kernel<bf16_t>, dim3(g), dim3(256), 0, st, x, (bf16_t*)col, B, H, W, C, k, stride, pad, Ho, Wo, Kp));
+               T3D_LAUNCH(im2col_nchw_kernel<float>, dim3(g), dim3(256), 0, st, x, (float*)col, B, H, W, C, k, stride, pad, Ho, Wo, Kp),
+               T3D_LAUNCH(im2col_nchw_kernel<bf16_t>, dim3(g), dim3(256), 0, st, x, (bf16_t*)col, B, H, W, C, k, stride, pad, Ho, Wo, Kp));
   T3D_CHECK_LAUNCH();
   return T3D_OK;
 }
@@ -780,7 +780,7 @@ extern "C" int t3d_col2im_bwd(int dtype, const void* dcol, const void* x_raw, co
     int ppw;
     const int g = runs_for((long long)B * H * W, 4096, &ppw), nrep = g_t3d_reduce.nrep;
     const long long rs = g_t3d_reduce.stats_stride;
-#define T3D_C2I(TT, SS) hipLaunchKernelGGL((col2im_bwd_v_kernel<TT, SS>), dim3(g), dim3(256), lds, st, (const TT*)dcol, (const TT*)x_raw, sc, sh, act, (TT*)dx, stats, B, H, W, C, k, pad, Ho, Wo, Kp, nrep, rs, ppw)
+#define T3D_C2I(TT, SS) T3D_LAUNCH((col2im_bwd_v_kernel<TT, SS>), dim3(g), dim3(256), lds, st, (const TT*)dcol, (const TT*)x_raw, sc, sh, act, (TT*)dx, stats, B, H, W, C, k, pad, Ho, Wo, Kp, nrep, rs, ppw)
     if (stride == 1) T3D_DISPATCH(dtype, T3D_C2I(float, 1), T3D_C2I(bf16_t, 1));
     else T3D_DISPATCH(dtype, T3D_C2I(float, 2), T3D_C2I(bf16_t, 2));
 #undef T3D_C2I
@@ -789,8 +789,8 @@ extern "C" int t3d_col2im_bwd(int dtype, const void* dcol, const void* x_raw, co
   }
   const int g = grid_for_c((long long)B * H * W * C, C);
   T3D_DISPATCH(dtype,
-               hipLaunchKernelGGL(col2im_bwd_kernel<float>, dim3(g), dim3(256), lds, st, (const float*)dcol, (const float*)x_raw, sc, sh, act, (float*)dx, stats, B, H, W, C, k, stride, pad, Ho, Wo, Kp, g_t3d_reduce.nrep, g_t3d_reduce.stats_stride),
-               hipLaunchKernelGGL(col2im_bwd_kernel<bf16_t>, dim3(g), dim3(256), lds, st, (const bf16_t*)dcol, (const bf16_t*)x_raw, sc, sh, act, (bf16_t*)dx, stats, B, H, W, C, k, stride, pad, Ho, Wo, Kp, g_t3d_reduce.nrep, g_t3d_reduce.stats_stride));
+               T3D_LAUNCH(col2im_bwd_kernel<float>, dim3(g), dim3(256), lds, st, (const float*)dcol, (const float*)x_raw, sc, sh, act, (float*)dx, stats, B, H, W, C, k, stride, pad, Ho, Wo, Kp, g_t3d_reduce.nrep, g_t3d_reduce.stats_stride),
+               T3D_LAUNCH(col2im_bwd_kernel<bf16_t>, dim3(g), dim3(256), lds, st, (const bf16_t*)dcol, (const bf16_t*)x_raw, sc, sh, act, (bf16_t*)dx, stats, B, H, W, C, k, stride, pad, Ho, Wo, Kp, g_t3d_reduce.nrep, g_t3d_reduce.stats_stride));
   T3D_CHECK_LAUNCH();
   return T3D_OK;
 }
@@ -799,15 +799,15 @@ extern "C" int t3d_pack_conv_weight(int dtype, const float* w, void* out, int N,
   if (!w || !out || N <= 0 || C <= 0 || k <= 0 || Kp < k * k * C) return T3D_ERR_ARG;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   const int g = cdiv(N * Kp, 256);
-  T3D_DISPATCH(dtype, hipLaunchKernelGGL(pack_conv_kernel<float>, dim3(g), dim3(256), 0, st, w, (float*)out, N, C, k, Kp),
-               hipLaunchKernelGGL(pack_conv_kernel<bf16_t>, dim3(g), dim3(256), 0, st, w, (bf16_t*)out, N, C, k, Kp));
+  T3D_DISPATCH(dtype, T3D_LAUNCH(pack_conv_kernel<float>, dim3(g), dim3(256), 0, st, w, (float*)out, N, C, k, Kp),
+               T3D_LAUNCH(pack_conv_kernel<bf16_t>, dim3(g), dim3(256), 0, st, w, (bf16_t*)out, N, C, k, Kp));
   T3D_CHECK_LAUNCH();
   return T3D_OK;
 }
 
 extern "C" int t3d_unpack_conv_grad(const float* dw_packed, float* dw, int N, int C, int k, int Kp, void* stream) {
   if (!dw_packed || !dw || N <= 0 || C <= 0 || k <= 0 || Kp < k * k * C) return T3D_ERR_ARG;
-  hipLaunchKernelGGL(unpack_conv_grad_kernel, dim3(cdiv(N * C * k * k, 256)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+  T3D_LAUNCH(unpack_conv_grad_kernel, dim3(cdiv(N * C * k * k, 256)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
                      dw_packed, dw, N, C, k, Kp);
   T3D_CHECK_LAUNCH();
   return T3D_OK;
@@ -828,15 +828,15 @@ extern "C" int t3d_maxpool_fwd(int dtype, const void* y, const t3d_prologue* pro
     int ppw;
     const int g = runs_for((long long)B * Ho * Wo, 8192, &ppw);
     T3D_DISPATCH(dtype,
-                 hipLaunchKernelGGL(maxpool_fwd_v_kernel<float>, dim3(g), dim3(256), 0, st, (const float*)y, sc, sh, act, (float*)out, argmax, B, H, W, C, Ho, Wo, ppw),
-                 hipLaunchKernelGGL(maxpool_fwd_v_kernel<bf16_t>, dim3(g), dim3(256), 0, st, (const bf16_t*)y, sc, sh, act, (bf16_t*)out, argmax, B, H, W, C, Ho, Wo, ppw));
+                 T3D_LAUNCH(maxpool_fwd_v_kernel<float>, dim3(g), dim3(256), 0, st, (const float*)y, sc, sh, act, (float*)out, argmax, B, H, W, C, Ho, Wo, ppw),
+                 T3D_LAUNCH(maxpool_fwd_v_kernel<bf16_t>, dim3(g), dim3(256), 0, st, (const bf16_t*)y, sc, sh, act, (bf16_t*)out, argmax, B, H, W, C, Ho, Wo, ppw));
     T3D_CHECK_LAUNCH();
     return T3D_OK;
   }
   const int g = grid_for((long long)B * Ho * Wo * C);
   T3D_DISPATCH(dtype,
-               hipLaunchKernelGGL(maxpool_fwd_kernel<float>, dim3(g), dim3(256), 0, st, (const float*)y, sc, sh, act, (float*)out, argmax, B, H, W, C, Ho, Wo),
-               hipLaunchKernelGGL(maxpool_fwd_kernel<bf16_t>, dim3(g), dim3(256), 0, st, (const bf16_t*)y, sc, sh, act, (bf16_t*)out, argmax, B, H, W, C, Ho, Wo));
+               T3D_LAUNCH(maxpool_fwd_kernel<float>, dim3(g), dim3(256), 0, st, (const float*)y, sc, sh, act, (float*)out, argmax, B, H, W, C, Ho, Wo),
+               T3D_LAUNCH(maxpool_fwd_kernel<bf16_t>, dim3(g), dim3(256), 0, st, (const bf16_t*)y, sc, sh, act, (bf16_t*)out, argmax, B, H, W, C, Ho, Wo));
   T3D_CHECK_LAUNCH();
   return T3D_OK;
 }
@@ -856,15 +856,15 @@ extern "C" int t3d_maxpool_bwd(int dtype, const void* dout, const unsigned char*
     const int g = runs_for((long long)B * H * W, 4096, &ppw), nrep = g_t3d_reduce.nrep;
     const long long rs = g_t3d_reduce.stats_stride;
     T3D_DISPATCH(dtype,
-                 hipLaunchKernelGGL(maxpool_bwd_v_kernel<float>, dim3(g), dim3(256), lds, st, (const float*)dout, argmax, (const float*)y, sc, sh, act, (float*)dy, stats, B, H, W, C, Ho, Wo, nrep, rs, ppw),
-                 hipLaunchKernelGGL(maxpool_bwd_v_kernel<bf16_t>, dim3(g), dim3(256), lds, st, (const bf16_t*)dout, argmax, (const bf16_t*)y, sc, sh, act, (bf16_t*)dy, stats, B, H, W, C, Ho, Wo, nrep, rs, ppw));
+                 T3D_LAUNCH(maxpool_bwd_v_kernel<float>, dim3(g), dim3(256), lds, st, (const float*)dout, argmax, (const float*)y, sc, sh, act, (float*)dy, stats, B, H, W, C, Ho, Wo, nrep, rs, ppw),
+                 T3D_LAUNCH(maxpool_bwd_v_kernel<bf16_t>, dim3(g), dim3(256), lds, st, (const bf16_t*)dout, argmax, (const bf16_t*)y, sc, sh, act, (bf16_t*)dy, stats, B, H, W, C, Ho, Wo, nrep, rs, ppw));
     T3D_CHECK_LAUNCH();
     return T3D_OK;
   }
   const int g = grid_for_c((long long)B * H * W * C, C);
   T3D_DISPATCH(dtype,
-               hipLaunchKernelGGL(maxpool_bwd_kernel<float>, dim3(g), dim3(256), lds, st, (const float*)dout, argmax, (const float*)y, sc, sh, act, (float*)dy, stats, B, H, W, C, Ho, Wo, g_t3d_reduce.nrep, g_t3d_reduce.stats_stride),
-               hipLaunchKernelGGL(maxpool_bwd_kernel<bf16_t>, dim3(g), dim3(256), lds, st, (const bf16_t*)dout, argmax, (const bf16_t*)y, sc, sh, act, (bf16_t*)dy, stats, B, H, W, C, Ho, Wo, g_t3d_reduce.nrep, g_t3d_reduce.stats_stride));
+               T3D_LAUNCH(maxpool_bwd_kernel<float>, dim3(g), dim3(256), lds, st, (const float*)dout, argmax, (const float*)y, sc, sh, act, (float*)dy, stats, B, H, W, C, Ho, Wo, g_t3d_reduce.nrep, g_t3d_reduce.stats_stride),
+               T3D_LAUNCH(maxpool_bwd_kernel<bf16_t>, dim3(g), dim3(256), lds, st, (const bf16_t*)dout, argmax, (const bf16_t*)y, sc, sh, act, (bf16_t*)dy, stats, B, H, W, C, Ho, Wo, g_t3d_reduce.nrep, g_t3d_reduce.stats_stride));
   T3D_CHECK_LAUNCH();
   return T3D_OK;
 }
@@ -884,15 +884,15 @@ extern "C" int t3d_res_relu_fwd(int dtype, const void* y3, const t3d_prologue* p
     int g = (int)std::min<long long>(2048, (total / 8 + 256 * 4 - 1) / (256 * 4));
     while ((long long)g * 256 < C8) ++g;
     T3D_DISPATCH(dtype,
-                 hipLaunchKernelGGL(res_relu_fwd_v_kernel<float>, dim3(g), dim3(256), 0, st, (const float*)y3, pro3->scale, pro3->shift, (const float*)shortcut, ss, ts, (float*)z, total / 8, C8),
-                 hipLaunchKernelGGL(res_relu_fwd_v_kernel<bf16_t>, dim3(g), dim3(256), 0, st, (const bf16_t*)y3, pro3->scale, pro3->shift, (const bf16_t*)shortcut, ss, ts, (bf16_t*)z, total / 8, C8));
+                 T3D_LAUNCH(res_relu_fwd_v_kernel<float>, dim3(g), dim3(256), 0, st, (const float*)y3, pro3->scale, pro3->shift, (const float*)shortcut, ss, ts, (float*)z, total / 8, C8),
+                 T3D_LAUNCH(res_relu_fwd_v_kernel<bf16_t>, dim3(g), dim3(256), 0, st, (const bf16_t*)y3, pro3->scale, pro3->shift, (const bf16_t*)shortcut, ss, ts, (bf16_t*)z, total / 8, C8));
     T3D_CHECK_LAUNCH();
     return T3D_OK;
   }
   const int g = grid_for(total);
   T3D_DISPATCH(dtype,
-               hipLaunchKernelGGL(res_relu_fwd_kernel<float>, dim3(g), dim3(256), 0, st, (const float*)y3, pro3->scale, pro3->shift, (const float*)shortcut, ss, ts, (float*)z, total, C),
-               hipLaunchKernelGGL(res_relu_fwd_kernel<bf16_t>, dim3(g), dim3(256), 0, st, (const bf16_t*)y3, pro3->scale, pro3->shift, (const bf16_t*)shortcut, ss, ts, (bf16_t*)z, total, C));
+               T3D_LAUNCH(res_relu_fwd_kernel<float>, dim3(g), dim3(256), 0, st, (const float*)y3, pro3->scale, pro3->shift, (const float*)shortcut, ss, ts, (float*)z, total, C),
+               T3D_LAUNCH(res_relu_fwd_kernel<bf16_t>, dim3(g), dim3(256), 0, st, (const bf16_t*)y3, pro3->scale, pro3->shift, (const bf16_t*)shortcut, ss, ts, (bf16_t*)z, total, C));
   T3D_CHECK_LAUNCH();
   return T3D_OK;
 }
@@ -909,7 +909,7 @@ extern "C" int t3d_res_relu_bwd(int dtype, const void* dz, const void* z, const 
     const size_t ldsv = (size_t)3 * C * sizeof(double);
     const int nrep = g_t3d_reduce.nrep;
     const long long rs = g_t3d_reduce.stats_stride;
-#define T3D_RRB(TT, PP) hipLaunchKernelGGL((res_relu_bwd_v_kernel<TT, PP>), dim3(gv), dim3(256), ldsv, st, (const TT*)dz, (const TT*)z, (const TT*)y3, (const TT*)yd, (TT*)g, stats3, statsd, total / 8, C, nrep, rs)
+#define T3D_RRB(TT, PP) T3D_LAUNCH((res_relu_bwd_v_kernel<TT, PP>), dim3(gv), dim3(256), ldsv, st, (const TT*)dz, (const TT*)z, (const TT*)y3, (const TT*)yd, (TT*)g, stats3, statsd, total / 8, C, nrep, rs)
     if (yd) T3D_DISPATCH(dtype, T3D_RRB(float, true), T3D_RRB(bf16_t, true));
     else T3D_DISPATCH(dtype, T3D_RRB(float, false), T3D_RRB(bf16_t, false));
 #undef T3D_RRB
@@ -919,8 +919,8 @@ extern "C" int t3d_res_relu_bwd(int dtype, const void* dz, const void* z, const 
   const int gr = grid_for_c(total, C);
   const size_t lds = (size_t)4 * C * sizeof(float);
   T3D_DISPATCH(dtype,
-               hipLaunchKernelGGL(res_relu_bwd_kernel<float>, dim3(gr), dim3(256), lds, st, (const float*)dz, (const float*)z, (const float*)y3, (const float*)yd, (float*)g, stats3, statsd, total, C, g_t3d_reduce.nrep, g_t3d_reduce.stats_stride),
-               hipLaunchKernelGGL(res_relu_bwd_kernel<bf16_t>, dim3(gr), dim3(256), lds, st, (const bf16_t*)dz, (const bf16_t*)z, (const bf16_t*)y3, (const bf16_t*)yd, (bf16_t*)g, stats3, statsd, total, C, g_t3d_reduce.nrep, g_t3d_reduce.stats_stride));
+               T3D_LAUNCH(res_relu_bwd_kernel<float>, dim3(gr), dim3(256), lds, st, (const float*)dz, (const float*)z, (const float*)y3, (const float*)yd, (float*)g, stats3, statsd, total, C, g_t3d_reduce.nrep, g_t3d_reduce.stats_stride),
+               T3D_LAUNCH(res_relu_bwd_kernel<bf16_t>, dim3(gr), dim3(256), lds, st, (const bf16_t*)dz, (const bf16_t*)z, (const bf16_t*)y3, (const bf16_t*)yd, (bf16_t*)g, stats3, statsd, total, C, g_t3d_reduce.nrep, g_t3d_reduce.stats_stride));
   T3D_CHECK_LAUNCH();
   return T3D_OK;
 }
@@ -935,15 +935,15 @@ extern "C" int t3d_subsample(int dtype, const void* x, void* out, int B, int H, 
     const unsigned t8 = (unsigned)(total / 8);
     const int g = (int)std::min<long long>(4096, (t8 + 255) / 256);
     T3D_DISPATCH(dtype,
-                 hipLaunchKernelGGL(subsample_v_kernel<float>, dim3(g), dim3(256), 0, st, (const float*)x, (float*)out, B, H, W, C / 8, stride, Ho, Wo, upsample, t8),
-                 hipLaunchKernelGGL(subsample_v_kernel<bf16_t>, dim3(g), dim3(256), 0, st, (const bf16_t*)x, (bf16_t*)out, B, H, W, C / 8, stride, Ho, Wo, upsample, t8));
+                 T3D_LAUNCH(subsample_v_kernel<float>, dim3(g), dim3(256), 0, st, (const float*)x, (float*)out, B, H, W, C / 8, stride, Ho, Wo, upsample, t8),
+                 T3D_LAUNCH(subsample_v_kernel<bf16_t>, dim3(g), dim3(256), 0, st, (const bf16_t*)x, (bf16_t*)out, B, H, W, C / 8, stride, Ho, Wo, upsample, t8));
     T3D_CHECK_LAUNCH();
     return T3D_OK;
   }
   const int g = grid_for(total);
   T3D_DISPATCH(dtype,
-               hipLaunchKernelGGL(subsample_kernel<float>, dim3(g), dim3(256), 0, st, (const float*)x, (float*)out, B, H, W, C, stride, Ho, Wo, upsample),
-               hipLaunchKernelGGL(subsample_kernel<bf16_t>, dim3(g), dim3(256), 0, st, (const bf16_t*)x, (bf16_t*)out, B, H, W, C, stride, Ho, Wo, upsample));
+               T3D_LAUNCH(subsample_kernel<float>, dim3(g), dim3(256), 0, st, (const float*)x, (float*)out, B, H, W, C, stride, Ho, Wo, upsample),
+               T3D_LAUNCH(subsample_kernel<bf16_t>, dim3(g), dim3(256), 0, st, (const bf16_t*)x, (bf16_t*)out, B, H, W, C, stride, Ho, Wo, upsample));
   T3D_CHECK_LAUNCH();
   return T3D_OK;
 }

@@ -405,9 +405,9 @@ extern "C" int t3d_se_fwd(const float* gap_sum, const float* scale, const float*
   a.m = m; a.h = h; a.q = q; a.s = s; a.B = B; a.C = C; a.R = R; a.HW = HW;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   if (hipMemsetAsync(h, 0, (size_t)B * R * sizeof(float), st) != hipSuccess) return T3D_ERR_LAUNCH;
-  hipLaunchKernelGGL(se_fc1_kernel, dim3(cdiv(R, OT), cdiv(B, 64), KSPLIT), dim3(256), 0, st, a);
-  hipLaunchKernelGGL(se_relu_bias_kernel, dim3(cdiv(B * R, 256)), dim3(256), 0, st, a);
-  hipLaunchKernelGGL(se_fc2_kernel, dim3(cdiv(C, OT), cdiv(B, 64)), dim3(256), 0, st, a);
+  T3D_LAUNCH(se_fc1_kernel, dim3(cdiv(R, OT), cdiv(B, 64), KSPLIT), dim3(256), 0, st, a);
+  T3D_LAUNCH(se_relu_bias_kernel, dim3(cdiv(B * R, 256)), dim3(256), 0, st, a);
+  T3D_LAUNCH(se_fc2_kernel, dim3(cdiv(C, OT), cdiv(B, 64)), dim3(256), 0, st, a);
   T3D_CHECK_LAUNCH();
   return T3D_OK;
 }
@@ -425,14 +425,14 @@ extern "C" int t3d_se_bwd(const float* ps_stats, const float* gap_sum, const flo
   a.g = g; a.dq = dq; a.dp = dp; a.stats = stats; a.dw1 = dw1; a.db1 = db1; a.dw2 = dw2; a.db2 = db2;
   a.B = B; a.C = C; a.R = R; a.HW = HW;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-  hipLaunchKernelGGL(se_dq_kernel, dim3(cdiv(B * C, 256)), dim3(256), 0, st, a);
+  T3D_LAUNCH(se_dq_kernel, dim3(cdiv(B * C, 256)), dim3(256), 0, st, a);
   if (hipMemsetAsync(dp, 0, (size_t)B * R * sizeof(float), st) != hipSuccess) return T3D_ERR_LAUNCH;
-  hipLaunchKernelGGL(se_dh_kernel, dim3(cdiv(R, OT), cdiv(B, 64), KSPLIT), dim3(256), 0, st, a);
-  hipLaunchKernelGGL(se_relu_mask_kernel, dim3(cdiv(B * R, 256)), dim3(256), 0, st, a);
-  hipLaunchKernelGGL(se_dm_kernel, dim3(cdiv(C, OT), cdiv(B, 64)), dim3(256), 0, st, a);
-  hipLaunchKernelGGL(se_wgrad_tile_kernel, dim3(cdiv(R, OT), cdiv(C, 64)), dim3(256), 0, st, a, 0);
-  hipLaunchKernelGGL(se_wgrad_tile_kernel, dim3(cdiv(C, OT), cdiv(R, 64)), dim3(256), 0, st, a, 1);
-  hipLaunchKernelGGL(se_bias_kernel, dim3(cdiv(C + R, 64)), dim3(256), 0, st, a);
+  T3D_LAUNCH(se_dh_kernel, dim3(cdiv(R, OT), cdiv(B, 64), KSPLIT), dim3(256), 0, st, a);
+  T3D_LAUNCH(se_relu_mask_kernel, dim3(cdiv(B * R, 256)), dim3(256), 0, st, a);
+  T3D_LAUNCH(se_dm_kernel, dim3(cdiv(C, OT), cdiv(B, 64)), dim3(256), 0, st, a);
+  T3D_LAUNCH(se_wgrad_tile_kernel, dim3(cdiv(R, OT), cdiv(C, 64)), dim3(256), 0, st, a, 0);
+  T3D_LAUNCH(se_wgrad_tile_kernel, dim3(cdiv(C, OT), cdiv(R, 64)), dim3(256), 0, st, a, 1);
+  T3D_LAUNCH(se_bias_kernel, dim3(cdiv(C + R, 64)), dim3(256), 0, st, a);
   T3D_CHECK_LAUNCH();
   return T3D_OK;
 }
@@ -453,11 +453,11 @@ extern "C" int t3d_se_fwd_fused(const float* gap_sum, const float* scale, const 
   const size_t lds = se_group_lds(C, R);
   static bool attr = false;
   if (!attr) {
-    (void)hipFuncSetAttribute((const void*)se_fwd_group_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
-    (void)hipFuncSetAttribute((const void*)se_bwd_group_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+    (void)t3d_max_lds((const void*)se_fwd_group_kernel, 96 * 1024);
+    (void)t3d_max_lds((const void*)se_bwd_group_kernel, 96 * 1024);
     attr = true;
   }
-  hipLaunchKernelGGL(se_fwd_group_kernel, dim3(cdiv(B, SPG)), dim3(SE_T), lds, reinterpret_cast<hipStream_t>(stream), a, w1t, w2t);
+  T3D_LAUNCH(se_fwd_group_kernel, dim3(cdiv(B, SPG)), dim3(SE_T), lds, reinterpret_cast<hipStream_t>(stream), a, w1t, w2t);
   T3D_CHECK_LAUNCH();
   return T3D_OK;
 }
@@ -474,10 +474,10 @@ extern "C" int t3d_se_bwd_data(const float* ps_stats, const float* gap_sum, cons
   a.g = g; a.dq = dq; a.dp = dp; a.stats = stats; a.B = B; a.C = C; a.R = R; a.HW = HW;
   static bool attr = false;
   if (!attr) {
-    (void)hipFuncSetAttribute((const void*)se_bwd_group_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+    (void)t3d_max_lds((const void*)se_bwd_group_kernel, 96 * 1024);
     attr = true;
   }
-  hipLaunchKernelGGL(se_bwd_group_kernel, dim3(cdiv(B, SPG)), dim3(SE_T), se_group_lds(C, R), reinterpret_cast<hipStream_t>(stream), a,
+  T3D_LAUNCH(se_bwd_group_kernel, dim3(cdiv(B, SPG)), dim3(SE_T), se_group_lds(C, R), reinterpret_cast<hipStream_t>(stream), a,
                      g_t3d_reduce.nrep, g_t3d_reduce.stats_stride);
   T3D_CHECK_LAUNCH();
   return T3D_OK;
@@ -492,9 +492,9 @@ extern "C" int t3d_se_bwd_weights(const float* m, const float* h, const float* d
   a.m = const_cast<float*>(m); a.h = const_cast<float*>(h); a.dq = const_cast<float*>(dq); a.dp = const_cast<float*>(dp);
   a.dw1 = dw1; a.db1 = db1; a.dw2 = dw2; a.db2 = db2; a.B = B; a.C = C; a.R = R; a.HW = 1;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-  hipLaunchKernelGGL(se_wgrad_tile_kernel, dim3(cdiv(R, OT), cdiv(C, 64)), dim3(256), 0, st, a, 0);
-  hipLaunchKernelGGL(se_wgrad_tile_kernel, dim3(cdiv(C, OT), cdiv(R, 64)), dim3(256), 0, st, a, 1);
-  hipLaunchKernelGGL(se_bias_kernel, dim3(cdiv(C + R, 64)), dim3(256), 0, st, a);
+  T3D_LAUNCH(se_wgrad_tile_kernel, dim3(cdiv(R, OT), cdiv(C, 64)), dim3(256), 0, st, a, 0);
+  T3D_LAUNCH(se_wgrad_tile_kernel, dim3(cdiv(C, OT), cdiv(R, 64)), dim3(256), 0, st, a, 1);
+  T3D_LAUNCH(se_bias_kernel, dim3(cdiv(C + R, 64)), dim3(256), 0, st, a);
   T3D_CHECK_LAUNCH();
   return T3D_OK;
 }

@@ -134,8 +134,8 @@ extern "C" int t3d_ssd_decode_nms(int dtype, int nlevels, const void* const* cls
   const size_t lds = (size_t)tot * 5 * sizeof(float);
   if (lds > 150 * 1024) return T3D_ERR_UNSUPPORTED;
   if (lds > 64 * 1024)
-    (void)hipFuncSetAttribute((const void*)ssd_decode_nms_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  hipLaunchKernelGGL(ssd_decode_nms_kernel, dim3(num_classes, B), dim3(256), lds, reinterpret_cast<hipStream_t>(stream), a);
+    (void)t3d_max_lds((const void*)ssd_decode_nms_kernel, (int)lds);
+  T3D_LAUNCH(ssd_decode_nms_kernel, dim3(num_classes, B), dim3(256), lds, reinterpret_cast<hipStream_t>(stream), a);
   T3D_CHECK_LAUNCH();
   return T3D_OK;
 }

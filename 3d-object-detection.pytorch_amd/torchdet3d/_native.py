@@ -125,6 +125,8 @@ SIGNATURES = {
     't3d_plan_destroy': [_P],
     't3d_plan_add_call': [_P, ctypes.c_char_p, _I, ctypes.POINTER(_I), ctypes.POINTER(ctypes.c_ulonglong), ctypes.POINTER(_I)],
     't3d_plan_add_fork': [_P, _P, _P],
+    't3d_plan_add_fork_after': [_P, _I, _P, _P],
+    't3d_launch_count': [ctypes.POINTER(ctypes.c_ulonglong), ctypes.POINTER(_P)],
     't3d_plan_add_copy_d2h': [_P, _I, _P, _L, _P],
     't3d_plan_add_event_record': [_P, _I, _P],
     't3d_plan_end_segment': [_P],
@@ -231,6 +233,11 @@ def call(name, *args, nbytes=None, slots=None):
     fn = getattr(lib(), name)
     if recorder is not None:
         recorder.add_call(name, args, nbytes, slots)
+        rc = fn(*args)
+        recorder.after_call()
+        if rc != 0:
+            raise RuntimeError(f'{name} failed with code {rc}')
+        return
     t = timer
     if t is not None and (t.only is None or name in t.only):
         e0, e1 = t.event(), t.event()
@@ -285,6 +292,9 @@ def double_bits(x):
     return struct.unpack('<Q', struct.pack('<d', float(x)))[0]
 
 
+HANDOFF = os.environ.get('T3D_PLAN_HANDOFF', '1') != '0'     # forks as device-side hand-offs (A/B switch)
+
+
 class PlanRecorder:
     """Builds a t3d_plan while the engine issues a step through `call` (which still executes every call).  `ptr_slots`:
     {device address: slot} -- any pointer argument equal to one of these addresses is bound to the slot (the batch's
@@ -299,6 +309,10 @@ class PlanRecorder:
         self.calls = []          # (name, int-args signature, nbytes) per call op, in order: what a timed replay reports against
         self.keep = []           # objects whose device memory the plan points into
         self.breaks = []         # host callbacks between segment i and i + 1
+        n = ctypes.c_ulonglong(0)
+        lib().t3d_launch_count(ctypes.byref(n), None)
+        self.launches, self.last_on = n.value, {}      # kernels launched so far; stream -> op index of the last call that launched there
+        self.broken = None       # why the recorded step cannot be replayed (something in it did not go through `call`)
 
     def add_call(self, name, args, nbytes, slots):
         types = SIGNATURES[name]
@@ -326,8 +340,23 @@ class PlanRecorder:
         self.calls.append((name, tuple(a for a in args[:-1] if isinstance(a, int) and not isinstance(a, bool) and 0 <= a < (1 << 31)),
                            nbytes))
 
+    def after_call(self):
+        """Did the call just recorded launch a kernel, and on which stream did its last one go?"""
+        n, st = ctypes.c_ulonglong(0), _P()
+        lib().t3d_launch_count(ctypes.byref(n), ctypes.byref(st))
+        if n.value != self.launches:
+            self.launches = n.value
+            self.last_on[st.value or 0] = lib().t3d_plan_num_ops(self.plan, -1) - 1
+
     def add_fork(self, from_stream, to_stream):
-        rc = lib().t3d_plan_add_fork(self.plan, from_stream, to_stream)
+        """`to_stream` waits for everything enqueued on `from_stream` so far: for the last kernel a recorded call launched
+        there (a hand-off through that kernel's own completion event, nothing enqueued on `from_stream`), or -- when nothing
+        of this plan has run there yet -- for an event recorded on it."""
+        prod = self.last_on.get(from_stream or 0) if HANDOFF else None
+        if prod is not None:
+            rc = lib().t3d_plan_add_fork_after(self.plan, prod, from_stream, to_stream)
+        else:
+            rc = lib().t3d_plan_add_fork(self.plan, from_stream, to_stream)
         if rc != 0:
             raise RuntimeError(f't3d_plan_add_fork failed with code {rc}')
 

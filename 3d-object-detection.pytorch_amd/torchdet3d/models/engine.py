@@ -278,11 +278,24 @@ class Net:
         if t is None:
             t = torch.empty(shape, device=self.device, dtype=dtype)
             self._bufs[key] = t
-            if zero:
-                t.zero_()
-        elif zero:
-            t.zero_()
+        if zero:
+            self._zero(t)
         return t
+
+    def _zero(self, t):
+        """Clears a device buffer on the current stream with the library's own kernel (`t3d_zero_batched`, one-row descriptor
+        kept per buffer): no framework launch inside the step, and a step plan being recorded sees the clear."""
+        nb = t.numel() * t.element_size()
+        if t.is_cuda and nb % 16 == 0 and t.is_contiguous():
+            zd = self.__dict__.setdefault('_zdescs', {})
+            d = zd.get((t.data_ptr(), nb))
+            if d is None:
+                d = zd[(t.data_ptr(), nb)] = torch.tensor([[t.data_ptr(), nb]], dtype=torch.int64, device=self.device)
+            N.call('t3d_zero_batched', N.ptr(d), 1, N.stream())
+        else:
+            if N.recorder is not None:
+                N.recorder.broken = 'a framework fill inside the step (buffer size not a multiple of 16 bytes)'
+            t.zero_()
 
     def _pack(self):
         """fp32 master weights -> storage dtype (+ transposed copies for the data-gradient GEMMs).  Re-done whenever
@@ -624,12 +637,7 @@ class Net:
         else:
             B, _, H, W = imgs.shape
         if train:
-            # the BatchNorm sum replicas of the step, cleared by the library's own kernel (no framework launch in the step)
-            if getattr(self, '_stat_zero_desc', None) is None:
-                nb = self._statbuf.numel() * 8
-                assert nb % 16 == 0
-                self._stat_zero_desc = torch.tensor([[self._statbuf.data_ptr(), nb]], dtype=torch.int64, device=self.device)
-            N.call('t3d_zero_batched', N.ptr(self._stat_zero_desc), 1, st)
+            self._zero(self._statbuf)       # the BatchNorm sum replicas of the step
         else:
             self._eval_affines()
         sv = dict(B=B, imgs=imgs, blocks=[])

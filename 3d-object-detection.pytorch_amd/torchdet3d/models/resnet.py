@@ -83,7 +83,7 @@ class ResNetEngine(Net):
         self._pack()
         B, _, H, W = imgs.shape
         if train:
-            self._statbuf.zero_()
+            self._zero(self._statbuf)
         else:
             self._eval_affines()
         sv = dict(B=B, imgs=imgs, blocks=[])

@@ -167,7 +167,11 @@ class StepPlan:
             N.recorder = None
         lm.last = out
         if rec is not None:
-            self.rec = rec
+            if rec.broken:
+                N.lib().t3d_plan_destroy(rec.plan)       # stays in the direct form
+                self.warm = -(1 << 30)
+            else:
+                self.rec = rec
         return out
 
     def _replay(self, imgs, gt_kp, cats, slot):

@@ -565,6 +565,14 @@ int t3d_plan_destroy(t3d_plan* plan);
 int t3d_plan_add_call(t3d_plan* plan, const char* entry, int nargs, const int* kinds, const unsigned long long* words,
                       const int* struct_bytes);
 int t3d_plan_add_fork(t3d_plan* plan, void* from_stream, void* to_stream);
+/* The fork without a packet in the producing queue: `to_stream` waits for the last kernel that call op `producer_op` (index in
+ * the plan, calls / forks / copies counted alike) launches on `from_stream`, through the STOP event of that kernel's own
+ * dispatch (hipExtLaunchKernelGGL) -- a device-side hand-off: the main queue of the step, whose every microsecond is on the
+ * critical path, carries no event records for the ~35 launches it hands to the weight-gradient stream.
+ * t3d_launch_count: how many kernels the library has launched so far and on which stream the last one went (what a recorder
+ * needs to know which call was the producer). */
+int t3d_plan_add_fork_after(t3d_plan* plan, int producer_op, void* from_stream, void* to_stream);
+int t3d_launch_count(unsigned long long* count, void** last_stream);
 int t3d_plan_add_copy_d2h(t3d_plan* plan, int dst_slot, const void* src, long long bytes, void* stream);
 int t3d_plan_add_event_record(t3d_plan* plan, int event_slot, void* stream);
 int t3d_plan_end_segment(t3d_plan* plan);
