@@ -86,6 +86,13 @@ class Evaluator:
         meters = [AverageMeter() for _ in range(4)]                      # ADD SADD ACC IOU
         cls_meters = [[AverageMeter() for _ in range(4)] for _ in range(self.num_classes)]
         self.model.eval()
+        if world_size() > 1:
+            # every rank trains with its own BatchNorm running statistics (per-replica BatchNorm, scripts/main.py:60-61);
+            # nn.DataParallel validates -- and save_snap writes -- with replica 0's: take rank 0's buffers on every rank first,
+            # so that the all-reduced metrics below describe the model the checkpoint holds
+            sync = getattr(self.model, 'grad_sync', None)
+            if sync is not None and hasattr(self.model, 'net'):
+                sync.broadcast(list(self.model.net.buffers.values()))
         for it, (imgs, gt_kp, gt_cats) in enumerate(self.val_loader):
             per_cls, ADD, SADD, IOU, ACC = self.val_step(imgs, gt_kp, gt_cats, compute_iou)
             n = imgs.size(0)

@@ -221,6 +221,14 @@ class Net:
         if sh is None:
             self.reset_parameters()
 
+    def nonfinite(self):
+        """True when a BatchNorm of the latest steps saw a non-finite batch sum.  The 16-bit kernels form ReLU6 with the clamp
+        modifier (DESIGN.md finding 30), which turns a NaN pre-activation into 0 where the reference's hardtanh propagates it, so
+        a diverged step can end in a finite loss; the fp64 batch sums are taken on the RAW convolution outputs and still see
+        it, and every coefficient derived from them (scale / shift / mean / invstd, the backward's alpha / beta / gamma) is then
+        non-finite.  One small reduction + a host sync: call it where the loop already waits (Trainer.train's drain, bench.py)."""
+        return not bool(torch.isfinite(self._aff).all())
+
     def _view(self, key, shape, n=None, g=False):
         o, m = self.offsets[key]
         return (self.gflat if g else self.flat)[o:o + (n or m)].view(shape)

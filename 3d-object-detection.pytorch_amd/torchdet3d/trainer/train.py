@@ -141,6 +141,11 @@ class Trainer:
                 ns = flat[4 * len(backlog):]
                 backlog[:] = [(dict(zip(('loss', 'ADD', 'SADD', 'acc'), (v / ns[j] for v in flat[4 * j:4 * j + 4]))), int(ns[j]), gs)
                               for j, (_, _, gs) in enumerate(backlog)]
+            net = getattr(self.model, 'net', None)
+            if backlog and net is not None and hasattr(net, 'nonfinite') and net.nonfinite():
+                # a non-finite activation somewhere in the network: the reference's loss would read NaN from here on (its
+                # hardtanh propagates it; the clamp form of the 16-bit kernels does not) -- report it as that
+                backlog[:] = [({**dict(r), 'loss': float('nan')}, n, gs) for r, n, gs in backlog]
             for r, n, gs in backlog:
                 for k in ('loss', 'ADD', 'SADD', 'acc'):
                     meters[k].update(r[k], n)

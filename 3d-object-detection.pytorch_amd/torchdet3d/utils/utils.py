@@ -84,13 +84,15 @@ def save_snap(model, optimizer, scheduler, epoch, log_path):
     if not is_main():
         barrier()
         return
-    snap = {'state_dict': model.state_dict(), 'optimizer': optimizer.state_dict(),
-            'scheduler': scheduler.state_dict() if scheduler is not None else None, 'epoch': epoch}
-    mkdir_if_missing(log_path)
-    name = osp.join(log_path, f'snap_{epoch}.pth')
-    print(f'==> saving checkpoint to {name}')
-    torch.save(snap, name)
-    barrier()
+    try:
+        snap = {'state_dict': model.state_dict(), 'optimizer': optimizer.state_dict(),
+                'scheduler': scheduler.state_dict() if scheduler is not None else None, 'epoch': epoch}
+        mkdir_if_missing(log_path)
+        name = osp.join(log_path, f'snap_{epoch}.pth')
+        print(f'==> saving checkpoint to {name}')
+        torch.save(snap, name)
+    finally:
+        barrier()          # (also when the write fails: the other ranks are waiting in theirs)
 
 
 def load_checkpoint(fpath, map_location=None):

@@ -114,7 +114,9 @@ def parse():
     ap.add_argument('--model', default='mobilenetv2')
     ap.add_argument('--dtype', default='bf16', choices=['bf16', 'f32'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--cpu-batch', type=int, default=16)
+    ap.add_argument('--cpu-batch', type=int, default=32)
+    ap.add_argument('--cpu-threads', type=int, default=0, help='host threads of the CPU leg (0: the count the recorded sweep '
+                    'found fastest, profiles/r5_cpu_baseline_thread_sweep.txt, capped by the host)')
     ap.add_argument('--cpu-steps', type=int, default=60)
     ap.add_argument('--cpu-baseline-only', action='store_true', help=argparse.SUPPRESS)
     ap.add_argument('--eval', action='store_true', help='time the validation step instead of the train step: `Evaluator.val_step` '
@@ -132,14 +134,18 @@ def parse():
     return ap.parse_args()
 
 
-def cpu_baseline(model, size, batch, steps, budget_s=20.0):
+CPU_THREADS_BEST = 32     # profiles/r5_cpu_baseline_thread_sweep.txt: B = 32 train step of the oracle at 8 / 16 / 32 / 64 / 128 threads
+
+
+def cpu_baseline(model, size, batch, steps, budget_s=25.0, threads=0):
     """The oracle's train step (fwd + losses + autograd bwd + AdamW) on the host cores, on a BOUNDED sample:
-    at most `steps` steps and ~`budget_s` seconds.  Threads are capped at 32: with every hardware thread of a
-    256-thread host the small convolutions of this network oversubscribe and run ~50x slower."""
+    at most `steps` steps and ~`budget_s` seconds, batch 32.  Thread count: the fastest of a one-off
+    sweep on the GPU box's host (recorded under profiles/): with every hardware thread of a 256-thread host the small
+    convolutions of this network oversubscribe and run ~50x slower."""
     from oracle import losses as OL
     from oracle import model as OMod
     from oracle.weights import make_inputs, make_state_dict
-    cores = min(os.cpu_count() or 1, 32)
+    cores = min(os.cpu_count() or 1, threads or CPU_THREADS_BEST)
     torch.set_num_threads(cores)
     sd = make_state_dict(model, 9)
     params = {k: v.clone().requires_grad_(v.dtype.is_floating_point and 'running' not in k) for k, v in sd.items()}
@@ -179,19 +185,19 @@ def cpu_baseline_guarded(args):
     never stall the benchmark (the child never touches the GPU)."""
     import subprocess
     cmd = [sys.executable, os.path.abspath(__file__), '--cpu-baseline-only', '--model', args.model, '--size', str(args.size),
-           '--cpu-batch', str(args.cpu_batch), '--cpu-steps', str(args.cpu_steps)]
+           '--cpu-batch', str(args.cpu_batch), '--cpu-steps', str(args.cpu_steps), '--cpu-threads', str(args.cpu_threads)]
     try:
         out = subprocess.run(cmd, capture_output=True, text=True, timeout=150)
         return json.loads(out.stdout.strip().split('\n')[-1])
     except Exception as e:  # noqa: BLE001  (timeout, crash, unparsable output)
-        return dict(value=None, unit='crops/s', cores=min(os.cpu_count() or 1, 32), kind='port',
+        return dict(value=None, unit='crops/s', cores=min(os.cpu_count() or 1, args.cpu_threads or CPU_THREADS_BEST), kind='port',
                     sample=f'CPU leg did not finish within its 150 s limit ({type(e).__name__})')
 
 
 def main():
     args = parse()
     if args.cpu_baseline_only:
-        print(json.dumps(cpu_baseline(args.model, args.size, args.cpu_batch, args.cpu_steps)), flush=True)
+        print(json.dumps(cpu_baseline(args.model, args.size, args.cpu_batch, args.cpu_steps, threads=args.cpu_threads)), flush=True)
         return
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
         spawn_ranks(args)
@@ -360,6 +366,8 @@ def main():
         dt = t.item()
     loss = (last[0][1] if args.eval else last[0]['loss']) if use_api else out[0].item()      # (--eval through the API: the batch's ADD)
     assert loss == loss or os.environ.get('T3D_ABLATE'), 'loss is NaN'
+    # (the clamp-form ReLU6 of the 16-bit kernels maps a NaN pre-activation to 0: a diverged step is seen in the BatchNorm sums)
+    assert args.eval or not net.nonfinite() or os.environ.get('T3D_ABLATE'), 'a BatchNorm saw non-finite batch sums'
 
     eval_dt = None
     if args.eval:
@@ -417,9 +425,18 @@ def main():
             if tf and args.model == 'mobilenetv2' and S == 224 and B == 256 and args.dtype == 'bf16' and not args.eval:
                 pm = json.load(open(tf))
                 fam_t = pm.get('kernels', {}).get(top['kernel'])
-                if fam_t:
+                # the pass is only quoted while the depthwise kernels it was collected on are the ones in the tree: the file
+                # carries the hash of csrc/dwconv3*_stream.hip at collection time (tools/pmc_traffic.sh); anything else is stale
+                import hashlib
+                h = hashlib.sha256()
+                cs = os.path.join(ROOT, '3d-object-detection.pytorch_amd', 'csrc')
+                for f in sorted(x for x in os.listdir(cs) if x.startswith('dwconv3') and x.endswith('_stream.hip')):
+                    h.update(open(os.path.join(cs, f), 'rb').read())
+                if fam_t and pm.get('dw3_source_sha256') == h.hexdigest()[:16]:
                     traffic = round(fam_t['hbm_bytes_per_step'] / top['launches_per_step'])
                     tsrc = f"profiles/{os.path.basename(tf)} (committed rocprofv3 --pmc pass at {pm.get('commit', '?')})"
+                elif fam_t:
+                    tsrc = 'stale'          # (traffic stays null: the depthwise sources changed since the last tools/pmc_traffic.sh pass)
             res['roofline'] = {'bound': 'hbm', 'kernel': top['kernel'], 'entry': top['entry'], 'achieved': top['achieved'],
                                'peak': HBM_PEAK / 1e9, 'unit': 'GB/s', 'frac': top['frac'], 'traffic': traffic,
                                'traffic_source': tsrc,

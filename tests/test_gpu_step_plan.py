@@ -154,3 +154,17 @@ def test_plan_entry_table_rejects_unknown_names_and_wrong_arity():
     assert lib.t3d_plan_run(plan, 0, None, 0, None, 0) == -1          # no such segment
     assert lib.t3d_plan_run(plan, -1, None, 0, None, 0) == 0           # an empty plan
     lib.t3d_plan_destroy(plan)
+
+
+def test_a_non_finite_activation_is_seen_in_the_batchnorm_sums():
+    """the clamp form of ReLU6 (16-bit kernels) maps a NaN pre-activation to 0, so a diverged step can end in a
+    finite loss; `Net.nonfinite()` reads it off the BatchNorm coefficients (the batch sums are taken on the raw conv outputs)."""
+    model, opt, lm, tr = _objects('mobilenetv2', 'bf16')
+    imgs, gts, cats = _batches(8, 96, nb=2)
+    for i in range(4):
+        r = dict(tr.train_step(imgs[i % 2], gts[i % 2], cats[i % 2], i))
+    assert r['loss'] == r['loss'] and not model.net.nonfinite()
+    bad = imgs[0].clone()
+    bad[3, 1, 40:44, 40:44] = float('inf')
+    dict(tr.train_step(bad, gts[0], cats[0], 4))
+    assert model.net.nonfinite()

@@ -47,7 +47,14 @@ for c, key in (('FETCH_SIZE', 'fetch_kb'), ('WRITE_SIZE', 'write_kb')):
             kern[m.group(1)][key] += float(r['Counter_Value'])
             if c == 'FETCH_SIZE': kern[m.group(1)]['dispatches'] += 1
 for v in kern.values(): v['hbm_bytes_per_step'] = round((2 * v['fetch_kb'] + v['write_kb']) * 1024 / nsteps)
-res = dict(note='rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over `bench.py --steps 3 --warmup 2` (7 steps: 2 warm-up, 2 host-issue probes, 3 timed), '
+import hashlib, os
+def src_hash():
+    h = hashlib.sha256()
+    d = os.path.join('3d-object-detection.pytorch_amd', 'csrc')
+    for f in sorted(x for x in os.listdir(d) if x.startswith('dwconv3') and x.endswith('_stream.hip')):
+        h.update(open(os.path.join(d, f), 'rb').read())
+    return h.hexdigest()[:16]
+res = dict(dw3_source_sha256=src_hash(), note='rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over `bench.py --steps 3 --warmup 2` (7 steps: 2 warm-up, 2 host-issue probes, 3 timed), '
                 'MobileNetV2 224^2 B=256 bf16; FETCH_SIZE doubled per the gfx950 correction; per-family sums (tools/pmc_traffic.sh)',
            commit=(sys.argv[3] if len(sys.argv) > 3 else '?'), kernels=kern,
            steps=nsteps, all_kernels_hbm_bytes_per_step=round((2 * tot['FETCH_SIZE'] + tot['WRITE_SIZE']) * 1024 / nsteps), families=fam)
