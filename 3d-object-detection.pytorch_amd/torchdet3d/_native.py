@@ -120,6 +120,7 @@ SIGNATURES = {
     't3d_dropout_mask': [_P, _L, ctypes.c_ulonglong, ctypes.c_ulonglong, _F, _P],
     't3d_loss_fwd_bwd': [_LP, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P],
     't3d_metrics_per_sample': [_P, _P, _P, _P, _P, _I, _I, _P],
+    't3d_expdw_fwd': [_I, _P, _P, _P, _P, _I, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
     # step plans (csrc/plan.hip): record once, replay with one call
     't3d_plan_create': [ctypes.POINTER(_P)],
     't3d_plan_destroy': [_P],
@@ -213,7 +214,7 @@ class KernelTimer:
 
 
 timer = None    # set to a KernelTimer to time launches
-_KERNEL_TIMED = frozenset(('t3d_dwconv_fwd', 't3d_dwconv_bwd'))     # entry points whose main kernel takes t3d_set_launch_events
+_KERNEL_TIMED = frozenset(('t3d_dwconv_fwd', 't3d_dwconv_bwd', 't3d_expdw_fwd'))     # entry points whose main kernel takes t3d_set_launch_events
 # measurement aid (tools/ablate.sh): entry points whose launches are SKIPPED -- the results are then garbage, only the
 # step time means something (an upper bound on what removing / fusing that family of launches can buy)
 _ABLATE = frozenset(x for x in os.environ.get('T3D_ABLATE', '').split(',') if x)

@@ -39,6 +39,7 @@ MAIN_WORKSPACE_BYTES = 16 << 20
 # y-free expand-layer backward (csrc/pwconv_yfree.hip): minimum M*N elements of the expanded tensor; 0 disables
 YFREE_MIN_ELEMS = int(os.environ.get('T3D_YFREE_MIN', 8 << 20))
 YFREE_FUSED = os.environ.get('T3D_YFREE_FUSED', '1') != '0'     # one-pass expand-layer backward (t3d_pwconv_bwd_yfree)
+EXPDW_EVAL = os.environ.get('T3D_EXPDW_EVAL', '1') != '0'      # fused expand + depthwise forward in 16-bit inference (A/B switch)
 HOOK_MIN = 1 << 20              # gradient-exchange granularity (elements): parallel.GradSync's bucket size
 HOOK_ON_SIDE = True              # (round 3: the gradient exchange is issued from the second stream; the other order stalled the main one)
 
@@ -741,6 +742,16 @@ class Net:
         lds = mt * 16 * (blk.cin + 8) * 2 + P * 68 * 4 + mt * 16 * 72 * 2 + 64 * (blk.cin + 8) * 2 + blk.cout * 72 * 2 + 64 * 9 * 4 + 4 * 64 * 4
         return lds <= 160 * 1024
 
+    def _expdw_ok(self, blk, x):
+        """Inference mode, bf16 / fp16 storage: may expand + depthwise of this block run as ONE launch (csrc/expdw_fwd.hip)?  In
+        training mode the expansion's BatchNorm needs its batch statistics first, which costs a statistics-only pass of the 1x1
+        conv (DESIGN.md finding 40: no gain with the raw expansion still stored for the backward)."""
+        if self.training or not EXPDW_EVAL or self.dt not in (N.BF16, N.F16) or x.pro is not None or x.zbuf is not None:
+            return False
+        act = blk.act if isinstance(blk.act, str) else None
+        return bool(blk.expand and not blk.se and blk.k == 3 and blk.cin <= 32 and blk.cin % 8 == 0 and act in ('relu', 'relu6')
+                    and x.W >= 8 and x.B * x.H * x.W * blk.cexp * 2 < (1 << 32))
+
     def _block_fwd(self, i, blk, x, sv):
         st, dt = N.stream(), self.dt
         p = f'features.{i + 1}.conv'
@@ -755,6 +766,24 @@ class Net:
                    B, H, W, blk.cin, blk.cexp, blk.cout, st,
                    nbytes=B * H * W * (2 * blk.cin + 4 * blk.cexp + 2 * blk.cout) * self.esz)
             return _Src(z, None, B, H, W, blk.cout, raw=None, bn=bn3, gpro=None)
+        if self._expdw_ok(blk, x):
+            # inference, 16-bit storage, the 112x112 .. 28x28 blocks: expand 1x1 + BatchNorm + activation + depthwise 3x3 in ONE
+            # launch, the expanded tensor never leaves LDS (csrc/expdw_fwd.hip; DESIGN.md finding 40)
+            bn1, bn2, bn3 = self.bns[p + '.1'], self.bns[p + '.4'], self.bns[p + '.8']
+            Ho, Wo = (H + 2 - 3) // blk.s + 1, (W + 2 - 3) // blk.s + 1
+            M2 = B * Ho * Wo
+            y2 = self._buf(f'y2:{i}', (M2, blk.cexp))
+            N.call('t3d_expdw_fwd', dt, N.ptr(x.t), N.ptr(self.w[p + '.0.weight']), N.ptr(bn1.scale), N.ptr(bn1.shift),
+                   N.ACT[blk.act] if isinstance(blk.act, str) else blk.act, N.ptr(self.p[p + '.3.weight']), None, N.ptr(y2), None,
+                   B, H, W, blk.cin, blk.cexp, blk.s, st, nbytes=(B * H * W * blk.cin + M2 * blk.cexp) * self.esz)
+            pro2 = self._bn_fwd(bn2, M2, blk.act)
+            y3 = self._buf(f'y3:{i}', (M2, blk.cout))
+            wd, wp = self._wsel(self.w[p + '.7.weight'])
+            N.call('t3d_pwconv_fwd', wd, N.ptr(y2), pro2, wp, None, N.ptr(y3), None, M2, Ho * Wo, blk.cexp, blk.cout, st,
+                   nbytes=M2 * (blk.cexp + blk.cout) * self.esz)
+            out = _Src(y3, self._bn_fwd(bn3, M2, 'none'), B, Ho, Wo, blk.cout, raw=y3, bn=bn3, gpro=None)
+            out.zres, out.zbuf = (x.t if blk.res else None), self._buf(f'z:{i}', (M2, blk.cout))
+            return self._resolve(out)
         if x.zbuf is not None and not blk.expand:
             self._resolve(x)                   # (the depthwise conv of a no-expand block reads the finished tensor)
         if blk.res and x.pro is not None and x.zbuf is None:

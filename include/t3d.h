@@ -537,6 +537,19 @@ int t3d_dropout_mask(float* mask, long long n, unsigned long long seed, unsigned
  * (the per-step clears of the gradient buffer, the BatchNorm sum replicas and the depthwise weight-gradient replicas). */
 int t3d_zero_batched(const long long* desc, int n, void* stream);
 
+/* Fused expand 1x1 conv + BatchNorm + activation + depthwise 3x3 conv forward of an inverted-residual block (round 5;
+ * csrc/expdw_fwd.hip): y2 = dwconv3x3(act(scale1 * round(W1 z) + shift1)), dtype T3D_BF16 or T3D_F16 (inference), K <= 32 (the 112x112 .. 28x28 blocks of
+ * MobileNetV2), act in {T3D_ACT_RELU, T3D_ACT_RELU6}.  Replaces nn.Conv2d(K, C, 1) + nn.BatchNorm2d(C) + activation +
+ * nn.Conv2d(C, C, 3, s, 1, groups=C) + the statistics pass of the following BatchNorm2d (models/mobilenetv3.py:146-153) without
+ * the expanded tensor's round trip through HBM: the stencil reads it out of LDS.
+ *   z [B,H,W,K] finished block input, w1 [C,K] bf16, scale1 / shift1 [C] fp32: the expansion's BatchNorm affine -- its batch
+ *   statistics must exist beforehand (a statistics-only pass: t3d_pwconv_fwd / _fwd_mat with y = NULL), wdw [C,9] fp32,
+ *   y1 [B,H,W,C] raw expansion or NULL (stored only for a backward that reads it), y2 [B,Ho,Wo,C] raw depthwise output,
+ *   stats2 [2*C] fp64 replicas or NULL: += sum(y2), sum(y2^2) (order-independent, as t3d_dwconv_fwd).
+ * T3D_ERR_UNSUPPORTED for shapes it does not take (the caller runs t3d_pwconv_fwd + t3d_dwconv_fwd). */
+int t3d_expdw_fwd(int dtype, const void* z, const void* w1, const float* scale1, const float* shift1, int act, const float* wdw,
+                  void* y1, void* y2, double* stats2, int B, int H, int W, int K, int C, int stride, void* stream);
+
 /* Step plans (round 5; csrc/plan.hip): the whole train iteration as ONE host call.
  * Replaces the per-launch host loop of torchdet3d/trainer/train.py:44-55 + builders/optim_builder.py:10-12 (model forward,
  * losses, loss.backward(), optimizer.step()): ~230 enqueue-only calls of this header that are the same from step to step

@@ -1,0 +1,96 @@
+"""GPU: the fused expand 1x1 + BatchNorm + activation + depthwise 3x3 forward (`t3d_expdw_fwd`, csrc/expdw_fwd.hip;
+models/mobilenetv3.py:146-153 of the reference) against torch-CPU fp64 on the same bf16 operands and against the two launches
+it replaces: the depthwise output, the optional raw expansion and the BatchNorm sums, at small shapes (every stride / tile
+edge case) and at production shapes of MobileNetV2 @224 (sampled)."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def _ref(z, w1, sc, sh, act, wdw, s):
+    """z [B,H,W,K] bf16, w1 [C,K] bf16 -> (y1 [B,H,W,C] fp64, y2 [B,Ho,Wo,C] fp64); the activation sees the bf16-rounded y1."""
+    y1 = torch.einsum('bhwk,ck->bhwc', z.double(), w1.double())
+    u = y1.to(torch.bfloat16).double() * sc.double() + sh.double()
+    a = {1: lambda t: t.clamp(min=0), 2: lambda t: t.clamp(0, 6)}[act](u)
+    y2 = F.conv2d(a.permute(0, 3, 1, 2), wdw.double().view(-1, 1, 3, 3), stride=s, padding=1, groups=a.shape[3])
+    return y1, y2.permute(0, 2, 3, 1)
+
+
+def _run(z, w1, sc, sh, act, wdw, s, store, nrep=4):
+    from torchdet3d import _native as N
+    B, H, W, K = z.shape
+    C = w1.shape[0]
+    Ho, Wo = (H - 1) // s + 1, (W - 1) // s + 1
+    y1 = torch.full((B, H, W, C), 7.0, dtype=torch.bfloat16, device='cuda') if store else None
+    y2 = torch.full((B, Ho, Wo, C), 7.0, dtype=torch.bfloat16, device='cuda')
+    stats = torch.zeros(nrep, 2 * C, dtype=torch.float64, device='cuda')
+    N.call('t3d_set_reduction_replicas', nrep, 2 * C)
+    try:
+        N.call('t3d_expdw_fwd', N.BF16, N.ptr(z), N.ptr(w1), N.ptr(sc), N.ptr(sh), act, N.ptr(wdw), N.ptr(y1), N.ptr(y2),
+               N.ptr(stats), B, H, W, K, C, s, N.stream())
+    finally:
+        N.call('t3d_set_reduction_replicas', 1, 0)
+    torch.cuda.synchronize()
+    return y1, y2, stats.sum(0)
+
+
+@pytest.mark.parametrize('B,H,W,K,C,s,act,store', [
+    (2, 28, 28, 32, 192, 2, 2, True), (2, 28, 28, 32, 192, 1, 2, True), (2, 23, 19, 24, 144, 1, 1, True),
+    (2, 23, 19, 24, 144, 2, 2, False), (3, 56, 56, 24, 144, 1, 2, True), (3, 56, 56, 24, 144, 2, 2, True),
+    (2, 112, 112, 16, 96, 2, 2, True), (5, 9, 33, 8, 40, 2, 1, False), (9, 14, 14, 32, 64, 1, 2, True), (1, 8, 8, 16, 32, 1, 2, True)])
+def test_expdw_fwd_matches_torch(B, H, W, K, C, s, act, store):
+    g = torch.Generator().manual_seed(B * 1000 + H + C)
+    z = torch.randn(B, H, W, K, generator=g).to(torch.bfloat16)
+    w1 = (torch.randn(C, K, generator=g) / K ** 0.5).to(torch.bfloat16)
+    sc, sh = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g) * 0.5
+    wdw = torch.randn(C, 9, generator=g) * 0.3
+    y1, y2, st = _run(z.cuda(), w1.cuda(), sc.cuda(), sh.cuda(), act, wdw.cuda(), s, store)
+    r1, r2 = _ref(z, w1, sc, sh, act, wdw, s)
+    if store:
+        # the MFMA's fp32 sum against fp64: equal after rounding except where the sum sits on a rounding boundary
+        d = (y1.cpu().double() - r1).abs()
+        assert (d <= 2 ** -8 * r1.abs() + 1e-6).all(), d.max().item()
+    got = y2.cpu().double()
+    # one bf16 rounding of the output (2^-8 relative), fp32 accumulation order, and the occasional y1 whose bf16 rounding falls the
+    # other way than the fp64 reference's (one bf16 ulp of y1 through the BatchNorm scale and a stencil weight)
+    tol = 0.03 + 2 ** -7 * r2.abs()
+    assert ((got - r2).abs() <= tol).all(), (got - r2).abs().max().item()
+    assert torch.allclose(st[:C].cpu(), got.sum((0, 1, 2)), rtol=1e-5, atol=1e-3)
+    assert torch.allclose(st[C:].cpu(), (got * got).sum((0, 1, 2)), rtol=1e-5, atol=1e-3)
+
+
+@pytest.mark.parametrize('H,K,C,s', [(112, 16, 96, 2), (56, 24, 144, 1), (56, 24, 144, 2), (28, 32, 192, 1), (28, 32, 192, 2)])
+def test_expdw_fwd_against_the_two_launches_at_production_shapes(H, K, C, s):
+    """B = 256 at the block shapes of MobileNetV2 @224: same y1 bit for bit (the same MFMA on the same operands), y2 within the
+    output rounding of the depthwise kernel it replaces, identical-to-1e-6 BatchNorm sums; and run twice: bit-identical."""
+    from torchdet3d import _native as N
+    B = 256
+    g = torch.Generator(device='cuda').manual_seed(H + C)
+    z = torch.randn(B, H, H, K, device='cuda', generator=g).to(torch.bfloat16)
+    w1 = (torch.randn(C, K, device='cuda', generator=g) / K ** 0.5).to(torch.bfloat16)
+    sc, sh = torch.rand(C, device='cuda', generator=g) + 0.5, torch.randn(C, device='cuda', generator=g) * 0.5
+    wdw = torch.randn(C, 9, device='cuda', generator=g) * 0.3
+    y1, y2, st = _run(z, w1, sc, sh, 2, wdw, s, True, nrep=16)
+    y1b, y2b, stb = _run(z, w1, sc, sh, 2, wdw, s, True, nrep=16)
+    assert torch.equal(y1, y1b) and torch.equal(y2, y2b) and torch.equal(st, stb)
+    Ho = (H - 1) // s + 1
+    M = B * H * H
+    p1 = torch.empty(B, H, H, C, device='cuda', dtype=torch.bfloat16)
+    p2 = torch.empty(B, Ho, Ho, C, device='cuda', dtype=torch.bfloat16)
+    stats = torch.zeros(16, 2 * C, device='cuda', dtype=torch.float64)
+    N.call('t3d_set_reduction_replicas', 16, 2 * C)
+    try:
+        N.call('t3d_pwconv_fwd', N.BF16, N.ptr(z), None, N.ptr(w1), None, N.ptr(p1), None, M, H * H, K, C, N.stream())
+        N.call('t3d_dwconv_fwd', N.BF16, N.ptr(p1), N.prologue(sc, sh, None, 'relu6', False), N.ptr(wdw), N.ptr(p2), N.ptr(stats),
+               None, B, H, H, C, 3, s, N.stream())
+    finally:
+        N.call('t3d_set_reduction_replicas', 1, 0)
+    torch.cuda.synchronize()
+    assert torch.equal(y1, p1)
+    d = (y2.float() - p2.float()).abs()
+    assert (d <= 2 ** -7 * p2.float().abs() + 1e-3).all(), d.max().item()
+    assert (d > 0).float().mean().item() < 0.05          # a different summation order flips few roundings
+    sp = stats.sum(0)
+    assert torch.allclose(st, sp, rtol=2e-4, atol=1.0)
