@@ -292,7 +292,8 @@ extern "C" int t3d_dropout_mask(float* mask, long long n, unsigned long long see
 
 extern "C" int t3d_zero_batched(const long long* desc, int n, void* stream) {
   if (!desc || n <= 0) return T3D_ERR_ARG;
-  T3D_LAUNCH(zero_batched_kernel, dim3(n, 64), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), desc);
+  // (64 workgroups per buffer when there are many; a single large buffer -- a 9-MB weight-gradient matrix -- gets the chip)
+  T3D_LAUNCH(zero_batched_kernel, dim3(n, n >= 16 ? 64 : 1024 / n), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), desc);
   T3D_CHECK_LAUNCH();
   return T3D_OK;
 }

@@ -76,7 +76,7 @@ const Entry kEntries[] = {
     T3D_E(t3d_fold_request), T3D_E(t3d_pack_weights_batched), T3D_E(t3d_pwconv_pack_frag), T3D_E(t3d_adamw_step),
     T3D_E(t3d_zero_batched), T3D_E(t3d_copy_cols), T3D_E(t3d_bn_bias_grad), T3D_E(t3d_se_bwd_affine), T3D_E(t3d_dropout_mask),
     T3D_E(t3d_loss_fwd_bwd), T3D_E(t3d_metrics_per_sample), T3D_E(t3d_iou3d), T3D_E(t3d_box_iou3d), T3D_E(t3d_ssd_decode_nms),
-    T3D_E(t3d_expdw_fwd),
+    T3D_E(t3d_expdw_fwd), T3D_E(t3d_conv3x3_fwd), T3D_E(t3d_conv3x3_dgrad), T3D_E(t3d_conv3x3_wgrad), T3D_E(t3d_pack_conv3x3_dgrad_weight),
 };
 #undef T3D_E
 constexpr int kNumEntries = (int)(sizeof(kEntries) / sizeof(kEntries[0]));

@@ -32,6 +32,12 @@ struct GemmArgs {
   // the finished block output that t3d_bn_apply would have written; the blocks of output chunk 0 also STORE it to z_out
   const void* z_res;
   void* z_out;
+  // implicit 3x3 convolution (deep-contraction kernel only; resnet.hip: t3d_conv3x3_fwd / _dgrad): the operand row of pixel m
+  // is GATHERED -- k = tap * cv.Cs + c reads channel c of the source pixel that tap (ky, kx) pairs with destination pixel m --
+  // instead of read from a patch matrix in HBM.  mode 1 (forward): source = destination * stride - 1 + (ky, kx); mode 2 (data
+  // gradient): source = (destination + 1 - (ky, kx)) / stride where that divides.  Out-of-range taps contribute zero AFTER
+  // the operand transform (the convolution pads the activated tensor; the BatchNorm-backward affine has a constant term).
+  struct Conv3 { int mode, Dh, Dw, Sh, Sw, Cs, lgCs, stride; } cv;
   int wfrag;             // `w` is the fragment-order copy (include/t3d.h: T3D_W_FRAG; streaming and deep-contraction kernels)
   T3dQuant quant;        // forward BatchNorm sums snapped onto a fixed grid (order-independent, common.h); q == 0: off
 };

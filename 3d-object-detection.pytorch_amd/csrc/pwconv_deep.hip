@@ -101,16 +101,53 @@ __global__ __launch_bounds__(64 * NW, 1) void pw_deep_kernel(const GemmArgs a, c
     }
   };
   // operand rows of this wave's staging items
-  const size_t arow = (size_t)min(m0 + wave * 16 + lc, a.M - 1) * a.Kin + lg * 8;
+  const int mrow = min(m0 + wave * 16 + lc, a.M - 1);
+  const size_t arow = (size_t)mrow * a.Kin + lg * 8;
   const bool rok = m0 + wave * 16 + lc < a.M;
+  // implicit 3x3 convolution (pwconv_common.h: Conv3): this lane's destination pixel, once
+  const bool cv = a.cv.mode != 0;
+  int cvb = 0, cvy = 0, cvx = 0;
+  if (cv) {
+    cvx = mrow % a.cv.Dw;
+    const int t = mrow / a.cv.Dw;
+    cvy = t % a.cv.Dh;
+    cvb = t / a.cv.Dh;
+  }
+  // k-step ks (wave-uniform) -> element offset of the lane's 8 operand channels in the source tensor, or -1: the tap falls
+  // outside the source (zero after the transform)
+  auto cv_off = [&](const int ks) -> long long {
+    const int k0 = min(ks * 32, a.Kin - 32);
+    const int tap = k0 >> a.cv.lgCs, c = k0 & (a.cv.Cs - 1);
+    const int ky = (tap * 11) >> 5, kx = tap - 3 * ky;             // tap / 3, tap % 3 for tap <= 8
+    int sy, sx;
+    bool ok;
+    if (a.cv.mode == 1) {
+      sy = cvy * a.cv.stride - 1 + ky;
+      sx = cvx * a.cv.stride - 1 + kx;
+      ok = true;
+    } else {
+      const int ty = cvy + 1 - ky, tx = cvx + 1 - kx, sm = a.cv.stride - 1;       // stride 1 or 2
+      ok = ((ty | tx) & sm) == 0;
+      sy = ty >> sm;
+      sx = tx >> sm;
+    }
+    ok = ok && (unsigned)sy < (unsigned)a.cv.Sh && (unsigned)sx < (unsigned)a.cv.Sw;
+    return ok ? ((long long)(cvb * a.cv.Sh + sy) * a.cv.Sw + sx) * a.cv.Cs + c + lg * 8 : -1;
+  };
   bf16x8 pa[2][IT], pb[DG ? 2 : 1][DG ? IT : 1];
   auto a_issue = [&](auto slot_tag, const int ph) {
     constexpr int SL = decltype(slot_tag)::value;
 #pragma unroll
     for (int j = 0; j < IT; ++j) {
-      const int k = min((ph * KSP + j) * 32, a.Kin - 8 - lg * 8);
-      pa[SL][j] = *reinterpret_cast<const bf16x8*>(A0 + arow + k);
-      if (DG) pb[DG ? SL : 0][DG ? j : 0] = *reinterpret_cast<const bf16x8*>(A1 + arow + k);
+      size_t o;
+      if (cv) {
+        const long long g = cv_off(ph * KSP + j);
+        o = g < 0 ? (size_t)lg * 8 : (size_t)g;                 // (an out-of-range tap reads a valid address; zeroed later)
+      } else {
+        o = arow + min((ph * KSP + j) * 32, a.Kin - 8 - lg * 8);
+      }
+      pa[SL][j] = *reinterpret_cast<const bf16x8*>(A0 + o);
+      if (DG) pb[DG ? SL : 0][DG ? j : 0] = *reinterpret_cast<const bf16x8*>(A1 + o);
     }
   };
   w_issue(std::integral_constant<int, 0>{}, 0);
@@ -125,21 +162,32 @@ __global__ __launch_bounds__(64 * NW, 1) void pw_deep_kernel(const GemmArgs a, c
     ecoef[i] = v ? a.e_scale[n] : 1.f;
     ecoef[BN + i] = v ? a.e_shift[n] : 0.f;
   }
+  // (implicit 3x3 convolution: the coefficients are per SOURCE channel, Cs of them, repeated for each of the nine taps)
+  const int ncoef = cv ? a.cv.Cs : a.Kin;
   if (a.fold) {
     for (int i = a.Kin + tid; i < kpad; i += 64 * NW) {
       coef[i] = DG ? 0.f : 1.f; coef[kpad + i] = 0.f; coef[2 * kpad + i] = 0.f;
     }
-    t3d_fold_block(a.fold, 0, a.Kin, coef, kpad, blockIdx.x == 0 && blockIdx.y == 0);
+    t3d_fold_block(a.fold, 0, ncoef, coef, kpad, blockIdx.x == 0 && blockIdx.y == 0);
+    if (cv) {
+      for (int i = ncoef + tid; i < a.Kin; i += 64 * NW) {
+        const int c = i & (ncoef - 1);
+        coef[i] = coef[c]; coef[kpad + i] = coef[kpad + c];
+        if (DG) coef[2 * kpad + i] = coef[2 * kpad + c];
+      }
+      __syncthreads();
+    }
   } else {
     for (int i = tid; i < kpad; i += 64 * NW) {
       const bool v = i < a.Kin;
+      const int c = cv ? (i & (ncoef - 1)) : i;
       if (!DG) {
-        coef[i] = (v && a.p0) ? a.p0[i] : 1.f;
-        coef[kpad + i] = (v && a.p0) ? a.p1[i] : 0.f;
+        coef[i] = (v && a.p0) ? a.p0[c] : 1.f;
+        coef[kpad + i] = (v && a.p0) ? a.p1[c] : 0.f;
       } else {
-        coef[i] = v ? a.p0[i] : 0.f;
-        coef[kpad + i] = v ? a.p1[i] : 0.f;
-        coef[2 * kpad + i] = v ? a.p2[i] : 0.f;
+        coef[i] = v ? a.p0[c] : 0.f;
+        coef[kpad + i] = v ? a.p1[c] : 0.f;
+        coef[2 * kpad + i] = v ? a.p2[c] : 0.f;
       }
     }
     __syncthreads();
@@ -167,7 +215,7 @@ __global__ __launch_bounds__(64 * NW, 1) void pw_deep_kernel(const GemmArgs a, c
 #pragma unroll
     for (int j = 0; j < IT; ++j) {
       const int k = (ph * KSP + j) * 32 + lg * 8;
-      const bool ok = rok && (k < a.Kin);
+      const bool ok = rok && (k < a.Kin) && (!cv || cv_off(ph * KSP + j) >= 0);
       const int kc = min(k, kpad - 8);
       const float4 c0a = *reinterpret_cast<const float4*>(coef + kc), c0b = *reinterpret_cast<const float4*>(coef + kc + 4);
       const float4 c1a = *reinterpret_cast<const float4*>(coef + kpad + kc),
@@ -365,7 +413,9 @@ int deep_launch(GemmArgs& a, hipStream_t st) {
   if (a.a2 || a.z_out || a.per_sample || a.ps_stats || a.e_se || a.bias || (!a.dgrad && a.p2)) return T3D_ERR_UNSUPPORTED;
   if (a.row0 && a.row0 != a.Kin) return T3D_ERR_UNSUPPORTED;
   if (a.dgrad && (!a.a1 || !a.p0 || !a.p1 || !a.p2)) return T3D_ERR_UNSUPPORTED;
-  if (!deep_shape(a.Kin, a.Nout)) return T3D_ERR_UNSUPPORTED;
+  if (!a.cv.mode && !deep_shape(a.Kin, a.Nout)) return T3D_ERR_UNSUPPORTED;
+  if (a.cv.mode && (a.Kin != 9 * a.cv.Cs || (a.cv.Cs & (a.cv.Cs - 1)) || a.cv.Cs < 32 || (a.cv.stride != 1 && a.cv.stride != 2)))
+    return T3D_ERR_UNSUPPORTED;
   const int KS = cdiv(a.Kin, 32);
   const int pairs = cdiv(a.Nout, 32);
   // chunks of <= 6 pairs of tiles (192 channels), evenly sized; every chunk stages the operand again (from L2)

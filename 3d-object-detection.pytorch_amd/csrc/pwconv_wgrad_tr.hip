@@ -55,6 +55,10 @@ struct WgtArgs {
   double* stats;          // [2][K] replicas or null
   int nrep;
   long long rstride;
+  // implicit 3x3 convolution (conv3x3.hip): the a side [M][K = 9 C] is not a patch matrix in memory -- column k = tap * C + c
+  // of output pixel m reads channel c of input pixel (oy * stride - 1 + ky, ox * stride - 1 + kx) of x [B][H][W][C] (raw, the
+  // BatchNorm + activation prologue per channel c), zero outside the image
+  struct { int on, H, W, Ho, Wo, C, lgC, stride; unsigned mulW, mulH; } cv;
   int assign;             // dw is WRITTEN, not accumulated into (the y-free product matrix: no clear needed ahead of the launch)
 };
 
@@ -144,8 +148,9 @@ __global__ __launch_bounds__(256 * G) void pw_wgrad_tr_kernel(const WgtArgs a) {
   for (int i = threadIdx.x; i < aB; i += 256 * G) {
     const int k = a0c + i;
     const bool v = k < a.K;
-    ca[i] = ((v && a.scale) ? a.scale[k] : 1.f) * (c6 ? T3D_SIXTH : 1.f);
-    ca[aB + i] = ((v && a.scale) ? a.shift[k] : 0.f) * (c6 ? T3D_SIXTH : 1.f);
+    const int kc = a.cv.on ? (k & (a.cv.C - 1)) : k;
+    ca[i] = ((v && a.scale) ? a.scale[kc] : 1.f) * (c6 ? T3D_SIXTH : 1.f);
+    ca[aB + i] = ((v && a.scale) ? a.shift[kc] : 0.f) * (c6 ? T3D_SIXTH : 1.f);
   }
   if constexpr (DGF) {
     for (int i = threadIdx.x; i < QB * (PB / 8); i += 256 * G) {
@@ -168,7 +173,7 @@ __global__ __launch_bounds__(256 * G) void pw_wgrad_tr_kernel(const WgtArgs a) {
   // DGF units of a step: (16-pixel tile, 16-channel tile) pairs, dealt round-robin to the pipeline's four waves
   constexpr int NU = DGF ? (STEP / 16) * NTQ : 1, UPW = (NU + 3) / 4;
   struct Epi { bf16x4 res[UPW], xr[UPW]; };
-  struct Regs { bf16x8 rz[VDY], ry[VDY], rx[VA]; Epi e; };
+  struct Regs { bf16x8 rz[VDY], ry[VDY], rx[VA]; Epi e; unsigned okm; };      // okm: implicit 3x3 -- bit i: vector i's tap is inside the image
   Regs rr[D];
   Epi ecur;                     // epilogue operands of the step that is in LDS now
   const int lgq = lane >> 4, lcq = lane & 15;
@@ -193,11 +198,24 @@ __global__ __launch_bounds__(256 * G) void pw_wgrad_tr_kernel(const WgtArgs a) {
         R.ry[i] = *reinterpret_cast<const bf16x8*>(yy + (size_t)m * a.N + n);
       }
     }
+    R.okm = ~0u;
 #pragma unroll
     for (int i = 0; i < VA; ++i) {
       const int v = min(tid + 256 * i, nav - 1);
       const int row = v / aV, k = min(a0c + (v % aV) * 8, a.K - 8), m = min(m0 + row, a.M - 1);
-      R.rx[i] = *reinterpret_cast<const bf16x8*>(xx + (size_t)m * a.K + k);
+      if (a.cv.on) {
+        const int tap = k >> a.cv.lgC, c = k & (a.cv.C - 1);
+        const int ky = (tap * 11) >> 5, kx = tap - 3 * ky;
+        const int t = (int)__umulhi((unsigned)m, a.cv.mulW), ox = m - t * a.cv.Wo;       // m / Wo, m % Wo (exact: launcher)
+        const int b = (int)__umulhi((unsigned)t, a.cv.mulH), oy = t - b * a.cv.Ho;
+        const int iy = oy * a.cv.stride - 1 + ky, ix = ox * a.cv.stride - 1 + kx;
+        const bool ok = (unsigned)iy < (unsigned)a.cv.H && (unsigned)ix < (unsigned)a.cv.W;
+        const size_t o = ok ? ((size_t)(b * a.cv.H + iy) * a.cv.W + ix) * a.cv.C + c : 0;
+        R.rx[i] = *reinterpret_cast<const bf16x8*>(xx + o);
+        if (!ok) R.okm &= ~(1u << i);
+      } else {
+        R.rx[i] = *reinterpret_cast<const bf16x8*>(xx + (size_t)m * a.K + k);
+      }
     }
     if constexpr (DGF) {
 #pragma unroll
@@ -265,7 +283,7 @@ __global__ __launch_bounds__(256 * G) void pw_wgrad_tr_kernel(const WgtArgs a) {
       const int v = tid + 256 * i;
       if (v < nav) {
         const int row = v / aV, cl = (v % aV) * 8, m = m0 + row;
-        const bool ok = m < mend && a0c + cl < a.K;
+        const bool ok = m < mend && a0c + cl < a.K && ((R.okm >> i) & 1u);
         bf16x8 o = rx[i];
         if (!plain_a) {
           float u[8], sc[8], sh[8];
@@ -690,6 +708,27 @@ int t3d_pw_wgrad_tr_entry(const void* dz, const void* y, const t3d_bnbwd* bb, co
   } else {
     a.fold = t3d_take_fold(a.alpha);
   }
+  return choose_and_launch(a, st);
+}
+
+// implicit 3x3 convolution weight gradient (conv3x3.hip): dw [N][9 C] (patch-column order) += dy^T * gathered act(x)
+int t3d_pw_wgrad_tr_conv3(const void* dz, const void* y, const t3d_bnbwd* bb, const void* x, const t3d_prologue* pro, float* dw,
+                          int B, int H, int W, int C, int N, int stride, hipStream_t st) {
+  WgtArgs a{};
+  a.dz = dz; a.y = y; a.x = x;
+  a.alpha = bb->alpha; a.beta = bb->beta; a.gamma = bb->gamma;
+  if (pro) { a.scale = pro->scale; a.shift = pro->shift; a.act = pro->act; }
+  const int Ho = (H + 2 - 3) / stride + 1, Wo = (W + 2 - 3) / stride + 1;
+  a.dw = dw; a.M = B * Ho * Wo; a.HW = Ho * Wo; a.K = 9 * C; a.N = N;
+  int lg = 0;
+  while ((1 << lg) < C) ++lg;
+  // m / Wo and (m / Wo) / Ho as __umulhi(n, ceil(2^32 / d)): exact while n < 2^32 / d
+  if ((unsigned long long)a.M * (unsigned)(Wo > Ho ? Wo : Ho) >= (1ull << 32)) return T3D_ERR_UNSUPPORTED;
+  a.cv.on = 1; a.cv.H = H; a.cv.W = W; a.cv.Ho = Ho; a.cv.Wo = Wo; a.cv.C = C; a.cv.lgC = lg; a.cv.stride = stride;
+  a.cv.mulW = (unsigned)(((1ull << 32) + Wo - 1) / Wo);
+  a.cv.mulH = (unsigned)(((1ull << 32) + Ho - 1) / Ho);
+  a.fold = t3d_take_fold(a.alpha);
+  a.assign = 1;          // dw_packed is written (by the partial-tile reduction, or cleared first): the caller need not zero it
   return choose_and_launch(a, st);
 }
 

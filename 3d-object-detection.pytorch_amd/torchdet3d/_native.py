@@ -121,6 +121,10 @@ SIGNATURES = {
     't3d_loss_fwd_bwd': [_LP, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P],
     't3d_metrics_per_sample': [_P, _P, _P, _P, _P, _I, _I, _P],
     't3d_expdw_fwd': [_I, _P, _P, _P, _P, _I, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
+    't3d_conv3x3_fwd': [_I, _P, _PP, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
+    't3d_conv3x3_dgrad': [_I, _P, _P, _BP, _P, _P, _PP, _P, _P, _I, _I, _I, _I, _I, _I, _P],
+    't3d_conv3x3_wgrad': [_I, _P, _P, _BP, _P, _PP, _P, _I, _I, _I, _I, _I, _I, _P],
+    't3d_pack_conv3x3_dgrad_weight': [_P, _P, _I, _I, _P],
     # step plans (csrc/plan.hip): record once, replay with one call
     't3d_plan_create': [ctypes.POINTER(_P)],
     't3d_plan_destroy': [_P],

@@ -410,7 +410,7 @@ class Net:
     # backward half costs nothing either (7.64 ms both ways, 18 launches fewer), so both are on)
     _LAZY_DW = '1'
     DERIVING = frozenset(('t3d_pwconv_fwd', 't3d_pwconv_fwd_mat', 't3d_bn_apply', 't3d_pool_fwd', 't3d_pwconv_dgrad', 't3d_pwconv_yfree_prep',
-                          't3d_pwconv_yfree_prep2')
+                          't3d_pwconv_yfree_prep2', 't3d_conv3x3_dgrad')
                          + (('t3d_dwconv_fwd',) if _LAZY_DW in ('1', 'fwd') else ())
                          + (('t3d_dwconv_bwd',) if _LAZY_DW in ('1', 'bwd') else ()))
 
@@ -881,7 +881,7 @@ class Net:
         # (only where the bf16 transposed kernel will take the request: on the fp32-storage / T3D_WGRAD_TILED paths the entry
         # point would serve it with a PUBLISHING finalize launch on the side stream while the data gradient of the main
         # stream publishes the same values -- there the standalone finalize runs once, on the main stream, ahead of both)
-        req = (ro is not None and ro.pend[1] and self._lazy and entry == 't3d_pwconv_wgrad' and self.dt == N.BF16
+        req = (ro is not None and ro.pend[1] and self._lazy and entry in ('t3d_pwconv_wgrad', 't3d_conv3x3_wgrad') and self.dt == N.BF16
                and not os.environ.get('T3D_WGRAD_TILED'))
         if ro is not None and ro.pend[1] and not req:
             self._settle_b(ro)

@@ -13,10 +13,17 @@ gradient buffers, raw tensors + BatchNorm sums from the producing kernel, finali
 First version: correct, not tuned (the patch matrices cost 9x the activation traffic; an implicit-GEMM 3x3 kernel is the
 obvious next step for this model).
 """
+import os
+
 import torch
 
 from .. import _native as N
 from .engine import Net, _Src
+
+# 3x3 layers as gather-form implicit GEMMs (csrc/conv3x3.hip): OFF by default -- measured slower than the patch-matrix path at
+# config 4's shape (19.6 against 16.7 ms per step, DESIGN.md finding 41: the operand's BatchNorm transform is paid once per tap
+# inside the GEMM instead of once in the gather); T3D_IMPLICIT3=1 switches them on
+IMPLICIT3 = os.environ.get('T3D_IMPLICIT3', '0') != '0'
 
 
 class ResNetEngine(Net):
@@ -24,7 +31,7 @@ class ResNetEngine(Net):
     def _pack_extra(self, st):
         """k x k conv weights -> [N, Kp] patch-column order (storage dtype) + transposed copy for the data gradient."""
         if getattr(self, '_conv_pack', None) is None:
-            self._conv_pack = []
+            self._conv_pack, self._conv3 = [], {}
             for k, (s, kind) in self.shapes.items():
                 if kind == 'param' and len(s) == 4 and s[2] > 1:
                     n, c, kk = s[0], s[1], s[2]
@@ -42,6 +49,15 @@ class ResNetEngine(Net):
                         if lib.t3d_pwconv_wants_frag(n, kp):
                             frt = self._buf('wctf:' + k, (lib.t3d_pwconv_frag_bytes(kp, n) // 2,), zero=True)
                             self._frag[self.wt[k].data_ptr()] = frt
+                    # implicit-GEMM 3x3 layers (csrc/conv3x3.hip, bf16 storage): the forward streams the fragment-order copy of
+                    # the [N][9C] matrix whatever its shape, the data gradient that of the [C][9N] matrix
+                    if kk == 3 and self._implicit3(c, n):
+                        lib = N.lib()
+                        if fr is None:
+                            fr = self._buf('wcf:' + k, (lib.t3d_pwconv_frag_bytes(n, kp) // 2,), zero=True)
+                        wd = self._buf('wcd:' + k, (c, 9 * n))
+                        wdf = self._buf('wcdf:' + k, (lib.t3d_pwconv_frag_bytes(c, 9 * n) // 2,), zero=True)
+                        self._conv3[k] = (fr, wd, wdf)
                     self._conv_pack.append((k, n, c, kk, kp, w32, fr, frt))
         for k, n, c, kk, kp, w32, fr, frt in self._conv_pack:
             N.call('t3d_pack_conv_weight', N.F32, N.ptr(self.p[k]), N.ptr(w32), n, c, kk, kp, st)
@@ -52,6 +68,15 @@ class ResNetEngine(Net):
                 N.call('t3d_pwconv_pack_frag', N.ptr(self.w[k]), N.ptr(fr), n, kp, st)
             if frt is not None:
                 N.call('t3d_pwconv_pack_frag', N.ptr(self.wt[k]), N.ptr(frt), kp, n, st)
+            if k in self._conv3:
+                _, wd, wdf = self._conv3[k]
+                N.call('t3d_pack_conv3x3_dgrad_weight', N.ptr(self.p[k]), N.ptr(wd), n, c, st)
+                N.call('t3d_pwconv_pack_frag', N.ptr(wd), N.ptr(wdf), c, 9 * n, st)
+
+    def _implicit3(self, c, n):
+        """Dense 3x3 layer as an implicit GEMM (csrc/conv3x3.hip)?  bf16 storage, power-of-two channel counts >= 32; fp32 storage
+        (the parity mode) keeps the patch-matrix path."""
+        return IMPLICIT3 and self.dt == N.BF16 and c >= 32 and (c & (c - 1)) == 0 and n % 8 == 0
 
     def _kp(self, key):
         return self.w[key].shape[1]
@@ -122,10 +147,17 @@ class ResNetEngine(Net):
         Ho, Wo = (H + 2 - 3) // s + 1, (W + 2 - 3) // s + 1
         M2 = B * Ho * Wo
         kp = self._kp(p + '.conv2.weight')
-        col = self._buf('col:' + p, (M2, kp))
-        N.call('t3d_im2col', dt, N.ptr(y1), pro1, N.ptr(col), B, H, W, w, 3, s, 1, kp, st)
         y2 = self._buf('y2:' + p, (M2, w))
-        self._pw(col, None, self.w[p + '.conv2.weight'], y2, bn2, M2, Ho * Wo, kp, w)
+        c3 = self._conv3.get(p + '.conv2.weight')
+        if c3 is not None:
+            # implicit GEMM: the kernel gathers the activated 3x3 neighbourhood itself, no patch matrix in HBM
+            col = None
+            N.call('t3d_conv3x3_fwd', dt | N.W_FRAG, N.ptr(y1), pro1, N.ptr(c3[0]), N.ptr(y2), self._st(bn2), B, H, W, w, w, s, st,
+                   nbytes=(M + M2) * w * self.esz)
+        else:
+            col = self._buf('col:' + p, (M2, kp))
+            N.call('t3d_im2col', dt, N.ptr(y1), pro1, N.ptr(col), B, H, W, w, 3, s, 1, kp, st)
+            self._pw(col, None, self.w[p + '.conv2.weight'], y2, bn2, M2, Ho * Wo, kp, w)
         pro2 = self._bnf(bn2, M2, 'relu')
         y3 = self._buf('y3:' + p, (M2, 4 * w))
         self._pw(y2, pro2, self.w[p + '.conv3.weight'], y3, bn3, M2, Ho * Wo, w, 4 * w)
@@ -216,12 +248,24 @@ class ResNetEngine(Net):
         bb2 = self._bn_bwd(bn2)
         # ---- conv2 (3x3, stride s): GEMM against the patch matrix, gradient back through the gather
         kp = self._kp(p + '.conv2.weight')
-        self._conv_wgrad(p + '.conv2.weight', dv2, rec['y2'], bb2, rec['col'], M2, HW2, w, w, 3, bn=bn2)
-        dcol = self._buf('dcol:' + p, (M2, kp))
-        self._dgrad(dv2, rec['y2'], bb2, self.wt[p + '.conv2.weight'], None, None, None, dcol, None, M2, HW2, kp, w, bn=bn2)
         d1 = self._buf('d1:' + p, (M, w))
-        N.call('t3d_col2im_bwd', dt, N.ptr(dcol), N.ptr(rec['y1']), rec['pro1'], N.ptr(d1), self._bst(bn1), B, H, W, w, 3, s, 1,
-               kp, st)
+        c3 = self._conv3.get(p + '.conv2.weight')
+        if c3 is not None:
+            # implicit GEMMs: dW from the gathered activations (second stream), dx by the transposed gather -- the gradient
+            # lands at BN1's output with the ReLU mask and BN1's backward sums, as the 1x1 data gradients do
+            key = p + '.conv2.weight'
+            dwp = self._buf('dwp:' + key, (w, kp), torch.float32)          # (written by the launch: no clear)
+            self._wgrad(dt, N.ptr(dv2), N.ptr(rec['y2']), bb2, N.ptr(rec['y1']), rec['pro1'], N.ptr(dwp), B, H, W, w, w, s,
+                        entry='t3d_conv3x3_wgrad', ro=bn2, nbytes=(M + M2) * w * self.esz)
+            self._wgrad(N.ptr(dwp), N.ptr(self.g[key]), w, w, 3, kp, entry='t3d_unpack_conv_grad')
+            self._c('t3d_conv3x3_dgrad', dt | N.W_FRAG, N.ptr(dv2), N.ptr(rec['y2']), bb2, N.ptr(c3[2]), N.ptr(rec['y1']),
+                    rec['pro1'], N.ptr(d1), self._bst(bn1), B, H, W, w, w, s, st, bwd=bn2, nbytes=(M + M2) * w * self.esz)
+        else:
+            self._conv_wgrad(p + '.conv2.weight', dv2, rec['y2'], bb2, rec['col'], M2, HW2, w, w, 3, bn=bn2)
+            dcol = self._buf('dcol:' + p, (M2, kp))
+            self._dgrad(dv2, rec['y2'], bb2, self.wt[p + '.conv2.weight'], None, None, None, dcol, None, M2, HW2, kp, w, bn=bn2)
+            N.call('t3d_col2im_bwd', dt, N.ptr(dcol), N.ptr(rec['y1']), rec['pro1'], N.ptr(d1), self._bst(bn1), B, H, W, w, 3, s, 1,
+                   kp, st)
         bb1 = self._bn_bwd(bn1)
         # ---- shortcut
         if down:

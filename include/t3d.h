@@ -537,6 +537,28 @@ int t3d_dropout_mask(float* mask, long long n, unsigned long long seed, unsigned
  * (the per-step clears of the gradient buffer, the BatchNorm sum replicas and the depthwise weight-gradient replicas). */
 int t3d_zero_batched(const long long* desc, int n, void* stream);
 
+/* Dense 3x3 convolution (pad 1, stride 1 or 2) as an implicit GEMM, bf16 storage (round 5; csrc/conv3x3.hip): the three GEMMs of
+ * ResNet-50's conv2 layers gather their operand rows from the activation tensor themselves -- no patch matrix in HBM.  Replaces
+ * nn.Conv2d(C, N, 3, stride, 1, bias=False) and its autograd in a torchvision Bottleneck, the backbone BASELINE config 4 builds
+ * through torchdet3d/builders/model_builder.py:73-151 (t3d_im2col / t3d_col2im_bwd + the 1x1 kernels remain for fp32 storage
+ * and the 7x7 stem).  C a power of two >= 32 (>= 8 for the weight gradient), N % 8 == 0.
+ *   _fwd    dtype = T3D_BF16 | T3D_W_FRAG; x [B,H,W,C] raw + `pro` (BatchNorm affine + activation of its producer, may be NULL);
+ *           w_frag = t3d_pwconv_pack_frag of the [N][9C] patch-column-order weights (t3d_pack_conv_weight);
+ *           y [B,Ho,Wo,N] raw, stats [2N] fp64 replicas or NULL as t3d_pwconv_fwd;
+ *   _dgrad  dx [B,H,W,C] = gradient at the producer's BatchNorm output: sum over (tap, n) of the BatchNorm-backward affine of
+ *           (dz, y) [B,Ho,Wo,N] times wd, times act'(x_raw through pro_in), stats += sum(dx), sum(dx * x_raw) as t3d_pwconv_dgrad;
+ *           wd_frag = t3d_pwconv_pack_frag of the [C][9N] matrix t3d_pack_conv3x3_dgrad_weight writes (wd[c][t*N+n] = w[n][c][t]);
+ *   _wgrad  dw_packed [N][9C] fp32 = (BatchNorm-backward affine of (dz, y))^T * gathered act(x) (written, not added to), patch-column order
+ *           (t3d_unpack_conv_grad -> [N][C][3][3]); dtype T3D_BF16; the caller's workspace as t3d_pwconv_wgrad. */
+int t3d_conv3x3_fwd(int dtype, const void* x, const t3d_prologue* pro, const void* w_frag, void* y, double* stats, int B, int H,
+                    int W, int C, int N, int stride, void* stream);
+int t3d_conv3x3_dgrad(int dtype, const void* dz, const void* y, const t3d_bnbwd* bb, const void* wd_frag, const void* x_raw,
+                      const t3d_prologue* pro_in, void* dx, double* stats, int B, int H, int W, int C, int N, int stride,
+                      void* stream);
+int t3d_conv3x3_wgrad(int dtype, const void* dz, const void* y, const t3d_bnbwd* bb, const void* x, const t3d_prologue* pro,
+                      float* dw_packed, int B, int H, int W, int C, int N, int stride, void* stream);
+int t3d_pack_conv3x3_dgrad_weight(const float* w, void* out, int N, int C, void* stream);
+
 /* Fused expand 1x1 conv + BatchNorm + activation + depthwise 3x3 conv forward of an inverted-residual block (round 5;
  * csrc/expdw_fwd.hip): y2 = dwconv3x3(act(scale1 * round(W1 z) + shift1)), dtype T3D_BF16 or T3D_F16 (inference), K <= 32 (the 112x112 .. 28x28 blocks of
  * MobileNetV2), act in {T3D_ACT_RELU, T3D_ACT_RELU6}.  Replaces nn.Conv2d(K, C, 1) + nn.BatchNorm2d(C) + activation +
