@@ -29,6 +29,17 @@ def test_one_rank_rccl_gradient_exchange_matches_plain_step():
     assert 'RCCL_OK world=1' in r.stdout, r.stdout[-2000:]
 
 
+def test_step_plan_replay_under_rccl():
+    """The recorded step plan under a launcher: segments cut at the gradient exchange's callbacks, RCCL collectives issued from
+    Python between two `t3d_plan_run` calls -- bit-identical to the launch-by-launch step (tests/_rccl_plan_worker.py)."""
+    env = dict(os.environ, T3D_FORCE_SYNC='1', HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'))
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node=1', '--master-addr', '127.0.0.1',
+           '--master-port', str(_free_port()), os.path.join(ROOT, 'tests', '_rccl_plan_worker.py')]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    assert 'RCCL_PLAN_OK' in r.stdout, r.stdout[-2000:]
+
+
 def test_bench_spawns_its_own_ranks_and_reports_them():
     """`python bench.py --gpus 1` under the launcher (what the driver does for N > 1) reports rccl_ranks = 1; run
     plainly with --gpus 2 on a one-GPU box it must fail loudly instead of silently benchmarking one GPU."""

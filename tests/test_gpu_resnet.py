@@ -342,3 +342,37 @@ def test_dense_3x3_conv_as_gather_plus_gemm_matches_torch(B, H, C, Nn, s):
     dw = torch.empty(Nn, C, 3, 3, device='cuda')
     N.call('t3d_unpack_conv_grad', N.ptr(dwp), N.ptr(dw), Nn, C, 3, Kp, N.stream())
     np.testing.assert_allclose(dw.cpu().numpy(), wr.grad.numpy(), atol=1e-4, rtol=1e-4)
+
+
+def test_resnet50_train_step_with_implicit_gemm_3x3_layers(monkeypatch):
+    """The opt-in gather-form implicit GEMMs (csrc/conv3x3.hip, T3D_IMPLICIT3=1) against the default patch-matrix path of the same
+    engine: one bf16 train step, same weights and crops -- same loss and gradients up to the bf16 rounding of two summation
+    orders."""
+    from oracle.weights import make_inputs, make_state_dict
+    from test_gpu_engine import _loss_cfg
+    from torchdet3d import _native as N
+    from torchdet3d.models import resnet as RM
+    B, HW, nc = 8, 96, 9
+    imgs, gt_kp, cats = make_inputs(B, HW, HW, nc)
+    sd = make_state_dict('resnet50', nc)
+    mask = torch.full((B, 2048), 2.0).cuda()
+    cfg = _loss_cfg(['l1', 'add_loss', 'cross_entropy'], ([1., .1], [.2]))
+    res = {}
+    for on in (False, True):
+        monkeypatch.setattr(RM, 'IMPLICIT3', on)
+        net = RM.ResNetEngine('resnet50', nc, 'cuda', torch.bfloat16)
+        net.load_state_dict(sd)
+        kp, lg = net.forward(imgs.cuda(), cats.cuda(), train=True, dropout_mask=mask)
+        assert bool(net._conv3) == on
+        out = torch.zeros(16, device='cuda')
+        dkp, dlg = torch.empty(B, 18, device='cuda'), torch.empty(B, nc, device='cuda')
+        N.call('t3d_loss_fwd_bwd', cfg, N.ptr(kp), N.ptr(gt_kp.cuda().view(B, 18).contiguous()), N.ptr(lg), N.ptr(cats.cuda()),
+               N.ptr(out), N.ptr(dkp), N.ptr(dlg), B, nc, N.stream())
+        net.backward(dkp, dlg)
+        torch.cuda.synchronize()
+        res[on] = (out[0].item(), net.gflat.clone())
+        del net
+    (l0, g0), (l1, g1) = res[False], res[True]
+    rel = ((g0 - g1).double().norm() / g0.double().norm()).item()
+    print(f'   implicit 3x3: loss {l1:.6f} vs {l0:.6f}, whole-gradient relative L2 {rel:.3e}')
+    assert abs(l0 - l1) < 2e-2 and rel < 0.15
