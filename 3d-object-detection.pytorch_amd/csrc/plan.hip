@@ -13,6 +13,9 @@
 // from the declarations of include/t3d.h -- no ABI tricks), so host-side state such as the pending BatchNorm fold
 // request, the reduction replicas or the workspace pointers is driven exactly as in the eager step and the launches are
 // bit-identical (tests/test_gpu_step_plan.py).
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <utility>
@@ -102,12 +105,18 @@ struct Op {
 }  // namespace
 
 struct t3d_plan {
+  // T3D_PLAN_PROFILE=1 (debugging aid): host nanoseconds spent inside each entry point / fork, printed by t3d_plan_destroy
+  std::vector<unsigned long long> host_ns, host_calls;
+  bool profile = false;
   std::vector<Op> ops;
   std::vector<int> seg_end;     // op index one past each closed segment
   std::vector<uint64_t> arena;  // struct copies (8-byte aligned)
   std::vector<uint8_t> timed;   // per entry: attach caller events to this entry point's launches (t3d_plan_time_entry)
   int failed_op = -1, failed_rc = 0;
-  t3d_plan() : timed(kNumEntries, 0) {}
+  t3d_plan() : timed(kNumEntries, 0) {
+    profile = getenv("T3D_PLAN_PROFILE") != nullptr;
+    if (profile) { host_ns.assign(kNumEntries + 4, 0); host_calls.assign(kNumEntries + 4, 0); }
+  }
 };
 
 static int find_entry(const char* name) {
@@ -124,6 +133,15 @@ extern "C" int t3d_plan_create(t3d_plan** out) {
 
 extern "C" int t3d_plan_destroy(t3d_plan* p) {
   if (!p) return T3D_OK;
+  if (p->profile) {
+    unsigned long long tot = 0;
+    for (size_t i = 0; i < p->host_ns.size(); ++i) tot += p->host_ns[i];
+    fprintf(stderr, "t3d_plan host profile: %.1f us per op list run in total\n", tot / 1e3);
+    for (size_t i = 0; i < p->host_ns.size(); ++i)
+      if (p->host_calls[i])
+        fprintf(stderr, "  %-34s %7llu calls %9.1f us  %6.2f us/call\n", i < (size_t)kNumEntries ? kEntries[i].name : (i == (size_t)kNumEntries + 1 ? "fork" : "copy/event"),
+                p->host_calls[i], p->host_ns[i] / 1e3, p->host_ns[i] / 1e3 / p->host_calls[i]);
+  }
   for (Op& o : p->ops)
     if (o.ev && !(o.kind == OP_FORK && o.w[2])) (void)hipEventDestroy(o.ev);
   delete p;
@@ -255,6 +273,8 @@ extern "C" int t3d_plan_run(t3d_plan* p, int segment, const unsigned long long* 
   for (int i = lo; i < hi; ++i) {
     const Op& o = p->ops[i];
     int rc = T3D_OK;
+    std::chrono::steady_clock::time_point t_begin;
+    if (p->profile) t_begin = std::chrono::steady_clock::now();
     switch (o.kind) {
       case OP_CALL: {
         for (int a = 0; a < o.nargs; ++a) {
@@ -299,6 +319,11 @@ extern "C" int t3d_plan_run(t3d_plan* p, int segment, const unsigned long long* 
         break;
       }
       default: rc = T3D_ERR_ARG;
+    }
+    if (p->profile) {
+      const int slot = o.kind == OP_CALL ? o.entry : kNumEntries + o.kind;
+      p->host_ns[slot] += (unsigned long long)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t_begin).count();
+      p->host_calls[slot] += 1;
     }
     if (rc != T3D_OK) {
       p->failed_op = i;

@@ -134,7 +134,7 @@ def parse():
     return ap.parse_args()
 
 
-CPU_THREADS_BEST = 32     # profiles/r5_cpu_baseline_thread_sweep.txt: B = 32 train step of the oracle at 8 / 16 / 32 / 64 / 128 threads
+CPU_THREADS_BEST = 16     # profiles/r5_cpu_baseline_thread_sweep.txt: B = 32 train step of the oracle at 8 / 16 / 32 / 64 / 128 threads: 50.6 / 53.0 / 40.4 / 18.8 / 8.7 crops/s
 
 
 def cpu_baseline(model, size, batch, steps, budget_s=25.0, threads=0):
