@@ -30,7 +30,8 @@ import torch  # noqa: E402
 HBM_PEAK = 8.0e12          # B/s, MI355X HBM3E spec (/opt/skills/guides/MI355X_MICROARCH.md)
 MNV2_TRAIN_MB_PER_CROP = 80.66   # algorithmic bytes, bf16, fwd + dgrad + wgrad
 CONV_KERNELS = ('t3d_dwconv_fwd', 't3d_dwconv_bwd', 't3d_pwconv_fwd', 't3d_pwconv_dgrad', 't3d_pwconv_wgrad',
-                't3d_pwconv_dgrad_yfree', 't3d_pwconv_wgrad_yfree')
+                't3d_pwconv_dgrad_yfree', 't3d_pwconv_wgrad_yfree', 't3d_pwconv_fwd_mat', 't3d_pwconv_bwd_yfree',
+                't3d_pwconv_wgrad_yfree_finish', 't3d_pwconv_yfree_prep', 't3d_pwconv_yfree_prep2')
 DW_ENTRIES = ('t3d_dwconv_fwd', 't3d_dwconv_bwd')
 # (entry point, k, stride) -> kernel name as rocprofv3 prints it (csrc/dwconv3_stream.hip, dwconv3_bwd_stream.hip,
 # dwconvk_stream.hip, dwconv5_bwd_stream.hip, dwconv_bwd.hip), bf16 storage

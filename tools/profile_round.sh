@@ -1,7 +1,7 @@
 #!/bin/bash
 # everything the round's profiles/ are made of, in one GPU call.  usage: tools/profile_round.sh <tag> <commit>
 cd $GRAFT_REPO_ROOT; export TMPDIR=/tmp
-tag=${1:-r4}; commit=${2:-?}; o=gpurun_out/$tag; mkdir -p $o
+tag=${1:-r5}; commit=${2:-?}; o=gpurun_out/$tag; mkdir -p $o
 python3 bench.py --steps 30 --warmup 8 > $o/bench_bf16.json 2> $o/bench_bf16.err
 python3 bench.py --steps 30 --warmup 8 --no-cpu-baseline --profile-all > /dev/null 2> $o/bench_bf16_families.txt
 python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline --per-launch > /dev/null 2> $o/bench_bf16_per_launch.txt
@@ -13,6 +13,10 @@ python3 bench.py --steps 20 --warmup 5 --model mobilenetv3_small --no-cpu-baseli
 python3 bench.py --steps 30 --warmup 8 --eval --eval-dtype f16 --no-cpu-baseline > $o/bench_eval_f16.json 2> /dev/null
 python3 bench.py --steps 20 --warmup 5 --model resnet50 --batch 64 --no-cpu-baseline > $o/bench_resnet50.json 2> /dev/null
 python3 bench.py --steps 30 --warmup 8 --engine --no-cpu-baseline > $o/bench_bf16_engine_loop.json 2> /dev/null
+T3D_STEP_PLAN=0 python3 bench.py --steps 30 --warmup 8 --no-cpu-baseline > $o/bench_bf16_direct_step.json 2> /dev/null
+T3D_PLAN_HANDOFF=0 python3 bench.py --steps 30 --warmup 8 --no-cpu-baseline > $o/bench_bf16_event_forks.json 2> /dev/null
+T3D_IMPLICIT3=1 python3 bench.py --steps 20 --warmup 5 --model resnet50 --batch 64 --no-cpu-baseline > $o/bench_resnet50_implicit3x3.json 2> /dev/null
+python3 tools/time_expdw.py > $o/expdw_fused_forward_timings.txt 2>&1
 bash tools/time_kernels.sh > $o/isolated_kernel_timings.txt 2>&1
 python3 tools/bench_two_stage.py --detector 2> /dev/null | tail -1 > $o/two_stage_pipeline_bench.jsonl
 python3 tools/bench_two_stage.py --dets 64 2> /dev/null | tail -1 >> $o/two_stage_pipeline_bench.jsonl
