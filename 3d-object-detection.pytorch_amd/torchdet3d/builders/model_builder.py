@@ -254,13 +254,27 @@ class ModelWrapper(nn.Module):
             kp, logits = self.net.forward(x, cats, train=True, dropout_mask=dropout_mask)
             self.net.saved = None
             return kp, (logits if self.num_classes > 1 else cats.unsqueeze(1))
-        if not train and self.net_eval is not self.net:
+        if not train and (self.net_eval is not self.net or not torch.is_grad_enabled()):
+            # eval-mode forward (validation / serving): no autograd node; replayed from a recorded plan by one host call where
+            # the inputs allow it (trainer/step_plan.py: ForwardPlan)
             with torch.no_grad():
-                kp, logits = self.net_eval.forward(x, cats, train=False)
+                fp = self._forward_plan()
+                if fp is not None and fp.accepts(x, cats):
+                    kp, logits = fp(x, cats)
+                else:
+                    kp, logits = self.net_eval.forward(x, cats, train=False)
             return kp, (logits if self.num_classes > 1 else cats.unsqueeze(1))
         kp, logits = _Run.apply(self.flat, self, x, cats, dropout_mask, train)
         targets = logits if self.num_classes > 1 else cats.unsqueeze(1)     # model_builder.py:141-144
         return kp, targets
+
+    def _forward_plan(self):
+        fp = self.__dict__.get('_fplan')
+        if fp is None or fp.net is not self.net_eval:
+            from ..trainer.step_plan import ForwardPlan
+            fp = ForwardPlan(self.net_eval)
+            object.__setattr__(self, '_fplan', fp)
+        return fp
 
     @torch.no_grad()
     def forward_to_onnx(self, x):

@@ -139,6 +139,13 @@ class StepPlan:
             ncls = lg.shape[1] if lg is not None else 1
             N.call('t3d_loss_fwd_bwd', lm.loss_cfg(), N.ptr(kp), N.ptr(gt_kp), N.ptr(lg), N.ptr(cats), N.ptr(out), N.ptr(dkp),
                    N.ptr(dlg) if lg is not None else None, B, ncls, st)
+            # the metrics' way to the host (replayed steps): copied by the SECOND stream, handed off by the loss kernel itself --
+            # the copy and its event packet then ride beside the backward instead of sitting in the main queue between the
+            # optimizer kernel and the next step (a ~14-us bubble in front of every step's first kernels)
+            rb_side = rec is not None and net._side is not None
+            if rb_side:
+                rec.add_fork(st, net._side.cuda_stream)
+                rec.add_readback(N.SLOT_RB_DST, out, 64, N.SLOT_RB_EVENT, net._side.cuda_stream)
             sync = model.grad_sync
             if sync is not None:
                 sync.start()
@@ -160,7 +167,8 @@ class StepPlan:
             if p.grad is not net.gflat:
                 p.grad = net.gflat                           # what `loss.backward()` leaves in the eager form
             if rec is not None:
-                rec.add_readback(N.SLOT_RB_DST, out, 64, N.SLOT_RB_EVENT, st)
+                if not rb_side:
+                    rec.add_readback(N.SLOT_RB_DST, out, 64, N.SLOT_RB_EVENT, st)
                 rec.end_segment()
                 rec.keep += [out, dkp, dlg, kp, logits, state['exp_avg'], state['exp_avg_sq']]
         finally:
@@ -264,3 +272,78 @@ class PlanTiming:
                 name, sig, nb = calls[ci]
                 out.append((name, sig, evs[2 * j].elapsed_time(evs[2 * j + 1]), nb))
         return out
+
+
+class ForwardPlan:
+    """The eval-mode forward of `ModelWrapper.forward` (validation, serving: model_builder.py:126-146 under `model.eval()`) as ONE
+    host call: the engine's ~110 forward launches recorded once per (input shape, dtype, stream) and replayed by
+    `t3d_plan_run` with the batch's two device pointers as slots.  The replay writes kp / logits into engine buffers; the
+    caller gets fresh tensors (two small device copies), as from the launch-by-launch forward.  Bit-identical to it
+    (tests/test_gpu_step_plan.py)."""
+
+    def __init__(self, net):
+        self.net = net
+        self.rec, self.key, self.warm = None, None, 0
+        self.slots = (ctypes.c_ulonglong * N.NSLOTS)()
+        self.replays = 0
+
+    def accepts(self, x, cats):
+        B = x.shape[0]
+        return (REPLAY and N.timer is None and x.is_cuda and x.is_contiguous() and x.dtype in (torch.float32, torch.uint8) and x.dim() == 4
+                and cats is not None and cats.is_cuda and cats.dtype == torch.int64 and cats.is_contiguous() and cats.numel() == B
+                and x.device == self.net.device and x.data_ptr() != cats.data_ptr())
+
+    def __call__(self, x, cats):
+        net = self.net
+        key = (tuple(x.shape), x.dtype, N.stream(), id(net._side))
+        if key != self.key:
+            self.drop()
+            self.key, self.warm = key, 0
+        net._pack()                                  # (weights moved since the last forward: re-packed outside the plan)
+        if self.rec is not None:
+            s = self.slots
+            s[N.SLOT_IMGS], s[N.SLOT_CATS] = x.data_ptr(), cats.data_ptr()
+            rc = N.lib().t3d_plan_run(self.rec.plan, 0, s, N.NSLOTS, None, 0)
+            if rc < 0:
+                code = ctypes.c_int(0)
+                op = N.lib().t3d_plan_failed_op(self.rec.plan, ctypes.byref(code))
+                raise RuntimeError(f't3d_plan_run failed at op {op} with code {code.value}')
+            self.replays += 1
+            kp, logits = self.out
+            net.saved = None
+            return kp.clone(), (logits.clone() if logits is not None else None)
+        rec = None
+        if self.warm >= WARM_STEPS:
+            rec = N.PlanRecorder({x.data_ptr(): N.SLOT_IMGS, cats.data_ptr(): N.SLOT_CATS})
+        N.recorder = rec
+        try:
+            net.persistent_outputs = True
+            try:
+                kp, logits = net.forward(x, cats, train=False)
+            finally:
+                net.persistent_outputs = False
+            if rec is not None:
+                rec.end_segment()
+                rec.keep += [kp, logits]
+        finally:
+            N.recorder = None
+        self.warm += 1
+        if rec is not None:
+            if rec.broken or rec.breaks:
+                N.lib().t3d_plan_destroy(rec.plan)
+                self.warm = -(1 << 30)
+            else:
+                self.rec, self.out = rec, (kp, logits)
+        return kp.clone(), (logits.clone() if logits is not None else None)
+
+    def drop(self):
+        if self.rec is not None:
+            N.lib().t3d_plan_destroy(self.rec.plan)
+            self.rec = None
+
+    def __del__(self):
+        try:
+            self.drop()
+        except Exception:       # noqa: BLE001
+            pass
+

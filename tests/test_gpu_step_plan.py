@@ -168,3 +168,51 @@ def test_a_non_finite_activation_is_seen_in_the_batchnorm_sums():
     bad[3, 1, 40:44, 40:44] = float('inf')
     dict(tr.train_step(bad, gts[0], cats[0], 4))
     assert model.net.nonfinite()
+
+
+@pytest.mark.parametrize('name,dtype,evdt', [('mobilenetv2', 'bf16', 'f32'), ('mobilenetv2', 'bf16', 'f16'), ('mobilenetv2', 'bf16', 'bf16'),
+                                             ('mobilenetv3_large', 'f32', None), ('resnet50', 'bf16', 'f32')])
+def test_eval_forward_replayed_from_a_plan_equals_the_launch_by_launch_forward(name, dtype, evdt):
+    """`model.eval(); model(x, cats)` (validation / serving) records its launches once and replays them by one `t3d_plan_run`
+    (trainer/step_plan.py: ForwardPlan): same outputs bit for bit, fresh output tensors, and the packed weights follow a
+    training step in between."""
+    from torchdet3d.builders import build_loss, build_model, build_optimizer
+    from torchdet3d.losses import LossManager
+    from torchdet3d.trainer import Trainer
+    cfg = _cfg(name)
+    cfg.model.storage_dtype = dtype
+    cfg.model.eval_storage_dtype = evdt
+    torch.manual_seed(1)
+    m = build_model(cfg).to('cuda')
+    m.net.reset_parameters(seed=1)
+    opt = build_optimizer(cfg, m)
+    lm = LossManager(build_loss(cfg), cfg.loss.coeffs, cfg.loss.alwa)
+    tr = Trainer(m, None, opt, None, lm, None, 1, '', device='cuda', save_chkpt=False)
+    B, S = (96, 96) if name == 'mobilenetv2' else (8, 96)          # (B >= 96: the fused 14x14 / 7x7 inference blocks are in the plan)
+    imgs, gts, cats = _batches(B, S, nb=3)
+
+    def eager(i):
+        with torch.no_grad():
+            kp, lg = m.net_eval.forward(imgs[i], cats[i], train=False)
+        return kp.clone(), lg.clone()
+
+    m.eval()
+    outs = []
+    with torch.no_grad():
+        for i in range(6):
+            kp, tg = m(imgs[i % 3], cats[i % 3])
+            outs.append((kp, tg))
+            ek, el = eager(i % 3)
+            assert torch.equal(kp, ek) and torch.equal(tg, el), i
+    fp = m._fplan
+    assert fp.replays == 3 and outs[3][0].data_ptr() != outs[4][0].data_ptr()
+    assert torch.equal(outs[0][0], outs[3][0])                       # batch 0 again, through the plan this time
+    m.train()
+    for i in range(4):
+        dict(tr.train_step(imgs[i % 3], gts[i % 3], cats[i % 3], i))
+    m.eval()
+    with torch.no_grad():
+        kp, tg = m(imgs[0], cats[0])
+        ek, el = eager(0)
+    assert torch.equal(kp, ek) and torch.equal(tg, el) and not torch.equal(kp, outs[0][0])      # new weights, same plan
+    assert m._fplan.replays == 4
