@@ -318,8 +318,13 @@ __device__ __forceinline__ void bufstore(const RV& v, __amdgpu_buffer_rsrc_t r, 
 // RES: a skip-connection gradient is added to dx (compile time: its two loads per row ride in the prefetch ring -- loaded on
 // demand in the epilogue, as rounds 2-3 did, each one sat behind `s_waitcnt vmcnt(0)`, i.e. drained the whole ring twice per
 // row in 10 of the 13 stride-1 launches of MobileNetV2; found in the ISA, round 4)
+#ifdef T3D_DWB_WAVES
+#define T3D_DWB_OCC __attribute__((amdgpu_waves_per_eu(T3D_DWB_WAVES, T3D_DWB_WAVES)))
+#else
+#define T3D_DWB_OCC
+#endif
 template <typename T, int PF, int NTH, int CH, int ACT, bool RES>
-__global__ __launch_bounds__(NTH) void dw3_bwd2_kernel(const Dw3BArgs a) {
+__global__ __launch_bounds__(NTH) T3D_DWB_OCC void dw3_bwd2_kernel(const Dw3BArgs a) {
   constexpr int H2 = CH / 2;
   constexpr bool C6 = std::is_same<T, bf16_t>::value && ACT == T3D_ACT_RELU6;
   extern __shared__ float lred[];       // [9][Cb] weights by tap, [3][Cb] derived coefficients; end of kernel: [11][Cb] fp64 accumulators

@@ -57,7 +57,8 @@ constexpr int NW = 4;        // waves per block
 constexpr int NTW = 3;       // 16-row tiles per wave: tiles wave, wave + 4, wave + 8 of the chunk (<= 12 tiles = 192 channels)
 constexpr int IT = RT * KSP / NW;   // staging items (16 rows x 32 k) per wave per phase: row tile `wave`, every k-step
 
-template <bool DG>
+// CV: implicit 3x3 convolution (GemmArgs::cv) -- a compile-time variant: the plain kernel's phase loop stays branch-free
+template <bool DG, bool CV = false>
 __global__ __launch_bounds__(64 * NW, 1) void pw_deep_kernel(const GemmArgs a, const int KS, const int ntiles, const int nrep,
                                                              const long long rstride) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -105,9 +106,9 @@ __global__ __launch_bounds__(64 * NW, 1) void pw_deep_kernel(const GemmArgs a, c
   const size_t arow = (size_t)mrow * a.Kin + lg * 8;
   const bool rok = m0 + wave * 16 + lc < a.M;
   // implicit 3x3 convolution (pwconv_common.h: Conv3): this lane's destination pixel, once
-  const bool cv = a.cv.mode != 0;
+  constexpr bool cv = CV;
   int cvb = 0, cvy = 0, cvx = 0;
-  if (cv) {
+  if constexpr (cv) {
     cvx = mrow % a.cv.Dw;
     const int t = mrow / a.cv.Dw;
     cvy = t % a.cv.Dh;
@@ -140,7 +141,7 @@ __global__ __launch_bounds__(64 * NW, 1) void pw_deep_kernel(const GemmArgs a, c
 #pragma unroll
     for (int j = 0; j < IT; ++j) {
       size_t o;
-      if (cv) {
+      if constexpr (cv) {
         const long long g = cv_off(ph * KSP + j);
         o = g < 0 ? (size_t)lg * 8 : (size_t)g;                 // (an out-of-range tap reads a valid address; zeroed later)
       } else {
@@ -169,7 +170,7 @@ __global__ __launch_bounds__(64 * NW, 1) void pw_deep_kernel(const GemmArgs a, c
       coef[i] = DG ? 0.f : 1.f; coef[kpad + i] = 0.f; coef[2 * kpad + i] = 0.f;
     }
     t3d_fold_block(a.fold, 0, ncoef, coef, kpad, blockIdx.x == 0 && blockIdx.y == 0);
-    if (cv) {
+    if constexpr (cv) {
       for (int i = ncoef + tid; i < a.Kin; i += 64 * NW) {
         const int c = i & (ncoef - 1);
         coef[i] = coef[c]; coef[kpad + i] = coef[kpad + c];
@@ -215,7 +216,8 @@ __global__ __launch_bounds__(64 * NW, 1) void pw_deep_kernel(const GemmArgs a, c
 #pragma unroll
     for (int j = 0; j < IT; ++j) {
       const int k = (ph * KSP + j) * 32 + lg * 8;
-      const bool ok = rok && (k < a.Kin) && (!cv || cv_off(ph * KSP + j) >= 0);
+      bool ok = rok && (k < a.Kin);
+      if constexpr (cv) ok = ok && cv_off(ph * KSP + j) >= 0;
       const int kc = min(k, kpad - 8);
       const float4 c0a = *reinterpret_cast<const float4*>(coef + kc), c0b = *reinterpret_cast<const float4*>(coef + kc + 4);
       const float4 c1a = *reinterpret_cast<const float4*>(coef + kpad + kc),
@@ -362,15 +364,15 @@ __global__ __launch_bounds__(64 * NW, 1) void pw_deep_kernel(const GemmArgs a, c
   DEEP_STAMP(5);
 }
 
-template <bool DG>
+template <bool DG, bool CV = false>
 int launch_deep(GemmArgs& a, int KS, int ntiles, int nchunks, hipStream_t st) {
   const size_t lds = (size_t)2 * RT * KSP * 1024 + (size_t)3 * KS * 32 * 4 + (size_t)ntiles * 16 * (2 * 4 + 2 * 8);
   if (lds > 150 * 1024) return T3D_ERR_UNSUPPORTED;
-  const void* fn = (const void*)pw_deep_kernel<DG>;
+  const void* fn = (const void*)pw_deep_kernel<DG, CV>;
   if (lds > 64 * 1024) (void)t3d_max_lds(fn, (int)lds);
   a.quant = (!DG && a.stats && !getenv("T3D_NO_SNAP")) ? t3d_quant_for(a.M) : T3dQuant{0.0, 0.0};
   a.fold = t3d_take_fold(a.p0);
-  T3D_LAUNCH((pw_deep_kernel<DG>), dim3(cdiv(a.M, 16 * RT), nchunks), dim3(64 * NW), lds, st, a, KS, ntiles,
+  T3D_LAUNCH((pw_deep_kernel<DG, CV>), dim3(cdiv(a.M, 16 * RT), nchunks), dim3(64 * NW), lds, st, a, KS, ntiles,
                      g_t3d_reduce.nrep, g_t3d_reduce.stats_stride);
   T3D_CHECK_LAUNCH();
   return T3D_OK;
@@ -420,6 +422,7 @@ int deep_launch(GemmArgs& a, hipStream_t st) {
   const int pairs = cdiv(a.Nout, 32);
   // chunks of <= 6 pairs of tiles (192 channels), evenly sized; every chunk stages the operand again (from L2)
   const int nchunks = cdiv(pairs, NW * NTW / 2), ntiles = 2 * cdiv(pairs, nchunks);
+  if (a.cv.mode) return a.dgrad ? launch_deep<true, true>(a, KS, ntiles, nchunks, st) : launch_deep<false, true>(a, KS, ntiles, nchunks, st);
   return a.dgrad ? launch_deep<true>(a, KS, ntiles, nchunks, st) : launch_deep<false>(a, KS, ntiles, nchunks, st);
 }
 

@@ -86,7 +86,8 @@ __device__ __forceinline__ bf16x8 tr_frag(const bf16_t* tile, int rs, int ch0, i
 // read as they lie (pixel-major, 8 consecutive virtual channels per lane), D[k][pixel] -> a lane holds 4 consecutive
 // channels of one pixel: 8-byte stores; the skip gradient and the raw tensor of the producer (BatchNorm-backward sums of x's
 // producer, exactly as in the streaming kernel's epilogue) are fetched with the step's operands.
-template <int NTPW, int NTQ, bool SWAP, int G, int D, bool GEN, bool YF, int SK = 1, bool DGF = false>
+// CV: implicit 3x3 convolution on the a side (WgtArgs::cv) -- a compile-time variant, the plain kernels' staging is untouched
+template <int NTPW, int NTQ, bool SWAP, int G, int D, bool GEN, bool YF, int SK = 1, bool DGF = false, bool CV = false>
 __global__ __launch_bounds__(256 * G) void pw_wgrad_tr_kernel(const WgtArgs a) {
   static_assert(!DGF || (YF && !SWAP), "the fused data gradient exists for the y-free layout only");
   constexpr int PB = 64 * NTPW, QB = 16 * NTQ;
@@ -148,7 +149,7 @@ __global__ __launch_bounds__(256 * G) void pw_wgrad_tr_kernel(const WgtArgs a) {
   for (int i = threadIdx.x; i < aB; i += 256 * G) {
     const int k = a0c + i;
     const bool v = k < a.K;
-    const int kc = a.cv.on ? (k & (a.cv.C - 1)) : k;
+    const int kc = CV ? (k & (a.cv.C - 1)) : k;
     ca[i] = ((v && a.scale) ? a.scale[kc] : 1.f) * (c6 ? T3D_SIXTH : 1.f);
     ca[aB + i] = ((v && a.scale) ? a.shift[kc] : 0.f) * (c6 ? T3D_SIXTH : 1.f);
   }
@@ -173,7 +174,9 @@ __global__ __launch_bounds__(256 * G) void pw_wgrad_tr_kernel(const WgtArgs a) {
   // DGF units of a step: (16-pixel tile, 16-channel tile) pairs, dealt round-robin to the pipeline's four waves
   constexpr int NU = DGF ? (STEP / 16) * NTQ : 1, UPW = (NU + 3) / 4;
   struct Epi { bf16x4 res[UPW], xr[UPW]; };
-  struct Regs { bf16x8 rz[VDY], ry[VDY], rx[VA]; Epi e; unsigned okm; };      // okm: implicit 3x3 -- bit i: vector i's tap is inside the image
+  struct NoMask {};
+  // okm (implicit 3x3 only): bit i = vector i's tap is inside the image
+  struct Regs { bf16x8 rz[VDY], ry[VDY], rx[VA]; Epi e; typename std::conditional<CV, unsigned, NoMask>::type okm; };
   Regs rr[D];
   Epi ecur;                     // epilogue operands of the step that is in LDS now
   const int lgq = lane >> 4, lcq = lane & 15;
@@ -198,12 +201,12 @@ __global__ __launch_bounds__(256 * G) void pw_wgrad_tr_kernel(const WgtArgs a) {
         R.ry[i] = *reinterpret_cast<const bf16x8*>(yy + (size_t)m * a.N + n);
       }
     }
-    R.okm = ~0u;
+    if constexpr (CV) R.okm = ~0u;
 #pragma unroll
     for (int i = 0; i < VA; ++i) {
       const int v = min(tid + 256 * i, nav - 1);
       const int row = v / aV, k = min(a0c + (v % aV) * 8, a.K - 8), m = min(m0 + row, a.M - 1);
-      if (a.cv.on) {
+      if constexpr (CV) {
         const int tap = k >> a.cv.lgC, c = k & (a.cv.C - 1);
         const int ky = (tap * 11) >> 5, kx = tap - 3 * ky;
         const int t = (int)__umulhi((unsigned)m, a.cv.mulW), ox = m - t * a.cv.Wo;       // m / Wo, m % Wo (exact: launcher)
@@ -283,7 +286,8 @@ __global__ __launch_bounds__(256 * G) void pw_wgrad_tr_kernel(const WgtArgs a) {
       const int v = tid + 256 * i;
       if (v < nav) {
         const int row = v / aV, cl = (v % aV) * 8, m = m0 + row;
-        const bool ok = m < mend && a0c + cl < a.K && ((R.okm >> i) & 1u);
+        bool ok = m < mend && a0c + cl < a.K;
+        if constexpr (CV) ok = ok && ((R.okm >> i) & 1u);
         bf16x8 o = rx[i];
         if (!plain_a) {
           float u[8], sc[8], sh[8];
@@ -565,7 +569,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_tr_kernel(const float* __res
   }
 }
 
-template <int NTPW, int NTQ, bool SWAP, int D, bool GEN, bool YF = false, int SK = 1>
+template <int NTPW, int NTQ, bool SWAP, int D, bool GEN, bool YF = false, int SK = 1, bool CV = false>
 int launch_d(WgtArgs& a, hipStream_t st) {
   constexpr int G = 2;
   constexpr int STEP = 32 * SK;
@@ -598,9 +602,9 @@ int launch_d(WgtArgs& a, hipStream_t st) {
   // (atomics into dw: an assigned-to dw is cleared first; with partial tiles the reduction writes it)
   if (a.assign && !use_ws && hipMemsetAsync(a.dw, 0, (size_t)a.N * a.K * sizeof(float), st) != hipSuccess) return T3D_ERR_LAUNCH;
   if (lds > 64 * 1024)
-    (void)t3d_max_lds((const void*)pw_wgrad_tr_kernel<NTPW, NTQ, SWAP, G, D, GEN, YF, SK>, (int)lds);
+    (void)t3d_max_lds((const void*)pw_wgrad_tr_kernel<NTPW, NTQ, SWAP, G, D, GEN, YF, SK, false, CV>, (int)lds);
   a.nsplit = S;
-  T3D_LAUNCH((pw_wgrad_tr_kernel<NTPW, NTQ, SWAP, G, D, GEN, YF, SK>), dim3(tiles * S), dim3(256 * G), lds, st, a);
+  T3D_LAUNCH((pw_wgrad_tr_kernel<NTPW, NTQ, SWAP, G, D, GEN, YF, SK, false, CV>), dim3(tiles * S), dim3(256 * G), lds, st, a);
   if (use_ws) {
     // split groups inside the workgroup: enough parallelism for a small dW with hundreds of splits
 #define T3D_WGR(SPV)                                                                                                              \
@@ -624,6 +628,10 @@ int launch_d(WgtArgs& a, hipStream_t st) {
 template <int NTPW, int NTQ, bool SWAP>
 int launch_sw(WgtArgs& a, hipStream_t st) {
   const int depth = 2;   // 2 measured best (1: -12 %, 3: -2 %)
+  if (a.cv.on) {          // implicit 3x3 convolution: K = 9 C > N, i.e. the swapped orientation, wide tiles only
+    if constexpr (SWAP && NTQ >= 4) return launch_d<NTPW, NTQ, true, 2, false, false, 1, true>(a, st);
+    else return T3D_ERR_UNSUPPORTED;
+  }
   if (a.yfree) {
     if constexpr (!SWAP) {
       const int sk_env = 0;

@@ -76,7 +76,7 @@ class ResNetEngine(Net):
     def _implicit3(self, c, n):
         """Dense 3x3 layer as an implicit GEMM (csrc/conv3x3.hip)?  bf16 storage, power-of-two channel counts >= 32; fp32 storage
         (the parity mode) keeps the patch-matrix path."""
-        return IMPLICIT3 and self.dt == N.BF16 and c >= 32 and (c & (c - 1)) == 0 and n % 8 == 0
+        return IMPLICIT3 and self.dt == N.BF16 and c >= 64 and n >= 64 and (c & (c - 1)) == 0 and n % 8 == 0
 
     def _kp(self, key):
         return self.w[key].shape[1]

@@ -541,7 +541,7 @@ int t3d_zero_batched(const long long* desc, int n, void* stream);
  * ResNet-50's conv2 layers gather their operand rows from the activation tensor themselves -- no patch matrix in HBM.  Replaces
  * nn.Conv2d(C, N, 3, stride, 1, bias=False) and its autograd in a torchvision Bottleneck, the backbone BASELINE config 4 builds
  * through torchdet3d/builders/model_builder.py:73-151 (t3d_im2col / t3d_col2im_bwd + the 1x1 kernels remain for fp32 storage
- * and the 7x7 stem).  C a power of two >= 32 (>= 8 for the weight gradient), N % 8 == 0.
+ * and the 7x7 stem).  C a power of two >= 32 (the weight gradient: N >= 64 as well), N % 8 == 0.
  *   _fwd    dtype = T3D_BF16 | T3D_W_FRAG; x [B,H,W,C] raw + `pro` (BatchNorm affine + activation of its producer, may be NULL);
  *           w_frag = t3d_pwconv_pack_frag of the [N][9C] patch-column-order weights (t3d_pack_conv_weight);
  *           y [B,Ho,Wo,N] raw, stats [2N] fp64 replicas or NULL as t3d_pwconv_fwd;

@@ -24,7 +24,8 @@ def _run(cfg, p, t, logits, cats):
     dlg = torch.empty(B, nc, device='cuda') if logits is not None else None
     pd, td = p.cuda().view(B, 18).contiguous(), t.cuda().view(B, 18).contiguous()
     ld = logits.cuda().contiguous() if logits is not None else None
-    N.call('t3d_loss_fwd_bwd', cfg, N.ptr(pd), N.ptr(td), N.ptr(ld), N.ptr(cats.cuda()), N.ptr(out), N.ptr(dkp),
+    cd = cats.cuda()                 # (kept alive: raw pointers cross the boundary)
+    N.call('t3d_loss_fwd_bwd', cfg, N.ptr(pd), N.ptr(td), N.ptr(ld), N.ptr(cd), N.ptr(out), N.ptr(dkp),
            N.ptr(dlg), B, nc, N.stream())
     torch.cuda.synchronize()
     return out.cpu(), dkp.cpu().view(B, 9, 2), (dlg.cpu() if dlg is not None else None)

@@ -366,8 +366,9 @@ def test_resnet50_train_step_with_implicit_gemm_3x3_layers(monkeypatch):
         assert bool(net._conv3) == on
         out = torch.zeros(16, device='cuda')
         dkp, dlg = torch.empty(B, 18, device='cuda'), torch.empty(B, nc, device='cuda')
-        N.call('t3d_loss_fwd_bwd', cfg, N.ptr(kp), N.ptr(gt_kp.cuda().view(B, 18).contiguous()), N.ptr(lg), N.ptr(cats.cuda()),
-               N.ptr(out), N.ptr(dkp), N.ptr(dlg), B, nc, N.stream())
+        gtd, cd = gt_kp.cuda().view(B, 18).contiguous(), cats.cuda()     # (kept alive: raw pointers cross the boundary)
+        N.call('t3d_loss_fwd_bwd', cfg, N.ptr(kp), N.ptr(gtd), N.ptr(lg), N.ptr(cd), N.ptr(out), N.ptr(dkp), N.ptr(dlg), B, nc,
+               N.stream())
         net.backward(dkp, dlg)
         torch.cuda.synchronize()
         res[on] = (out[0].item(), net.gflat.clone())
