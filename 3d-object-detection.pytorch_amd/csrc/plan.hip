@@ -67,7 +67,7 @@ const Entry kEntries[] = {
     T3D_E(t3d_pwconv_fwd), T3D_E(t3d_pwconv_dgrad), T3D_E(t3d_pack_weight), T3D_E(t3d_sum_replicas_batched),
     T3D_E(t3d_set_dw_slots), T3D_E(t3d_set_exact_pool), T3D_E(t3d_sum_slots_batched), T3D_E(t3d_dwconv_bwd),
     T3D_E(t3d_pwconv_wgrad), T3D_E(t3d_pwconv_yfree_prep), T3D_E(t3d_pwconv_dgrad_yfree), T3D_E(t3d_pwconv_wgrad_yfree),
-    T3D_E(t3d_pwconv_yfree_prep2), T3D_E(t3d_pwconv_bwd_yfree), T3D_E(t3d_pwconv_wgrad_yfree_finish),
+    T3D_E(t3d_pwconv_yfree_prep2), T3D_E(t3d_pwconv_bwd_yfree), T3D_E(t3d_pwconv_bwd_yfree_w), T3D_E(t3d_pwconv_wgrad_yfree_finish),
     T3D_E(t3d_bn_bwd_finalize), T3D_E(t3d_stem_im2col), T3D_E(t3d_stem_im2col_u8), T3D_E(t3d_crop_resize_u8),
     T3D_E(t3d_pwconv_fwd_mat), T3D_E(t3d_im2col), T3D_E(t3d_im2col_nchw), T3D_E(t3d_col2im_bwd), T3D_E(t3d_pack_conv_weight),
     T3D_E(t3d_unpack_conv_grad), T3D_E(t3d_maxpool_fwd), T3D_E(t3d_maxpool_bwd), T3D_E(t3d_res_relu_fwd),

@@ -50,6 +50,10 @@ struct WgtArgs {
                           // (the data-gradient kernel of the main stream publishes; common.h)
   // fused y-free backward (DGF): the data gradient of the same layer from the staged [dz | x | 1] rows
   const bf16_t* wd;       // [QB][PB]: row k = [alpha_n W[n][k] (n < Nz) | Q[k][.] (K) | c[k] | 0 ...], the P tile's column order
+  // ... or, with wd == null, built in the kernel's prologue from the transposed weights wtr [K][Nz] and the expansion's
+  // BatchNorm-backward coefficients (alpha / beta / gamma, or derived from `fold`): what t3d_pwconv_yfree_prep2 computes as a
+  // launch of its own on the critical stream (13 us x 6 per step), same arithmetic in the same order
+  const bf16_t* wtr;
   const void *e_res, *e_y;   // skip-connection gradient [M][K] or null; raw tensor of x's producer [M][K] or null (its sums)
   void* dx;               // [M][K] bf16
   double* stats;          // [2][K] replicas or null
@@ -154,9 +158,93 @@ __global__ __launch_bounds__(256 * G) void pw_wgrad_tr_kernel(const WgtArgs a) {
     ca[aB + i] = ((v && a.scale) ? a.shift[kc] : 0.f) * (c6 ? T3D_SIXTH : 1.f);
   }
   if constexpr (DGF) {
-    for (int i = threadIdx.x; i < QB * (PB / 8); i += 256 * G) {
-      const int r = i / (PB / 8), c = (i % (PB / 8)) * 8;
-      *reinterpret_cast<bf16x8*>(wdl + r * RSW + c) = *reinterpret_cast<const bf16x8*>(a.wd + (size_t)r * PB + c);
+    if (a.wd) {
+      for (int i = threadIdx.x; i < QB * (PB / 8); i += 256 * G) {
+        const int r = i / (PB / 8), c = (i % (PB / 8)) * 8;
+        *reinterpret_cast<bf16x8*>(wdl + r * RSW + c) = *reinterpret_cast<const bf16x8*>(a.wd + (size_t)r * PB + c);
+      }
+    } else {
+      // ---- the data gradient's weight rows built here (yfree_prep_kernel's arithmetic, pwconv_yfree.hip, step for step: the
+      // contraction of Q split over four waves by step mod 4 and summed in wave order, c by 16-lane rows, alpha . W rounded
+      // the same way -- the two ways of getting wd agree bit for bit, tests/test_gpu_pwconv.py)
+      const int Nz = a.Nz, K = a.K;
+      float* fco = cdy;                              // [3][dyB] (free in the y-free layout): alpha, beta, gamma of the expansion's BN
+      if (a.fold) {
+        for (int i = Nz + threadIdx.x; i < dyB; i += 256 * G) fco[i] = fco[dyB + i] = fco[2 * dyB + i] = 0.f;
+        t3d_fold_block(a.fold, 0, Nz, fco, dyB, blockIdx.x == 0);
+      } else {
+        for (int i = threadIdx.x; i < dyB; i += 256 * G) {
+          const bool v = i < Nz;
+          fco[i] = v ? a.alpha[i] : 0.f; fco[dyB + i] = v ? a.beta[i] : 0.f; fco[2 * dyB + i] = v ? a.gamma[i] : 0.f;
+        }
+      }
+      for (int i = threadIdx.x; i < QB * (RSW / 8); i += 256 * G) *reinterpret_cast<bf16x8*>(wdl + i * 8) = bf16x8{};
+      __syncthreads();
+      const float *alpha = fco, *beta = fco + dyB, *gamma = fco + 2 * dyB;
+      const bf16_t* __restrict__ wtr = a.wtr;
+      // alpha . W: row k = wt row k scaled by alpha
+      for (int i = threadIdx.x; i < QB * (Nz / 8); i += 256 * G) {
+        const int k = i / (Nz / 8), n = (i % (Nz / 8)) * 8;
+        if (k < K) {
+          const bf16x8 v = *reinterpret_cast<const bf16x8*>(wtr + (size_t)k * Nz + n);
+          bf16x8 o;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) o[j] = (bf16_t)(alpha[n + j] * (float)v[j]);
+          *reinterpret_cast<bf16x8*>(wdl + k * RSW + n) = o;
+        }
+      }
+      // Q[k][k2] = sum_n W[n][k] beta_n W[n][k2]: one 16 x 16 tile at a time, pipeline 0's four waves split the contraction
+      f32x4* qred = reinterpret_cast<f32x4*>(tiles);          // [3][64] exchange (the staging buffers are not in use yet)
+      const int lgq_ = lane >> 4, lcq_ = lane & 15;
+      const int nst = (Nz + 31) / 32;
+      for (int kt = 0; kt < QB / 16; ++kt)
+        for (int qt2 = 0; qt2 < QB / 16; ++qt2) {
+          f32x4 qa = {0.f, 0.f, 0.f, 0.f};
+          if (grp == 0) {
+            const int ka = min(kt * 16 + lcq_, K - 1), kb = min(qt2 * 16 + lcq_, K - 1);
+            const bf16_t* ra = wtr + (size_t)ka * Nz;
+            const bf16_t* rb = wtr + (size_t)kb * Nz;
+            for (int st = wave; st < nst; st += 4) {
+              const int n = st * 32 + 8 * lgq_;
+              const bool live = n < Nz;
+              const int nc = min(n, Nz - 8);
+              const bf16x8 fa = *reinterpret_cast<const bf16x8*>(ra + nc);
+              const bf16x8 fb = *reinterpret_cast<const bf16x8*>(rb + nc);
+              bf16x8 b;
+#pragma unroll
+              for (int j = 0; j < 8; ++j) b[j] = (bf16_t)(live ? beta[nc + j] * (float)fb[j] : 0.f);
+              qa = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa, b, qa, 0, 0, 0);
+            }
+            if (wave) qred[(wave - 1) * 64 + lane] = qa;
+          }
+          __syncthreads();
+          if (grp == 0 && wave == 0) {
+            qa += qred[lane];
+            qa += qred[64 + lane];
+            qa += qred[128 + lane];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const int k = kt * 16 + 4 * lgq_ + r, k2 = qt2 * 16 + lcq_;
+              if (k < K && k2 < K) wdl[k * RSW + Nz + k2] = (bf16_t)qa[r];
+            }
+          }
+          __syncthreads();
+        }
+      // c[k] = sum_n gamma_n W[n][k]: 16 lanes per row
+      if (grp == 0) {
+        for (int kb = 0; kb < QB; kb += 16) {
+          const int row = tid >> 4, sub = tid & 15, k = kb + row;
+          float s2 = 0.f;
+          if (k < K)
+            for (int n = sub * 8; n < Nz; n += 128) {
+              const bf16x8 v = *reinterpret_cast<const bf16x8*>(wtr + (size_t)k * Nz + n);
+#pragma unroll
+              for (int j = 0; j < 8; ++j) s2 = fmaf(gamma[n + j], (float)v[j], s2);
+            }
+          s2 = row16_sum(s2);
+          if (sub == 0 && k < K) wdl[k * RSW + Nz + K] = (bf16_t)s2;
+        }
+      }
     }
     for (int i = threadIdx.x; i < 2 * QB; i += 256 * G) dstat[i] = 0.0;
   }
@@ -786,12 +874,17 @@ size_t t3d_pw_bwd_yfree_scratch(int M, int K, int N) {
 }
 
 // dx = [dz | x | 1] Wd^T (+ residual) AND the partial tiles of [dz | x | 1]^T x into `scratch` (main stream)
-int t3d_pw_bwd_yfree_launch(const void* dz, const void* x, const void* wd, const void* x_raw, const void* residual, void* dx,
-                            double* stats, void* scratch, int M, int HW, int K, int N, hipStream_t st) {
+int t3d_pw_bwd_yfree_launch(const void* dz, const void* x, const void* wd, const void* wt, const t3d_bnbwd* bb, const void* x_raw,
+                            const void* residual, void* dx, double* stats, void* scratch, int M, int HW, int K, int N, hipStream_t st) {
   YfCfg c;
   if (!yf_cfg(M, K, N, c)) return T3D_ERR_UNSUPPORTED;
   WgtArgs a{};
   a.dz = dz; a.x = x; a.y = dz;
+  if (!wd) {              // weight rows built in the prologue (from the transposed weights + BatchNorm-backward coefficients)
+    a.wtr = reinterpret_cast<const bf16_t*>(wt);
+    a.alpha = bb->alpha; a.beta = bb->beta; a.gamma = bb->gamma;
+    a.fold = t3d_take_fold(bb->alpha);
+  }
   a.M = M; a.HW = HW; a.K = K;
   a.yfree = 1; a.Nz = N; a.N = N + K + 8;
   a.ws = reinterpret_cast<float*>(scratch);

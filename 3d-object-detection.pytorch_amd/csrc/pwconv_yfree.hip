@@ -20,8 +20,8 @@
 int t3d_pw_wgrad_tr_yfree(const void* dz, const void* x, float* tmp, int M, int HW, int K, int N, hipStream_t st);
 // fused y-free backward (pwconv_wgrad_tr.hip)
 size_t t3d_pw_bwd_yfree_scratch(int M, int K, int N);
-int t3d_pw_bwd_yfree_launch(const void* dz, const void* x, const void* wd, const void* x_raw, const void* residual, void* dx,
-                            double* stats, void* scratch, int M, int HW, int K, int N, hipStream_t st);
+int t3d_pw_bwd_yfree_launch(const void* dz, const void* x, const void* wd, const void* wt, const t3d_bnbwd* bb, const void* x_raw,
+                            const void* residual, void* dx, double* stats, void* scratch, int M, int HW, int K, int N, hipStream_t st);
 int t3d_pw_bwd_yfree_reduce(void* scratch, float** tmp_out, int M, int K, int N, hipStream_t st);
 
 namespace {
@@ -181,7 +181,22 @@ extern "C" int t3d_pwconv_bwd_yfree(const void* dz, const void* x, const void* w
   if (pro_in && (pro_in->se || pro_in->act != T3D_ACT_NONE || pro_in->scale)) return T3D_ERR_UNSUPPORTED;   // (a linear block output)
   const size_t need = t3d_pw_bwd_yfree_scratch(M, K, N);
   if (!need || (size_t)scratch_bytes < need) return T3D_ERR_UNSUPPORTED;
-  return t3d_pw_bwd_yfree_launch(dz, x, wd, x_raw, residual, dx, stats, scratch, M, HW, K, N, reinterpret_cast<hipStream_t>(stream));
+  return t3d_pw_bwd_yfree_launch(dz, x, wd, nullptr, nullptr, x_raw, residual, dx, stats, scratch, M, HW, K, N,
+                                 reinterpret_cast<hipStream_t>(stream));
+}
+
+// the same launch with the data gradient's weight rows built in its own prologue: no t3d_pwconv_yfree_prep2 launch in front
+extern "C" int t3d_pwconv_bwd_yfree_w(const void* dz, const void* x, const void* wt, const t3d_bnbwd* bb, const void* x_raw,
+                                      const t3d_prologue* pro_in, const void* residual, void* dx, double* stats, void* scratch,
+                                      long long scratch_bytes, int M, int HW, int K, int N, void* stream) {
+  if (!dz || !x || !wt || !bb || !bb->alpha || !bb->beta || !bb->gamma || !dx || !scratch || M <= 0 || HW <= 0 || K <= 0 || N <= 0 ||
+      (K % 8) || (N % 8))
+    return T3D_ERR_ARG;
+  if (bb->per_sample || (pro_in && (pro_in->se || pro_in->act != T3D_ACT_NONE || pro_in->scale))) return T3D_ERR_UNSUPPORTED;
+  const size_t need = t3d_pw_bwd_yfree_scratch(M, K, N);
+  if (!need || (size_t)scratch_bytes < need) return T3D_ERR_UNSUPPORTED;
+  return t3d_pw_bwd_yfree_launch(dz, x, nullptr, wt, bb, x_raw, residual, dx, stats, scratch, M, HW, K, N,
+                                 reinterpret_cast<hipStream_t>(stream));
 }
 
 extern "C" int t3d_pwconv_wgrad_yfree_finish(void* scratch, const t3d_bnbwd* bb, const void* w, float* dw, int M, int K, int N,

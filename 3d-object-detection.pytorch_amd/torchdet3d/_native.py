@@ -65,6 +65,7 @@ SIGNATURES = {
     't3d_pwconv_yfree_prep2': [_P, _BP, _P, _P, _P, _I, _I, _P],
     't3d_pwconv_bwd_yfree_scratch': [_I, _I, _I],
     't3d_pwconv_bwd_yfree': [_P, _P, _P, _P, _PP, _P, _P, _P, _P, _L, _I, _I, _I, _I, _P],
+    't3d_pwconv_bwd_yfree_w': [_P, _P, _P, _BP, _P, _PP, _P, _P, _P, _P, _L, _I, _I, _I, _I, _P],
     't3d_pwconv_wgrad_yfree_finish': [_P, _BP, _P, _P, _I, _I, _I, _P],
     't3d_bn_bwd_finalize': [_P, _I, _D, _P, _P, _P, _P, _P, _P, _P, _P, _P],
     't3d_stem_im2col': [_I, _P, _P, _I, _I, _I, _P],

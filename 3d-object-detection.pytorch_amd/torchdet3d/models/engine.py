@@ -39,6 +39,7 @@ MAIN_WORKSPACE_BYTES = 16 << 20
 # y-free expand-layer backward (csrc/pwconv_yfree.hip): minimum M*N elements of the expanded tensor; 0 disables
 YFREE_MIN_ELEMS = int(os.environ.get('T3D_YFREE_MIN', 8 << 20))
 YFREE_FUSED = os.environ.get('T3D_YFREE_FUSED', '1') != '0'     # one-pass expand-layer backward (t3d_pwconv_bwd_yfree)
+YFREE_PREP_FUSED = os.environ.get('T3D_YFREE_PREP_FUSED', '1') != '0'   # ... with its weight rows built in its own prologue (A/B switch)
 EXPDW_EVAL = os.environ.get('T3D_EXPDW_EVAL', '1') != '0'      # fused expand + depthwise forward in 16-bit inference (A/B switch)
 HOOK_MIN = 1 << 20              # gradient-exchange granularity (elements): parallel.GradSync's bucket size
 HOOK_ON_SIDE = True              # (round 3: the gradient exchange is issued from the second stream; the other order stalled the main one)
@@ -410,7 +411,7 @@ class Net:
     # backward half costs nothing either (7.64 ms both ways, 18 launches fewer), so both are on)
     _LAZY_DW = '1'
     DERIVING = frozenset(('t3d_pwconv_fwd', 't3d_pwconv_fwd_mat', 't3d_bn_apply', 't3d_pool_fwd', 't3d_pwconv_dgrad', 't3d_pwconv_yfree_prep',
-                          't3d_pwconv_yfree_prep2', 't3d_conv3x3_dgrad')
+                          't3d_pwconv_yfree_prep2', 't3d_conv3x3_dgrad', 't3d_pwconv_bwd_yfree_w')
                          + (('t3d_dwconv_fwd',) if _LAZY_DW in ('1', 'fwd') else ())
                          + (('t3d_dwconv_bwd',) if _LAZY_DW in ('1', 'bwd') else ()))
 
@@ -1143,14 +1144,21 @@ class Net:
         # reduces and combines.  (The pair below reads d1 twice, from two streams at the same time.)
         need = N.lib().t3d_pwconv_bwd_yfree_scratch(M, K, Nn) if (YFREE_FUSED and not (with_stats and x.gpro is not None)) else 0
         if need > 0:
-            key = (f'wd:{i}', ((K + 15) // 16 * 16, (Nn + K + 8 + 63) // 64 * 64), self.dtype)
-            wd = self._bufs.get(key) if key in self._bufs else self._buf(key[0], key[1], zero=True)   # cleared ONCE: prep2 writes the non-zero entries
             scratch = self._buf(f'yfscr:{i}', (need,), torch.uint8)
-            self._c('t3d_pwconv_yfree_prep2', N.ptr(self.wt[wname]), bb1, N.ptr(wcat), N.ptr(cvec), N.ptr(wd), K, Nn, st, bwd=bn1)
             dx = self._buf(f'dzin:{i}', (M, K))
-            N.call('t3d_pwconv_bwd_yfree', N.ptr(d1), N.ptr(x.t), N.ptr(wd), N.ptr(x.raw) if with_stats else None, None,
-                   N.ptr(res) if res is not None else None, N.ptr(dx), self._bst(x.bn) if with_stats else None, N.ptr(scratch), need,
-                   M, HW, K, Nn, st, nbytes=M * (K + Nn) * self.esz)
+            if YFREE_PREP_FUSED:
+                # the data gradient's weight rows are built in the launch's own prologue (and the BatchNorm-backward finalize
+                # derived there): no t3d_pwconv_yfree_prep2 launch on the critical stream (round 5: -13 us x 6 per step)
+                self._c('t3d_pwconv_bwd_yfree_w', N.ptr(d1), N.ptr(x.t), N.ptr(self.wt[wname]), bb1, N.ptr(x.raw) if with_stats else None,
+                        None, N.ptr(res) if res is not None else None, N.ptr(dx), self._bst(x.bn) if with_stats else None,
+                        N.ptr(scratch), need, M, HW, K, Nn, st, nbytes=M * (K + Nn) * self.esz, bwd=bn1)
+            else:
+                key = (f'wd:{i}', ((K + 15) // 16 * 16, (Nn + K + 8 + 63) // 64 * 64), self.dtype)
+                wd = self._bufs.get(key) if key in self._bufs else self._buf(key[0], key[1], zero=True)   # cleared ONCE: prep2 writes the non-zero entries
+                self._c('t3d_pwconv_yfree_prep2', N.ptr(self.wt[wname]), bb1, N.ptr(wcat), N.ptr(cvec), N.ptr(wd), K, Nn, st, bwd=bn1)
+                N.call('t3d_pwconv_bwd_yfree', N.ptr(d1), N.ptr(x.t), N.ptr(wd), N.ptr(x.raw) if with_stats else None, None,
+                       N.ptr(res) if res is not None else None, N.ptr(dx), self._bst(x.bn) if with_stats else None, N.ptr(scratch), need,
+                       M, HW, K, Nn, st, nbytes=M * (K + Nn) * self.esz)
             self._wgrad(N.ptr(scratch), bb1, N.ptr(self.w[wname]), N.ptr(self.g[wname]), M, K, Nn, entry='t3d_pwconv_wgrad_yfree_finish')
             if x.finished_act:
                 dx = self._act_bwd(dx, x, f'dzin:{i}:a')

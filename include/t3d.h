@@ -167,6 +167,12 @@ int t3d_pwconv_wgrad_yfree(const void* dz, const void* x, const t3d_bnbwd* bb, c
  *   _wgrad_yfree_finish (any stream ordered behind it): dw [N,K] += the combined weight gradient, from `scratch`.
  * Replaces the autograd of nn.Conv2d(K, N, 1) + nn.BatchNorm2d(N) (models/mobilenetv3.py:148-149), as the pair does. */
 int t3d_pwconv_yfree_prep2(const void* wt, const t3d_bnbwd* bb, void* wcat, float* cvec, void* wd, int K, int N, void* stream);
+/* _bwd_yfree_w (round 5): t3d_pwconv_bwd_yfree with the weight rows `wd` built in the launch's own prologue from wt [K,N] (the
+ * transposed bf16 weights) and the BatchNorm-backward coefficients `bb` (or the pending finalize request for them): the same
+ * numbers bit for bit, without the t3d_pwconv_yfree_prep2 launch in front of it on the critical stream. */
+int t3d_pwconv_bwd_yfree_w(const void* dz, const void* x, const void* wt, const t3d_bnbwd* bb, const void* x_raw,
+                           const t3d_prologue* pro_in, const void* residual, void* dx, double* stats, void* scratch,
+                           long long scratch_bytes, int M, int HW, int K, int N, void* stream);
 int t3d_pwconv_bwd_yfree_scratch(int M, int K, int N);
 int t3d_pwconv_bwd_yfree(const void* dz, const void* x, const void* wd, const void* x_raw, const t3d_prologue* pro_in,
                          const void* residual, void* dx, double* stats, void* scratch, long long scratch_bytes, int M, int HW,

@@ -359,6 +359,17 @@ def test_pw_yfree_backward(M, HW, K, N, res):
         np.testing.assert_allclose(st3[K:].cpu().numpy(), ref1.cpu().numpy(), rtol=1e-4, atol=1e-3 * M ** .5)
         # the same numbers as the pair up to the bf16 rounding of the bias c (it rides in the weight matrix here)
         assert (dx3.float() - dx.float()).abs().max().item() <= 2e-2 * sx
+        # ---- round 5: the weight rows built in the launch's own prologue (t3d_pwconv_bwd_yfree_w) -- bit for bit what prep2 +
+        # t3d_pwconv_bwd_yfree give: data gradient, BatchNorm-backward sums, partial weight-gradient tiles
+        scratch4 = torch.empty(need, device=dev, dtype=torch.uint8)
+        dx4 = torch.empty(M, K, device=dev, dtype=bf)
+        st4 = torch.zeros(2 * K, device=dev, dtype=torch.float64)
+        dw4 = torch.zeros(N, K, device=dev)
+        N_.call('t3d_pwconv_bwd_yfree_w', N_.ptr(dzd), N_.ptr(xd), N_.ptr(wtd), bb, N_.ptr(yraw), None, N_.ptr(rd) if res else None,
+                N_.ptr(dx4), N_.ptr(st4), N_.ptr(scratch4), need, M, HW, K, N, N_.stream())
+        N_.call('t3d_pwconv_wgrad_yfree_finish', N_.ptr(scratch4), bb, N_.ptr(wd), N_.ptr(dw4), M, K, N, N_.stream())
+        torch.cuda.synchronize()
+        assert torch.equal(dx4, dx3) and torch.equal(st4, st3) and torch.equal(dw4, dw3)
 
 
 @pytest.mark.parametrize('dt', ['f32', 'bf16'])
