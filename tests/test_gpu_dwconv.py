@@ -217,3 +217,58 @@ def test_dwconv_bwd_weight_gradient_slots_are_exactly_reproducible(B, C, H, W, k
     if not tiled:
         for o, n, _ in results[1:]:
             assert n == nused and torch.equal(o, out)
+
+
+@pytest.mark.parametrize('s', [1, 2])
+def test_dwconv_bwd_refused_by_the_streaming_kernel_keeps_its_pending_finalize(s):
+    """a tensor of >= 2 GB is refused by the streaming 3x3 backward (32-bit buffer offsets) and goes to the
+    tiled kernel -- which must still find the pending BatchNorm-backward finalize request (round 4 consumed it in front of the
+    refusal: the fallback then read alpha / beta / gamma before anyone had computed them).  bf16, 128 x 112 x 112 x 672 = 2.16 GB
+    per tensor; compared with the same launch after a standalone t3d_bn_bwd_finalize: identical coefficients and gradients."""
+    from torchdet3d import _native as N
+    B, H, W, C = 128, 112, 112, 672
+    Ho, Wo = (H - 1) // s + 1, (W - 1) // s + 1
+    assert B * H * W * C * 2 >= 1 << 31
+    g = torch.Generator(device='cuda').manual_seed(4)
+    x = torch.randn(B * H * W, C, device='cuda', generator=g).to(torch.bfloat16)
+    dz = (torch.randn(B * Ho * Wo, C, device='cuda', generator=g) * 0.1).to(torch.bfloat16)
+    y = torch.randn(B * Ho * Wo, C, device='cuda', generator=g).to(torch.bfloat16)
+    w = torch.randn(C, 9, device='cuda', generator=g) * 0.3
+    sc, sh = torch.rand(C, device='cuda', generator=g) + 0.5, torch.randn(C, device='cuda', generator=g) * 0.2
+    pro = N.prologue(sc, sh, None, 'relu6', False)
+    gamma, mean, invstd = torch.rand(C, device='cuda', generator=g) + 0.5, torch.randn(C, device='cuda', generator=g) * 0.1, torch.rand(C, device='cuda', generator=g) + 0.5
+    count = float(B * Ho * Wo)
+    bst = torch.zeros(1, 2 * C, device='cuda', dtype=torch.float64)           # sum(dz), sum(dz * y) of the gradient's BatchNorm
+    bst[0, :C] = dz.double().sum(0)
+    bst[0, C:] = (dz.double() * y.double()).sum(0)
+    res = {}
+    for lazy in (False, True):
+        al, be, ga = (torch.full((C,), float('nan'), device='cuda') for _ in range(3))
+        dg, db = torch.empty(C, device='cuda'), torch.empty(C, device='cuda')
+        bb = N.bnbwd(al, be, ga, False)
+        dx = torch.empty_like(x)
+        dw = torch.zeros(C, 9, device='cuda')
+        N.call('t3d_set_reduction_replicas', 1, 2 * C)
+        try:
+            if lazy:
+                f = N.BnFold()
+                f.kind, f.C, f.count, f.nrep, f.rstride = 2, C, count, 1, 2 * C
+                f.gamma, f.stats, f.mean, f.invstd = N.ptr(gamma), N.ptr(bst), N.ptr(mean), N.ptr(invstd)
+                f.o0, f.o1, f.o2, f.o3, f.o4 = N.ptr(al), N.ptr(be), N.ptr(ga), N.ptr(dg), N.ptr(db)
+                desc = torch.frombuffer(bytearray(bytes(f)), dtype=torch.uint8).cuda()
+                N.call('t3d_fold_request', N.ptr(desc), N.ptr(al))
+            else:
+                N.call('t3d_bn_bwd_finalize', N.ptr(bst), C, count, N.ptr(gamma), N.ptr(mean), N.ptr(invstd), N.ptr(al), N.ptr(be),
+                       N.ptr(ga), N.ptr(dg), N.ptr(db), N.stream())
+            N.call('t3d_dwconv_bwd', N.BF16, N.ptr(dz), N.ptr(y), bb, N.ptr(w), N.ptr(x), pro, None, N.ptr(dx), None, N.ptr(dw),
+                   B, H, W, C, 3, s, N.stream())
+            assert not N.lib().t3d_fold_pending()
+        finally:
+            N.call('t3d_set_reduction_replicas', 1, 0)
+        torch.cuda.synchronize()
+        res[lazy] = (al.clone(), be.clone(), ga.clone(), dx[:4 * H * W].clone(), dx[-H * W:].clone(), dw.clone())
+        del dx
+    for a, b in zip(res[False][:5], res[True][:5]):
+        assert torch.isfinite(a.float()).all() and torch.equal(a, b)
+    # (the weight gradient of the tiled kernel without slots is a sum of fp32 atomics: equal up to their order)
+    assert torch.allclose(res[False][5], res[True][5], rtol=1e-4, atol=1e-3)
