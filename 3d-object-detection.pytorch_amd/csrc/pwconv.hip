@@ -365,7 +365,12 @@ int dispatch(int dtype, GemmArgs& a, void* stream) {
   }
   // the LDS-tiled kernel reads finished coefficients: a pending derive request for them becomes a launch of its own
   if (const int rc = t3d_fold_fallback(a.p0, st)) return rc;
-  if (dtype == T3D_F32) return launch<float>(a, st);
+  if (dtype == T3D_F32) {
+    // inference forwards of many-pixel layers: the register-operand fp32 kernel (pwconv_f32_reg.hip; T3D_F32_TILED=1: round 1's)
+    const bool tiled = getenv("T3D_F32_TILED") != nullptr;
+    const int rc = tiled ? T3D_ERR_UNSUPPORTED : f32_reg_launch(a, st);
+    return rc != T3D_ERR_UNSUPPORTED ? rc : launch<float>(a, st);
+  }
   if (dtype == T3D_BF16) return launch<bf16_t>(a, st);
   return T3D_ERR_ARG;
 }

@@ -63,5 +63,7 @@ int deep_launch(GemmArgs& a, hipStream_t st);
 bool deep_shape(int Kin, int Nout);
 // the same kernel in fp16 storage, inference forward only (pwconv_stream_f16.hip)
 int stream_launch_f16(GemmArgs& a, hipStream_t st);
+// fp32 storage, inference forward of many-pixel layers (pwconv_f32_reg.hip); T3D_ERR_UNSUPPORTED for everything else
+int f32_reg_launch(GemmArgs& a, hipStream_t st);
 
 }  // namespace t3d_pw

@@ -264,6 +264,13 @@ def call(name, *args, nbytes=None, slots=None):
         raise RuntimeError(f'{name} failed with code {rc}')
 
 
+def launch_count():
+    """Kernels launched by the library so far in this process (t3d_launch_count)."""
+    n = ctypes.c_ulonglong(0)
+    lib().t3d_launch_count(ctypes.byref(n), None)
+    return n.value
+
+
 def prologue(scale=None, shift=None, se=None, act='none', se_after_act=False):
     """Keeps the referenced tensors alive on the returned object."""
     p = Prologue(ptr(scale), ptr(shift), ptr(se), ACT[act] if isinstance(act, str) else act, int(se_after_act))

@@ -149,6 +149,37 @@ def test_pwconv_fwd(B, HW, K, N, dt, mode):
         np.testing.assert_allclose(st[1].numpy(), (got.double() ** 2).sum(0).numpy(), rtol=1e-5, atol=1e-4)
 
 
+# fp32 storage, inference forward (no statistics) of layers with >= 1024 pixels: the fp32 streaming kernel
+# (csrc/pwconv_f32_stream.hip) -- MobileNetV2's layer shapes, ragged contraction (24, 40, 72: not multiples of 16), ragged pixel
+# counts, several output chunks (960 -> 160: two tiles per chunk), bias; 1e-5 against fp64 like the tiled kernel it replaces
+@pytest.mark.parametrize('M,K,N', [(4096, 16, 96), (3001, 24, 144), (2048, 144, 24), (1500, 32, 192), (1024, 192, 64),
+                                   (1031, 384, 96), (1200, 576, 160), (1024, 960, 160), (1024, 960, 320), (1100, 160, 960),
+                                   (1024, 320, 1280), (5000, 72, 40), (1111, 40, 240), (2000, 8, 8), (1024, 1280, 8)])
+@pytest.mark.parametrize('mode', ['plain', 'bias', 'relu6', 'hswish'])
+def test_pwconv_fwd_f32_inference_streaming_kernel(M, K, N, mode):
+    from torchdet3d import _native as Nt
+    g = torch.Generator().manual_seed(M + K + N)
+    x = torch.randn(M, K, generator=g)
+    w = torch.randn(N, K, generator=g) / K ** 0.5
+    bias = torch.randn(N, generator=g) if mode == 'bias' else None
+    scale, shift = torch.rand(K, generator=g) + 0.5, torch.randn(K, generator=g) * 0.3
+    a = x if mode in ('plain', 'bias') else _act(x * scale + shift, mode)
+    ref = a.double() @ w.double().t()
+    if bias is not None:
+        ref = ref + bias.double()
+    xd, wd = x.cuda(), w.cuda()
+    keep = [scale.cuda(), shift.cuda()]
+    bd = bias.cuda() if bias is not None else None
+    p = None if mode in ('plain', 'bias') else Nt.prologue(keep[0], keep[1], None, mode, False)
+    y = torch.full((M + 1, N), 7.0, device='cuda')          # (one guard row past the output)
+    n0 = Nt.launch_count()
+    Nt.call('t3d_pwconv_fwd', Nt.F32, Nt.ptr(xd), p, Nt.ptr(wd), Nt.ptr(bd), Nt.ptr(y), None, M, 1, K, N, Nt.stream())
+    torch.cuda.synchronize()
+    assert Nt.launch_count() - n0 == 1
+    assert torch.all(y[M] == 7.0)
+    np.testing.assert_allclose(y[:M].cpu().numpy(), ref.float().numpy(), atol=1e-5 * max(1., ref.abs().max().item()), rtol=1e-5)
+
+
 # projection-conv data gradients of the 14x14 / 7x7 stages: contraction over 96 / 160 / 320 channels -> the deep-round
 # variants with hoisted epilogue loads (pwconv_stream.hip: HOIST), incl. ragged widths
 DEEP_DG = [(16, 196, 576, 96), (8, 49, 960, 160), (3, 49, 960, 320), (5, 100, 384, 96), (7, 33, 200, 88), (2, 49, 104, 152)]
