@@ -82,14 +82,41 @@ def compute_2d_based_iou(pred_kp, gt_kp, reduce_mean=True):
     return total / B if reduce_mean else total
 
 
+class PendingMetrics:
+    """A batch's per-class metrics between their launches and their read-back: `result()` waits for the batch's ONE device ->
+    host copy and takes the per-class sums on the host in fp64.  `Evaluator.val` enqueues batch i + 1 before it asks for
+    batch i's result, so neither the 3-D IoU kernel nor the copy nor the host arithmetic sits between two forwards."""
+
+    def __init__(self, bs, compute_iou, host=None, event=None, keep=()):
+        self.bs, self.compute_iou, self.host, self.event, self.keep = bs, compute_iou, host, event, keep
+
+    def result(self):
+        bs, compute_iou = self.bs, self.compute_iou
+        if bs == 0:
+            return [], 0., 0., 0., 0.
+        self.event.synchronize()
+        host = self.host.numpy()
+        self.keep = ()
+        cl_of = host[:, 3].astype('int64')
+        out = []
+        tA = tS = tI = tC = 0.
+        for cl in sorted(set(cl_of.tolist())):
+            m = cl_of == cl
+            A, S, C = float(host[m, 0].sum()), float(host[m, 1].sum()), float(host[m, 2].sum())
+            I = float(host[m, 4].sum()) if compute_iou else 0.
+            n = int(m.sum())
+            out.append((int(cl), A / n, S / n, I / n, C / n))
+            tA, tS, tI, tC = tA + A, tS + S, tI + I, tC + C
+        return out, tA / bs, tS / bs, tI / bs, tC / bs
+
+
 @torch.no_grad()
-def compute_metrics_per_cls(pred_kp, gt_kp, pred_cats, gt_cats, compute_iou=True):
-    """metrics.py:39-68: per class present in the batch, sums / class count; totals / batch size.  Two launches (per-sample
-    ADD / SADD / hit summands, per-sample 3-D IoU) and ONE read-back per batch; the per-class sums are taken on the host in
-    fp64 (the reference: a python loop over the classes with two tiny-kernel chains and three syncs each)."""
+def enqueue_metrics_per_cls(pred_kp, gt_kp, pred_cats, gt_cats, compute_iou=True):
+    """The launches of `compute_metrics_per_cls` on torch's current stream (per-sample ADD / SADD / hit summands, per-sample 3-D
+    IoU) and the batch's one device -> host copy into pinned memory, without waiting for any of it -> PendingMetrics."""
     bs = pred_kp.shape[0]
     if bs == 0:
-        return [], 0., 0., 0., 0.
+        return PendingMetrics(0, compute_iou)
     if not pred_kp.is_cuda:
         raise RuntimeError('metrics run on the HIP path only (no CPU fallback)')
     dev = pred_kp.device
@@ -105,15 +132,17 @@ def compute_metrics_per_cls(pred_kp, gt_kp, pred_cats, gt_cats, compute_iou=True
     cols = [ps.double(), cats.double()[:, None]]
     if compute_iou:
         cols.append(iou3d_per_sample(pred_kp, gt_kp)[:, None])
-    host = torch.cat(cols, 1).cpu().numpy()              # the batch's one device -> host copy
-    cl_of = host[:, 3].astype('int64')
-    out = []
-    tA = tS = tI = tC = 0.
-    for cl in sorted(set(cl_of.tolist())):
-        m = cl_of == cl
-        A, S, C = float(host[m, 0].sum()), float(host[m, 1].sum()), float(host[m, 2].sum())
-        I = float(host[m, 4].sum()) if compute_iou else 0.
-        n = int(m.sum())
-        out.append((int(cl), A / n, S / n, I / n, C / n))
-        tA, tS, tI, tC = tA + A, tS + S, tI + I, tC + C
-    return out, tA / bs, tS / bs, tI / bs, tC / bs
+    devm = torch.cat(cols, 1)
+    host = torch.empty(devm.shape, dtype=devm.dtype, pin_memory=True)
+    host.copy_(devm, non_blocking=True)                  # the batch's one device -> host copy
+    ev = torch.cuda.Event()
+    ev.record()
+    return PendingMetrics(bs, compute_iou, host, ev, keep=(p, t, cats, logits, ps, devm, pred_kp, gt_kp, pred_cats, gt_cats))
+
+
+@torch.no_grad()
+def compute_metrics_per_cls(pred_kp, gt_kp, pred_cats, gt_cats, compute_iou=True):
+    """metrics.py:39-68: per class present in the batch, sums / class count; totals / batch size.  Two launches (per-sample
+    ADD / SADD / hit summands, per-sample 3-D IoU) and ONE read-back per batch; the per-class sums are taken on the host in
+    fp64 (the reference: a python loop over the classes with two tiny-kernel chains and three syncs each)."""
+    return enqueue_metrics_per_cls(pred_kp, gt_kp, pred_cats, gt_cats, compute_iou).result()

@@ -123,6 +123,8 @@ def parse():
     ap.add_argument('--eval', action='store_true', help='time the validation step instead of the train step: `Evaluator.val_step` '
                     'of a model built by build_model (eval-mode forward on the engine `model.eval_storage_dtype` selects -- fp32 '
                     'storage by default, also for a bf16 model -- + ADD / SADD / accuracy / 3-D IoU per class)')
+    ap.add_argument('--eval-sync', action='store_true', help='--eval: time Evaluator.val_step (waits for its own batch) instead of the '
+                    "validation loop's pipelined body (Evaluator.val: one batch in flight)")
     ap.add_argument('--eval-dtype', default='', choices=['', 'bf16', 'f16', 'f32'], help="model.eval_storage_dtype for --eval; 'bf16' is "
                     'the OPT-IN throughput inference, outside the 1e-3 3-D-IoU bound for MobileNetV2 (labelled in the output)')
     ap.add_argument('--engine', action='store_true', help='drive models.engine.Net + the loss / optimizer kernels directly '
@@ -251,11 +253,20 @@ def main():
     dkp, dlg = torch.empty(B, 18, device=dev), torch.empty(B, 9, device=dev)
 
     last = [None]
+    pend = [None]              # --eval: the validation batch in flight
 
     def eval_step(i):
         j = i % nb
         if use_api:
-            last[0] = trainer.val_step(imgs[j], gts[j].view(B, 9, 2), cats[j], compute_iou=True)     # (trainer = the Evaluator)
+            # (trainer = the Evaluator)  the body of `Evaluator.val`'s loop: batch i's metrics are read back after batch i + 1
+            # is enqueued; --eval-sync: `Evaluator.val_step`, which waits for its own batch
+            if args.eval_sync:
+                last[0] = trainer.val_step(imgs[j], gts[j].view(B, 9, 2), cats[j], compute_iou=True)
+                return
+            cur = trainer.val_enqueue(imgs[j], gts[j].view(B, 9, 2), cats[j], compute_iou=True)
+            if pend[0] is not None:
+                last[0] = pend[0].result()
+            pend[0] = cur
             return
         kp, lg = net.forward(imgs[j], cats[j], train=False)
         N.call('t3d_loss_fwd_bwd', cfg, N.ptr(kp), N.ptr(gts[j]), N.ptr(lg), N.ptr(cats[j]), N.ptr(out), None, None, B, 9,
@@ -352,6 +363,8 @@ def main():
             N.timer = rtimer if i % every == 0 else None
         step(i)
         marks[i + 1].record()
+    if pend[0] is not None:                      # --eval: the last batch's read-back belongs to the timed region
+        last[0], pend[0] = pend[0].result(), None
     N.timer = None
     barrier()
     dt = time.perf_counter() - t0
@@ -380,14 +393,15 @@ def main():
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(dt / args.steps * 1e3, 3),
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': eval_dt if args.eval else args.dtype, 'data': 'synthetic',
             'config': {'workload': f'{args.model} 9-class Objectron keypoint regression, '
-                                   + ((f'validation step (Evaluator.val_step: eval-mode forward in {eval_dt} storage + per-class ADD / SADD / '
+                                   + ((f'validation step ({"Evaluator.val_step" if args.eval_sync else "the body of Evaluator.val, one batch in flight"}: '
+                                       f'eval-mode forward in {eval_dt} storage + per-class ADD / SADD / '
                                        'accuracy / 3-D IoU, one read-back per batch)' if use_api else
                                        'inference forward (running BatchNorm statistics) + loss / metric values')
                                       if args.eval else
                                       f'train step (fwd + l1/add/CE losses + bwd + AdamW{" + RCCL grad all-reduce" if world > 1 else ""})')
                                    + f', {S}x{S} crops, per-GPU batch {B}', 'global_batch': B * world, 'parallelism': f'dp{world}',
                        'final_loss': round(loss, 5), 'host_issue_ms_per_step': round(t_issue * 1e3, 3),
-                       'driven_through': (('torchdet3d.builders.build_model / Evaluator.val_step' if args.eval else
+                       'driven_through': ((('torchdet3d.builders.build_model / Evaluator.val_step' if args.eval_sync else 'torchdet3d.builders.build_model / Evaluator.val_enqueue + PendingMetrics.result (= Evaluator.val)') if args.eval else
                                            'torchdet3d.builders.build_model / build_optimizer / LossManager / Trainer.train_step')
                                           if use_api else 'models.engine.Net + loss / optimizer entry points'),
                        'step_form': (('one t3d_plan_run call per step (recorded step plan: %d launches, %d stream forks)'

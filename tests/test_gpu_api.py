@@ -153,6 +153,19 @@ def test_trainer_and_evaluator_on_synthetic_loader(tmp_path):
     assert any(r[0] == 'Val/IOU' for r in w.rows)
     per, *_ = ev.val_step(*next(iter(val_loader)))
     assert all(len(row) == 5 for row in per)
+    # `val` keeps one batch in flight (val_enqueue / PendingMetrics.result, metric kernels on a second stream): the same numbers
+    # as the batch-by-batch `val_step` sums, to the last bit
+    tot = np.zeros(4)
+    cnt = 0
+    for imgs, gt_kp, gt_cats in val_loader:
+        _, ADD, SADD, IOU, ACC = ev.val_step(imgs, gt_kp, gt_cats)
+        tot += np.array([ADD, SADD, ACC, IOU]) * imgs.size(0)
+        cnt += imgs.size(0)
+    res2 = ev.val(compute_iou=True)
+    assert [res2[k] for k in ('ADD', 'SADD', 'ACC', 'IOU')] == list(tot / cnt)
+    p0 = ev.val_enqueue(*next(iter(val_loader)))
+    p1 = ev.val_enqueue(*next(iter(val_loader)))                       # two batches in flight, collected out of order
+    assert p1.result() == p0.result() == ev.val_step(*next(iter(val_loader)))
 
 
 def test_train_mode_under_no_grad_uses_and_updates_batch_statistics_like_the_reference():
