@@ -8,6 +8,9 @@ python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline --per-launch > /dev/nul
 python3 bench.py --steps 10 --warmup 3 --dtype f32 --no-cpu-baseline > $o/bench_f32.json 2> /dev/null
 python3 bench.py --steps 30 --warmup 8 --eval --no-cpu-baseline > $o/bench_eval.json 2> /dev/null
 python3 bench.py --steps 30 --warmup 8 --eval --eval-dtype bf16 --no-cpu-baseline > $o/bench_eval_bf16_optin.json 2> /dev/null
+python3 bench.py --steps 30 --warmup 8 --eval --eval-sync --no-cpu-baseline > $o/bench_eval_val_step.json 2> /dev/null
+python3 bench.py --steps 30 --warmup 8 --eval --eval-sync --eval-dtype bf16 --no-cpu-baseline > $o/bench_eval_bf16_optin_val_step.json 2> /dev/null
+T3D_F32_TILED=1 python3 bench.py --steps 30 --warmup 8 --eval --no-cpu-baseline > $o/bench_eval_f32_tiled_kernel.json 2> /dev/null
 python3 bench.py --steps 20 --warmup 5 --model mobilenetv3_large --no-cpu-baseline > $o/bench_mnv3_large.json 2> /dev/null
 python3 bench.py --steps 20 --warmup 5 --model mobilenetv3_small --no-cpu-baseline > $o/bench_mnv3_small.json 2> /dev/null
 python3 bench.py --steps 30 --warmup 8 --eval --eval-dtype f16 --no-cpu-baseline > $o/bench_eval_f16.json 2> /dev/null
@@ -17,6 +20,7 @@ T3D_STEP_PLAN=0 python3 bench.py --steps 30 --warmup 8 --no-cpu-baseline > $o/be
 T3D_PLAN_HANDOFF=0 python3 bench.py --steps 30 --warmup 8 --no-cpu-baseline > $o/bench_bf16_event_forks.json 2> /dev/null
 T3D_IMPLICIT3=1 python3 bench.py --steps 20 --warmup 5 --model resnet50 --batch 64 --no-cpu-baseline > $o/bench_resnet50_implicit3x3.json 2> /dev/null
 python3 tools/time_expdw.py > $o/expdw_fused_forward_timings.txt 2>&1
+python3 tools/time_pw_f32.py > $o/pw_f32_reg_vs_tiled.txt 2>&1
 bash tools/time_kernels.sh > $o/isolated_kernel_timings.txt 2>&1
 python3 tools/bench_two_stage.py --detector 2> /dev/null | tail -1 > $o/two_stage_pipeline_bench.jsonl
 python3 tools/bench_two_stage.py --dets 64 2> /dev/null | tail -1 >> $o/two_stage_pipeline_bench.jsonl
