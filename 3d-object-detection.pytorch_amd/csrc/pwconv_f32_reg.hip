@@ -28,10 +28,14 @@ namespace {
 // The operand transform is branch-free: act(u) = clamp(u, lo, hi) with (lo, hi) = (0, 6) ReLU6, (0, inf) ReLU, (-inf, inf) none
 // -- v_med3_f32, bit-identical to the switch of common.h: act_affine_vec -- and scale = 1, shift = 0 without a prologue; hard-
 // swish is the HS instantiation.  Coefficients past K are scale = shift = 0: those lanes' (clamped, valid) loads become zeros.
-template <int R, int NT, bool HS, bool ONE>
+// Variant V: 0 the clamp form; 1 hard-swish; 2 one step (K <= 16: one operand buffer -- 40 registers less, a third wave per SIMD
+// at 4 x 6); 3 / 4 the MATERIALISING forward (t3d_pwconv_fwd_mat): the operand is the finished block output z = scale x + shift
+// (3) + residual (4: one more float4 per pixel row and step), and the workgroups of output chunk 0 also store it to z_out.
+template <int R, int NT, int V>
 __global__ __launch_bounds__(256) void pw_f32_reg_kernel(const GemmArgs a, const int KG, const int nchunks, const float lo,
                                                          const float hi) {
   extern __shared__ __attribute__((aligned(16))) float smem_f[];
+  constexpr bool HS = V == 1, ONE = V == 2, ZM = V >= 3, ZR = V == 4;
   constexpr int KS = 16;                                              // contraction indices per step
   float* coef = smem_f;                                               // [2][KG * KS]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lc = lane & 15, lg = lane >> 4;
@@ -56,11 +60,20 @@ __global__ __launch_bounds__(256) void pw_f32_reg_kernel(const GemmArgs a, const
   for (int r = 0; r < R; ++r) xp[r] = x + (size_t)min(m0 + 16 * r + lc, a.M - 1) * K;
 #pragma unroll
   for (int t = 0; t < NT; ++t) wp[t] = w + (size_t)min(n0 + 16 * t + lc, N - 1) * K;
-  f32x4 xa[ONE ? 1 : 2][R], wa[ONE ? 1 : 2][NT];
+  f32x4 xa[ONE ? 1 : 2][R], wa[ONE ? 1 : 2][NT], ra[ZR ? 2 : 1][ZR ? R : 1];
+  const float* __restrict__ res = reinterpret_cast<const float*>(a.z_res);
+  float* __restrict__ zo = reinterpret_cast<float*>(a.z_out);
+  size_t roff[R];                                          // (ZM: residual / z_out rows = the operand's rows)
+#pragma unroll
+  for (int r = 0; r < R; ++r) roff[r] = (size_t)min(m0 + 16 * r + lc, a.M - 1) * K;
   auto load = [&](int g, int b) {
     const int k = min(KS * g + 4 * lg, K - 4);            // (past K: a valid address; the coefficients there are zeros)
 #pragma unroll
     for (int r = 0; r < R; ++r) xa[b][r] = *reinterpret_cast<const f32x4*>(xp[r] + k);
+    if constexpr (ZR) {
+#pragma unroll
+      for (int r = 0; r < R; ++r) ra[b][r] = *reinterpret_cast<const f32x4*>(res + roff[r] + k);
+    }
 #pragma unroll
     for (int t = 0; t < NT; ++t) wa[b][t] = *reinterpret_cast<const f32x4*>(wp[t] + k);
   };
@@ -73,6 +86,21 @@ __global__ __launch_bounds__(256) void pw_f32_reg_kernel(const GemmArgs a, const
     const int k = KS * g + 4 * lg;
     const f32x4 sc = *reinterpret_cast<const f32x4*>(coef + k);
     const f32x4 sh = *reinterpret_cast<const f32x4*>(coef + kpad + k);
+    if constexpr (ZM) {
+      // z = scale x + shift (+ residual): the fp32 value t3d_bn_apply would have written (fma, then the add); stored by chunk 0
+      const bool kin = k < K;
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        f32x4 z;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          z[j] = fmaf(xa[b][r][j], sc[j], sh[j]);
+          if constexpr (ZR) z[j] += ra[b][r][j];
+        }
+        if (chunk == 0 && kin && m0 + 16 * r + lc < a.M) *reinterpret_cast<f32x4*>(zo + roff[r] + k) = z;
+        xa[b][r] = kin ? z : f32x4{0.f, 0.f, 0.f, 0.f};       // (with a residual the zero coefficients past K are not enough)
+      }
+    } else {
 #pragma unroll
     for (int r = 0; r < R; ++r)
 #pragma unroll
@@ -80,6 +108,7 @@ __global__ __launch_bounds__(256) void pw_f32_reg_kernel(const GemmArgs a, const
         const float u = fmaf(xa[b][r][j], sc[j], sh[j]);
         xa[b][r][j] = HS ? u * (__builtin_amdgcn_fmed3f(u + 3.f, 0.f, 6.f) * T3D_SIXTH) : __builtin_amdgcn_fmed3f(u, lo, hi);
       }
+    }
 #pragma unroll
     for (int j = 0; j < 4; ++j)
 #pragma unroll
@@ -90,7 +119,7 @@ __global__ __launch_bounds__(256) void pw_f32_reg_kernel(const GemmArgs a, const
   // (sched_barrier: the loads of step g + 1 are ISSUED before the MFMAs of step g -- left alone, the scheduler sinks them behind
   // the MFMAs into one register buffer and waits for them at the top of the next step)
   load(0, 0);
-  if (ONE) step(0, 0);         // (K <= 16: one step, one operand buffer -- 40 registers less, a third wave per SIMD at 4 x 6)
+  if (ONE) step(0, 0);
   for (int g = 0; !ONE && g < KG; g += 2) {
     load(min(g + 1, KG - 1), ONE ? 0 : 1);
     __builtin_amdgcn_sched_barrier(0);
@@ -125,12 +154,16 @@ int launch_reg(GemmArgs& a, hipStream_t st) {
   const size_t lds = (size_t)2 * KG * 16 * 4;
   const float inf = __builtin_inff();
   const float lo = (a.act == T3D_ACT_RELU || a.act == T3D_ACT_RELU6) ? 0.f : -inf, hi = a.act == T3D_ACT_RELU6 ? 6.f : inf;
-  if (a.act == T3D_ACT_HSWISH)
-    T3D_LAUNCH((pw_f32_reg_kernel<R, NT, true, false>), dim3((unsigned)grid), dim3(256), lds, st, a, KG, nchunks, lo, hi);
+  if (a.z_out && a.z_res)
+    T3D_LAUNCH((pw_f32_reg_kernel<R, NT, 4>), dim3((unsigned)grid), dim3(256), lds, st, a, KG, nchunks, lo, hi);
+  else if (a.z_out)
+    T3D_LAUNCH((pw_f32_reg_kernel<R, NT, 3>), dim3((unsigned)grid), dim3(256), lds, st, a, KG, nchunks, lo, hi);
+  else if (a.act == T3D_ACT_HSWISH)
+    T3D_LAUNCH((pw_f32_reg_kernel<R, NT, 1>), dim3((unsigned)grid), dim3(256), lds, st, a, KG, nchunks, lo, hi);
   else if (KG == 1)
-    T3D_LAUNCH((pw_f32_reg_kernel<R, NT, false, true>), dim3((unsigned)grid), dim3(256), lds, st, a, KG, nchunks, lo, hi);
+    T3D_LAUNCH((pw_f32_reg_kernel<R, NT, 2>), dim3((unsigned)grid), dim3(256), lds, st, a, KG, nchunks, lo, hi);
   else
-    T3D_LAUNCH((pw_f32_reg_kernel<R, NT, false, false>), dim3((unsigned)grid), dim3(256), lds, st, a, KG, nchunks, lo, hi);
+    T3D_LAUNCH((pw_f32_reg_kernel<R, NT, 0>), dim3((unsigned)grid), dim3(256), lds, st, a, KG, nchunks, lo, hi);
   T3D_CHECK_LAUNCH();
   return T3D_OK;
 }
@@ -150,8 +183,8 @@ int launch_reg_nt(GemmArgs& a, int NT, hipStream_t st) {
 
 // fp32 storage, inference forward; T3D_ERR_UNSUPPORTED = "not a launch for this kernel" (pwconv.hip takes it)
 int f32_reg_launch(GemmArgs& a, hipStream_t st) {
-  if (a.dgrad || a.stats || a.ps_stats || a.p2 || a.a1 || a.a2 || a.z_out || a.z_res || a.cv.mode || a.fold || a.per_sample ||
-      a.e_se || a.kz > 1 || a.wfrag)
+  if (a.dgrad || a.stats || a.ps_stats || a.p2 || a.a1 || a.a2 || a.cv.mode || a.fold || a.per_sample || a.e_se || a.kz > 1 ||
+      a.wfrag || (a.z_res && !a.z_out) || (a.z_out && (a.act != T3D_ACT_NONE || a.bias)))
     return T3D_ERR_UNSUPPORTED;
   if ((a.Kin % 8) || (a.Nout % 8) || a.M < 1024) return T3D_ERR_UNSUPPORTED;      // (few-pixel layers: the split-contraction path)
   // Task shape (tools/time_pw_f32.py --sweep): output tiles per wave = the count that pads the layer's tiles least, 5 and 4

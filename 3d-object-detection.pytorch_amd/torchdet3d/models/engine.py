@@ -862,7 +862,9 @@ class Net:
         # (t3d_pwconv_fwd_mat) -- one launch and one pass over the narrow tensor less per block
         out = _Src(y3, pro3, B, Ho, Wo, blk.cout, raw=y3, bn=bn3, gpro=None)
         out.zres, out.zbuf = (x.t if blk.res else None), z
-        if not (self.training and self._zfuse):
+        # (inference: only the fp32 engine keeps it pending -- its 1x1 kernel materialises on load, csrc/pwconv_f32_reg.hip; the
+        # 16-bit inference engines read finished tensors in their fused block / expand + depthwise kernels)
+        if not ((self.training or self.dt == N.F32) and self._zfuse):
             self._resolve(out)
         rec.update(src=src, s2=s2, y3=y3, bn3=bn3, out=out, names=(dwn, pwn), blk=blk, idx=i)
         sv['blocks'].append(rec)

@@ -180,6 +180,32 @@ def test_pwconv_fwd_f32_inference_streaming_kernel(M, K, N, mode):
     np.testing.assert_allclose(y[:M].cpu().numpy(), ref.float().numpy(), atol=1e-5 * max(1., ref.abs().max().item()), rtol=1e-5)
 
 
+# fp32 storage, inference: the materialising forward in ONE launch (csrc/pwconv_f32_reg.hip, variants 3 / 4): z is bit-equal to
+# t3d_bn_apply's, y within 1e-5 of fp64; ragged contraction (24, 40: the store and the operand past K), ragged pixel counts
+@pytest.mark.parametrize('M,K,N', [(4096, 16, 96), (3001, 24, 144), (1500, 32, 192), (1031, 96, 576), (1100, 160, 960),
+                                   (1024, 320, 1280), (1111, 40, 240), (2000, 8, 8)])
+@pytest.mark.parametrize('res', [False, True])
+def test_pwconv_fwd_mat_f32_inference_one_launch(M, K, N, res):
+    from torchdet3d import _native as Nt
+    g = torch.Generator().manual_seed(M + K + N + res)
+    y3 = torch.randn(M, K, generator=g).cuda()
+    r = torch.randn(M, K, generator=g).cuda() if res else None
+    w = (torch.randn(N, K, generator=g) / K ** 0.5).cuda()
+    sc, sh = (torch.rand(K, generator=g) + 0.5).cuda(), (torch.randn(K, generator=g) * 0.3).cuda()
+    p = Nt.prologue(sc, sh, None, 'none', False)
+    z_ref = torch.empty(M, K, device='cuda')
+    Nt.call('t3d_bn_apply', Nt.F32, Nt.ptr(y3), p, Nt.ptr(r), Nt.ptr(z_ref), M, K, Nt.stream())
+    z = torch.full((M + 1, K), 7.0, device='cuda')
+    y = torch.full((M + 1, N), 7.0, device='cuda')
+    n0 = Nt.launch_count()
+    Nt.call('t3d_pwconv_fwd_mat', Nt.F32, Nt.ptr(y3), p, Nt.ptr(r), Nt.ptr(z), Nt.ptr(w), Nt.ptr(y), None, M, 1, K, N, Nt.stream())
+    torch.cuda.synchronize()
+    assert Nt.launch_count() - n0 == 1
+    assert torch.equal(z[:M], z_ref) and torch.all(z[M] == 7.0) and torch.all(y[M] == 7.0)
+    ref = z_ref.double() @ w.double().t()
+    np.testing.assert_allclose(y[:M].cpu().numpy(), ref.float().cpu().numpy(), atol=1e-5 * max(1., ref.abs().max().item()), rtol=1e-5)
+
+
 # projection-conv data gradients of the 14x14 / 7x7 stages: contraction over 96 / 160 / 320 channels -> the deep-round
 # variants with hoisted epilogue loads (pwconv_stream.hip: HOIST), incl. ragged widths
 DEEP_DG = [(16, 196, 576, 96), (8, 49, 960, 160), (3, 49, 960, 320), (5, 100, 384, 96), (7, 33, 200, 88), (2, 49, 104, 152)]
