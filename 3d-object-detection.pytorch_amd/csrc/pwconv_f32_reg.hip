@@ -30,29 +30,39 @@ namespace {
 // swish is the HS instantiation.  Coefficients past K are scale = shift = 0: those lanes' (clamped, valid) loads become zeros.
 // Variant V: 0 the clamp form; 1 hard-swish; 2 one step (K <= 16: one operand buffer -- 40 registers less, a third wave per SIMD
 // at 4 x 6); 3 / 4 the MATERIALISING forward (t3d_pwconv_fwd_mat): the operand is the finished block output z = scale x + shift
-// (3) + residual (4: one more float4 per pixel row and step), and the workgroups of output chunk 0 also store it to z_out.
+// (3) + residual (4: one more float4 per pixel row and step), and the workgroups of output chunk 0 also store it to z_out;
+// 5 the TRAINING forward: BatchNorm sums of the output (column sums of y and y^2 over the valid pixels) -- the workgroups are
+// persistent over the pixel blocks, the column sums of every 16-pixel group (fp32, DPP) go to fp64 LDS accumulators and leave
+// as one fp64 atomic per channel and workgroup into a reduction replica.  fp32 values added in fp64: exact, so the sums do not
+// depend on the order (run-to-run bit-identical like the tiled kernel's).
 template <int R, int NT, int V>
 __global__ __launch_bounds__(256) void pw_f32_reg_kernel(const GemmArgs a, const int KG, const int nchunks, const float lo,
-                                                         const float hi) {
+                                                         const float hi, const int nrep, const long long rstride) {
   extern __shared__ __attribute__((aligned(16))) float smem_f[];
-  constexpr bool HS = V == 1, ONE = V == 2, ZM = V >= 3, ZR = V == 4;
+  constexpr bool HS = V == 1, ONE = V == 2, ZM = V == 3 || V == 4, ZR = V == 4, ST = V == 5;
   constexpr int KS = 16;                                              // contraction indices per step
   float* coef = smem_f;                                               // [2][KG * KS]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lc = lane & 15, lg = lane >> 4;
   const int xcd = blockIdx.x & 7, jj = blockIdx.x >> 3;
-  const int chunk = jj % nchunks, pb = ((jj / nchunks) * 8 + xcd) * 4 + wave;      // output chunk; block of R pixel groups
+  const int chunk = jj % nchunks, wgp = (jj / nchunks) * 8 + xcd;      // output chunk; workgroup index along the pixels
+  const int npw = gridDim.x / nchunks;
   const int n0 = chunk * 16 * NT;
   const float* __restrict__ x = reinterpret_cast<const float*>(a.a0);
   const float* __restrict__ w = reinterpret_cast<const float*>(a.w);
   float* __restrict__ y = reinterpret_cast<float*>(a.out);
   const int K = a.Kin, N = a.Nout, kpad = KG * KS;
+  double* lstat = reinterpret_cast<double*>(smem_f + 2 * kpad);      // [NT * 16][2] (ST)
   for (int i = tid; i < kpad; i += 256) {
     coef[i] = i < K ? (a.p0 ? a.p0[i] : 1.f) : 0.f;
     coef[kpad + i] = (i < K && a.p0) ? a.p1[i] : 0.f;
   }
+  if (ST)
+    for (int i = tid; i < NT * 32; i += 256) lstat[i] = 0.0;
   __syncthreads();
-  const int m0 = pb * R * 16;
-  if (m0 >= a.M) return;
+  // a wave takes the block of R pixel groups (wgp + it * npw) * 4 + wave; every variant but ST is launched with one block per wave
+  for (int it = 0;; ++it) {
+  const int m0 = ((wgp + it * npw) * 4 + wave) * R * 16;
+  if (m0 >= a.M) break;
 
   const float* xp[R];
   const float* wp[NT];
@@ -138,9 +148,44 @@ __global__ __launch_bounds__(256) void pw_f32_reg_kernel(const GemmArgs a, const
       const int n = n0 + 16 * t + 4 * lg;
       if (m < a.M && n < N) {
         f32x4 o = acc[r][t];
-        if (a.bias) o += *reinterpret_cast<const f32x4*>(a.bias + n);
+        if (a.bias) {
+          o += *reinterpret_cast<const f32x4*>(a.bias + n);
+          if (ST) acc[r][t] = o;                         // (the sums below are those of the STORED values)
+        }
         *reinterpret_cast<f32x4*>(y + (size_t)m * N + n) = o;
       }
+    }
+  }
+  if constexpr (ST) {
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      const int nl = 16 * t + 4 * lg;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        // fp32 only over the 16 pixels of a group (as the tiled kernel: pwconv.hip), fp64 from there on
+        double s1 = 0.0, s2 = 0.0;
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+          const float v = m0 + 16 * r + lc < a.M ? acc[r][t][j] : 0.f;      // (rows past M: clamped repeats of the last row)
+          s1 += (double)row16_sum(v);
+          s2 += (double)row16_sum(v * v);
+        }
+        if (lc == 0 && n0 + nl < N) {
+          atomicAdd(lstat + (nl + j) * 2, s1);
+          atomicAdd(lstat + (nl + j) * 2 + 1, s2);
+        }
+      }
+    }
+  } else {
+    break;
+  }
+  }   // blocks of this wave
+  if constexpr (ST) {
+    __syncthreads();
+    double* st = a.stats + (size_t)(blockIdx.x % nrep) * rstride;
+    for (int i = tid; i < NT * 32; i += 256) {
+      const int n = n0 + (i >> 1);
+      if (n < N) atomicAdd(st + (size_t)(i & 1) * N + n, lstat[i]);
     }
   }
 }
@@ -149,21 +194,27 @@ template <int R, int NT>
 int launch_reg(GemmArgs& a, hipStream_t st) {
   const int KG = cdiv(a.Kin, 16), nchunks = cdiv(cdiv(a.Nout, 16), NT);
   const int npb4 = cdiv(cdiv(cdiv(a.M, 16), R), 4);          // workgroups along the pixels: 4 waves, R pixel groups each
-  const long long grid = (long long)cdiv(npb4, 8) * 8 * nchunks;
+  long long npw = (long long)cdiv(npb4, 8) * 8;
+  if (a.stats) {                                             // persistent: two workgroups per CU, whole XCD lanes
+    const long long cap = (512 / nchunks) / 8 * 8;
+    if (npw > (cap < 8 ? 8 : cap)) npw = cap < 8 ? 8 : cap;
+  }
+  const long long grid = npw * nchunks;
   if (grid >= (1ll << 31)) return T3D_ERR_UNSUPPORTED;
-  const size_t lds = (size_t)2 * KG * 16 * 4;
+  const size_t lds = (size_t)2 * KG * 16 * 4 + (a.stats ? (size_t)NT * 32 * 8 : 0);
+  const int nrep = g_t3d_reduce.nrep > 0 ? g_t3d_reduce.nrep : 1;
+  const long long rstride = g_t3d_reduce.stats_stride;
   const float inf = __builtin_inff();
   const float lo = (a.act == T3D_ACT_RELU || a.act == T3D_ACT_RELU6) ? 0.f : -inf, hi = a.act == T3D_ACT_RELU6 ? 6.f : inf;
-  if (a.z_out && a.z_res)
-    T3D_LAUNCH((pw_f32_reg_kernel<R, NT, 4>), dim3((unsigned)grid), dim3(256), lds, st, a, KG, nchunks, lo, hi);
-  else if (a.z_out)
-    T3D_LAUNCH((pw_f32_reg_kernel<R, NT, 3>), dim3((unsigned)grid), dim3(256), lds, st, a, KG, nchunks, lo, hi);
-  else if (a.act == T3D_ACT_HSWISH)
-    T3D_LAUNCH((pw_f32_reg_kernel<R, NT, 1>), dim3((unsigned)grid), dim3(256), lds, st, a, KG, nchunks, lo, hi);
-  else if (KG == 1)
-    T3D_LAUNCH((pw_f32_reg_kernel<R, NT, 2>), dim3((unsigned)grid), dim3(256), lds, st, a, KG, nchunks, lo, hi);
-  else
-    T3D_LAUNCH((pw_f32_reg_kernel<R, NT, 0>), dim3((unsigned)grid), dim3(256), lds, st, a, KG, nchunks, lo, hi);
+#define T3D_REG_LAUNCH(VV) \
+  T3D_LAUNCH((pw_f32_reg_kernel<R, NT, VV>), dim3((unsigned)grid), dim3(256), lds, st, a, KG, nchunks, lo, hi, nrep, rstride)
+  if (a.stats) T3D_REG_LAUNCH(5);
+  else if (a.z_out && a.z_res) T3D_REG_LAUNCH(4);
+  else if (a.z_out) T3D_REG_LAUNCH(3);
+  else if (a.act == T3D_ACT_HSWISH) T3D_REG_LAUNCH(1);
+  else if (KG == 1) T3D_REG_LAUNCH(2);
+  else T3D_REG_LAUNCH(0);
+#undef T3D_REG_LAUNCH
   T3D_CHECK_LAUNCH();
   return T3D_OK;
 }
@@ -183,8 +234,9 @@ int launch_reg_nt(GemmArgs& a, int NT, hipStream_t st) {
 
 // fp32 storage, inference forward; T3D_ERR_UNSUPPORTED = "not a launch for this kernel" (pwconv.hip takes it)
 int f32_reg_launch(GemmArgs& a, hipStream_t st) {
-  if (a.dgrad || a.stats || a.ps_stats || a.p2 || a.a1 || a.a2 || a.cv.mode || a.fold || a.per_sample || a.e_se || a.kz > 1 ||
-      a.wfrag || (a.z_res && !a.z_out) || (a.z_out && (a.act != T3D_ACT_NONE || a.bias)))
+  if (a.dgrad || a.ps_stats || a.p2 || a.a1 || a.a2 || a.cv.mode || a.fold || a.per_sample || a.e_se || a.kz > 1 ||
+      a.wfrag || (a.z_res && !a.z_out) || (a.z_out && (a.act != T3D_ACT_NONE || a.bias || a.stats)) ||
+      (a.stats && (a.act == T3D_ACT_HSWISH || !a.out)))
     return T3D_ERR_UNSUPPORTED;
   if ((a.Kin % 8) || (a.Nout % 8) || a.M < 1024) return T3D_ERR_UNSUPPORTED;      // (few-pixel layers: the split-contraction path)
   // Task shape (tools/time_pw_f32.py --sweep): output tiles per wave = the count that pads the layer's tiles least, 5 and 4

@@ -180,6 +180,45 @@ def test_pwconv_fwd_f32_inference_streaming_kernel(M, K, N, mode):
     np.testing.assert_allclose(y[:M].cpu().numpy(), ref.float().numpy(), atol=1e-5 * max(1., ref.abs().max().item()), rtol=1e-5)
 
 
+# fp32 storage, TRAINING forward (BatchNorm sums) of layers with >= 1024 pixels: the register-operand kernel's persistent variant
+# -- output as in inference, the sums = column sums of the stored output (fp32 partials over a wave's 16 R pixels, added in fp64:
+# exact adds, so the order does not matter), spread over the reduction replicas, bit-identical from run to run
+@pytest.mark.parametrize('M,K,N', [(4096, 16, 96), (3001, 24, 144), (2048, 144, 24), (1031, 384, 96), (1024, 960, 160),
+                                   (1100, 160, 960), (100000, 32, 16), (1111, 40, 240), (2000, 8, 8)])
+@pytest.mark.parametrize('mode', ['plain', 'relu6', 'bias'])
+@pytest.mark.parametrize('nrep', [1, 16])
+def test_pwconv_fwd_f32_training_forward_register_kernel(M, K, N, mode, nrep):
+    from torchdet3d import _native as Nt
+    g = torch.Generator().manual_seed(M + K + N)
+    x = torch.randn(M, K, generator=g).cuda()
+    w = (torch.randn(N, K, generator=g) / K ** 0.5).cuda()
+    sc, sh = (torch.rand(K, generator=g) + 0.5).cuda(), (torch.randn(K, generator=g) * 0.3).cuda()
+    p = None if mode in ('plain', 'bias') else Nt.prologue(sc, sh, None, mode, False)
+    a = x if mode in ('plain', 'bias') else _act(x * sc + sh, mode)
+    bias = (torch.randn(N, generator=g) * 3).cuda() if mode == 'bias' else None
+    ref = a.double() @ w.double().t() + (bias.double() if bias is not None else 0.)
+    runs = []
+    for _ in range(2):
+        y = torch.full((M + 1, N), 7.0, device='cuda')
+        stats = torch.zeros(nrep, 2 * N, device='cuda', dtype=torch.float64)
+        Nt.call('t3d_set_reduction_replicas', nrep, 2 * N)
+        n0 = Nt.launch_count()
+        try:
+            Nt.call('t3d_pwconv_fwd', Nt.F32, Nt.ptr(x), p, Nt.ptr(w), Nt.ptr(bias), Nt.ptr(y), Nt.ptr(stats), M, 1, K, N, Nt.stream())
+        finally:
+            Nt.call('t3d_set_reduction_replicas', 1, 0)
+        torch.cuda.synchronize()
+        assert Nt.launch_count() - n0 == 1 and torch.all(y[M] == 7.0)
+        runs.append((y[:M].clone(), stats.sum(0).view(2, N).clone()))
+        if nrep > 1 and M >= 4096:
+            assert (stats.abs().sum(1) > 0).sum() > 1          # more than one replica received sums
+    (y, st), (y2, st2) = runs
+    assert torch.equal(y, y2) and torch.equal(st, st2)
+    np.testing.assert_allclose(y.cpu().numpy(), ref.float().cpu().numpy(), atol=1e-5 * max(1., ref.abs().max().item()), rtol=1e-5)
+    np.testing.assert_allclose(st[0].cpu().numpy(), y.double().sum(0).cpu().numpy(), rtol=1e-5, atol=1e-4 * M ** .5)
+    np.testing.assert_allclose(st[1].cpu().numpy(), (y.double() ** 2).sum(0).cpu().numpy(), rtol=1e-5, atol=1e-4)
+
+
 # fp32 storage, inference: the materialising forward in ONE launch (csrc/pwconv_f32_reg.hip, variants 3 / 4): z is bit-equal to
 # t3d_bn_apply's, y within 1e-5 of fp64; ragged contraction (24, 40: the store and the operand past K), ragged pixel counts
 @pytest.mark.parametrize('M,K,N', [(4096, 16, 96), (3001, 24, 144), (1500, 32, 192), (1031, 96, 576), (1100, 160, 960),
