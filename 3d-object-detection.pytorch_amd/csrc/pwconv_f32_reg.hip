@@ -34,12 +34,16 @@ namespace {
 // 5 the TRAINING forward: BatchNorm sums of the output (column sums of y and y^2 over the valid pixels) -- the workgroups are
 // persistent over the pixel blocks, the column sums of every 16-pixel group (fp32, DPP) go to fp64 LDS accumulators and leave
 // as one fp64 atomic per channel and workgroup into a reduction replica.  fp32 values added in fp64: exact, so the sums do not
-// depend on the order (run-to-run bit-identical like the tiled kernel's).
+// depend on the order (run-to-run bit-identical like the tiled kernel's);
+// 6 the DATA GRADIENT (t3d_pwconv_dgrad without gates / per-sample coefficients): the operand is the BatchNorm-backward affine of
+// two tensors, alpha dz + beta y + gamma (one more float4 per pixel row and step); epilogue: x the activation derivative at the
+// differentiated conv's input (e_y, e_scale, e_shift, e_act), + the residual gradient, and the sums of dx and dx . e_y (or dx^2)
+// for the producer's BatchNorm backward -- persistent like 5.
 template <int R, int NT, int V>
 __global__ __launch_bounds__(256) void pw_f32_reg_kernel(const GemmArgs a, const int KG, const int nchunks, const float lo,
                                                          const float hi, const int nrep, const long long rstride) {
   extern __shared__ __attribute__((aligned(16))) float smem_f[];
-  constexpr bool HS = V == 1, ONE = V == 2, ZM = V == 3 || V == 4, ZR = V == 4, ST = V == 5;
+  constexpr bool HS = V == 1, ONE = V == 2, ZM = V == 3 || V == 4, ZR = V == 4, DG = V == 6, ST = V == 5 || DG;
   constexpr int KS = 16;                                              // contraction indices per step
   float* coef = smem_f;                                               // [2][KG * KS]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lc = lane & 15, lg = lane >> 4;
@@ -51,10 +55,16 @@ __global__ __launch_bounds__(256) void pw_f32_reg_kernel(const GemmArgs a, const
   const float* __restrict__ w = reinterpret_cast<const float*>(a.w);
   float* __restrict__ y = reinterpret_cast<float*>(a.out);
   const int K = a.Kin, N = a.Nout, kpad = KG * KS;
-  double* lstat = reinterpret_cast<double*>(smem_f + 2 * kpad);      // [NT * 16][2] (ST)
+  double* lstat = reinterpret_cast<double*>(smem_f + 3 * kpad);      // [NT * 16][2] (ST)
   for (int i = tid; i < kpad; i += 256) {
-    coef[i] = i < K ? (a.p0 ? a.p0[i] : 1.f) : 0.f;
-    coef[kpad + i] = (i < K && a.p0) ? a.p1[i] : 0.f;
+    if (DG) {                                                         // alpha | beta | gamma (zeros past K)
+      coef[i] = i < K ? a.p0[i] : 0.f;
+      coef[kpad + i] = i < K ? a.p1[i] : 0.f;
+      coef[2 * kpad + i] = i < K ? a.p2[i] : 0.f;
+    } else {
+      coef[i] = i < K ? (a.p0 ? a.p0[i] : 1.f) : 0.f;
+      coef[kpad + i] = (i < K && a.p0) ? a.p1[i] : 0.f;
+    }
   }
   if (ST)
     for (int i = tid; i < NT * 32; i += 256) lstat[i] = 0.0;
@@ -70,8 +80,8 @@ __global__ __launch_bounds__(256) void pw_f32_reg_kernel(const GemmArgs a, const
   for (int r = 0; r < R; ++r) xp[r] = x + (size_t)min(m0 + 16 * r + lc, a.M - 1) * K;
 #pragma unroll
   for (int t = 0; t < NT; ++t) wp[t] = w + (size_t)min(n0 + 16 * t + lc, N - 1) * K;
-  f32x4 xa[ONE ? 1 : 2][R], wa[ONE ? 1 : 2][NT], ra[ZR ? 2 : 1][ZR ? R : 1];
-  const float* __restrict__ res = reinterpret_cast<const float*>(a.z_res);
+  f32x4 xa[ONE ? 1 : 2][R], wa[ONE ? 1 : 2][NT], ra[ZR || DG ? 2 : 1][ZR || DG ? R : 1];
+  const float* __restrict__ res = reinterpret_cast<const float*>(DG ? a.a1 : a.z_res);      // second operand tensor
   float* __restrict__ zo = reinterpret_cast<float*>(a.z_out);
   size_t roff[R];                                          // (ZM: residual / z_out rows = the operand's rows)
 #pragma unroll
@@ -80,7 +90,7 @@ __global__ __launch_bounds__(256) void pw_f32_reg_kernel(const GemmArgs a, const
     const int k = min(KS * g + 4 * lg, K - 4);            // (past K: a valid address; the coefficients there are zeros)
 #pragma unroll
     for (int r = 0; r < R; ++r) xa[b][r] = *reinterpret_cast<const f32x4*>(xp[r] + k);
-    if constexpr (ZR) {
+    if constexpr (ZR || DG) {
 #pragma unroll
       for (int r = 0; r < R; ++r) ra[b][r] = *reinterpret_cast<const f32x4*>(res + roff[r] + k);
     }
@@ -96,7 +106,14 @@ __global__ __launch_bounds__(256) void pw_f32_reg_kernel(const GemmArgs a, const
     const int k = KS * g + 4 * lg;
     const f32x4 sc = *reinterpret_cast<const f32x4*>(coef + k);
     const f32x4 sh = *reinterpret_cast<const f32x4*>(coef + kpad + k);
-    if constexpr (ZM) {
+    if constexpr (DG) {
+      // BatchNorm backward through the differentiated conv's output: alpha dz + beta y + gamma (the tiled kernel's expression)
+      const f32x4 ga = *reinterpret_cast<const f32x4*>(coef + 2 * kpad + k);
+#pragma unroll
+      for (int r = 0; r < R; ++r)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) xa[b][r][j] = sc[j] * xa[b][r][j] + sh[j] * ra[b][r][j] + ga[j];
+    } else if constexpr (ZM) {
       // z = scale x + shift (+ residual): the fp32 value t3d_bn_apply would have written (fma, then the add); stored by chunk 0
       const bool kin = k < K;
 #pragma unroll
@@ -140,13 +157,32 @@ __global__ __launch_bounds__(256) void pw_f32_reg_kernel(const GemmArgs a, const
     if (g + 1 < KG) step(g + 1, ONE ? 0 : 1);
     __builtin_amdgcn_sched_barrier(0);
   }
+  f32x4 sq[DG ? R : 1][DG ? NT : 1];                      // (DG: the second sum's summands)
 #pragma unroll
   for (int r = 0; r < R; ++r) {
     const int m = m0 + 16 * r + lc;
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
       const int n = n0 + 16 * t + 4 * lg;
-      if (m < a.M && n < N) {
+      if (DG) {
+        if (m < a.M && n < N) {
+          f32x4 o = acc[r][t], yv = f32x4{0.f, 0.f, 0.f, 0.f};
+          if (a.e_y) {
+            yv = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(a.e_y) + (size_t)m * N + n);
+            const f32x4 es = a.e_scale ? *reinterpret_cast<const f32x4*>(a.e_scale + n) : f32x4{1.f, 1.f, 1.f, 1.f};
+            const f32x4 eh = a.e_scale ? *reinterpret_cast<const f32x4*>(a.e_shift + n) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) o[j] *= act_grad(yv[j] * es[j] + eh[j], a.e_act);
+          }
+          if (a.e_res) o += *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(a.e_res) + (size_t)m * N + n);
+          *reinterpret_cast<f32x4*>(y + (size_t)m * N + n) = o;
+          acc[r][t] = o;
+          if (a.e_y) sq[r][t] = o * yv;                       // second sum: dx . e_y
+          else sq[r][t] = o * o;
+        } else {
+          acc[r][t] = sq[r][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+      } else if (m < a.M && n < N) {
         f32x4 o = acc[r][t];
         if (a.bias) {
           o += *reinterpret_cast<const f32x4*>(a.bias + n);
@@ -156,7 +192,7 @@ __global__ __launch_bounds__(256) void pw_f32_reg_kernel(const GemmArgs a, const
       }
     }
   }
-  if constexpr (ST) {
+  if (ST && a.stats) {
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
       const int nl = 16 * t + 4 * lg;
@@ -168,7 +204,8 @@ __global__ __launch_bounds__(256) void pw_f32_reg_kernel(const GemmArgs a, const
         for (int r = 0; r < R; ++r) {
           const float v = m0 + 16 * r + lc < a.M ? acc[r][t][j] : 0.f;      // (rows past M: clamped repeats of the last row)
           s1 += (double)row16_sum(v);
-          s2 += (double)row16_sum(v * v);
+          if constexpr (DG) s2 += (double)row16_sum(sq[r][t][j]);
+          else s2 += (double)row16_sum(v * v);
         }
         if (lc == 0 && n0 + nl < N) {
           atomicAdd(lstat + (nl + j) * 2, s1);
@@ -176,11 +213,10 @@ __global__ __launch_bounds__(256) void pw_f32_reg_kernel(const GemmArgs a, const
         }
       }
     }
-  } else {
-    break;
   }
+  if (!ST) break;
   }   // blocks of this wave
-  if constexpr (ST) {
+  if (ST && a.stats) {
     __syncthreads();
     double* st = a.stats + (size_t)(blockIdx.x % nrep) * rstride;
     for (int i = tid; i < NT * 32; i += 256) {
@@ -195,20 +231,25 @@ int launch_reg(GemmArgs& a, hipStream_t st) {
   const int KG = cdiv(a.Kin, 16), nchunks = cdiv(cdiv(a.Nout, 16), NT);
   const int npb4 = cdiv(cdiv(cdiv(a.M, 16), R), 4);          // workgroups along the pixels: 4 waves, R pixel groups each
   long long npw = (long long)cdiv(npb4, 8) * 8;
-  if (a.stats) {                                             // persistent: two workgroups per CU, whole XCD lanes
+  if constexpr (R == 4 && NT > 4) {
+    if (a.dgrad) return launch_reg<2, NT>(a, st);            // (three operand streams: 308 / 364 registers at 4 x 5 / 4 x 6)
+    if (a.stats && NT == 6) return launch_reg<2, NT>(a, st); // (260 registers with the sums' epilogue)
+  }
+  if (a.stats || a.dgrad) {                                  // persistent: two workgroups per CU, whole XCD lanes
     const long long cap = (512 / nchunks) / 8 * 8;
     if (npw > (cap < 8 ? 8 : cap)) npw = cap < 8 ? 8 : cap;
   }
   const long long grid = npw * nchunks;
   if (grid >= (1ll << 31)) return T3D_ERR_UNSUPPORTED;
-  const size_t lds = (size_t)2 * KG * 16 * 4 + (a.stats ? (size_t)NT * 32 * 8 : 0);
+  const size_t lds = (size_t)3 * KG * 16 * 4 + (size_t)NT * 32 * 8;
   const int nrep = g_t3d_reduce.nrep > 0 ? g_t3d_reduce.nrep : 1;
   const long long rstride = g_t3d_reduce.stats_stride;
   const float inf = __builtin_inff();
   const float lo = (a.act == T3D_ACT_RELU || a.act == T3D_ACT_RELU6) ? 0.f : -inf, hi = a.act == T3D_ACT_RELU6 ? 6.f : inf;
 #define T3D_REG_LAUNCH(VV) \
   T3D_LAUNCH((pw_f32_reg_kernel<R, NT, VV>), dim3((unsigned)grid), dim3(256), lds, st, a, KG, nchunks, lo, hi, nrep, rstride)
-  if (a.stats) T3D_REG_LAUNCH(5);
+  if (a.dgrad) T3D_REG_LAUNCH(6);
+  else if (a.stats) T3D_REG_LAUNCH(5);
   else if (a.z_out && a.z_res) T3D_REG_LAUNCH(4);
   else if (a.z_out) T3D_REG_LAUNCH(3);
   else if (a.act == T3D_ACT_HSWISH) T3D_REG_LAUNCH(1);
@@ -234,7 +275,12 @@ int launch_reg_nt(GemmArgs& a, int NT, hipStream_t st) {
 
 // fp32 storage, inference forward; T3D_ERR_UNSUPPORTED = "not a launch for this kernel" (pwconv.hip takes it)
 int f32_reg_launch(GemmArgs& a, hipStream_t st) {
-  if (a.dgrad || a.ps_stats || a.p2 || a.a1 || a.a2 || a.cv.mode || a.fold || a.per_sample || a.e_se || a.kz > 1 ||
+  if (a.dgrad) {
+    if (!a.a1 || !a.p0 || !a.p1 || !a.p2 || a.per_sample || a.ps_stats || a.e_se || a.a2 || a.cv.mode || a.fold || a.kz > 1 ||
+        a.wfrag || a.bias || a.z_out || a.z_res || !a.out)
+      return T3D_ERR_UNSUPPORTED;
+  } else
+  if (a.ps_stats || a.p2 || a.a1 || a.a2 || a.cv.mode || a.fold || a.per_sample || a.e_se || a.kz > 1 ||
       a.wfrag || (a.z_res && !a.z_out) || (a.z_out && (a.act != T3D_ACT_NONE || a.bias || a.stats)) ||
       (a.stats && (a.act == T3D_ACT_HSWISH || !a.out)))
     return T3D_ERR_UNSUPPORTED;

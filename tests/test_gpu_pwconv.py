@@ -318,6 +318,63 @@ def test_pwconv_dgrad(B, HW, K, N, dt, mode):
         np.testing.assert_allclose(psst.cpu()[..., 1].numpy(), p2.numpy(), rtol=1e-4, atol=1e-3)
 
 
+# fp32 storage, data gradient of layers with >= 1024 pixels: the register-operand kernel's variant 6 (csrc/pwconv_f32_reg.hip)
+# against round 1's LDS-tiled kernel on the same inputs (T3D_F32_TILED=1) and against fp64 -- values, both BatchNorm-backward
+# sums (sum dx, sum dx . x_raw), spread over the reduction replicas, bit-identical from run to run
+@pytest.mark.parametrize('M,K,N', [(4096, 16, 96), (3001, 24, 144), (2048, 144, 24), (1031, 96, 576), (1024, 160, 960),
+                                   (1100, 960, 160), (50000, 32, 16), (1111, 40, 240), (2000, 8, 8)])
+@pytest.mark.parametrize('mode', ['input', 'input_res', 'relu6', 'relu6_res', 'none_stats'])
+def test_pwconv_dgrad_f32_register_kernel(M, K, N, mode):
+    import os
+    from torchdet3d import _native as Nt
+    g = torch.Generator().manual_seed(M + K + N + 3)
+    dz, y = torch.randn(M, N, generator=g).cuda(), torch.randn(M, N, generator=g).cuda()
+    wt = (torch.randn(K, N, generator=g) / N ** 0.5).cuda()            # [fwd input channels][fwd output channels]
+    xraw, res = torch.randn(M, K, generator=g).cuda() * 3, torch.randn(M, K, generator=g).cuda()
+    scale, shift = (torch.rand(K, generator=g) + 0.5).cuda(), (torch.randn(K, generator=g) * 0.3 + 2).cuda()
+    alpha, beta, gamma = (torch.rand(N, generator=g) + 0.5).cuda(), (torch.randn(N, generator=g) * 0.2).cuda(), (torch.randn(N, generator=g) * 0.1).cuda()
+    bb = Nt.bnbwd(alpha, beta, gamma, False)
+    has_x = mode in ('relu6', 'relu6_res', 'none_stats')
+    act = 'relu6' if mode.startswith('relu6') else 'none'
+    pin = Nt.prologue(scale, shift, None, act, False) if has_x else None
+    with_res = mode.endswith('_res')
+    dy = (alpha * dz + beta * y + gamma).double()
+    ref = dy @ wt.double().t()
+    if act == 'relu6':
+        u = (xraw * scale + shift).double()
+        ref = ref * ((u > 0) & (u < 6)).double()
+    if with_res:
+        ref = ref + res.double()
+    outs = {}
+    for tag in ('reg', 'reg2', 'tiled'):
+        os.environ.pop('T3D_F32_TILED', None)
+        if tag == 'tiled':
+            os.environ['T3D_F32_TILED'] = '1'
+        dx = torch.full((M + 1, K), 7.0, device='cuda')
+        nrep = 1 if tag == 'tiled' else 8
+        stats = torch.zeros(nrep, 2 * K, device='cuda', dtype=torch.float64)
+        Nt.call('t3d_set_reduction_replicas', nrep, 2 * K)
+        n0 = Nt.launch_count()
+        try:
+            Nt.call('t3d_pwconv_dgrad', Nt.F32, Nt.ptr(dz), Nt.ptr(y), bb, Nt.ptr(wt), Nt.ptr(xraw) if has_x else None, pin,
+                    Nt.ptr(res) if with_res else None, Nt.ptr(dx), Nt.ptr(stats) if has_x else None, None, M, 1, K, N, Nt.stream())
+        finally:
+            Nt.call('t3d_set_reduction_replicas', 1, 0)
+            os.environ.pop('T3D_F32_TILED', None)
+        torch.cuda.synchronize()
+        assert Nt.launch_count() - n0 == 1 and torch.all(dx[M] == 7.0)
+        outs[tag] = (dx[:M].clone(), stats.sum(0).view(2, K).clone())
+    (dx, st), (dx2, st2), (dxt, stt) = outs['reg'], outs['reg2'], outs['tiled']
+    assert torch.equal(dx, dx2) and torch.equal(st, st2)
+    scale_ = max(1., ref.abs().max().item())
+    np.testing.assert_allclose(dx.cpu().numpy(), ref.float().cpu().numpy(), atol=2e-5 * scale_, rtol=2e-5)
+    np.testing.assert_allclose(dx.cpu().numpy(), dxt.cpu().numpy(), atol=2e-5 * scale_, rtol=2e-5)
+    if has_x:
+        np.testing.assert_allclose(st[0].cpu().numpy(), dx.double().sum(0).cpu().numpy(), rtol=1e-5, atol=1e-4 * M ** .5)
+        np.testing.assert_allclose(st[1].cpu().numpy(), (dx.double() * xraw.double()).sum(0).cpu().numpy(), rtol=1e-5, atol=1e-4 * M ** .5)
+        np.testing.assert_allclose(st.cpu().numpy(), stt.cpu().numpy(), rtol=1e-5, atol=1e-3 * M ** .5)
+
+
 @pytest.mark.parametrize('B,HW,K,N', SHAPES + [(16, 196, 96, 576), (64, 49, 160, 960), (2, 49, 320, 1280), (3, 49, 960, 160)])
 @pytest.mark.parametrize('dt', ['f32', 'bf16'])
 @pytest.mark.parametrize('mode', ['plain', 'bnact', 'se_pre_ps'])
