@@ -193,6 +193,8 @@ __global__ __launch_bounds__(256, 2) void pw_wgrad_kernel(const WgArgs a) {
 
 int t3d_pw_wgrad_tr_entry(const void* dz, const void* y, const t3d_bnbwd* bb, const void* x, const t3d_prologue* pro,
                           float* dw, int M, int HW, int K, int N, hipStream_t st);   // pwconv_wgrad_tr.hip (bf16)
+int t3d_pw_wgrad_f32_reg(const float* dz, const float* y, const t3d_bnbwd* bb, const float* x, const t3d_prologue* pro, float* dw,
+                         int M, int K, int N, hipStream_t st);                       // pwconv_f32_wgrad.hip (fp32)
 // fixed-order sum of partial tiles ws [S][tiles][PB][QB] into dw [N][K] (pwconv_wgrad_tr.hip)
 int t3d_pw_wgrad_reduce(const float* ws, float* dw, int N, int K, int PB, int QB, int qtiles, int tiles, int S, hipStream_t st);
 
@@ -201,8 +203,14 @@ extern "C" int t3d_pwconv_wgrad(int dtype, const void* dz, const void* y, const 
   if (!dz || !y || !bb || !x || !dw || M <= 0 || K <= 0 || N <= 0 || (K % 8) || (N % 8) || HW <= 0) return T3D_ERR_ARG;
   if (dtype == T3D_BF16 && !getenv("T3D_WGRAD_TILED"))
     return t3d_pw_wgrad_tr_entry(dz, y, bb, x, pro, dw, M, HW, K, N, reinterpret_cast<hipStream_t>(stream));
-  // the tiled kernel reads finished coefficients: a pending derive request for them becomes a launch of its own
+  // the kernels below read finished coefficients: a pending derive request for them becomes a launch of its own
   if (const int rc = t3d_fold_fallback(bb->alpha, reinterpret_cast<hipStream_t>(stream))) return rc;
+  if (dtype == T3D_F32 && !getenv("T3D_F32_TILED")) {
+    // fp32 storage: the register-operand kernel (pwconv_f32_wgrad.hip) where it takes the launch
+    const int rc = t3d_pw_wgrad_f32_reg(reinterpret_cast<const float*>(dz), reinterpret_cast<const float*>(y), bb,
+                                        reinterpret_cast<const float*>(x), pro, dw, M, K, N, reinterpret_cast<hipStream_t>(stream));
+    if (rc != T3D_ERR_UNSUPPORTED) return rc;
+  }
   WgArgs a{};
   a.dz = dz; a.y = y; a.x = x;
   a.alpha = bb->alpha; a.beta = bb->beta; a.gamma = bb->gamma; a.per_sample = bb->per_sample;

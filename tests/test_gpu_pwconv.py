@@ -422,6 +422,47 @@ def test_pwconv_wgrad(B, HW, K, N, dt, mode):
     np.testing.assert_allclose(dw.cpu().numpy(), ref.float().numpy(), atol=tol * max(1., ref.abs().max().item()), rtol=tol)
 
 
+# fp32 storage, weight gradient of layers with >= 1024 pixels, with the caller's workspace set: the register-operand kernel
+# (csrc/pwconv_f32_wgrad.hip) against fp64 and against round 1's LDS-tiled kernel (T3D_F32_TILED=1); accumulates into dw; ragged
+# channel counts on both sides (24, 40, 144: blocks past the matrix edge), ragged pixel counts, bit-identical from run to run
+@pytest.mark.parametrize('M,K,N', [(4096, 16, 96), (3001, 24, 144), (2048, 144, 24), (1031, 96, 576), (1024, 160, 960),
+                                   (1100, 960, 160), (100000, 32, 16), (1111, 40, 240), (2000, 8, 8), (5000, 320, 1280)])
+@pytest.mark.parametrize('mode', ['plain', 'relu6', 'hswish'])
+def test_pwconv_wgrad_f32_register_kernel(M, K, N, mode):
+    import os
+    from torchdet3d import _native as Nt
+    g = torch.Generator().manual_seed(M + K + N + 5)
+    dz, y = torch.randn(M, N, generator=g).cuda(), torch.randn(M, N, generator=g).cuda()
+    x = torch.randn(M, K, generator=g).cuda() * 3
+    scale, shift = (torch.rand(K, generator=g) + 0.5).cuda(), (torch.randn(K, generator=g) * 0.3 + 1).cuda()
+    alpha, beta, gamma = (torch.rand(N, generator=g) + 0.5).cuda(), (torch.randn(N, generator=g) * 0.2).cuda(), (torch.randn(N, generator=g) * 0.1).cuda()
+    bb = Nt.bnbwd(alpha, beta, gamma, False)
+    pro = None if mode == 'plain' else Nt.prologue(scale, shift, None, mode, False)
+    a = x if mode == 'plain' else _act(x * scale + shift, mode)
+    ref = (alpha * dz + beta * y + gamma).double().t() @ a.double()
+    ws = torch.empty(64 << 20, dtype=torch.uint8, device='cuda')
+    base = torch.randn(N, K, generator=g).cuda()
+    outs = {}
+    for tag in ('reg', 'reg2', 'tiled'):
+        os.environ.pop('T3D_F32_TILED', None)
+        if tag == 'tiled':
+            os.environ['T3D_F32_TILED'] = '1'
+        dw = base.clone()
+        Nt.call('t3d_set_workspace', Nt.ptr(ws), ws.numel())
+        n0 = Nt.launch_count()
+        try:
+            Nt.call('t3d_pwconv_wgrad', Nt.F32, Nt.ptr(dz), Nt.ptr(y), bb, Nt.ptr(x), pro, Nt.ptr(dw), M, 1, K, N, Nt.stream())
+        finally:
+            Nt.call('t3d_set_workspace', None, 0)
+            os.environ.pop('T3D_F32_TILED', None)
+        torch.cuda.synchronize()
+        outs[tag] = (dw - base, Nt.launch_count() - n0)
+    assert torch.equal(outs['reg'][0], outs['reg2'][0])
+    tol = 2e-5 * max(1., ref.abs().max().item())
+    np.testing.assert_allclose(outs['reg'][0].cpu().numpy(), ref.float().cpu().numpy(), atol=tol, rtol=2e-5)
+    np.testing.assert_allclose(outs['reg'][0].cpu().numpy(), outs['tiled'][0].cpu().numpy(), atol=tol, rtol=2e-5)
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize('M,HW,K,N', [(4096, 64, 16, 96), (3000, 100, 24, 144), (2048, 64, 32, 192), (1024, 16, 64, 384),
                                       (520, 8, 16, 96), (2048, 64, 8, 48)])     # K=8, N=48: N+K+8 = 64, the pair only
