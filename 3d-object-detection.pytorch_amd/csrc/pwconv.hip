@@ -416,14 +416,14 @@ extern "C" int t3d_pwconv_fwd_mat(int dtype, const void* y_in, const t3d_prologu
     if (rc != T3D_ERR_UNSUPPORTED || wfrag) return rc;
   }
   if (wfrag) return T3D_ERR_ARG;
-  if (dtype == T3D_F32 && !stats && !getenv("T3D_F32_TILED")) {
-    // fp32 storage, inference: the register-operand kernel materialises the block output itself (pwconv_f32_reg.hip)
+  if (dtype == T3D_F32 && !getenv("T3D_F32_TILED")) {
+    // fp32 storage: the register-operand kernel materialises the block output itself (pwconv_f32_reg.hip)
     if (const int rc = t3d_fold_fallback(pro_in->scale, reinterpret_cast<hipStream_t>(stream))) return rc;
     GemmArgs a{};
     a.a0 = y_in;
     a.p0 = pro_in->scale; a.p1 = pro_in->shift; a.act = pro_in->act;
     a.z_res = residual; a.z_out = z_out;
-    a.w = w; a.out = y;
+    a.w = w; a.out = y; a.stats = stats;
     a.M = M; a.HW = HW; a.Kin = K; a.Nout = N;
     const int rc = f32_reg_launch(a, reinterpret_cast<hipStream_t>(stream));
     if (rc != T3D_ERR_UNSUPPORTED) return rc;

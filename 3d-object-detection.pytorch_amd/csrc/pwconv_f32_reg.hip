@@ -31,19 +31,19 @@ namespace {
 // Variant V: 0 the clamp form; 1 hard-swish; 2 one step (K <= 16: one operand buffer -- 40 registers less, a third wave per SIMD
 // at 4 x 6); 3 / 4 the MATERIALISING forward (t3d_pwconv_fwd_mat): the operand is the finished block output z = scale x + shift
 // (3) + residual (4: one more float4 per pixel row and step), and the workgroups of output chunk 0 also store it to z_out;
-// 5 the TRAINING forward: BatchNorm sums of the output (column sums of y and y^2 over the valid pixels) -- the workgroups are
+// SF (any of 0, 1, 3, 4) the TRAINING forward: BatchNorm sums of the output (column sums of y and y^2 over the valid pixels) -- the workgroups are
 // persistent over the pixel blocks, the column sums of every 16-pixel group (fp32, DPP) go to fp64 LDS accumulators and leave
 // as one fp64 atomic per channel and workgroup into a reduction replica.  fp32 values added in fp64: exact, so the sums do not
 // depend on the order (run-to-run bit-identical like the tiled kernel's);
 // 6 the DATA GRADIENT (t3d_pwconv_dgrad without gates / per-sample coefficients): the operand is the BatchNorm-backward affine of
 // two tensors, alpha dz + beta y + gamma (one more float4 per pixel row and step); epilogue: x the activation derivative at the
 // differentiated conv's input (e_y, e_scale, e_shift, e_act), + the residual gradient, and the sums of dx and dx . e_y (or dx^2)
-// for the producer's BatchNorm backward -- persistent like 5.
-template <int R, int NT, int V>
+// for the producer's BatchNorm backward -- persistent like the SF variants.
+template <int R, int NT, int V, bool SF>
 __global__ __launch_bounds__(256) void pw_f32_reg_kernel(const GemmArgs a, const int KG, const int nchunks, const float lo,
                                                          const float hi, const int nrep, const long long rstride) {
   extern __shared__ __attribute__((aligned(16))) float smem_f[];
-  constexpr bool HS = V == 1, ONE = V == 2, ZM = V == 3 || V == 4, ZR = V == 4, DG = V == 6, ST = V == 5 || DG;
+  constexpr bool HS = V == 1, ONE = V == 2, ZM = V == 3 || V == 4, ZR = V == 4, DG = V == 6, ST = SF || DG;
   constexpr int KS = 16;                                              // contraction indices per step
   float* coef = smem_f;                                               // [2][KG * KS]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lc = lane & 15, lg = lane >> 4;
@@ -233,7 +233,7 @@ int launch_reg(GemmArgs& a, hipStream_t st) {
   long long npw = (long long)cdiv(npb4, 8) * 8;
   if constexpr (R == 4 && NT > 4) {
     if (a.dgrad) return launch_reg<2, NT>(a, st);            // (three operand streams: 308 / 364 registers at 4 x 5 / 4 x 6)
-    if (a.stats && NT == 6) return launch_reg<2, NT>(a, st); // (260 registers with the sums' epilogue)
+    if (a.stats && (NT == 6 || a.z_res)) return launch_reg<2, NT>(a, st); // (260 registers with the sums' epilogue at 4 x 6)
   }
   if (a.stats || a.dgrad) {                                  // persistent: two workgroups per CU, whole XCD lanes
     const long long cap = (512 / nchunks) / 8 * 8;
@@ -246,15 +246,20 @@ int launch_reg(GemmArgs& a, hipStream_t st) {
   const long long rstride = g_t3d_reduce.stats_stride;
   const float inf = __builtin_inff();
   const float lo = (a.act == T3D_ACT_RELU || a.act == T3D_ACT_RELU6) ? 0.f : -inf, hi = a.act == T3D_ACT_RELU6 ? 6.f : inf;
-#define T3D_REG_LAUNCH(VV) \
-  T3D_LAUNCH((pw_f32_reg_kernel<R, NT, VV>), dim3((unsigned)grid), dim3(256), lds, st, a, KG, nchunks, lo, hi, nrep, rstride)
-  if (a.dgrad) T3D_REG_LAUNCH(6);
-  else if (a.stats) T3D_REG_LAUNCH(5);
-  else if (a.z_out && a.z_res) T3D_REG_LAUNCH(4);
-  else if (a.z_out) T3D_REG_LAUNCH(3);
-  else if (a.act == T3D_ACT_HSWISH) T3D_REG_LAUNCH(1);
-  else if (KG == 1) T3D_REG_LAUNCH(2);
-  else T3D_REG_LAUNCH(0);
+#define T3D_REG_LAUNCH(VV, SS) \
+  T3D_LAUNCH((pw_f32_reg_kernel<R, NT, VV, SS>), dim3((unsigned)grid), dim3(256), lds, st, a, KG, nchunks, lo, hi, nrep, rstride)
+  if (a.dgrad) T3D_REG_LAUNCH(6, false);
+  else if (a.stats) {
+    if (a.z_out && a.z_res) T3D_REG_LAUNCH(4, true);
+    else if (a.z_out) T3D_REG_LAUNCH(3, true);
+    else if (a.act == T3D_ACT_HSWISH) T3D_REG_LAUNCH(1, true);
+    else T3D_REG_LAUNCH(0, true);
+  }
+  else if (a.z_out && a.z_res) T3D_REG_LAUNCH(4, false);
+  else if (a.z_out) T3D_REG_LAUNCH(3, false);
+  else if (a.act == T3D_ACT_HSWISH) T3D_REG_LAUNCH(1, false);
+  else if (KG == 1) T3D_REG_LAUNCH(2, false);
+  else T3D_REG_LAUNCH(0, false);
 #undef T3D_REG_LAUNCH
   T3D_CHECK_LAUNCH();
   return T3D_OK;
@@ -281,8 +286,8 @@ int f32_reg_launch(GemmArgs& a, hipStream_t st) {
       return T3D_ERR_UNSUPPORTED;
   } else
   if (a.ps_stats || a.p2 || a.a1 || a.a2 || a.cv.mode || a.fold || a.per_sample || a.e_se || a.kz > 1 ||
-      a.wfrag || (a.z_res && !a.z_out) || (a.z_out && (a.act != T3D_ACT_NONE || a.bias || a.stats)) ||
-      (a.stats && (a.act == T3D_ACT_HSWISH || !a.out)))
+      a.wfrag || (a.z_res && !a.z_out) || (a.z_out && (a.act != T3D_ACT_NONE || a.bias)) ||
+      (a.stats && !a.out))
     return T3D_ERR_UNSUPPORTED;
   if ((a.Kin % 8) || (a.Nout % 8) || a.M < 1024) return T3D_ERR_UNSUPPORTED;      // (few-pixel layers: the split-contraction path)
   // Task shape (tools/time_pw_f32.py --sweep): output tiles per wave = the count that pads the layer's tiles least, 5 and 4

@@ -185,7 +185,7 @@ def test_pwconv_fwd_f32_inference_streaming_kernel(M, K, N, mode):
 # exact adds, so the order does not matter), spread over the reduction replicas, bit-identical from run to run
 @pytest.mark.parametrize('M,K,N', [(4096, 16, 96), (3001, 24, 144), (2048, 144, 24), (1031, 384, 96), (1024, 960, 160),
                                    (1100, 160, 960), (100000, 32, 16), (1111, 40, 240), (2000, 8, 8)])
-@pytest.mark.parametrize('mode', ['plain', 'relu6', 'bias'])
+@pytest.mark.parametrize('mode', ['plain', 'relu6', 'bias', 'hswish'])
 @pytest.mark.parametrize('nrep', [1, 16])
 def test_pwconv_fwd_f32_training_forward_register_kernel(M, K, N, mode, nrep):
     from torchdet3d import _native as Nt
@@ -224,7 +224,8 @@ def test_pwconv_fwd_f32_training_forward_register_kernel(M, K, N, mode, nrep):
 @pytest.mark.parametrize('M,K,N', [(4096, 16, 96), (3001, 24, 144), (1500, 32, 192), (1031, 96, 576), (1100, 160, 960),
                                    (1024, 320, 1280), (1111, 40, 240), (2000, 8, 8)])
 @pytest.mark.parametrize('res', [False, True])
-def test_pwconv_fwd_mat_f32_inference_one_launch(M, K, N, res):
+@pytest.mark.parametrize('train', [False, True])
+def test_pwconv_fwd_mat_f32_inference_one_launch(M, K, N, res, train):
     from torchdet3d import _native as Nt
     g = torch.Generator().manual_seed(M + K + N + res)
     y3 = torch.randn(M, K, generator=g).cuda()
@@ -236,13 +237,24 @@ def test_pwconv_fwd_mat_f32_inference_one_launch(M, K, N, res):
     Nt.call('t3d_bn_apply', Nt.F32, Nt.ptr(y3), p, Nt.ptr(r), Nt.ptr(z_ref), M, K, Nt.stream())
     z = torch.full((M + 1, K), 7.0, device='cuda')
     y = torch.full((M + 1, N), 7.0, device='cuda')
+    # train: the training forward (BatchNorm sums of y into reduction replicas) in the same single launch
+    stats = torch.zeros(8, 2 * N, device='cuda', dtype=torch.float64) if train else None
+    if train:
+        Nt.call('t3d_set_reduction_replicas', 8, 2 * N)
     n0 = Nt.launch_count()
-    Nt.call('t3d_pwconv_fwd_mat', Nt.F32, Nt.ptr(y3), p, Nt.ptr(r), Nt.ptr(z), Nt.ptr(w), Nt.ptr(y), None, M, 1, K, N, Nt.stream())
+    try:
+        Nt.call('t3d_pwconv_fwd_mat', Nt.F32, Nt.ptr(y3), p, Nt.ptr(r), Nt.ptr(z), Nt.ptr(w), Nt.ptr(y), Nt.ptr(stats), M, 1, K, N, Nt.stream())
+    finally:
+        Nt.call('t3d_set_reduction_replicas', 1, 0)
     torch.cuda.synchronize()
     assert Nt.launch_count() - n0 == 1
     assert torch.equal(z[:M], z_ref) and torch.all(z[M] == 7.0) and torch.all(y[M] == 7.0)
     ref = z_ref.double() @ w.double().t()
     np.testing.assert_allclose(y[:M].cpu().numpy(), ref.float().cpu().numpy(), atol=1e-5 * max(1., ref.abs().max().item()), rtol=1e-5)
+    if train:
+        st = stats.sum(0).view(2, N)
+        np.testing.assert_allclose(st[0].cpu().numpy(), y[:M].double().sum(0).cpu().numpy(), rtol=1e-5, atol=1e-4 * M ** .5)
+        np.testing.assert_allclose(st[1].cpu().numpy(), (y[:M].double() ** 2).sum(0).cpu().numpy(), rtol=1e-5, atol=1e-4)
 
 
 # projection-conv data gradients of the 14x14 / 7x7 stages: contraction over 96 / 160 / 320 channels -> the deep-round
