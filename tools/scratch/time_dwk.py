@@ -1,8 +1,8 @@
 """Isolated timing of MobileNetV3-large's 5x5 / squeeze-excite depthwise layers (csrc/dwconvk_stream.hip forward,
-csrc/dwconv5_bwd_stream.hip backward) at batch 256, bf16 storage, per channels-per-thread setting (T3D_DWK_CH).
+csrc/dwconv5_bwd_stream.hip backward) at batch 256, bf16 storage, per channels-per-thread setting (T3D_DWK_NC).
 usage: python tools/time_dwk.py"""
 import os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path[:0] = [ROOT, os.path.join(ROOT, '3d-object-detection.pytorch_amd')]
 import torch
 from torchdet3d import _native as N
