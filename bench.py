@@ -406,7 +406,11 @@ def main():
                                           if use_api else 'models.engine.Net + loss / optimizer entry points'),
                        'step_form': (('one t3d_plan_run call per step (recorded step plan: %d launches, %d stream forks)'
                                       % (N.lib().t3d_plan_num_ops(sp.rec.plan, 0), N.lib().t3d_plan_num_ops(sp.rec.plan, 1)))
-                                     if ptimer is not None else 'one host call per launch'),
+                                     if ptimer is not None else
+                                     ('eval-mode forward replayed from a recorded plan (one t3d_plan_run, %d launches) + the metric launches'
+                                      % N.lib().t3d_plan_num_ops(model._forward_plan().rec.plan, 0))
+                                     if (args.eval and use_api and getattr(model._forward_plan(), 'rec', None) is not None) else
+                                     'one host call per launch'),
                        'roofline_sampled_steps': nsampled,
                        'device_warmup_s': device_warmup_s, 'step_ms_min_med_max': [round(per_step[0], 3), round(per_step[len(per_step) // 2], 3), round(per_step[-1], 3)], 'side_stream_probe': list(__import__('torchdet3d.models.engine', fromlist=['x'])._concurrent_stream.log), 'rccl_ranks': world if dist.is_initialized() else 0},
         }
