@@ -120,9 +120,16 @@ int t3d_pw_wgrad_f32_reg(const float* dz, const float* y, const t3d_bnbwd* bb, c
   a.M = M; a.K = K; a.N = N;
   const int tn = cdiv(N, 64), tk = cdiv(K, 64);
   a.tk = tk;
-  // pixel splits: ~3072 waves over the chip (two per SIMD and half a round more; <= 48 MB of partial tiles), at least 128 steps
-  // each, whole ring rounds
-  int S = 3072 / (tn * tk);
+  // pixel splits: whole rounds of workgroups -- 256 k workgroups of four splits each over the (tn tk) blocks, the largest k <= 3 that
+  // leaves a split >= 512 pixels (128 steps); measured per layer (tools/time_pw_f32_bwd.py): 28x28 x 256, 3 blocks: 392 splits
+  // = 294 workgroups 97 us, 340 splits = 255 workgroups 67 us; <= 48 MB of partial tiles
+  int SGsel = 0;
+  for (int k = 3; k >= 1 && !SGsel; --k) {
+    const int sg = (256 * k) / (tn * tk);
+    if (sg >= 1 && (M / (4 * sg) >= 512 || k == 1)) SGsel = sg;
+  }
+  int S = 4 * (SGsel > 0 ? SGsel : 1);
+  if (const char* e = getenv("T3D_WG32_WAVES")) S = atoi(e) / (tn * tk);      // (sweep knob)
   const int maxs = cdiv(M, 512);
   if (S > maxs) S = maxs;
   if (S < 4) S = 4;
