@@ -38,12 +38,14 @@ namespace {
 // 6 the DATA GRADIENT (t3d_pwconv_dgrad without gates / per-sample coefficients): the operand is the BatchNorm-backward affine of
 // two tensors, alpha dz + beta y + gamma (one more float4 per pixel row and step); epilogue: x the activation derivative at the
 // differentiated conv's input (e_y, e_scale, e_shift, e_act), + the residual gradient, and the sums of dx and dx . e_y (or dx^2)
-// for the producer's BatchNorm backward -- persistent like the SF variants.
+// for the producer's BatchNorm backward -- persistent like the SF variants;
+// 7 / 8 the clamp form / hard-swish with a squeeze-excite gate on the operand (p2 [B][K], multiplied in before or after the activation).
 template <int R, int NT, int V, bool SF>
 __global__ __launch_bounds__(256) void pw_f32_reg_kernel(const GemmArgs a, const int KG, const int nchunks, const float lo,
                                                          const float hi, const int nrep, const long long rstride) {
   extern __shared__ __attribute__((aligned(16))) float smem_f[];
-  constexpr bool HS = V == 1, ONE = V == 2, ZM = V == 3 || V == 4, ZR = V == 4, DG = V == 6, ST = SF || DG;
+  constexpr bool GT = V == 7 || V == 8;           // squeeze-excite gate of the operand: p2 [B][K], before or after the activation
+  constexpr bool HS = V == 1 || V == 8, ONE = V == 2, ZM = V == 3 || V == 4, ZR = V == 4, DG = V == 6, ST = SF || DG;
   constexpr int KS = 16;                                              // contraction indices per step
   float* coef = smem_f;                                               // [2][KG * KS]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lc = lane & 15, lg = lane >> 4;
@@ -80,17 +82,17 @@ __global__ __launch_bounds__(256) void pw_f32_reg_kernel(const GemmArgs a, const
   for (int r = 0; r < R; ++r) xp[r] = x + (size_t)min(m0 + 16 * r + lc, a.M - 1) * K;
 #pragma unroll
   for (int t = 0; t < NT; ++t) wp[t] = w + (size_t)min(n0 + 16 * t + lc, N - 1) * K;
-  f32x4 xa[ONE ? 1 : 2][R], wa[ONE ? 1 : 2][NT], ra[ZR || DG ? 2 : 1][ZR || DG ? R : 1];
-  const float* __restrict__ res = reinterpret_cast<const float*>(DG ? a.a1 : a.z_res);      // second operand tensor
+  f32x4 xa[ONE ? 1 : 2][R], wa[ONE ? 1 : 2][NT], ra[ZR || DG || GT ? 2 : 1][ZR || DG || GT ? R : 1];
+  const float* __restrict__ res = GT ? a.p2 : reinterpret_cast<const float*>(DG ? a.a1 : a.z_res);      // second operand tensor / gates
   float* __restrict__ zo = reinterpret_cast<float*>(a.z_out);
   size_t roff[R];                                          // (ZM: residual / z_out rows = the operand's rows)
 #pragma unroll
-  for (int r = 0; r < R; ++r) roff[r] = (size_t)min(m0 + 16 * r + lc, a.M - 1) * K;
+  for (int r = 0; r < R; ++r) roff[r] = (size_t)(GT ? min(m0 + 16 * r + lc, a.M - 1) / a.HW : min(m0 + 16 * r + lc, a.M - 1)) * K;     // (GT: the sample's gate row)
   auto load = [&](int g, int b) {
     const int k = min(KS * g + 4 * lg, K - 4);            // (past K: a valid address; the coefficients there are zeros)
 #pragma unroll
     for (int r = 0; r < R; ++r) xa[b][r] = *reinterpret_cast<const f32x4*>(xp[r] + k);
-    if constexpr (ZR || DG) {
+    if constexpr (ZR || DG || GT) {
 #pragma unroll
       for (int r = 0; r < R; ++r) ra[b][r] = *reinterpret_cast<const f32x4*>(res + roff[r] + k);
     }
@@ -132,8 +134,11 @@ __global__ __launch_bounds__(256) void pw_f32_reg_kernel(const GemmArgs a, const
     for (int r = 0; r < R; ++r)
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        const float u = fmaf(xa[b][r][j], sc[j], sh[j]);
-        xa[b][r][j] = HS ? u * (__builtin_amdgcn_fmed3f(u + 3.f, 0.f, 6.f) * T3D_SIXTH) : __builtin_amdgcn_fmed3f(u, lo, hi);
+        float u = fmaf(xa[b][r][j], sc[j], sh[j]);
+        if constexpr (GT) u *= a.se_after ? 1.f : ra[b][r][j];
+        u = HS ? u * (__builtin_amdgcn_fmed3f(u + 3.f, 0.f, 6.f) * T3D_SIXTH) : __builtin_amdgcn_fmed3f(u, lo, hi);
+        if constexpr (GT) u *= a.se_after ? ra[b][r][j] : 1.f;
+        xa[b][r][j] = u;
       }
     }
 #pragma unroll
@@ -234,6 +239,7 @@ int launch_reg(GemmArgs& a, hipStream_t st) {
   if constexpr (R == 4 && NT > 4) {
     if (a.dgrad) return launch_reg<2, NT>(a, st);            // (three operand streams: 308 / 364 registers at 4 x 5 / 4 x 6)
     if (a.stats && (NT == 6 || a.z_res)) return launch_reg<2, NT>(a, st); // (260 registers with the sums' epilogue at 4 x 6)
+    if (a.p2 && !a.dgrad) return launch_reg<2, NT>(a, st);                // (gates: one more float4 per pixel row and step)
   }
   if (a.stats || a.dgrad) {                                  // persistent: two workgroups per CU, whole XCD lanes
     const long long cap = (512 / nchunks) / 8 * 8;
@@ -249,6 +255,10 @@ int launch_reg(GemmArgs& a, hipStream_t st) {
 #define T3D_REG_LAUNCH(VV, SS) \
   T3D_LAUNCH((pw_f32_reg_kernel<R, NT, VV, SS>), dim3((unsigned)grid), dim3(256), lds, st, a, KG, nchunks, lo, hi, nrep, rstride)
   if (a.dgrad) T3D_REG_LAUNCH(6, false);
+  else if (a.p2) {
+    if (a.stats) { if (a.act == T3D_ACT_HSWISH) T3D_REG_LAUNCH(8, true); else T3D_REG_LAUNCH(7, true); }
+    else { if (a.act == T3D_ACT_HSWISH) T3D_REG_LAUNCH(8, false); else T3D_REG_LAUNCH(7, false); }
+  }
   else if (a.stats) {
     if (a.z_out && a.z_res) T3D_REG_LAUNCH(4, true);
     else if (a.z_out) T3D_REG_LAUNCH(3, true);
@@ -285,7 +295,7 @@ int f32_reg_launch(GemmArgs& a, hipStream_t st) {
         a.wfrag || a.bias || a.z_out || a.z_res || !a.out)
       return T3D_ERR_UNSUPPORTED;
   } else
-  if (a.ps_stats || a.p2 || a.a1 || a.a2 || a.cv.mode || a.fold || a.per_sample || a.e_se || a.kz > 1 ||
+  if (a.ps_stats || (a.p2 && a.z_out) || a.a1 || a.a2 || a.cv.mode || a.fold || a.per_sample || a.e_se || a.kz > 1 ||
       a.wfrag || (a.z_res && !a.z_out) || (a.z_out && (a.act != T3D_ACT_NONE || a.bias)) ||
       (a.stats && !a.out))
     return T3D_ERR_UNSUPPORTED;

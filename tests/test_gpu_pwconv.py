@@ -219,6 +219,43 @@ def test_pwconv_fwd_f32_training_forward_register_kernel(M, K, N, mode, nrep):
     np.testing.assert_allclose(st[1].cpu().numpy(), (y.double() ** 2).sum(0).cpu().numpy(), rtol=1e-5, atol=1e-4)
 
 
+# fp32 storage, squeeze-excite gated operand (MobileNetV3's projection convs) on the register-operand kernel (variants 7 / 8): gate
+# before the activation (hard-swish) or after it (ReLU), inference and training forward (BatchNorm sums); against fp64
+@pytest.mark.parametrize('B,HW,K,N', [(8, 196, 72, 40), (9, 130, 120, 40), (16, 100, 480, 112), (5, 333, 960, 160), (256, 49, 672, 160)])
+@pytest.mark.parametrize('mode', ['se_pre', 'se_post'])
+@pytest.mark.parametrize('train', [False, True])
+def test_pwconv_fwd_f32_gated_register_kernel(B, HW, K, N, mode, train):
+    from torchdet3d import _native as Nt
+    g = torch.Generator().manual_seed(B + HW + K + N + 1)
+    M = B * HW
+    x = torch.randn(M, K, generator=g).cuda()
+    w = (torch.randn(N, K, generator=g) / K ** 0.5).cuda()
+    sc, sh = (torch.rand(K, generator=g) + 0.5).cuda(), (torch.randn(K, generator=g) * 0.3).cuda()
+    se = torch.rand(B, K, generator=g).cuda()
+    sev = se.repeat_interleave(HW, 0)
+    act = 'hswish' if mode == 'se_pre' else 'relu'
+    u = x * sc + sh
+    a = _act(u * sev, act) if mode == 'se_pre' else _act(u, act) * sev
+    ref = a.double() @ w.double().t()
+    p = Nt.prologue(sc, sh, se, act, mode == 'se_post')
+    y = torch.full((M + 1, N), 7.0, device='cuda')
+    stats = torch.zeros(4, 2 * N, device='cuda', dtype=torch.float64) if train else None
+    if train:
+        Nt.call('t3d_set_reduction_replicas', 4, 2 * N)
+    n0 = Nt.launch_count()
+    try:
+        Nt.call('t3d_pwconv_fwd', Nt.F32, Nt.ptr(x), p, Nt.ptr(w), None, Nt.ptr(y), Nt.ptr(stats), M, HW, K, N, Nt.stream())
+    finally:
+        Nt.call('t3d_set_reduction_replicas', 1, 0)
+    torch.cuda.synchronize()
+    assert Nt.launch_count() - n0 == 1 and torch.all(y[M] == 7.0)
+    np.testing.assert_allclose(y[:M].cpu().numpy(), ref.float().cpu().numpy(), atol=1e-5 * max(1., ref.abs().max().item()), rtol=1e-5)
+    if train:
+        st = stats.sum(0).view(2, N)
+        np.testing.assert_allclose(st[0].cpu().numpy(), y[:M].double().sum(0).cpu().numpy(), rtol=1e-5, atol=1e-4 * M ** .5)
+        np.testing.assert_allclose(st[1].cpu().numpy(), (y[:M].double() ** 2).sum(0).cpu().numpy(), rtol=1e-5, atol=1e-4)
+
+
 # fp32 storage, inference: the materialising forward in ONE launch (csrc/pwconv_f32_reg.hip, variants 3 / 4): z is bit-equal to
 # t3d_bn_apply's, y within 1e-5 of fp64; ragged contraction (24, 40: the store and the operand past K), ragged pixel counts
 @pytest.mark.parametrize('M,K,N', [(4096, 16, 96), (3001, 24, 144), (1500, 32, 192), (1031, 96, 576), (1100, 160, 960),
