@@ -8,8 +8,10 @@
 // 64 / 32 output channels, so the launch splits into 3 - 10 output chunks and every chunk reads AND TRANSFORMS the whole
 // operand again (BatchNorm affine + activation, or the two-tensor BatchNorm-backward affine): 320 <- 1280 at 7x7 ran 126 us
 // for 10 GFLOP.  Here the roles are swapped:
-//   * a workgroup (4 waves, ONE per SIMD: the whole 512-register budget each) owns 64 pixels and all output channels of its
-//     chunk (<= 192); the operand is read and transformed ONCE, in phases of 8 k-steps, into a double-buffered LDS tile in
+//   * a workgroup (8 waves, two per SIMD -- round 5: the weight stream of ONE wave per SIMD with the whole register file, a phase
+//     of 8 k-steps x 3 tiles ahead, ran at ~25 GB/s per CU; eight waves with 4 k-steps x 2 tiles ahead each: 960 -> 160 @7x7
+//     22.6 -> 18.3 us, 320 <- 1280 83.8 -> 59.4, ResNet-50's 1024 <- 2048 @7x7 111 -> 45) owns 64 pixels and all output channels
+//     of its chunk (<= 256); the operand is read and transformed ONCE, in phases of 4 k-steps, into a double-buffered LDS tile in
 //     MFMA-fragment order ([row tile][k-step][lane] x 16 B: linear, conflict-free writes and reads);
 //   * the WEIGHTS are streamed from L2 straight into registers, a whole phase ahead.  They have to be in fragment order in
 //     memory ([16-row tile][k-step][lane] x 16 B, rows in the streaming kernel's pair permutation, zero padded: include/t3d.h):
@@ -52,14 +54,14 @@ __device__ unsigned long long g_deep_trace[16];
 #endif
 
 constexpr int RT = 4;        // row tiles (16 pixels) per block
-constexpr int KSP = 8;       // k-steps per phase (one LDS buffer = RT * KSP KB)
-constexpr int NW = 4;        // waves per block
-constexpr int NTW = 3;       // 16-row tiles per wave: tiles wave, wave + 4, wave + 8 of the chunk (<= 12 tiles = 192 channels)
-constexpr int IT = RT * KSP / NW;   // staging items (16 rows x 32 k) per wave per phase: row tile `wave`, every k-step
+constexpr int KSP = 4;       // k-steps per phase (one LDS buffer = RT * KSP KB)
+constexpr int NW = 8;        // waves per block: two per SIMD (round 5; one per SIMD with the whole register file before)
+constexpr int NTW = 2;       // 16-row tiles per wave: tiles wave, wave + 8 of the chunk (<= 16 tiles = 256 channels)
+constexpr int IT = RT * KSP / NW;   // staging items (16 rows x 32 k) per wave per phase: row tile wave % RT, k-steps (wave / RT) * IT .. + IT - 1
 
 // CV: implicit 3x3 convolution (GemmArgs::cv) -- a compile-time variant: the plain kernel's phase loop stays branch-free
 template <bool DG, bool CV = false>
-__global__ __launch_bounds__(64 * NW, 1) void pw_deep_kernel(const GemmArgs a, const int KS, const int ntiles, const int nrep,
+__global__ __launch_bounds__(64 * NW) void pw_deep_kernel(const GemmArgs a, const int KS, const int ntiles, const int nrep,
                                                              const long long rstride) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   bf16x8* Af = reinterpret_cast<bf16x8*>(smem);                                   // [2][RT][KSP][64]
@@ -102,9 +104,10 @@ __global__ __launch_bounds__(64 * NW, 1) void pw_deep_kernel(const GemmArgs a, c
     }
   };
   // operand rows of this wave's staging items
-  const int mrow = min(m0 + wave * 16 + lc, a.M - 1);
+  const int srt = wave % RT, sks = (wave / RT) * IT;      // this wave's staging items: row tile srt, k-steps sks .. sks + IT - 1 of a phase
+  const int mrow = min(m0 + srt * 16 + lc, a.M - 1);
   const size_t arow = (size_t)mrow * a.Kin + lg * 8;
-  const bool rok = m0 + wave * 16 + lc < a.M;
+  const bool rok = m0 + srt * 16 + lc < a.M;
   // implicit 3x3 convolution (pwconv_common.h: Conv3): this lane's destination pixel, once
   constexpr bool cv = CV;
   int cvb = 0, cvy = 0, cvx = 0;
@@ -142,10 +145,10 @@ __global__ __launch_bounds__(64 * NW, 1) void pw_deep_kernel(const GemmArgs a, c
     for (int j = 0; j < IT; ++j) {
       size_t o;
       if constexpr (cv) {
-        const long long g = cv_off(ph * KSP + j);
+        const long long g = cv_off(ph * KSP + sks + j);
         o = g < 0 ? (size_t)lg * 8 : (size_t)g;                 // (an out-of-range tap reads a valid address; zeroed later)
       } else {
-        o = arow + min((ph * KSP + j) * 32, a.Kin - 8 - lg * 8);
+        o = arow + min((ph * KSP + sks + j) * 32, a.Kin - 8 - lg * 8);
       }
       pa[SL][j] = *reinterpret_cast<const bf16x8*>(A0 + o);
       if (DG) pb[DG ? SL : 0][DG ? j : 0] = *reinterpret_cast<const bf16x8*>(A1 + o);
@@ -215,9 +218,9 @@ __global__ __launch_bounds__(64 * NW, 1) void pw_deep_kernel(const GemmArgs a, c
     // ---- transform + store this phase's operand rows (issued two phases ago)
 #pragma unroll
     for (int j = 0; j < IT; ++j) {
-      const int k = (ph * KSP + j) * 32 + lg * 8;
+      const int k = (ph * KSP + sks + j) * 32 + lg * 8;
       bool ok = rok && (k < a.Kin);
-      if constexpr (cv) ok = ok && cv_off(ph * KSP + j) >= 0;
+      if constexpr (cv) ok = ok && cv_off(ph * KSP + sks + j) >= 0;
       const int kc = min(k, kpad - 8);
       const float4 c0a = *reinterpret_cast<const float4*>(coef + kc), c0b = *reinterpret_cast<const float4*>(coef + kc + 4);
       const float4 c1a = *reinterpret_cast<const float4*>(coef + kpad + kc),
@@ -248,7 +251,7 @@ __global__ __launch_bounds__(64 * NW, 1) void pw_deep_kernel(const GemmArgs a, c
       bf16x8 b;
 #pragma unroll
       for (int e = 0; e < 8; ++e) b[e] = ok ? (bf16_t)x[e] : (bf16_t)0.f;
-      Ab[(wave * KSP + j) * 64 + lane] = b;
+      Ab[(srt * KSP + sks + j) * 64 + lane] = b;
     }
     __syncthreads();
     if (ph == 0) DEEP_STAMP(2);
