@@ -54,15 +54,16 @@ __device__ unsigned long long g_deep_trace[16];
 #endif
 
 constexpr int RT = 4;        // row tiles (16 pixels) per block
-constexpr int KSP = 4;       // k-steps per phase (one LDS buffer = RT * KSP KB)
 constexpr int NW = 8;        // waves per block: two per SIMD (round 5; one per SIMD with the whole register file before)
-constexpr int NTW = 2;       // 16-row tiles per wave: tiles wave, wave + 8 of the chunk (<= 16 tiles = 256 channels)
-constexpr int IT = RT * KSP / NW;   // staging items (16 rows x 32 k) per wave per phase: row tile wave % RT, k-steps (wave / RT) * IT .. + IT - 1
 
 // CV: implicit 3x3 convolution (GemmArgs::cv) -- a compile-time variant: the plain kernel's phase loop stays branch-free
-template <bool DG, bool CV = false>
+template <bool DG, bool CV, int NTW, int KSP>
 __global__ __launch_bounds__(64 * NW) void pw_deep_kernel(const GemmArgs a, const int KS, const int ntiles, const int nrep,
                                                              const long long rstride) {
+  // NTW 16-row tiles per wave (tiles wave, wave + 8, .. of the chunk: <= 8 NTW tiles), KSP k-steps per phase (one LDS buffer = RT KSP KB);
+  // IT staging items (16 rows x 32 k) per wave per phase: row tile wave % RT, k-steps (wave / RT) * IT .. + IT - 1
+  constexpr int IT = RT * KSP / NW;
+  static_assert(IT >= 1 && IT * NW == RT * KSP, "staging items must divide over the waves");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   bf16x8* Af = reinterpret_cast<bf16x8*>(smem);                                   // [2][RT][KSP][64]
   const int kpad = KS * 32;
@@ -367,15 +368,15 @@ __global__ __launch_bounds__(64 * NW) void pw_deep_kernel(const GemmArgs a, cons
   DEEP_STAMP(5);
 }
 
-template <bool DG, bool CV = false>
+template <bool DG, bool CV, int NTW, int KSP>
 int launch_deep(GemmArgs& a, int KS, int ntiles, int nchunks, hipStream_t st) {
   const size_t lds = (size_t)2 * RT * KSP * 1024 + (size_t)3 * KS * 32 * 4 + (size_t)ntiles * 16 * (2 * 4 + 2 * 8);
   if (lds > 150 * 1024) return T3D_ERR_UNSUPPORTED;
-  const void* fn = (const void*)pw_deep_kernel<DG, CV>;
+  const void* fn = (const void*)pw_deep_kernel<DG, CV, NTW, KSP>;
   if (lds > 64 * 1024) (void)t3d_max_lds(fn, (int)lds);
   a.quant = (!DG && a.stats && !getenv("T3D_NO_SNAP")) ? t3d_quant_for(a.M) : T3dQuant{0.0, 0.0};
   a.fold = t3d_take_fold(a.p0);
-  T3D_LAUNCH((pw_deep_kernel<DG, CV>), dim3(cdiv(a.M, 16 * RT), nchunks), dim3(64 * NW), lds, st, a, KS, ntiles,
+  T3D_LAUNCH((pw_deep_kernel<DG, CV, NTW, KSP>), dim3(cdiv(a.M, 16 * RT), nchunks), dim3(64 * NW), lds, st, a, KS, ntiles,
                      g_t3d_reduce.nrep, g_t3d_reduce.stats_stride);
   T3D_CHECK_LAUNCH();
   return T3D_OK;
@@ -423,10 +424,21 @@ int deep_launch(GemmArgs& a, hipStream_t st) {
     return T3D_ERR_UNSUPPORTED;
   const int KS = cdiv(a.Kin, 32);
   const int pairs = cdiv(a.Nout, 32);
-  // chunks of <= 6 pairs of tiles (192 channels), evenly sized; every chunk stages the operand again (from L2)
-  const int nchunks = cdiv(pairs, NW * NTW / 2), ntiles = 2 * cdiv(pairs, nchunks);
-  if (a.cv.mode) return a.dgrad ? launch_deep<true, true>(a, KS, ntiles, nchunks, st) : launch_deep<false, true>(a, KS, ntiles, nchunks, st);
-  return a.dgrad ? launch_deep<true>(a, KS, ntiles, nchunks, st) : launch_deep<false>(a, KS, ntiles, nchunks, st);
+  // Two shapes of a wave's share (measured, tools/scratch/deep_rot_ab.sh): 2 tiles x 4 k-steps of weights ahead (chunks of <= 16
+  // tiles = 256 channels), or 3 tiles x 2 k-steps (<= 24 tiles = 384 channels) where that makes ONE chunk of two -- every chunk stages AND
+  // transforms the operand again: 960 -> 320 @7x7 35.2 us as two chunks of 10 tiles, 23.5 as one of 20; 320 <- 1280 59.4 / 39.1;
+  // 960 -> 160 (one chunk either way) 18.3 / 20.9.  Chunks evenly sized.
+  // OPT-IN (T3D_DEEP_WIDE=1): alone the two launches it changes get 12 and 20 us faster, the STEP does not (6.718 / 6.694 / 6.700
+  // ms with against 6.698 / 6.669 / 6.680 without, three same-box pairs) -- finding 20's lesson once more
+  const bool wide = pairs > 8 && pairs <= 12 && getenv("T3D_DEEP_WIDE");        // (one chunk instead of two; 32 pairs as 3 x 22 tiles ran 53 us, as 4 x 16 45)
+  const int per = wide ? 12 : 8;
+  const int nchunks = cdiv(pairs, per), ntiles = 2 * cdiv(pairs, nchunks);
+  if (wide) {
+    if (a.cv.mode) return a.dgrad ? launch_deep<true, true, 3, 2>(a, KS, ntiles, nchunks, st) : launch_deep<false, true, 3, 2>(a, KS, ntiles, nchunks, st);
+    return a.dgrad ? launch_deep<true, false, 3, 2>(a, KS, ntiles, nchunks, st) : launch_deep<false, false, 3, 2>(a, KS, ntiles, nchunks, st);
+  }
+  if (a.cv.mode) return a.dgrad ? launch_deep<true, true, 2, 4>(a, KS, ntiles, nchunks, st) : launch_deep<false, true, 2, 4>(a, KS, ntiles, nchunks, st);
+  return a.dgrad ? launch_deep<true, false, 2, 4>(a, KS, ntiles, nchunks, st) : launch_deep<false, false, 2, 4>(a, KS, ntiles, nchunks, st);
 }
 
 }  // namespace t3d_pw
