@@ -39,6 +39,11 @@ struct T3dReduceCfg {
 };
 extern T3dReduceCfg g_t3d_reduce;
 
+// Environment switches on launch paths are read ONCE per process (getenv walks the whole environment block): a
+// lambda per use site holds its own static.  The two switches the test suite flips inside one process (T3D_F32_TILED,
+// T3D_DW_TILED: A/B against the round-1 kernels) and the fp32 sweep knob T3D_F32_SHAPE stay plain getenv calls.
+#define T3D_ENV_SET(name) ([]() -> bool { static const bool v = getenv(name) != nullptr; return v; }())
+
 // Kernel-exact timing of the NEXT depthwise launch (t3d_set_launch_events, misc.hip): the two events are attached to the
 // kernel's own dispatch (hipExtLaunchKernelGGL), so their difference is the kernel's begin-to-end time -- what rocprofv3
 // reports -- and not that plus the ~5-9 us of event-record packets and dispatch latency an event pair AROUND the launch
@@ -52,6 +57,11 @@ extern T3dLaunchEvents g_t3d_time;
 // packet (an event recorded behind a kernel is a barrier packet of its own, and the kernel behind it started 6-30 us late:
 // ~35 of them per training step were most of the main queue's 0.3 ms of gaps).  Also counts launches, so that a plan being
 // recorded knows which calls launched a kernel and on which stream.
+// RULE (tests/test_abi.py::test_every_kernel_launch_goes_through_the_launch_macro holds the sources to it): the
+// hand-off waits for "the last kernel of the last call that launched on that stream", so (a) every kernel of the library is
+// launched through T3D_LAUNCH / T3D_LAUNCH_TIMED -- never a bare hipLaunchKernelGGL or <<< >>> -- and (b) an entry point
+// that enqueues non-kernel stream work (hipMemsetAsync) does so BEFORE its last kernel launch: the stream is in order, so
+// that kernel's completion covers it.  A trailing memset / copy would not be waited for by a replayed fork.
 struct T3dSignal { hipEvent_t ev; hipStream_t stream; };
 extern T3dSignal g_t3d_signal;
 extern unsigned long long g_t3d_launches;

@@ -792,7 +792,7 @@ int launch_s1c(Dw3BArgs& a, hipStream_t st) {
     a.dw_used = a.dw ? g_t3d_reduce.dw_used : nullptr;
   }
   const size_t lds = (size_t)22 * ((two_col && a.slab) ? 64 * CH : a.C) * sizeof(float);   // [11][Cb] fp64 reduction scratch (before it: [9][Cb] weights, [3][Cb] derived coefficients)
-  a.noflush = getenv("T3D_DEBUG_NOFLUSH") ? 1 : 0;
+  a.noflush = T3D_ENV_SET("T3D_DEBUG_NOFLUSH") ? 1 : 0;
   // a pending BatchNorm-backward finalize of this launch's gradient coefficients is derived in the two-column kernel
   if (two_col && !a.per_sample) {
     a.fold = t3d_take_fold(a.alpha);
@@ -1177,7 +1177,7 @@ int launch_s2(Dw3BArgs& a, hipStream_t st) {
     a.dw_used = a.dw ? g_t3d_reduce.dw_used : nullptr;
   }
   const size_t lds = (size_t)22 * (a.slab ? 64 * CH : a.C) * sizeof(float);   // [11][Cb] fp64
-  a.noflush = getenv("T3D_DEBUG_NOFLUSH") ? 1 : 0;
+  a.noflush = T3D_ENV_SET("T3D_DEBUG_NOFLUSH") ? 1 : 0;
   // (in front of t3d_take_fold: a refused launch leaves the pending finalize request to the tiled fallback)
   if ((size_t)a.B * a.H * a.W * a.C * sizeof(T) >= (1ull << 31)) return T3D_ERR_UNSUPPORTED;     // 32-bit buffer offsets
   if (!a.per_sample) {

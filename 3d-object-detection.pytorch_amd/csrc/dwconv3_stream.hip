@@ -630,7 +630,7 @@ int launch_ch(Dw3Args& a, int s, hipStream_t st) {
   a.fold = t3d_take_fold(a.scale);
   // (throughput mode only: in fp32 storage the sums' order noise stays at 1e-6 of the outputs and the grid would be one more
   // perturbation between the parity mode and the reference)
-  a.quant = (a.stats && std::is_same<T, bf16_t>::value && !getenv("T3D_NO_SNAP")) ? t3d_quant_for((long long)a.B * a.Ho * a.Wo)
+  a.quant = (a.stats && std::is_same<T, bf16_t>::value && !T3D_ENV_SET("T3D_NO_SNAP")) ? t3d_quant_for((long long)a.B * a.Ho * a.Wo)
                                                                                   : T3dQuant{0.0, 0.0};
   if (use2) {
     switch (a.act) {

@@ -331,7 +331,7 @@ extern "C" int t3d_dwconv_bwd(int dtype, const void* dz, const void* y, const t3
                               float* dw, int B, int H, int W, int C, int k, int stride, void* stream) {
   if (!dz || !y || !bb || !w || !x || !dx || B <= 0 || H <= 0 || W <= 0 || C <= 0 || (C % 8)) return T3D_ERR_ARG;
   if (pro && pro->se) return T3D_ERR_UNSUPPORTED;  // no SE gate ever precedes a depthwise conv
-  if (k == 3 && (stride == 1 || (stride == 2 && !getenv("T3D_DW_BWD_S2_TILED"))) && !getenv("T3D_DW_TILED")) {   // streaming kernel (dwconv3_bwd_stream.hip)
+  if (k == 3 && (stride == 1 || (stride == 2 && !T3D_ENV_SET("T3D_DW_BWD_S2_TILED"))) && !getenv("T3D_DW_TILED")) {   // streaming kernel (dwconv3_bwd_stream.hip)
     const int rc = t3d_dw3_bwd_stream(dtype, dz, y, bb, w, x, pro, residual, dx, stats, dw, B, H, W, C, stride,
                                       reinterpret_cast<hipStream_t>(stream));
     if (rc != T3D_ERR_UNSUPPORTED) return rc;

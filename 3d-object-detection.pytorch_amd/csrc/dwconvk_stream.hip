@@ -229,7 +229,7 @@ int launch_nc(DwkArgs& a, hipStream_t st) {
   }
   const size_t lds = (size_t)2 * (a.slab ? 64 * CH : a.C) * sizeof(double);
   // (throughput mode only, as in dwconv3_stream.hip)
-  a.quant = (a.stats && std::is_same<T, bf16_t>::value && !getenv("T3D_NO_SNAP")) ? t3d_quant_for((long long)a.B * a.Ho * a.Wo)
+  a.quant = (a.stats && std::is_same<T, bf16_t>::value && !T3D_ENV_SET("T3D_NO_SNAP")) ? t3d_quant_for((long long)a.B * a.Ho * a.Wo)
                                                                                   : T3dQuant{0.0, 0.0};
   T3D_LAUNCH_TIMED((dwk_fwd_kernel<T, K, S, NC>), grid, dim3(256), lds, st, a);
   T3D_CHECK_LAUNCH();

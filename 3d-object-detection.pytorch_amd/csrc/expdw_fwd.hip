@@ -307,16 +307,27 @@ __global__ __launch_bounds__(NTH) void expdw_fwd_kernel(const EdArgs a) {
   }
 }
 
+// threads per workgroup and 16-pixel fragment groups per wave for an input width (launch_s picks the instantiation from these)
+static int expdw_nth(int W) {
+  static const int nth_env = getenv("T3D_EXPDW_NTH") ? atoi(getenv("T3D_EXPDW_NTH")) : 0;
+  return nth_env ? nth_env : (W > 60 ? 512 : 256);
+}
+// input rows a workgroup can hold: the LDS budget and the per-wave fragment registers (gmax groups of 16 pixels) bound it;
+// fewer than 3 (one output row's stencil) means the shape is not served -- t3d_expdw_supported says so ahead of the launch
+static int expdw_rows(int W, int nth) {
+  static const int lds_kb_env = getenv("T3D_EXPDW_LDS_KB") ? atoi(getenv("T3D_EXPDW_LDS_KB")) : 0;
+  const int lds_kb = lds_kb_env ? lds_kb_env : (nth == 512 ? 150 : 76);
+  const int gmax = nth == 512 ? 5 : 7;
+  const size_t row_bytes = (size_t)(W + 2) * PS * 4;
+  const int ir = (int)(((size_t)lds_kb << 10) / row_bytes), ir_frag = (gmax * (nth / 64) * 16) / W;
+  return ir < ir_frag ? ir : ir_frag;
+}
+
 template <typename T, int S, int NTH, int ACT, int GMAX>
 int launch_g(EdArgs& a, hipStream_t st) {
-  constexpr int NW = NTH / 64;
-  // tile height: as many output rows as the LDS budget and the per-wave fragment registers (GMAX groups of 16 pixels) allow
-  static const int lds_kb_env = getenv("T3D_EXPDW_LDS_KB") ? atoi(getenv("T3D_EXPDW_LDS_KB")) : 0;
-  const int lds_kb = lds_kb_env ? lds_kb_env : (NTH == 512 ? 150 : 76);
+  static_assert(GMAX == (NTH == 512 ? 5 : 7), "expdw_rows assumes this pairing");
   const size_t row_bytes = (size_t)(a.W + 2) * PS * 4;
-  int ir = (int)(((size_t)lds_kb << 10) / row_bytes);
-  const int ir_frag = (GMAX * NW * 16) / a.W;
-  if (ir > ir_frag) ir = ir_frag;
+  const int ir = expdw_rows(a.W, NTH);
   if (ir < 3) return T3D_ERR_UNSUPPORTED;
   int th = (ir - 3) / S + 1;
   if (th > a.Ho) th = a.Ho;
@@ -343,7 +354,7 @@ int launch_g(EdArgs& a, hipStream_t st) {
   a.nrep = g_t3d_reduce.nrep;
   a.rstride = g_t3d_reduce.stats_stride;
   if (a.stats && a.nrep < 1) { a.nrep = 1; a.rstride = 0; }
-  a.quant = (a.stats && std::is_same<T, bf16_t>::value && !getenv("T3D_NO_SNAP")) ? t3d_quant_for((long long)a.B * a.Ho * a.Wo) : T3dQuant{0.0, 0.0};
+  a.quant = (a.stats && std::is_same<T, bf16_t>::value && !T3D_ENV_SET("T3D_NO_SNAP")) ? t3d_quant_for((long long)a.B * a.Ho * a.Wo) : T3dQuant{0.0, 0.0};
   T3D_LAUNCH_TIMED((expdw_fwd_kernel<T, S, NTH, ACT, GMAX>), dim3(grid), dim3(NTH), lds, st, a);
   T3D_CHECK_LAUNCH();
   return T3D_OK;
@@ -351,8 +362,7 @@ int launch_g(EdArgs& a, hipStream_t st) {
 
 template <typename T, int S, int ACT>
 int launch_s(EdArgs& a, hipStream_t st) {
-  static const int nth_env = getenv("T3D_EXPDW_NTH") ? atoi(getenv("T3D_EXPDW_NTH")) : 0;
-  const int nth = nth_env ? nth_env : (a.W > 60 ? 512 : 256);
+  const int nth = expdw_nth(a.W);
   if (nth == 512) return launch_g<T, S, 512, ACT, 5>(a, st);
   return launch_g<T, S, 256, ACT, 7>(a, st);
 }
@@ -364,6 +374,16 @@ int launch_t(EdArgs& a, int act, int stride, hipStream_t st) {
 }
 
 }  // namespace
+
+// include/t3d.h: would t3d_expdw_fwd take this shape?  (the same tests the launch makes, without launching)
+extern "C" int t3d_expdw_supported(int dtype, int act, int B, int H, int W, int K, int C, int stride) {
+  if (B <= 0 || H <= 0 || W <= 0 || K <= 0 || C <= 0) return 0;
+  if (dtype != T3D_BF16 && dtype != T3D_F16) return 0;
+  if ((K % 8) || (C % 8) || K > 32 || (stride != 1 && stride != 2) || W < 8) return 0;
+  if (act != T3D_ACT_RELU6 && act != T3D_ACT_RELU) return 0;
+  if ((size_t)B * H * W * C * 2 >= (1ull << 32)) return 0;
+  return expdw_rows(W, expdw_nth(W)) >= 3;
+}
 
 // include/t3d.h
 extern "C" int t3d_expdw_fwd(int dtype, const void* z, const void* w1, const float* scale1, const float* shift1, int act,

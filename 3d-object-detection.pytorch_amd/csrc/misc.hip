@@ -134,7 +134,9 @@ __global__ __launch_bounds__(256) void sum_slots_batched_kernel(const long long*
 __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g,
                                                     float* __restrict__ m, float* __restrict__ v, long long n4,
                                                     float decay, float omb1, float b2, float omb2, float step_size,
-                                                    float inv_sqrt_bc2, float eps, float gscale) {
+                                                    float inv_sqrt_bc2, float eps, float gscale, long long* watch,
+                                                    long long step) {
+  bool bad = false;
   for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
     float4 pp = reinterpret_cast<float4*>(p)[i];
     const float4 gg4 = reinterpret_cast<const float4*>(g)[i];
@@ -147,6 +149,7 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const float gj = ge[j] * gscale;
+      bad |= !(fabsf(gj) <= 3.4028235e38f);                         // inf or NaN
       const float pj = pe[j] * decay;
       const float mj = me[j] + (gj - me[j]) * omb1;                 // lerp(m, g, 1 - beta1)
       const float vj = ve[j] * b2 + omb2 * gj * gj;                 // 1 - beta taken in fp64 on the host, like PyTorch
@@ -159,6 +162,8 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
     reinterpret_cast<float4*>(m)[i] = mm;
     reinterpret_cast<float4*>(v)[i] = vv;
   }
+  // t3d_set_grad_watch: the first optimizer step that met a non-finite gradient (one atomic per wave that saw one)
+  if (watch && __any(bad) && (threadIdx.x & 63) == 0) atomicMin(reinterpret_cast<unsigned long long*>(watch), (unsigned long long)step);
 }
 
 // dst [rows][cd] <- src [rows][cs]: the leading min(cs, cd) columns are copied, further dst columns zeroed
@@ -235,6 +240,12 @@ __global__ void zero_batched_kernel(const long long* __restrict__ desc) {
 
 }  // namespace
 
+static long long* g_grad_watch = nullptr;
+extern "C" int t3d_set_grad_watch(long long* first_bad_step) {
+  g_grad_watch = first_bad_step;
+  return T3D_OK;
+}
+
 extern "C" int t3d_adamw_step(float* p, const float* g, float* m, float* v, long long n, double lr, double beta1,
                               double beta2, double eps, double weight_decay, long long step, double grad_scale,
                               void* stream) {
@@ -247,7 +258,7 @@ extern "C" int t3d_adamw_step(float* p, const float* g, float* m, float* v, long
   const int grid = (int)((n4 + 255) / 256 < 2048 ? (n4 + 255) / 256 : 2048);
   T3D_LAUNCH(adamw_kernel, dim3(grid), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), p, g, m, v, n4,
                      (float)(1.0 - lr * weight_decay), (float)(1.0 - b1d), (float)beta2, (float)(1.0 - b2d),
-                     (float)(lr / bc1), (float)(1.0 / sqrt(bc2)), (float)eps, (float)grad_scale);
+                     (float)(lr / bc1), (float)(1.0 / sqrt(bc2)), (float)eps, (float)grad_scale, g_grad_watch, step);
   T3D_CHECK_LAUNCH();
   return T3D_OK;
 }
@@ -417,10 +428,13 @@ extern "C" int t3d_set_workspace(void* ptr, long long bytes) {
 #include <mutex>
 #include <unordered_map>
 hipError_t t3d_max_lds(const void* fn, int bytes) {
+  // keyed by (device, kernel): a model moved to / built on a second GPU of the same process sets the attribute there too
   static std::mutex mu;
-  static std::unordered_map<const void*, int> seen;
+  static std::unordered_map<unsigned long long, int> seen;
+  int dev = 0;
+  (void)hipGetDevice(&dev);
   std::lock_guard<std::mutex> lock(mu);
-  int& cur = seen[fn];
+  int& cur = seen[(unsigned long long)reinterpret_cast<uintptr_t>(fn) * 64ull + (unsigned)dev];
   if (bytes <= cur) return hipSuccess;
   const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
   if (e == hipSuccess) cur = bytes;

@@ -76,7 +76,7 @@ const Entry kEntries[] = {
     T3D_E(t3d_linear_fwd), T3D_E(t3d_head_fwd_all), T3D_E(t3d_head_bwd), T3D_E(t3d_head_bwd_weights), T3D_E(t3d_se_fwd),
     T3D_E(t3d_se_bwd), T3D_E(t3d_se_fwd_fused), T3D_E(t3d_se_bwd_data), T3D_E(t3d_se_bwd_weights), T3D_E(t3d_se_after_sums),
     T3D_E(t3d_se_after_apply), T3D_E(t3d_set_reduction_replicas), T3D_E(t3d_set_workspace), T3D_E(t3d_set_main_workspace),
-    T3D_E(t3d_fold_request), T3D_E(t3d_pack_weights_batched), T3D_E(t3d_pwconv_pack_frag), T3D_E(t3d_adamw_step),
+    T3D_E(t3d_fold_request), T3D_E(t3d_pack_weights_batched), T3D_E(t3d_pwconv_pack_frag), T3D_E(t3d_adamw_step), T3D_E(t3d_set_grad_watch),
     T3D_E(t3d_zero_batched), T3D_E(t3d_copy_cols), T3D_E(t3d_bn_bias_grad), T3D_E(t3d_se_bwd_affine), T3D_E(t3d_dropout_mask),
     T3D_E(t3d_loss_fwd_bwd), T3D_E(t3d_metrics_per_sample), T3D_E(t3d_iou3d), T3D_E(t3d_box_iou3d), T3D_E(t3d_ssd_decode_nms),
     T3D_E(t3d_expdw_fwd), T3D_E(t3d_conv3x3_fwd), T3D_E(t3d_conv3x3_dgrad), T3D_E(t3d_conv3x3_wgrad), T3D_E(t3d_pack_conv3x3_dgrad_weight),

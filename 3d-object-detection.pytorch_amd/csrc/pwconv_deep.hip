@@ -374,7 +374,7 @@ int launch_deep(GemmArgs& a, int KS, int ntiles, int nchunks, hipStream_t st) {
   if (lds > 150 * 1024) return T3D_ERR_UNSUPPORTED;
   const void* fn = (const void*)pw_deep_kernel<DG, CV, NTW, KSP>;
   if (lds > 64 * 1024) (void)t3d_max_lds(fn, (int)lds);
-  a.quant = (!DG && a.stats && !getenv("T3D_NO_SNAP")) ? t3d_quant_for(a.M) : T3dQuant{0.0, 0.0};
+  a.quant = (!DG && a.stats && !T3D_ENV_SET("T3D_NO_SNAP")) ? t3d_quant_for(a.M) : T3dQuant{0.0, 0.0};
   a.fold = t3d_take_fold(a.p0);
   T3D_LAUNCH((pw_deep_kernel<DG, CV, NTW, KSP>), dim3(cdiv(a.M, 16 * RT), nchunks), dim3(64 * NW), lds, st, a, KS, ntiles,
                      g_t3d_reduce.nrep, g_t3d_reduce.stats_stride);
@@ -430,7 +430,7 @@ int deep_launch(GemmArgs& a, hipStream_t st) {
   // 960 -> 160 (one chunk either way) 18.3 / 20.9.  Chunks evenly sized.
   // OPT-IN (T3D_DEEP_WIDE=1): alone the two launches it changes get 12 and 20 us faster, the STEP does not (6.718 / 6.694 / 6.700
   // ms with against 6.698 / 6.669 / 6.680 without, three same-box pairs) -- finding 20's lesson once more
-  const bool wide = pairs > 8 && pairs <= 12 && getenv("T3D_DEEP_WIDE");        // (one chunk instead of two; 32 pairs as 3 x 22 tiles ran 53 us, as 4 x 16 45)
+  const bool wide = pairs > 8 && pairs <= 12 && T3D_ENV_SET("T3D_DEEP_WIDE");        // (one chunk instead of two; 32 pairs as 3 x 22 tiles ran 53 us, as 4 x 16 45)
   const int per = wide ? 12 : 8;
   const int nchunks = cdiv(pairs, per), ntiles = 2 * cdiv(pairs, nchunks);
   if (wide) {

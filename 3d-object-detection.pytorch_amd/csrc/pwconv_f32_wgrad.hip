@@ -129,7 +129,8 @@ int t3d_pw_wgrad_f32_reg(const float* dz, const float* y, const t3d_bnbwd* bb, c
     if (sg >= 1 && (M / (4 * sg) >= 512 || k == 1)) SGsel = sg;
   }
   int S = 4 * (SGsel > 0 ? SGsel : 1);
-  if (const char* e = getenv("T3D_WG32_WAVES")) S = atoi(e) / (tn * tk);      // (sweep knob)
+  static const int waves_env = getenv("T3D_WG32_WAVES") ? atoi(getenv("T3D_WG32_WAVES")) : 0;      // (sweep knob, read once)
+  if (waves_env) S = waves_env / (tn * tk);
   const int maxs = cdiv(M, 512);
   if (S > maxs) S = maxs;
   if (S < 4) S = 4;

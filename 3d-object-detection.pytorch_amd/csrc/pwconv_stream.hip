@@ -590,7 +590,7 @@ int launch_v(GemmArgs& a, int KS, hipStream_t st) {
   }
   // a pending BatchNorm-finalize request belongs to this launch when it names the coefficients of its operand
   // (per-sample coefficients and the y-free variant have none to derive)
-  a.quant = (!DG && a.stats && !getenv("T3D_NO_SNAP")) ? t3d_quant_for(a.M) : T3dQuant{0.0, 0.0};
+  a.quant = (!DG && a.stats && !T3D_ENV_SET("T3D_NO_SNAP")) ? t3d_quant_for(a.M) : T3dQuant{0.0, 0.0};
   if (YF || a.per_sample) {
     if (const int rc = t3d_fold_fallback(a.p0, st)) return rc;
     a.fold = nullptr;

@@ -201,7 +201,7 @@ int t3d_pw_wgrad_reduce(const float* ws, float* dw, int N, int K, int PB, int QB
 extern "C" int t3d_pwconv_wgrad(int dtype, const void* dz, const void* y, const t3d_bnbwd* bb, const void* x,
                                 const t3d_prologue* pro, float* dw, int M, int HW, int K, int N, void* stream) {
   if (!dz || !y || !bb || !x || !dw || M <= 0 || K <= 0 || N <= 0 || (K % 8) || (N % 8) || HW <= 0) return T3D_ERR_ARG;
-  if (dtype == T3D_BF16 && !getenv("T3D_WGRAD_TILED"))
+  if (dtype == T3D_BF16 && !T3D_ENV_SET("T3D_WGRAD_TILED"))
     return t3d_pw_wgrad_tr_entry(dz, y, bb, x, pro, dw, M, HW, K, N, reinterpret_cast<hipStream_t>(stream));
   // the kernels below read finished coefficients: a pending derive request for them becomes a launch of its own
   if (const int rc = t3d_fold_fallback(bb->alpha, reinterpret_cast<hipStream_t>(stream))) return rc;
@@ -227,7 +227,7 @@ extern "C" int t3d_pwconv_wgrad(int dtype, const void* dz, const void* y, const 
   // with a workspace (t3d_set_workspace) the pixel splits leave as plain stores and are added in a fixed order:
   // bit-reproducible weight gradients in the parity mode too
   const size_t need = (size_t)S * tn * tk * TN * TK * sizeof(float);
-  a.ws = (S > 1 && g_t3d_ws.ptr && (size_t)g_t3d_ws.bytes >= need && !getenv("T3D_WG_ATOMIC")) ? reinterpret_cast<float*>(g_t3d_ws.ptr) : nullptr;
+  a.ws = (S > 1 && g_t3d_ws.ptr && (size_t)g_t3d_ws.bytes >= need && !T3D_ENV_SET("T3D_WG_ATOMIC")) ? reinterpret_cast<float*>(g_t3d_ws.ptr) : nullptr;
   if (dtype == T3D_F32)
     T3D_LAUNCH(pw_wgrad_kernel<float>, dim3(tn, tk, S), dim3(256), 0, st, a);
   else if (dtype == T3D_BF16)

@@ -673,7 +673,7 @@ int launch_d(WgtArgs& a, hipStream_t st) {
   const long long cap_mb = 8;
   int S = (tgt_blocks + tiles - 1) / tiles;
   const long long tile_bytes = (long long)tiles * PB * QB * 4;
-  const bool use_ws = g_t3d_ws.ptr && g_t3d_ws.bytes >= tile_bytes && !getenv("T3D_WG_ATOMIC");
+  const bool use_ws = g_t3d_ws.ptr && g_t3d_ws.bytes >= tile_bytes && !T3D_ENV_SET("T3D_WG_ATOMIC");
   if (use_ws) {
     const long long fit = g_t3d_ws.bytes / tile_bytes;   // partial sets the workspace holds
     if (S > fit) S = (int)fit;

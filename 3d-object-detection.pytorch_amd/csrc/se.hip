@@ -451,12 +451,7 @@ extern "C" int t3d_se_fwd_fused(const float* gap_sum, const float* scale, const 
   a.gap = gap_sum; a.gapq = g_t3d_reduce.pool_exact; a.scale = scale; a.shift = shift; a.b1 = b1; a.b2 = b2;
   a.m = m; a.h = h; a.q = q; a.s = s; a.B = B; a.C = C; a.R = R; a.HW = HW;
   const size_t lds = se_group_lds(C, R);
-  static bool attr = false;
-  if (!attr) {
-    (void)t3d_max_lds((const void*)se_fwd_group_kernel, 96 * 1024);
-    (void)t3d_max_lds((const void*)se_bwd_group_kernel, 96 * 1024);
-    attr = true;
-  }
+  (void)t3d_max_lds((const void*)se_fwd_group_kernel, 96 * 1024);      // (cached per device and kernel, misc.hip)
   T3D_LAUNCH(se_fwd_group_kernel, dim3(cdiv(B, SPG)), dim3(SE_T), lds, reinterpret_cast<hipStream_t>(stream), a, w1t, w2t);
   T3D_CHECK_LAUNCH();
   return T3D_OK;
@@ -472,11 +467,7 @@ extern "C" int t3d_se_bwd_data(const float* ps_stats, const float* gap_sum, cons
   a.ps = ps_stats; a.gap = gap_sum; a.gapq = g_t3d_reduce.pool_exact; a.scale = scale; a.shift = shift; a.w1 = w1; a.w2 = w2;
   a.h = const_cast<float*>(h); a.q = const_cast<float*>(q); a.s = const_cast<float*>(s);
   a.g = g; a.dq = dq; a.dp = dp; a.stats = stats; a.B = B; a.C = C; a.R = R; a.HW = HW;
-  static bool attr = false;
-  if (!attr) {
-    (void)t3d_max_lds((const void*)se_bwd_group_kernel, 96 * 1024);
-    attr = true;
-  }
+  (void)t3d_max_lds((const void*)se_bwd_group_kernel, 96 * 1024);
   T3D_LAUNCH(se_bwd_group_kernel, dim3(cdiv(B, SPG)), dim3(SE_T), se_group_lds(C, R), reinterpret_cast<hipStream_t>(stream), a,
                      g_t3d_reduce.nrep, g_t3d_reduce.stats_stride);
   T3D_CHECK_LAUNCH();

@@ -114,6 +114,7 @@ SIGNATURES = {
     't3d_iou3d': [_P, _P, _I, _I, _P, _P, _P, _P, _P],
     't3d_box_iou3d': [_P, _I, _P, _P, _P],
     't3d_adamw_step': [_P, _P, _P, _P, _L, _D, _D, _D, _D, _D, _L, _D, _P],
+    't3d_set_grad_watch': [_P],
     't3d_zero_batched': [_P, _I, _P],
     't3d_copy_cols': [_P, _P, _I, _I, _I, _P],
     't3d_bn_bias_grad': [_P, _P, _I, _D, _P, _P, _P, _P, _P],
@@ -122,6 +123,7 @@ SIGNATURES = {
     't3d_loss_fwd_bwd': [_LP, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P],
     't3d_metrics_per_sample': [_P, _P, _P, _P, _P, _I, _I, _P],
     't3d_expdw_fwd': [_I, _P, _P, _P, _P, _I, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
+    't3d_expdw_supported': [_I, _I, _I, _I, _I, _I, _I, _I],
     't3d_conv3x3_fwd': [_I, _P, _PP, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
     't3d_conv3x3_dgrad': [_I, _P, _P, _BP, _P, _P, _PP, _P, _P, _I, _I, _I, _I, _I, _I, _P],
     't3d_conv3x3_wgrad': [_I, _P, _P, _BP, _P, _PP, _P, _I, _I, _I, _I, _I, _I, _P],
@@ -374,12 +376,26 @@ class PlanRecorder:
             raise RuntimeError(f't3d_plan_add_fork failed with code {rc}')
 
     def add_readback(self, dst_slot, src, nbytes, event_slot, stream_):
-        lib().t3d_plan_add_copy_d2h(self.plan, dst_slot, src.data_ptr(), nbytes, stream_)
-        lib().t3d_plan_add_event_record(self.plan, event_slot, stream_)
+        # (a plan that silently lacked the copy or its event would replay and hand back stale pinned memory)
+        rc = lib().t3d_plan_add_copy_d2h(self.plan, dst_slot, src.data_ptr(), nbytes, stream_)
+        if rc != 0:
+            raise RuntimeError(f't3d_plan_add_copy_d2h failed with code {rc}')
+        rc = lib().t3d_plan_add_event_record(self.plan, event_slot, stream_)
+        if rc != 0:
+            raise RuntimeError(f't3d_plan_add_event_record failed with code {rc}')
         self.keep.append(src)
 
     def end_segment(self):
-        return lib().t3d_plan_end_segment(self.plan)
+        rc = lib().t3d_plan_end_segment(self.plan)
+        if rc < 0:
+            raise RuntimeError(f't3d_plan_end_segment failed with code {rc}')
+        return rc
+
+    def close(self):
+        """Destroy the plan (a recording that failed or cannot be replayed); idempotent."""
+        if self.plan:
+            lib().t3d_plan_destroy(self.plan)
+            self.plan = _P()
 
     def host_break(self, what):
         """Host code runs here in the eager step (a gradient-exchange callback): close the segment, remember what to call."""

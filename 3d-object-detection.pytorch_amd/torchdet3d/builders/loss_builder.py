@@ -1,26 +1,25 @@
-"""Name -> criterion lists (torchdet3d/builders/loss_builder.py:4-28)."""
-from ..losses import (DiagLoss, ADD_loss, WingLoss, L1Loss, MSELoss, SmoothL1Loss, CrossEntropyLoss)
+"""Loss names -> (regression criterions, class criterions), the two lists `LossManager` takes
+(torchdet3d/builders/loss_builder.py:4-28 of the reference: same names, same grouping, criterions in the order the
+config lists them)."""
+from .. import losses as L
 
-AVAILABLE_LOSS = ['smoothl1', 'l1', 'cross_entropy', 'diag_loss', 'mse', 'add_loss', 'wing']
+# name -> (group, constructor taking cfg.loss); group 0 = keypoint regression, 1 = classification
+_TABLE = {
+    'smoothl1': (0, lambda c: L.SmoothL1Loss(beta=c.smoothl1_beta)),
+    'l1': (0, lambda c: L.L1Loss()),
+    'cross_entropy': (1, lambda c: L.CrossEntropyLoss()),
+    'diag_loss': (0, lambda c: L.DiagLoss()),
+    'mse': (0, lambda c: L.MSELoss()),
+    'add_loss': (0, lambda c: L.ADD_loss()),
+    'wing': (0, lambda c: L.WingLoss(w=c.w, eps=c.eps)),
+}
+AVAILABLE_LOSS = list(_TABLE)
 
 
 def build_loss(cfg):
-    "build losses in right order"
-    regress_criterions, class_criterions = [], []
-    for loss_name in cfg.loss.names:
-        assert loss_name in AVAILABLE_LOSS
-        if loss_name == 'cross_entropy':
-            class_criterions.append(CrossEntropyLoss())
-        elif loss_name == 'smoothl1':
-            regress_criterions.append(SmoothL1Loss(beta=cfg.loss.smoothl1_beta))
-        elif loss_name == 'l1':
-            regress_criterions.append(L1Loss())
-        elif loss_name == 'mse':
-            regress_criterions.append(MSELoss())
-        elif loss_name == 'wing':
-            regress_criterions.append(WingLoss(w=cfg.loss.w, eps=cfg.loss.eps))
-        elif loss_name == 'add_loss':
-            regress_criterions.append(ADD_loss())
-        elif loss_name == 'diag_loss':
-            regress_criterions.append(DiagLoss())
-    return regress_criterions, class_criterions
+    groups = ([], [])
+    for name in cfg.loss.names:
+        assert name in _TABLE, f'unknown loss {name!r}; available: {AVAILABLE_LOSS}'
+        group, make = _TABLE[name]
+        groups[group].append(make(cfg.loss))
+    return groups

@@ -20,6 +20,20 @@ class FusedAdamW(torch.optim.Optimizer):
             raise ValueError('invalid AdamW hyper-parameter')
         super().__init__(params, dict(lr=lr, betas=tuple(betas), eps=eps, weight_decay=weight_decay))
         self.grad_scale = grad_scale
+        self._watch = None            # device int64: the first step that met a non-finite gradient (t3d_set_grad_watch)
+
+    def watch_word(self, device):
+        if self._watch is None or self._watch.device != torch.device(device):
+            self._watch = torch.full((1,), torch.iinfo(torch.int64).max, dtype=torch.int64, device=device)
+        return self._watch
+
+    def first_nonfinite_step(self):
+        """The 1-based optimizer step whose gradient was the first to hold an inf / NaN, or None (one 8-byte read-back and a
+        wait: call it where the loop waits anyway)."""
+        if self._watch is None:
+            return None
+        v = int(self._watch.item())
+        return None if v == torch.iinfo(torch.int64).max else v
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -42,6 +56,7 @@ class FusedAdamW(torch.optim.Optimizer):
                     st['exp_avg_sq'] = torch.zeros_like(p, memory_format=torch.preserve_format)
                 st['step'] += 1                           # a host int (load_state_dict normalises a tensor step)
                 g = p.grad if p.grad.is_contiguous() else p.grad.contiguous()
+                N.call('t3d_set_grad_watch', N.ptr(self.watch_word(p.device)))
                 N.call('t3d_adamw_step', N.ptr(p), N.ptr(g), N.ptr(st['exp_avg']), N.ptr(st['exp_avg_sq']), p.numel(),
                        float(group['lr']), float(b1), float(b2), float(group['eps']), float(group['weight_decay']),
                        st['step'], float(self.grad_scale), N.stream())

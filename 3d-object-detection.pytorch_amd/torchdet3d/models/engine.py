@@ -749,9 +749,11 @@ class Net:
         conv (DESIGN.md finding 40: no gain with the raw expansion still stored for the backward)."""
         if self.training or not EXPDW_EVAL or self.dt not in (N.BF16, N.F16) or x.pro is not None or x.zbuf is not None:
             return False
-        act = blk.act if isinstance(blk.act, str) else None
-        return bool(blk.expand and not blk.se and blk.k == 3 and blk.cin <= 32 and blk.cin % 8 == 0 and act in ('relu', 'relu6')
-                    and x.W >= 8 and x.B * x.H * x.W * blk.cexp * 2 < (1 << 32))
+        if not (blk.expand and not blk.se and blk.k == 3 and isinstance(blk.act, str) and blk.act in ('relu', 'relu6')):
+            return False
+        # the kernel's own shape tests (channel counts, and an input row no wider than its fragment registers / LDS rows hold:
+        # W <= 213 -- a 448 ... 512-pixel crop reaches MobileNetV2's second block wider than that and takes the two launches)
+        return bool(N.lib().t3d_expdw_supported(self.dt, N.ACT[blk.act], x.B, x.H, x.W, blk.cin, blk.cexp, blk.s))
 
     def _block_fwd(self, i, blk, x, sv):
         st, dt = N.stream(), self.dt

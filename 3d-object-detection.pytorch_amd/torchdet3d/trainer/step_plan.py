@@ -99,7 +99,7 @@ class StepPlan:
 
     def _drop(self):
         if self.rec is not None:
-            N.lib().t3d_plan_destroy(self.rec.plan)
+            self.rec.close()
             self.rec = None
 
     def __del__(self):
@@ -160,6 +160,7 @@ class StepPlan:
             state = self._state()
             state['step'] += 1
             b1, b2 = g['betas']
+            N.call('t3d_set_grad_watch', N.ptr(opt.watch_word(p.device)))
             N.call('t3d_adamw_step', N.ptr(p), N.ptr(net.gflat), N.ptr(state['exp_avg']), N.ptr(state['exp_avg_sq']), p.numel(),
                    float(g['lr']), float(b1), float(b2), float(g['eps']), float(g['weight_decay']), state['step'],
                    float(opt.grad_scale), st, slots={5: N.SLOT_LR, 10: N.SLOT_STEP})
@@ -171,12 +172,16 @@ class StepPlan:
                     rec.add_readback(N.SLOT_RB_DST, out, 64, N.SLOT_RB_EVENT, st)
                 rec.end_segment()
                 rec.keep += [out, dkp, dlg, kp, logits, state['exp_avg'], state['exp_avg_sq']]
+        except BaseException:
+            if rec is not None:
+                rec.close()                              # (an exception while recording must not leak the plan)
+            raise
         finally:
             N.recorder = None
         lm.last = out
         if rec is not None:
             if rec.broken:
-                N.lib().t3d_plan_destroy(rec.plan)       # stays in the direct form
+                rec.close()                              # stays in the direct form
                 self.warm = -(1 << 30)
             else:
                 self.rec = rec
@@ -325,12 +330,16 @@ class ForwardPlan:
             if rec is not None:
                 rec.end_segment()
                 rec.keep += [kp, logits]
+        except BaseException:
+            if rec is not None:
+                rec.close()
+            raise
         finally:
             N.recorder = None
         self.warm += 1
         if rec is not None:
             if rec.broken or rec.breaks:
-                N.lib().t3d_plan_destroy(rec.plan)
+                rec.close()
                 self.warm = -(1 << 30)
             else:
                 self.rec, self.out = rec, (kp, logits)
@@ -338,7 +347,7 @@ class ForwardPlan:
 
     def drop(self):
         if self.rec is not None:
-            N.lib().t3d_plan_destroy(self.rec.plan)
+            self.rec.close()
             self.rec = None
 
     def __del__(self):

@@ -129,24 +129,38 @@ class Trainer:
             sampler.set_epoch(epoch)
         main, world = is_main(), world_size()
         start = time.time()
-        backlog = []        # (mapping, batch size, global step) of iterations whose numbers have not been looked at yet
+        backlog = []        # (mapping, batch size, global step, optimizer step) of iterations whose numbers have not been looked at yet
+
+        def opt_step():
+            st = self.optimizer.state.get(self.optimizer.param_groups[0]['params'][0], {}) if self.optimizer.param_groups else {}
+            v = st.get('step', 0)
+            return int(v) if not hasattr(v, 'item') else int(v.item())
 
         def drain():
             # meters and TensorBoard scalars in iteration order, with each iteration's own global step (train.py:57-65)
             if world > 1 and backlog:
                 # what the reference's single process sees is the GLOBAL batch (main.py:60-61): average the ranks' shares
                 # -- one small collective per drain (every rank drains at the same iterations), not per iteration
-                flat = all_reduce_sums([r[k] * n for r, n, _ in backlog for k in ('loss', 'ADD', 'SADD', 'acc')]
-                                       + [n for _, n, _ in backlog])
+                flat = all_reduce_sums([r[k] * n for r, n, _, _ in backlog for k in ('loss', 'ADD', 'SADD', 'acc')]
+                                       + [n for _, n, _, _ in backlog])
                 ns = flat[4 * len(backlog):]
-                backlog[:] = [(dict(zip(('loss', 'ADD', 'SADD', 'acc'), (v / ns[j] for v in flat[4 * j:4 * j + 4]))), int(ns[j]), gs)
-                              for j, (_, _, gs) in enumerate(backlog)]
-            net = getattr(self.model, 'net', None)
-            if backlog and net is not None and hasattr(net, 'nonfinite') and net.nonfinite():
-                # a non-finite activation somewhere in the network: the reference's loss would read NaN from here on (its
-                # hardtanh propagates it; the clamp form of the 16-bit kernels does not) -- report it as that
-                backlog[:] = [({**dict(r), 'loss': float('nan')}, n, gs) for r, n, gs in backlog]
-            for r, n, gs in backlog:
+                backlog[:] = [(dict(zip(('loss', 'ADD', 'SADD', 'acc'), (v / ns[j] for v in flat[4 * j:4 * j + 4]))), int(ns[j]), gs, os_)
+                              for j, (_, _, gs, os_) in enumerate(backlog)]
+            # A diverged network: the reference's loss reads NaN from the diverging step on (its hardtanh propagates a NaN; the
+            # clamp form of the 16-bit kernels does not, so the loss VALUE can stay finite here).  The optimizer kernel records
+            # the first step whose gradient held an inf / NaN (t3d_set_grad_watch): exactly the steps from that one on are
+            # reported as NaN -- per step, not per drain, and the same on every rank (the gradient is all-reduced first).
+            # Other optimizers: the BatchNorm sums of the latest steps (per rank; marks the whole backlog).
+            first_bad = None
+            if backlog and hasattr(self.optimizer, 'first_nonfinite_step'):
+                first_bad = self.optimizer.first_nonfinite_step()
+            elif backlog:
+                net = getattr(self.model, 'net', None)
+                if net is not None and hasattr(net, 'nonfinite') and net.nonfinite():
+                    first_bad = 0
+            if first_bad is not None:
+                backlog[:] = [(({**dict(r), 'loss': float('nan')} if os_ >= first_bad else r), n, gs, os_) for r, n, gs, os_ in backlog]
+            for r, n, gs, _ in backlog:
                 for k in ('loss', 'ADD', 'SADD', 'acc'):
                     meters[k].update(r[k], n)
                 if self.writer is not None and main:
@@ -158,7 +172,7 @@ class Trainer:
 
         for it, (imgs, gt_kp, gt_cats) in enumerate(self.train_loader):
             r = self.train_step(imgs, gt_kp, gt_cats, it)
-            backlog.append((r, imgs.size(0), self.global_step))
+            backlog.append((r, imgs.size(0), self.global_step, opt_step() if hasattr(self.optimizer, 'first_nonfinite_step') else 0))
             self.global_step += 1
             left = (self.num_iters - (it + 1)) + (self.max_epoch - (epoch + 1)) * self.num_iters
             show = it % self.print_freq == 0 or it == self.num_iters - 1
@@ -180,5 +194,9 @@ class Trainer:
         if self.save_chkpt and (epoch % self.save_freq == 0 or is_last_epoch) and not self.debug:
             save_snap(self.model, self.optimizer, self.scheduler, epoch, self.log_path)
         if self.scheduler is not None:
+            # a replayed step plan runs the optimizer launch itself, so `optimizer.step` (which torch's schedulers wrap to
+            # notice a scheduler stepped before any optimizer step) may never have been called: say that it was
+            if not getattr(self.optimizer, '_opt_called', False) and self.global_step > 0:
+                self.optimizer._opt_called = True
             self.scheduler.step()
         return {k: m.avg for k, m in meters.items()}

@@ -1,75 +1,63 @@
-"""EPnP-style lifting of 9 normalised 2-D keypoints to 3-D box vertices, numpy fp64 on the host exactly as the
-reference runs it (torchdet3d/utils/geometry.py:6-108; metric path, torchdet3d/evaluation/metrics.py:70-89).
-An on-device batched version is the first "next" row of SURVEY.md section 8(f)."""
+"""Geometry helpers of the reference's `torchdet3d.utils` (torchdet3d/utils/geometry.py:16-108; callers: demo / drawing
+code and `compute_2d_based_iou`, torchdet3d/evaluation/metrics.py:70-89).
+
+`lift_2d` is the DEVICE lift: the batched 12x12 eigen-decomposition of `t3d_iou3d` (csrc/geometry.hip), the same launch
+the validation metric uses, asked for its `lifted` output only.  There is no host copy of the algorithm in the product
+(the numpy restatement lives in `oracle/geometry.py`, test infrastructure); the camera helpers below are a few scalar
+operations each and stay on the host."""
 import numpy as np
+import torch
 
-# geometry.py:6-13 -- barycentric weights of the 8 box corners w.r.t. 4 control points
-EPNP_ALPHA = np.array([[4, -1, -1, -1], [2, -1, -1, 1], [2, -1, 1, -1], [0, -1, 1, 1],
-                       [2, 1, -1, -1], [0, 1, -1, 1], [0, 1, 1, -1], [-2, 1, 1, 1]], dtype=np.float64)
-
-
-def default_camera_matrix():                                   # geometry.py:16-19
-    return np.array([[1, 0, 0.5], [0, 1, 0.5], [0, 0, 1.]])
+from .. import _native as N
 
 
-def camera_matrix_to_ndc(m, img_shape=(1, 1)):                 # geometry.py:29-37
-    n = np.array(m, dtype=np.float64)
-    n[0, 0] *= 2.0 / img_shape[0]
-    n[1, 1] *= 2.0 / img_shape[1]
-    n[0, 2] = -n[0, 2] * 2.0 / img_shape[0] + 1.0
-    n[1, 2] = -n[1, 2] * 2.0 / img_shape[1] + 1.0
-    return n
+def get_default_camera_matrix():
+    """Unit focal length, principal point in the image centre (geometry.py:16-19)."""
+    cam = np.eye(3)
+    cam[:2, 2] = 0.5
+    return cam
 
 
-def project_3d_points(points, camera_matrix):                  # geometry.py:22-26
-    pr = (camera_matrix @ points.T).T
-    pr = pr / -pr[:, 2:3]
-    return pr[:, :2]
+def convert_camera_matrix_2_ndc(matrix, img_shape=(1, 1)):
+    """Pixel-space intrinsics -> normalised device coordinates (geometry.py:29-37)."""
+    sx, sy = 2.0 / img_shape[0], 2.0 / img_shape[1]
+    ndc = np.array(matrix, dtype=np.float64)
+    ndc[0, 0], ndc[1, 1] = ndc[0, 0] * sx, ndc[1, 1] * sy
+    ndc[0, 2], ndc[1, 2] = 1.0 - ndc[0, 2] * sx, 1.0 - ndc[1, 2] * sy
+    return ndc
 
 
-def to_ndc(points, portrait=False):                            # geometry.py:40-48
-    out = np.zeros_like(points)
+def project_3d_points(points, camera_matrix):
+    """Pinhole projection with the camera looking down -z (geometry.py:22-26)."""
+    homog = np.asarray(points) @ np.asarray(camera_matrix).T
+    return homog[:, :2] / -homog[:, 2:3]
+
+
+def convert_2d_to_ndc(points, portrait=False):
+    """[0, 1]^2 image coordinates -> NDC; portrait frames swap the axes (geometry.py:40-48)."""
+    pts = np.asarray(points)
     if portrait:
-        out[:, 0] = points[:, 1] * 2 - 1
-        out[:, 1] = points[:, 0] * 2 - 1
-    else:
-        out[:, 0] = points[:, 0] * 2 - 1
-        out[:, 1] = 1 - points[:, 1] * 2
-    return out
+        return pts[:, ::-1] * 2 - 1
+    return np.stack([pts[:, 0] * 2 - 1, 1 - pts[:, 1] * 2], axis=1)
 
 
-def lift_system(kp_set, portrait, fx, fy, cx, cy):
-    """The 16x12 matrix of geometry.py:65-88 (centre keypoint kp_set[0] unused)."""
-    m = np.zeros((16, 12))
-    # NDC in the keypoints' OWN dtype, like the reference's element-wise `kp[1] * 2 - 1` on float32 rows (:73-78)
-    uv = to_ndc(np.asarray(kp_set)[1:], portrait).astype(np.float64)
-    for i in range(8):
-        u, v = uv[i]
-        for j in range(4):
-            a = EPNP_ALPHA[i, j]
-            m[2 * i, 3 * j] = fx * a
-            m[2 * i, 3 * j + 2] = (cx + u) * a
-            m[2 * i + 1, 3 * j + 1] = fy * a
-            m[2 * i + 1, 3 * j + 2] = (cy + v) * a
-    return m
+def lift_2d(keypoint_sets, camera_matrix=None, portrait=False):
+    """9 normalised 2-D keypoints per box -> 9x3 vertices per box, fp64 numpy (geometry.py:51-108), computed by the
+    device kernel on the keypoints rounded to fp32 (what the network and the dataset hand over).  Needs a GPU: like
+    every other arithmetic entry of the product it raises instead of falling back."""
+    sets = [np.asarray(k) for k in keypoint_sets]
+    for k in sets:
+        assert len(k) == 9
+    if not sets:
+        return []
+    if not torch.cuda.is_available():
+        raise RuntimeError('lift_2d runs on the HIP path only (no CPU fallback)')
+    kp = torch.from_numpy(np.stack(sets).astype(np.float32)).reshape(len(sets), 18).cuda().contiguous()
+    cam = None
+    if camera_matrix is not None:
+        ndc = convert_camera_matrix_2_ndc(camera_matrix)
+        cam = (N.ctypes.c_double * 4)(ndc[0, 0], ndc[1, 1], ndc[0, 2], ndc[1, 2])
+    lifted = torch.empty(len(sets), 2, 9, 3, device='cuda', dtype=torch.float64)
+    N.call('t3d_iou3d', N.ptr(kp), N.ptr(kp), len(sets), int(bool(portrait)), cam, None, None, N.ptr(lifted), N.stream())
+    return list(lifted[:, 0].cpu().numpy())
 
-
-def lift_2d(keypoint_sets, camera_matrix=None, portrait=False):   # geometry.py:51-108
-    cam = camera_matrix_to_ndc(default_camera_matrix() if camera_matrix is None else camera_matrix)
-    fx, fy, cx, cy = cam[0, 0], cam[1, 1], cam[0, 2], cam[1, 2]
-    out = []
-    for kp_set in keypoint_sets:
-        assert len(kp_set) == 9
-        m = lift_system(kp_set, portrait, fx, fy, cx, cy)
-        w, v = np.linalg.eigh(m.T @ m)                         # :90-91, ascending eigenvalues
-        ctrl = v[:, 0].reshape(4, 3)
-        if ctrl[0, 2] > 0:                                     # :95-96 all points in front (z<0)
-            ctrl = -ctrl
-        out.append(np.vstack([ctrl[0:1], EPNP_ALPHA @ ctrl]))  # :98-105
-    return out
-
-
-# reference names (torchdet3d/utils/geometry.py:16-48)
-get_default_camera_matrix = default_camera_matrix
-convert_camera_matrix_2_ndc = camera_matrix_to_ndc
-convert_2d_to_ndc = to_ndc

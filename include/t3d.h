@@ -522,6 +522,13 @@ int t3d_pack_weights_batched(int dtype, const long long* desc, int n, void* stre
  * caller-owned moment buffers (zeroed before the first step). */
 int t3d_adamw_step(float* p, const float* g, float* m, float* v, long long n, double lr, double beta1, double beta2,
                    double eps, double weight_decay, long long step, double grad_scale, void* stream);
+/* Divergence watch for the optimizer steps that follow (process-wide, like t3d_set_reduction_replicas): with a DEVICE
+ * int64 word set (the caller initialises it to INT64_MAX), t3d_adamw_step does *word = min(*word, step) when it meets a
+ * non-finite gradient element; NULL switches it off.  Serves the loss the reference's loop reads at train.py:57 -- after a
+ * divergence `loss.item()` is NaN there, while the clamp-form ReLU6 of the 16-bit kernels can leave this path's loss
+ * finite: the trainer reports NaN from the first watched step on, per step and identically on every rank (the gradient is
+ * all-reduced before the optimizer reads it). */
+int t3d_set_grad_watch(long long* first_bad_step);
 
 /* Small bookkeeping kernels that keep the step free of framework arithmetic:
  *  _copy_cols   dst [rows,cols_dst] <- leading columns of src [rows,cols_src], rest zero (the stem's [C,27] <-> [C,32]
@@ -574,9 +581,13 @@ int t3d_pack_conv3x3_dgrad_weight(const float* w, void* out, int N, int C, void*
  *   statistics must exist beforehand (a statistics-only pass: t3d_pwconv_fwd / _fwd_mat with y = NULL), wdw [C,9] fp32,
  *   y1 [B,H,W,C] raw expansion or NULL (stored only for a backward that reads it), y2 [B,Ho,Wo,C] raw depthwise output,
  *   stats2 [2*C] fp64 replicas or NULL: += sum(y2), sum(y2^2) (order-independent, as t3d_dwconv_fwd).
- * T3D_ERR_UNSUPPORTED for shapes it does not take (the caller runs t3d_pwconv_fwd + t3d_dwconv_fwd). */
+ * T3D_ERR_UNSUPPORTED for shapes it does not take (the caller runs t3d_pwconv_fwd + t3d_dwconv_fwd);
+ * t3d_expdw_supported answers that question ahead of the launch: 1 when t3d_expdw_fwd would take (dtype, act, shape), else 0
+ * (an input row wider than the workgroup's fragment registers / LDS rows hold -- W > 213 -- is the case the channel tests do not
+ * show: 448 ... 512-pixel inputs reach MobileNetV2's second block at W = 224 ... 256). */
 int t3d_expdw_fwd(int dtype, const void* z, const void* w1, const float* scale1, const float* shift1, int act, const float* wdw,
                   void* y1, void* y2, double* stats2, int B, int H, int W, int K, int C, int stride, void* stream);
+int t3d_expdw_supported(int dtype, int act, int B, int H, int W, int K, int C, int stride);
 
 /* Step plans (round 5; csrc/plan.hip): the whole train iteration as ONE host call.
  * Replaces the per-launch host loop of torchdet3d/trainer/train.py:44-55 + builders/optim_builder.py:10-12 (model forward,

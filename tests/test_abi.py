@@ -27,3 +27,22 @@ def test_library_exports_every_declared_symbol():
 def test_version_call():
     from torchdet3d import _native as N
     assert N.lib().t3d_version() >= 1
+
+
+def test_every_kernel_launch_goes_through_the_launch_macro():
+    """csrc/common.h, the rule next to T3D_LAUNCH: a replayed fork waits for the last kernel a call launched through the macro,
+    so no source may launch a kernel any other way, and an async memset inside an entry point must be followed by a kernel
+    launch of the same entry point (in-order stream: that kernel's completion covers it)."""
+    csrc = os.path.join(ROOT, '3d-object-detection.pytorch_amd', 'csrc')
+    for f in sorted(os.listdir(csrc)):
+        if not f.endswith(('.hip', '.h')):
+            continue
+        lines = open(os.path.join(csrc, f)).read().split('\n')
+        code = [re.sub(r'//.*', '', ln) for ln in lines]
+        for i, ln in enumerate(code):
+            if f != 'common.h':
+                assert 'hipLaunchKernelGGL' not in ln and '<<<' not in ln, f'{f}:{i + 1}: raw kernel launch'
+            if 'hipMemsetAsync' in ln and f != 'plan.hip':
+                rest = code[i + 1:i + 60]
+                upto = next((j for j, r in enumerate(rest) if re.match(r'^(extern "C" )?\w[\w \*]*\(.*\{\s*$', r) or r.startswith('}')), len(rest))
+                assert any('T3D_LAUNCH' in r for r in rest[:upto]), f'{f}:{i + 1}: a memset that is not followed by a kernel launch'

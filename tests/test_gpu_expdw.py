@@ -94,3 +94,43 @@ def test_expdw_fwd_against_the_two_launches_at_production_shapes(H, K, C, s):
     assert (d > 0).float().mean().item() < 0.05          # a different summation order flips few roundings
     sp = stats.sum(0)
     assert torch.allclose(st, sp, rtol=2e-4, atol=1.0)
+
+
+def test_wide_inputs_take_the_two_launches_instead_of_failing():
+    """the kernel refuses input rows wider than its fragment registers / LDS rows hold (W > 213: MobileNetV2's
+    second block on 448 ... 512-pixel crops).  `t3d_expdw_supported` answers exactly what `t3d_expdw_fwd` would, the engine asks
+    it, and a 16-bit inference forward at 448 px runs -- on the two-launch path for that block -- and agrees with the fp32
+    engine like the 224-px forward does."""
+    from oracle.weights import make_inputs, make_state_dict
+    from torchdet3d import _native as N
+    from torchdet3d.models.engine import Net
+    sup = N.lib().t3d_expdw_supported
+    assert sup(N.BF16, N.ACT['relu6'], 2, 112, 112, 16, 96, 2) == 1
+    assert sup(N.BF16, N.ACT['relu6'], 2, 224, 213, 16, 96, 2) == 1
+    assert sup(N.BF16, N.ACT['relu6'], 2, 224, 224, 16, 96, 2) == 0          # too wide
+    assert sup(N.BF16, N.ACT['relu6'], 2, 56, 56, 40, 240, 1) == 0            # K > 32
+    assert sup(N.F32, N.ACT['relu6'], 2, 56, 56, 24, 144, 1) == 0
+    assert sup(N.BF16, N.ACT['hswish'], 2, 56, 56, 24, 144, 1) == 0
+    # the query and the launch agree on both sides of the width limit
+    for W in (213, 214):
+        z = torch.randn(1, 8, W, 16, device='cuda').to(torch.bfloat16)
+        w1 = torch.randn(96, 16, device='cuda').to(torch.bfloat16)
+        sc, sh, wdw = torch.ones(96, device='cuda'), torch.zeros(96, device='cuda'), torch.randn(96, 9, device='cuda')
+        y2 = torch.empty(1, 4, (W - 1) // 2 + 1, 96, device='cuda', dtype=torch.bfloat16)
+        rc = N.lib().t3d_expdw_fwd(N.BF16, N.ptr(z), N.ptr(w1), N.ptr(sc), N.ptr(sh), N.ACT['relu6'], N.ptr(wdw), None, N.ptr(y2),
+                                   None, 1, 8, W, 16, 96, 2, N.stream())
+        torch.cuda.synchronize()
+        assert (rc == 0) == bool(sup(N.BF16, N.ACT['relu6'], 1, 8, W, 16, 96, 2)), (W, rc)
+    B, HW = 4, 448
+    imgs, _, cats = make_inputs(B, HW, HW, 9)
+    sd = make_state_dict('mobilenetv2', 9)
+    outs = {}
+    for dt in (torch.bfloat16, torch.float32):
+        net = Net('mobilenetv2', 9, 'cuda', dt)
+        net.load_state_dict(sd)
+        with torch.no_grad():
+            kp, lg = net.forward(imgs.cuda(), cats.cuda(), train=False)
+        outs[dt] = (kp.float().cpu(), lg.float().cpu())
+        del net
+    assert (outs[torch.bfloat16][0] - outs[torch.float32][0]).abs().max().item() < 5e-3
+    assert torch.isfinite(outs[torch.bfloat16][1]).all()

@@ -42,6 +42,32 @@ def test_lift_matches_reference_golden(golden_dir):
     np.testing.assert_allclose(_lift_dev(k32, True), ref, atol=2e-7)       # eigen-gap conditioning of random sets
 
 
+def test_public_lift_2d_is_the_device_lift(golden_dir):
+    """`torchdet3d.utils.lift_2d` (the reference's public name, geometry.py:51-108) runs the device kernel: the
+    reference's golden lifts at fp32-input resolution, its own geometry tests (tests/test_geometry.py:25-40:
+    reprojection error < 1e-5, IoU > 0.5 under 1 % keypoint noise -- the IoU through `t3d_box_iou3d`), and a
+    non-default camera against the oracle on the same fp32 keypoints."""
+    from oracle import geometry as OG
+    from torchdet3d.utils import (convert_2d_to_ndc, convert_camera_matrix_2_ndc, get_default_camera_matrix, lift_2d,
+                                  project_3d_points)
+    g = np.load(os.path.join(golden_dir, 'geometry.npz'))
+    kps = g['test_kps']
+    lifted = lift_2d([kps], portrait=True)[0]
+    assert lifted.shape == (9, 3) and lifted.dtype == np.float64
+    np.testing.assert_allclose(lifted, g['lift_portrait'], atol=2e-6)
+    np.testing.assert_allclose(lift_2d([kps], portrait=False)[0], g['lift_landscape'], atol=2e-6)
+    np.testing.assert_allclose(np.stack(lift_2d(list(g['rand_kps']), portrait=True)), g['lift_rand'], atol=5e-6)
+    proj = project_3d_points(lifted, convert_camera_matrix_2_ndc(get_default_camera_matrix()))
+    assert np.abs(proj - convert_2d_to_ndc(kps, portrait=True)).max() < 1e-5
+    noisy = lift_2d([g['noisy_kps']], portrait=True)[0]
+    assert _box_iou_dev(np.stack([lifted, noisy])[None])[0] > 0.5
+    cam = np.array([[1.3, 0, 0.45], [0, 0.9, 0.55], [0, 0, 1.]])
+    k32 = g['rand_kps'].astype(np.float32)
+    ref = np.stack(OG.lift_2d([k.astype(np.float64) for k in k32], camera_matrix=cam, portrait=True))
+    np.testing.assert_allclose(np.stack(lift_2d(list(k32), camera_matrix=cam, portrait=True)), ref, atol=1e-6)
+    assert lift_2d([]) == []
+
+
 def _box_iou_dev(pairs):
     from torchdet3d import _native as N
     v = torch.as_tensor(np.asarray(pairs, dtype=np.float64)).cuda().contiguous()       # [n,2,9,3]

@@ -166,8 +166,38 @@ def test_a_non_finite_activation_is_seen_in_the_batchnorm_sums():
     assert r['loss'] == r['loss'] and not model.net.nonfinite()
     bad = imgs[0].clone()
     bad[3, 1, 40:44, 40:44] = float('inf')
+    assert opt.first_nonfinite_step() is None
     dict(tr.train_step(bad, gts[0], cats[0], 4))
     assert model.net.nonfinite()
+    # ... and in the gradient the optimizer kernel reads: the FIRST diverged step is on record (t3d_set_grad_watch), replayed
+    # steps included, so the trainer can report NaN from exactly that step on
+    assert opt.first_nonfinite_step() == 5
+    dict(tr.train_step(imgs[1], gts[1], cats[1], 5))
+    assert opt.first_nonfinite_step() == 5
+
+
+def test_trainer_reports_nan_from_the_diverging_step_on_and_not_before():
+    """`Trainer.train` looks at its numbers every print_freq iterations; a divergence inside such a window must turn the loss of
+    the diverging iteration and the later ones into NaN (what the reference's `loss.item()` shows, train.py:57) and leave the
+    finite iterations before it alone."""
+    from torchdet3d.trainer import Trainer
+    model, opt, lm, _ = _objects('mobilenetv2', 'bf16')
+    imgs, gts, cats = _batches(8, 96, nb=6)
+    imgs[4] = imgs[4].clone()
+    imgs[4][2, 0, 10:14, 10:14] = float('inf')
+
+    class W:
+        def __init__(self): self.rows = []
+        def add_scalar(self, tag, v, global_step=None):
+            if tag == 'Train/loss': self.rows.append((global_step, v))
+
+    w = W()
+    tr = Trainer(model, list(zip(imgs, gts, cats)), opt, None, lm, w, 1, '', device='cuda', save_chkpt=False, print_freq=100)
+    tr.train(0, False)
+    losses = [v for _, v in sorted(w.rows)]
+    assert len(losses) == 6
+    assert all(v == v for v in losses[:4]), losses
+    assert all(v != v for v in losses[4:]), losses
 
 
 @pytest.mark.parametrize('name,dtype,evdt', [('mobilenetv2', 'bf16', 'f32'), ('mobilenetv2', 'bf16', 'f16'), ('mobilenetv2', 'bf16', 'bf16'),

@@ -135,19 +135,17 @@ def test_gpu_path_fails_loudly_on_cpu():
         L1Loss()(torch.zeros(2, 9, 2), torch.zeros(2, 9, 2))
 
 
-def test_host_geometry_utilities_match_reference_cases(golden_dir):
-    """The numpy utilities of torchdet3d.utils (geometry.py:16-108; callers: demo / drawing code) against the
-    reference's golden lift and its own geometry tests (tests/test_geometry.py:25-40): reprojection error < 1e-5 and
-    IoU > 0.5 under 1 % keypoint noise (IoU by the oracle's box restatement; the metric path's IoU is the device
-    kernel, tests/test_gpu_geometry.py)."""
-    from oracle.box_iou import Box, IoU
-    from torchdet3d.utils import (convert_2d_to_ndc, convert_camera_matrix_2_ndc, get_default_camera_matrix, lift_2d,
-                                  project_3d_points)
+def test_host_camera_helpers_match_reference_cases(golden_dir):
+    """The host-side camera helpers of torchdet3d.utils (geometry.py:16-48) against the reference's golden values: NDC
+    camera, NDC keypoints, projection of the golden lift (`lift_2d` itself is the device kernel:
+    tests/test_gpu_geometry.py::test_public_lift_2d_is_the_device_lift)."""
+    from torchdet3d.utils import convert_2d_to_ndc, convert_camera_matrix_2_ndc, get_default_camera_matrix, project_3d_points
     g = np.load(os.path.join(golden_dir, 'geometry.npz'))
-    kps = g['test_kps']
-    lifted = lift_2d([kps], portrait=True)[0]
-    np.testing.assert_allclose(lifted, g['lift_portrait'], atol=1e-9)
-    proj = project_3d_points(lifted, convert_camera_matrix_2_ndc(get_default_camera_matrix()))
-    assert np.abs(proj - convert_2d_to_ndc(kps, portrait=True)).max() < 1e-5
-    noisy = lift_2d([g['noisy_kps']], portrait=True)[0]
-    assert IoU(Box(lifted), Box(noisy)).iou() > 0.5
+    ndc = convert_camera_matrix_2_ndc(get_default_camera_matrix())
+    np.testing.assert_allclose(ndc, g['ndc_cam'])
+    np.testing.assert_allclose(convert_2d_to_ndc(g['test_kps'], portrait=True), g['kps_ndc'])
+    np.testing.assert_allclose(project_3d_points(g['lift_portrait'], ndc), g['reproj'], atol=1e-9)
+    land = convert_2d_to_ndc(g['test_kps'], portrait=False)
+    np.testing.assert_allclose(land, np.stack([g['test_kps'][:, 0] * 2 - 1, 1 - g['test_kps'][:, 1] * 2], 1))
+    wide = convert_camera_matrix_2_ndc(np.array([[800., 0, 320], [0, 820, 240], [0, 0, 1]]), img_shape=(640, 480))
+    np.testing.assert_allclose(wide, [[2.5, 0, 0.], [0, 820 / 240, 0.], [0, 0, 1]], atol=1e-12)
