@@ -292,6 +292,11 @@ extern "C" int t3d_plan_run(t3d_plan* p, int segment, const unsigned long long* 
         rc = kEntries[o.entry].run(w);
         if (o.ev) g_t3d_signal = {nullptr, nullptr};
         if (timed) {
+          // (an entry point whose path had no kernel-exact launch site: the pair is recorded back to back, reads ~0)
+          if (g_t3d_time.start && g_t3d_last_stream) {
+            (void)hipEventRecord(g_t3d_time.start, g_t3d_last_stream);
+            (void)hipEventRecord(g_t3d_time.stop, g_t3d_last_stream);
+          }
           (void)t3d_set_launch_events(nullptr, nullptr);
           used += 2;
         }

@@ -331,7 +331,7 @@ int launch_nt(GemmArgs& a, hipStream_t st) {
       a.part = reinterpret_cast<float*>(g_t3d_ws_main.ptr);
     }
   }
-  T3D_LAUNCH((pw_gemm_kernel<T, NT>), dim3(gx, ny, a.kz), dim3(256), lds, st, a);
+  T3D_LAUNCH_TIMED((pw_gemm_kernel<T, NT>), dim3(gx, ny, a.kz), dim3(256), lds, st, a);
   if (a.kz > 1)
     T3D_LAUNCH(splitk_reduce_kernel, dim3(cdiv(a.Nout, 64), cdiv(a.M, 64)), dim3(256), 0, st, a.part, a.bias,
                        reinterpret_cast<float*>(a.out), a.stats, a.kz, a.M, a.Nout);

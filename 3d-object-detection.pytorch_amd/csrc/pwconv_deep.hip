@@ -376,7 +376,7 @@ int launch_deep(GemmArgs& a, int KS, int ntiles, int nchunks, hipStream_t st) {
   if (lds > 64 * 1024) (void)t3d_max_lds(fn, (int)lds);
   a.quant = (!DG && a.stats && !T3D_ENV_SET("T3D_NO_SNAP")) ? t3d_quant_for(a.M) : T3dQuant{0.0, 0.0};
   a.fold = t3d_take_fold(a.p0);
-  T3D_LAUNCH((pw_deep_kernel<DG, CV, NTW, KSP>), dim3(cdiv(a.M, 16 * RT), nchunks), dim3(64 * NW), lds, st, a, KS, ntiles,
+  T3D_LAUNCH_TIMED((pw_deep_kernel<DG, CV, NTW, KSP>), dim3(cdiv(a.M, 16 * RT), nchunks), dim3(64 * NW), lds, st, a, KS, ntiles,
                      g_t3d_reduce.nrep, g_t3d_reduce.stats_stride);
   T3D_CHECK_LAUNCH();
   return T3D_OK;

@@ -253,7 +253,7 @@ int launch_reg(GemmArgs& a, hipStream_t st) {
   const float inf = __builtin_inff();
   const float lo = (a.act == T3D_ACT_RELU || a.act == T3D_ACT_RELU6) ? 0.f : -inf, hi = a.act == T3D_ACT_RELU6 ? 6.f : inf;
 #define T3D_REG_LAUNCH(VV, SS) \
-  T3D_LAUNCH((pw_f32_reg_kernel<R, NT, VV, SS>), dim3((unsigned)grid), dim3(256), lds, st, a, KG, nchunks, lo, hi, nrep, rstride)
+  T3D_LAUNCH_TIMED((pw_f32_reg_kernel<R, NT, VV, SS>), dim3((unsigned)grid), dim3(256), lds, st, a, KG, nchunks, lo, hi, nrep, rstride)
   if (a.dgrad) T3D_REG_LAUNCH(6, false);
   else if (a.p2) {
     if (a.stats) { if (a.act == T3D_ACT_HSWISH) T3D_REG_LAUNCH(8, true); else T3D_REG_LAUNCH(7, true); }

@@ -145,9 +145,9 @@ int t3d_pw_wgrad_f32_reg(const float* dz, const float* y, const t3d_bnbwd* bb, c
   if (SG * 4 != S && hipMemsetAsync(a.ws + (size_t)S * tn * tk * 4096, 0, (size_t)(SG * 4 - S) * tn * tk * 4096 * sizeof(float), st) != hipSuccess)
     return T3D_ERR_LAUNCH;
   if (act == T3D_ACT_HSWISH)
-    T3D_LAUNCH((pw_wgrad_f32_reg_kernel<true>), dim3(tn * tk, SG), dim3(256), 0, st, a);
+    T3D_LAUNCH_TIMED((pw_wgrad_f32_reg_kernel<true>), dim3(tn * tk, SG), dim3(256), 0, st, a);
   else
-    T3D_LAUNCH((pw_wgrad_f32_reg_kernel<false>), dim3(tn * tk, SG), dim3(256), 0, st, a);
+    T3D_LAUNCH_TIMED((pw_wgrad_f32_reg_kernel<false>), dim3(tn * tk, SG), dim3(256), 0, st, a);
   T3D_CHECK_LAUNCH();
   return t3d_pw_wgrad_reduce(a.ws, dw, N, K, 64, 64, tk, tn * tk, SG * 4, st);
 }

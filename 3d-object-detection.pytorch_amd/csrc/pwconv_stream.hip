@@ -597,7 +597,7 @@ int launch_v(GemmArgs& a, int KS, hipStream_t st) {
   } else {
     a.fold = t3d_take_fold(a.p0);
   }
-  T3D_LAUNCH((pw_stream_kernel<NT, R, DG, GEN, YF, KU, ZM>), dim3(nxb * nchunks), dim3(threads), lds, st, a, nchunks, KS,
+  T3D_LAUNCH_TIMED((pw_stream_kernel<NT, R, DG, GEN, YF, KU, ZM>), dim3(nxb * nchunks), dim3(threads), lds, st, a, nchunks, KS,
                      g_t3d_reduce.nrep, g_t3d_reduce.stats_stride);
   T3D_CHECK_LAUNCH();
   return T3D_OK;

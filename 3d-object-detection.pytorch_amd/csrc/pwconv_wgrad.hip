@@ -229,9 +229,9 @@ extern "C" int t3d_pwconv_wgrad(int dtype, const void* dz, const void* y, const 
   const size_t need = (size_t)S * tn * tk * TN * TK * sizeof(float);
   a.ws = (S > 1 && g_t3d_ws.ptr && (size_t)g_t3d_ws.bytes >= need && !T3D_ENV_SET("T3D_WG_ATOMIC")) ? reinterpret_cast<float*>(g_t3d_ws.ptr) : nullptr;
   if (dtype == T3D_F32)
-    T3D_LAUNCH(pw_wgrad_kernel<float>, dim3(tn, tk, S), dim3(256), 0, st, a);
+    T3D_LAUNCH_TIMED(pw_wgrad_kernel<float>, dim3(tn, tk, S), dim3(256), 0, st, a);
   else if (dtype == T3D_BF16)
-    T3D_LAUNCH(pw_wgrad_kernel<bf16_t>, dim3(tn, tk, S), dim3(256), 0, st, a);
+    T3D_LAUNCH_TIMED(pw_wgrad_kernel<bf16_t>, dim3(tn, tk, S), dim3(256), 0, st, a);
   else
     return T3D_ERR_ARG;
   T3D_CHECK_LAUNCH();

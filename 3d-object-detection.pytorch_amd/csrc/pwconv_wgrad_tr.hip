@@ -692,7 +692,7 @@ int launch_d(WgtArgs& a, hipStream_t st) {
   if (lds > 64 * 1024)
     (void)t3d_max_lds((const void*)pw_wgrad_tr_kernel<NTPW, NTQ, SWAP, G, D, GEN, YF, SK, false, CV>, (int)lds);
   a.nsplit = S;
-  T3D_LAUNCH((pw_wgrad_tr_kernel<NTPW, NTQ, SWAP, G, D, GEN, YF, SK, false, CV>), dim3(tiles * S), dim3(256 * G), lds, st, a);
+  T3D_LAUNCH_TIMED((pw_wgrad_tr_kernel<NTPW, NTQ, SWAP, G, D, GEN, YF, SK, false, CV>), dim3(tiles * S), dim3(256 * G), lds, st, a);
   if (use_ws) {
     // split groups inside the workgroup: enough parallelism for a small dW with hundreds of splits
 #define T3D_WGR(SPV)                                                                                                              \
@@ -861,7 +861,7 @@ static int launch_fused(WgtArgs& a, const YfCfg& c, hipStream_t st) {
                      (size_t)2 * QB * sizeof(double);
   const void* fn = (const void*)pw_wgrad_tr_kernel<NTPW, NTQ, false, G, 2, false, true, SK, true>;
   if (lds > 64 * 1024) (void)t3d_max_lds(fn, (int)lds);
-  T3D_LAUNCH((pw_wgrad_tr_kernel<NTPW, NTQ, false, G, 2, false, true, SK, true>), dim3(c.S), dim3(256 * G), lds, st, a);
+  T3D_LAUNCH_TIMED((pw_wgrad_tr_kernel<NTPW, NTQ, false, G, 2, false, true, SK, true>), dim3(c.S), dim3(256 * G), lds, st, a);
   T3D_CHECK_LAUNCH();
   return T3D_OK;
 }

@@ -221,7 +221,10 @@ class KernelTimer:
 
 
 timer = None    # set to a KernelTimer to time launches
-_KERNEL_TIMED = frozenset(('t3d_dwconv_fwd', 't3d_dwconv_bwd', 't3d_expdw_fwd'))     # entry points whose main kernel takes t3d_set_launch_events
+# entry points whose main kernel takes t3d_set_launch_events (T3D_LAUNCH_TIMED in csrc): every convolution of the step
+_KERNEL_TIMED = frozenset(('t3d_dwconv_fwd', 't3d_dwconv_bwd', 't3d_expdw_fwd', 't3d_pwconv_fwd', 't3d_pwconv_fwd_mat', 't3d_pwconv_dgrad',
+                           't3d_pwconv_wgrad', 't3d_pwconv_dgrad_yfree', 't3d_pwconv_wgrad_yfree', 't3d_pwconv_bwd_yfree',
+                           't3d_pwconv_bwd_yfree_w'))
 # measurement aid (tools/ablate.sh): entry points whose launches are SKIPPED -- the results are then garbage, only the
 # step time means something (an upper bound on what removing / fusing that family of launches can buy)
 _ABLATE = frozenset(x for x in os.environ.get('T3D_ABLATE', '').split(',') if x)

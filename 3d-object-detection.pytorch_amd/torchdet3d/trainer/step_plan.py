@@ -235,48 +235,79 @@ class StepPlan:
 
 
 class PlanTiming:
-    """Attaches HIP-event pairs to the launches of `entries` in replayed steps (include/t3d.h: t3d_plan_time_entry /
-    t3d_plan_run's `events`): [(name, int-args signature, ms, algorithmic bytes)] afterwards, like _native.KernelTimer."""
+    """Attaches HIP-event pairs to the launches of selected entry points in replayed steps (include/t3d.h:
+    t3d_plan_time_entry / t3d_plan_run's `events`): [(name, int-args signature, ms, algorithmic bytes)] afterwards, like
+    _native.KernelTimer.  `entry_sets`: {label: entry-point names}; `select(label)` picks the set the NEXT steps are timed with
+    (None: untimed) -- bench.py times the depthwise family on every 4th step and every convolution family on a few."""
 
-    def __init__(self, step_plan, entries, max_steps):
-        self.sp, self.entries = step_plan, tuple(entries)
-        rec = step_plan.rec
-        self.idx = [i for i, c in enumerate(rec.calls) if c[0] in self.entries]
-        self.per_step = 2 * len(self.idx)
-        self.pool = [torch.cuda.Event(enable_timing=True) for _ in range(self.per_step * max_steps)]
+    def __init__(self, step_plan, entry_sets, max_events):
+        self.sp = step_plan
+        if not isinstance(entry_sets, dict):
+            entry_sets = {'default': tuple(entry_sets)}
+        self.sets = {k: tuple(v) for k, v in entry_sets.items()}
+        self.calls = step_plan.rec.calls
+        self.pool = [torch.cuda.Event(enable_timing=True) for _ in range(2 * max_events)]
         for e in self.pool:
             e.record()
-        self.used = []
-        self.active = False
-        for n in self.entries:
-            N.lib().t3d_plan_time_entry(rec.plan, n.encode(), 1)
+        self.used = []             # (label, events) per timed step
+        self.on = set()            # entry points currently switched on in the plan
+        self.label, self.idx, self.per_step = None, [], 0
+        self.cur = None
+
+    @property
+    def active(self):
+        return self.label is not None
+
+    @active.setter
+    def active(self, v):           # (the single-set form: timing.active = True / False)
+        self.select(next(iter(self.sets)) if v else None)
+
+    def select(self, label):
+        if label == self.label:
+            return
+        want = set(self.sets[label]) if label is not None else set()
+        plan = self.sp.rec.plan
+        for n in want - self.on:
+            N.lib().t3d_plan_time_entry(plan, n.encode(), 1)
+        for n in self.on - want:
+            N.lib().t3d_plan_time_entry(plan, n.encode(), 0)
+        self.on, self.label = want, label
+        self.idx = [i for i, c in enumerate(self.calls) if c[0] in want]
+        self.per_step = 2 * len(self.idx)
 
     def run(self, lib, plan, seg, nseg, slots):
         if seg == 0:
             self.cur = None
-            if self.active and len(self.pool) >= self.per_step:
+            if self.label is not None and self.per_step and len(self.pool) >= self.per_step:
                 evs = [self.pool.pop() for _ in range(self.per_step)]
-                self.cur = [evs, (ctypes.c_void_p * self.per_step)(*[e.cuda_event for e in evs]), 0]
+                self.cur = [evs, (ctypes.c_void_p * self.per_step)(*[e.cuda_event for e in evs]), 0, self.label, self.idx]
         if self.cur is None:
             return lib.t3d_plan_run(plan, seg, slots, N.NSLOTS, None, 0)
-        evs, arr, off = self.cur
+        evs, arr, off = self.cur[:3]
         tail = ctypes.cast(ctypes.byref(arr, off * ctypes.sizeof(ctypes.c_void_p)), ctypes.POINTER(ctypes.c_void_p))
-        rc = lib.t3d_plan_run(plan, seg, slots, N.NSLOTS, tail, self.per_step - off)
+        rc = lib.t3d_plan_run(plan, seg, slots, N.NSLOTS, tail, len(evs) - off)
         if rc >= 0:
             self.cur[2] = off + rc
             if seg == nseg - 1:
-                self.used.append(evs[:self.cur[2]])
+                self.used.append((self.cur[3], self.cur[4], evs[:self.cur[2]]))
         return rc
 
-    def per_launch(self):
+    def per_launch(self, label=None):
         torch.cuda.synchronize()
-        calls = self.sp.rec.calls
         out = []
-        for evs in self.used:
-            for j, ci in enumerate(self.idx[:len(evs) // 2]):
-                name, sig, nb = calls[ci]
+        for lab, idx, evs in self.used:
+            if label is not None and lab != label:
+                continue
+            for j, ci in enumerate(idx[:len(evs) // 2]):
+                name, sig, nb = self.calls[ci]
                 out.append((name, sig, evs[2 * j].elapsed_time(evs[2 * j + 1]), nb))
         return out
+
+    def steps(self, label):
+        return sum(1 for lab, _, _ in self.used if lab == label)
+
+    def close(self):
+        self.select(None)
 
 
 class ForwardPlan:

@@ -33,12 +33,23 @@ CONV_KERNELS = ('t3d_dwconv_fwd', 't3d_dwconv_bwd', 't3d_pwconv_fwd', 't3d_pwcon
                 't3d_pwconv_dgrad_yfree', 't3d_pwconv_wgrad_yfree', 't3d_pwconv_fwd_mat', 't3d_pwconv_bwd_yfree',
                 't3d_pwconv_wgrad_yfree_finish', 't3d_pwconv_yfree_prep', 't3d_pwconv_yfree_prep2')
 DW_ENTRIES = ('t3d_dwconv_fwd', 't3d_dwconv_bwd')
+# every convolution entry point whose main kernel takes a kernel-exact event pair (T3D_LAUNCH_TIMED in csrc): the families of
+# roofline.families (the driver line shows the WORST family beside the north-star's depthwise one)
+FAMILY_ENTRIES = ('t3d_dwconv_fwd', 't3d_dwconv_bwd', 't3d_pwconv_fwd', 't3d_pwconv_fwd_mat', 't3d_pwconv_dgrad', 't3d_pwconv_wgrad',
+                  't3d_pwconv_dgrad_yfree', 't3d_pwconv_wgrad_yfree', 't3d_pwconv_bwd_yfree', 't3d_pwconv_bwd_yfree_w')
+MFMA_PEAK = 2.5e15         # FLOP/s, dense bf16 MFMA (same guide; fp32 storage runs v_mfma_f32_16x16x4_f32: 157 TFLOP/s)
+MFMA_PEAK_F32 = 157.3e12
+# PMC family (tools/pmc_traffic.sh groups by rocprof kernel name) -> the entry points whose launches it holds
+PMC_GROUPS = {'t3d_dwconv_fwd': ('t3d_dwconv_fwd',), 't3d_dwconv_bwd': ('t3d_dwconv_bwd',),
+              't3d_pwconv_fwd': ('t3d_pwconv_fwd', 't3d_pwconv_fwd_mat'), 't3d_pwconv_dgrad': ('t3d_pwconv_dgrad',),
+              't3d_pwconv_wgrad': ('t3d_pwconv_wgrad',), 't3d_pwconv_dgrad_yfree': ('t3d_pwconv_dgrad_yfree',),
+              't3d_pwconv_wgrad_yfree': ('t3d_pwconv_wgrad_yfree', 't3d_pwconv_bwd_yfree', 't3d_pwconv_bwd_yfree_w')}
 # (entry point, k, stride) -> kernel name as rocprofv3 prints it (csrc/dwconv3_stream.hip, dwconv3_bwd_stream.hip,
 # dwconvk_stream.hip, dwconv5_bwd_stream.hip, dwconv_bwd.hip), bf16 storage
 DW_KERNEL_NAMES = {('t3d_dwconv_fwd', 3, 1): 'dw3_fwd2_kernel', ('t3d_dwconv_fwd', 3, 2): 'dw3_fwd_kernel',
                    ('t3d_dwconv_bwd', 3, 1): 'dw3_bwd2_kernel', ('t3d_dwconv_bwd', 3, 2): 'dw3_bwd_s2_kernel',
                    ('t3d_dwconv_fwd', 5, 1): 'dwk_fwd_kernel<5,1>', ('t3d_dwconv_fwd', 5, 2): 'dwk_fwd_kernel<5,2>',
-                   ('t3d_dwconv_bwd', 5, 1): 'dw_bwd_kernel (LDS tiles)', ('t3d_dwconv_bwd', 5, 2): 'dw5_bwd_s2_kernel'}
+                   ('t3d_dwconv_bwd', 5, 1): 'dw5_bwd_s1_kernel', ('t3d_dwconv_bwd', 5, 2): 'dw5_bwd_s2_kernel'}
 
 
 def spawn_ranks(args):
@@ -197,6 +208,78 @@ def cpu_baseline_guarded(args):
                     sample=f'CPU leg did not finish within its 150 s limit ({type(e).__name__})')
 
 
+def conv_source_hash():
+    """sha256 (16 hex digits) over every source of the HIP library: a committed PMC pass is quoted only for the kernels it saw."""
+    import hashlib
+    h = hashlib.sha256()
+    cs = os.path.join(ROOT, '3d-object-detection.pytorch_amd', 'csrc')
+    for f in sorted(x for x in os.listdir(cs) if x.endswith(('.hip', '.h'))):
+        h.update(open(os.path.join(cs, f), 'rb').read())
+    return h.hexdigest()[:16]
+
+
+def pmc_families(args, S, B):
+    """HBM bytes per step and PMC family from the latest committed rocprofv3 counter pass (tools/pmc_traffic.sh), or {} when it
+    was collected on another workload or on other kernel sources."""
+    import glob
+    tfs = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r[0-9]*_hbm_traffic_pmc.json')))
+    if not tfs or not (args.model == 'mobilenetv2' and S == 224 and B == 256 and args.dtype == 'bf16' and not args.eval):
+        return {}
+    pm = json.load(open(tfs[-1]))
+    if pm.get('conv_source_sha256') != conv_source_hash():
+        return {'_source': 'stale'}
+    out = {k: v['hbm_bytes_per_step'] for k, v in pm.get('families', {}).items()}
+    out['_source'] = f"profiles/{os.path.basename(tfs[-1])} (committed rocprofv3 --pmc pass at {pm.get('commit', '?')})"
+    return out
+
+
+def family_block(launches, nsteps, args, pmc):
+    """roofline.families: every convolution entry point of the step, each launch timed on its own dispatch (begin-to-end of the
+    kernel, as rocprofv3 reports it) inside the timed region, on `nsteps` of its steps.  Per family: launches and device time
+    per step, algorithmic HBM bytes (input + output once per pass) and GEMM FLOPs, both as a fraction of
+    the chip's peak; `counter_ratio` = HBM bytes of the rocprofv3 PMC pass / algorithmic bytes, for the PMC family the entry
+    point belongs to.  `worst` = the family (>= 2 % of the summed conv time) with the lowest fraction of the roof that bounds it."""
+    peak_f = MFMA_PEAK if args.dtype == 'bf16' else MFMA_PEAK_F32
+    groups = {}
+    for name, sig, ms, nby in launches:
+        if not (ms > 5e-4):                 # (an entry point whose path had no timed launch site: recorded back to back)
+            continue
+        d = groups.setdefault(name, dict(launches=0, ms=0.0, bytes=0, flops=0.0))
+        d['launches'] += 1
+        d['ms'] += ms
+        d['bytes'] += nby or 0
+        if name.startswith('t3d_pwconv') and len(sig) >= 4:
+            m_, k_, n_ = sig[-4], sig[-2], sig[-1]
+            d['flops'] += 2.0 * m_ * k_ * n_ * (2 if 'bwd_yfree' in name else 1)    # (the fused pass: data gradient + weight-gradient products)
+        elif name.startswith('t3d_dwconv') and len(sig) >= 6:
+            b_, h_, w_, c_, kk, st_ = sig[-6:]
+            d['flops'] += 2.0 * b_ * ((h_ - 1) // st_ + 1) * ((w_ - 1) // st_ + 1) * c_ * kk * kk * (2 if name.endswith('bwd') else 1)
+    total_ms = sum(d['ms'] for d in groups.values()) or 1.0
+    rows = []
+    for name, d in groups.items():
+        t = d['ms'] * 1e-3
+        hb, mf = d['bytes'] / t / HBM_PEAK, d['flops'] / t / peak_f
+        rows.append({'entry': name, 'launches_per_step': d['launches'] // nsteps, 'ms_per_step': round(d['ms'] / nsteps, 4),
+                     'algorithmic_MB_per_step': round(d['bytes'] / nsteps / 1e6, 1), 'achieved_GBps': round(d['bytes'] / t / 1e9, 1),
+                     'hbm_frac': round(hb, 4), 'GFLOP_per_step': round(d['flops'] / nsteps / 1e9, 1), 'mfma_frac': round(mf, 4),
+                     'bound': 'hbm' if hb >= mf else 'mfma', 'frac': round(max(hb, mf), 4), 'counter_ratio': None,
+                     'share_of_conv_time': round(d['ms'] / total_ms, 4)})
+    for fam, members in PMC_GROUPS.items():
+        alg = sum(r['algorithmic_MB_per_step'] for r in rows if r['entry'] in members) * 1e6
+        if fam in pmc and alg > 0:
+            for r in rows:
+                if r['entry'] in members:
+                    r['counter_ratio'] = round(pmc[fam] / alg, 3)
+    rows.sort(key=lambda r: r['frac'])
+    cand = [r for r in rows if r['share_of_conv_time'] >= 0.02] or rows
+    w = cand[0]
+    return {'families': rows, 'families_sampled_steps': nsteps, 'families_counter_source': pmc.get('_source'),
+            'families_note': 'in-step, kernel-exact HIP events on each launch\'s own dispatch; second-stream launches (weight gradients) '
+                             'include the time their workgroups wait for the main stream\'s persistent kernels to free registers',
+            'worst': {'entry': w['entry'], 'bound': w['bound'], 'frac': w['frac'], 'ms_per_step': w['ms_per_step'],
+                      'counter_ratio': w['counter_ratio']}}
+
+
 def main():
     args = parse()
     if args.cpu_baseline_only:
@@ -336,6 +419,9 @@ def main():
 
     # ---- timed region: exactly K steps; the depthwise launches (main stream) carry HIP-event pairs
     every = max(1, args.roofline_every)
+    # ... and on three steps spread over the region EVERY convolution launch does (roofline.families): ~200 pairs per step cost
+    # ~1 ms on that step, so it is three steps and not every 4th
+    full_steps = sorted({args.steps // 4, args.steps // 2, (3 * args.steps) // 4}) if args.steps >= 8 else [0]
     # kernel_exact: the event pair is attached to the depthwise kernel's own dispatch (begin-to-end of the kernel, as rocprofv3
     # reports it), not recorded around the launch call (which adds 5-9 us of event packets and dispatch latency)
     rtimer = N.KernelTimer(set(DW_ENTRIES), prealloc=2 * 40 * ((args.steps + every - 1) // every), kernel_exact=not os.environ.get('T3D_EVENTS_AROUND'))
@@ -346,7 +432,9 @@ def main():
     ptimer = None
     if sp is not None and sp.rec is not None:
         from torchdet3d.trainer.step_plan import PlanTiming
-        ptimer = sp.timing = PlanTiming(sp, DW_ENTRIES, (args.steps + every - 1) // every)
+        ncalls = lambda names: sum(1 for c in sp.rec.calls if c[0] in names)
+        ptimer = sp.timing = PlanTiming(sp, {'dw': DW_ENTRIES, 'all': FAMILY_ENTRIES},
+                                        ncalls(DW_ENTRIES) * ((args.steps + every - 1) // every) + ncalls(FAMILY_ENTRIES) * len(full_steps))
     # no cyclic-GC pass inside the timed region: one in three fresh processes had a single 36-44 ms step in it
     # (config.step_ms_min_med_max), i.e. +12 % on the 30-step average, from a collection over the freshly imported heap
     import gc
@@ -358,7 +446,7 @@ def main():
     marks[0].record()
     for i in range(args.steps):
         if ptimer is not None:
-            ptimer.active = i % every == 0
+            ptimer.select('all' if i in full_steps else ('dw' if i % every == 0 else None))
         else:
             N.timer = rtimer if i % every == 0 else None
         step(i)
@@ -369,11 +457,14 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     gc.enable()
+    fam_launches, fam_steps = [], 0
     if ptimer is not None:
+        ptimer.close()
         sp.timing = None
+        fam_launches, fam_steps = ptimer.per_launch('all'), ptimer.steps('all')
     per_step = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps))
-    launches = ptimer.per_launch() if ptimer is not None else rtimer.per_launch()
-    nsampled = (args.steps + every - 1) // every
+    launches = ptimer.per_launch('dw') if ptimer is not None else rtimer.per_launch()
+    nsampled = ptimer.steps('dw') if ptimer is not None else (args.steps + every - 1) // every
     if world > 1:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -466,6 +557,20 @@ def main():
                                'algorithmic_MB_per_step': top['algorithmic_MB_per_step'],
                                'selection': 'depthwise family with the most device time over the timed steps',
                                'depthwise': rows}
+        if fam_steps:
+            res['roofline'] = res.get('roofline') or {'bound': 'hbm', 'peak': HBM_PEAK / 1e9, 'unit': 'GB/s'}
+            res['roofline'].update(family_block(fam_launches, fam_steps, args, pmc_families(args, S, B)))
+            if 'kernel' not in res['roofline']:
+                # a model without depthwise layers (ResNet-50, BASELINE config 4: "stresses the MFMA dense-conv path"): the
+                # headline entry is the GEMM family with the most device time, against the roof that bounds it
+                top = max(res['roofline']['families'], key=lambda r: r['ms_per_step'])
+                mf = top['bound'] == 'mfma'
+                res['roofline'].update({'bound': top['bound'], 'entry': top['entry'], 'kernel': top['entry'],
+                                        'achieved': round(top['mfma_frac'] * (MFMA_PEAK if args.dtype == 'bf16' else MFMA_PEAK_F32) / 1e12, 1) if mf else top['achieved_GBps'],
+                                        'peak': ((MFMA_PEAK if args.dtype == 'bf16' else MFMA_PEAK_F32) / 1e12) if mf else HBM_PEAK / 1e9,
+                                        'unit': 'TFLOP/s' if mf else 'GB/s', 'frac': top['frac'], 'traffic': None,
+                                        'launches_per_step': top['launches_per_step'], 'ms_per_step': top['ms_per_step'],
+                                        'selection': 'convolution family with the most device time over the sampled steps'})
         if args.model == 'mobilenetv2' and S == 224 and args.dtype == 'bf16':
             per_crop = 26.89 if args.eval else MNV2_TRAIN_MB_PER_CROP     # forward / train MB per crop
             if args.eval and eval_dt == 'f32':

@@ -59,3 +59,31 @@ def test_bench_spawns_its_own_ranks_and_reports_them():
                             timeout=900)
         assert r2.returncode != 0
         assert 'GPU(s) visible' in (r2.stdout + r2.stderr)
+
+
+def test_rccl_path_costs_under_three_percent_at_the_headline_shape():
+    """VERDICT r5 #8 (multi-GPU readiness without the node): `bench.py --gpus 1` under the launcher with T3D_FORCE_SYNC=1 -- the
+    segmented step plan, the bucketed RCCL all-reduces issued from the backward's hooks, the second-stream joins -- at BASELINE
+    config 2's shape (MobileNetV2, B = 256 @224^2, bf16) against the plain one-process run on the same box: the exchange
+    machinery must not cost more than 3 % of the step.  (One rank: the collectives move no bytes over xGMI; what this holds
+    is everything around them.  The measured pair is recorded in DESIGN.md section 5.)"""
+    import json
+    base = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'))
+    args = ['--gpus', '1', '--steps', '40', '--warmup', '10', '--no-cpu-baseline']
+
+    def run(cmd, env):
+        r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stderr[-3000:]
+        return json.loads([l for l in r.stdout.splitlines() if l.startswith('{')][-1])
+
+    plain = run([sys.executable, os.path.join(ROOT, 'bench.py')] + args, base)
+    launcher = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node=1', '--master-addr', '127.0.0.1',
+                '--master-port', str(_free_port()), os.path.join(ROOT, 'bench.py')] + args
+    forced = run(launcher, dict(base, T3D_FORCE_SYNC='1'))
+    assert plain['config']['rccl_ranks'] == 0 and forced['config']['rccl_ranks'] == 1
+    # medians of the per-step times: one slow step (a clock dip on a fresh box) must not decide a 3 % comparison
+    a, b = plain['config']['step_ms_min_med_max'][1], forced['config']['step_ms_min_med_max'][1]
+    print(f'[rccl readiness] plain {plain["ms_per_step"]} ms/step (median {a}), under RCCL with forced sync '
+          f'{forced["ms_per_step"]} ms/step (median {b}): {100 * (b / a - 1):+.2f} %')
+    assert b <= 1.03 * a, (a, b)
+    assert abs(forced['config']['final_loss'] - plain['config']['final_loss']) < 5e-3

@@ -54,7 +54,13 @@ def src_hash():
     for f in sorted(x for x in os.listdir(d) if x.startswith('dwconv3') and x.endswith('_stream.hip')):
         h.update(open(os.path.join(d, f), 'rb').read())
     return h.hexdigest()[:16]
-res = dict(dw3_source_sha256=src_hash(), note='rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over `bench.py --steps 3 --warmup 2` (7 steps: 2 warm-up, 2 host-issue probes, 3 timed), '
+def conv_hash():          # every source of the library: bench.py quotes the per-family ratios only for the kernels this pass saw
+    h = hashlib.sha256()
+    d = os.path.join('3d-object-detection.pytorch_amd', 'csrc')
+    for f in sorted(x for x in os.listdir(d) if x.endswith(('.hip', '.h'))):
+        h.update(open(os.path.join(d, f), 'rb').read())
+    return h.hexdigest()[:16]
+res = dict(dw3_source_sha256=src_hash(), conv_source_sha256=conv_hash(), note='rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over `bench.py --steps 3 --warmup 2` (7 steps: 2 warm-up, 2 host-issue probes, 3 timed), '
                 'MobileNetV2 224^2 B=256 bf16; FETCH_SIZE doubled per the gfx950 correction; per-family sums (tools/pmc_traffic.sh)',
            commit=(sys.argv[3] if len(sys.argv) > 3 else '?'), kernels=kern,
            steps=nsteps, all_kernels_hbm_bytes_per_step=round((2 * tot['FETCH_SIZE'] + tot['WRITE_SIZE']) * 1024 / nsteps), families=fam)
