@@ -417,9 +417,11 @@ int launch5_s1(Dw5BArgs& a, hipStream_t st) {
   if (max_chunks < 1) max_chunks = 1;
   if (nchunks > max_chunks) nchunks = max_chunks;
   if (nchunks < 1) nchunks = 1;
+  static const int ch_env = getenv("T3D_DW5_CHUNKS") ? atoi(getenv("T3D_DW5_CHUNKS")) : 0;      // (sweep knobs)
+  if (ch_env) nchunks = ch_env;
   a.rows_per_chunk = cdiv(a.H, nchunks);
   a.nchunks = cdiv(a.H, a.rows_per_chunk);
-  const int tb_env = 0;
+  static const int tb_env = getenv("T3D_DW5_TB") ? atoi(getenv("T3D_DW5_TB")) : 0;
   const int target_blocks = tb_env ? tb_env : 512;
   a.nrep = g_t3d_reduce.nrep;
   a.rstride = g_t3d_reduce.stats_stride;
@@ -465,9 +467,11 @@ int launch5_s2(Dw5BArgs& a, hipStream_t st) {
   if (max_chunks < 1) max_chunks = 1;
   if (nchunks > max_chunks) nchunks = max_chunks;
   if (nchunks < 1) nchunks = 1;
+  static const int ch_env = getenv("T3D_DW5_CHUNKS") ? atoi(getenv("T3D_DW5_CHUNKS")) : 0;
+  if (ch_env) nchunks = ch_env;
   a.rows_per_chunk = cdiv(Ho, nchunks);
   a.nchunks = cdiv(Ho, a.rows_per_chunk);
-  const int tb_env = 0;
+  static const int tb_env = getenv("T3D_DW5_TB") ? atoi(getenv("T3D_DW5_TB")) : 0;
   const int target_blocks = tb_env ? tb_env : 512;
   a.nrep = g_t3d_reduce.nrep;
   a.rstride = g_t3d_reduce.stats_stride;

@@ -256,6 +256,9 @@ int t3d_dw3_fwd_stream(int dtype, const void* x, const t3d_prologue* pro, const 
 int t3d_dwk_fwd_stream(int dtype, const void* x, const t3d_prologue* pro, const float* w, void* y, double* stats,
                        float* gap_sum, int B, int H, int W, int C, int k, int stride, hipStream_t st);   // dwconvk_stream.hip
 
+int t3d_dw5_plane7_fwd(int dtype, const void* x, const t3d_prologue* pro, const float* w, void* y, double* stats, float* gap_sum,
+                       int B, int C, hipStream_t st);   // dwconv5_plane7.hip
+
 extern "C" int t3d_dwconv_fwd(int dtype, const void* x, const t3d_prologue* pro, const float* w, void* y,
                               double* stats, float* gap_sum, int B, int H, int W, int C, int k, int stride,
                               void* stream) {
@@ -265,6 +268,11 @@ extern "C" int t3d_dwconv_fwd(int dtype, const void* x, const t3d_prologue* pro,
   // the kernels below read finished coefficients: a pending derive request for them becomes a launch of its own
   if (pro)
     if (const int rc = t3d_fold_fallback(pro->scale, reinterpret_cast<hipStream_t>(stream))) return rc;
+  if (k == 5 && stride == 1 && H == 7 && W == 7 && !getenv("T3D_DW_TILED")) {
+    // 5x5 on 7x7 planes (the 1/32 stage of MobileNetV3): a thread per (image, channel pair) holds the plane (dwconv5_plane7.hip)
+    const int rc = t3d_dw5_plane7_fwd(dtype, x, pro, w, y, stats, gap_sum, B, C, reinterpret_cast<hipStream_t>(stream));
+    if (rc != T3D_ERR_UNSUPPORTED) return rc;
+  }
   if ((k == 3 || k == 5) && (stride == 1 || stride == 2) && !(pro && pro->se) && !getenv("T3D_DW_TILED")) {
     // 5x5 layers and the squeeze-excite blocks (per-sample pooled sums): generic streaming kernel
     const int rc = t3d_dwk_fwd_stream(dtype, x, pro, w, y, stats, gap_sum, B, H, W, C, k, stride,

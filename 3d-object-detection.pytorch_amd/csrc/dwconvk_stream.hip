@@ -197,15 +197,21 @@ int launch_nc(DwkArgs& a, hipStream_t st) {
   const int CG = a.C / CH;
   a.Wb = cdiv(a.Wo, NC);
   const long long per_row_chunk = (long long)a.B * a.Wb * CG;
-  int nchunks = (int)((256LL * 64 * 40 + per_row_chunk - 1) / per_row_chunk);
+  // row chunks per image: enough (thread, item) pairs to fill the chip once (~1600 waves) and no more -- every chunk re-reads
+  // K - 1 halo rows and pays the ring fill again.  (Round 6, isolated at B = 256: 28x28x120 5x5 s1 with four columns per
+  // thread ran 79 us in three chunks, 58 in one; the 40-fold target dates from the one-column kernel.)
+  const long long want = (K == 5 && S == 1 && NC > 1) ? 256LL * 64 * 6 : 256LL * 64 * 40;
+  int nchunks = (int)((want + per_row_chunk - 1) / per_row_chunk);
   int max_chunks = a.Ho / 8;
   if (max_chunks < 1) max_chunks = 1;
   if (nchunks > max_chunks) nchunks = max_chunks;
   if (nchunks < 1) nchunks = 1;
+  static const int ch_env = getenv("T3D_DWK_CHUNKS") ? atoi(getenv("T3D_DWK_CHUNKS")) : 0;      // (sweep knobs)
+  if (ch_env) nchunks = ch_env;
   a.rows_per_chunk = cdiv(a.Ho, nchunks);
   a.nchunks = cdiv(a.Ho, a.rows_per_chunk);
-  const int tb_env = 0;
-  const int target_blocks = tb_env ? tb_env : 768;
+  static const int tb_env = getenv("T3D_DWK_TB") ? atoi(getenv("T3D_DWK_TB")) : 0;
+  const int target_blocks = tb_env ? tb_env : ((K == 5 && S == 1) ? 1024 : 768);
   a.nrep = g_t3d_reduce.nrep;
   a.rstride = g_t3d_reduce.stats_stride;
   dim3 grid;

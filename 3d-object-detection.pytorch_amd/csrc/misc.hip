@@ -96,34 +96,32 @@ __global__ void sum_replicas_batched_kernel(const long long* __restrict__ desc, 
 // desc[t] = {src [slots][count] fp32, dst [count] fp32, count, used (device int*)}: dst = sum over the first *used slots, in
 // index order (overwrites) -- the deterministic end of the depthwise weight gradient (t3d_set_dw_slots)
 __global__ __launch_bounds__(256) void sum_slots_batched_kernel(const long long* __restrict__ desc) {
-  // 16 elements x 16 slot groups per workgroup: group g adds slots g, g + 16, ... in that order, the 16 group sums meet in
-  // LDS in index order (a thread per element over up to 512 slots was a 128-round latency chain for the small layers:
-  // 120 us beside the stem's weight gradient at the very end of the backward)
-  __shared__ float part[16][17];
+  // 64 elements x 4 slot groups per workgroup: a wave's lanes run along the elements (256 contiguous bytes per slot row),
+  // group g adds slots g, g + 4, ... in that order with eight loads in flight, the four group sums meet in LDS in index order.
+  // (Round 3's 16 x 16 shape read 64-byte pieces: 65 us at the tail of the backward for ~100 MB of slots; a thread per
+  // element over up to 512 slots was a 128-round latency chain before that.)
+  __shared__ float part[4][64];
   const long long* d = desc + (size_t)blockIdx.x * 4;
   const float* __restrict__ src = reinterpret_cast<const float*>(d[0]);
   float* __restrict__ dst = reinterpret_cast<float*>(d[1]);
   const int n = (int)d[2], nslots = *reinterpret_cast<const int*>(d[3]);
-  const int el = threadIdx.x & 15, g = threadIdx.x >> 4;
-  for (int i0 = blockIdx.y * 16; i0 < n; i0 += gridDim.y * 16) {
-    const int i = i0 + el;
+  const int el = threadIdx.x & 63, g = threadIdx.x >> 6;
+  for (int i0 = blockIdx.y * 64; i0 < n; i0 += gridDim.y * 64) {
+    const int i = min(i0 + el, n - 1);          // (clamped: branch-free loads, lanes past n are not written)
+    const float* col = src + i;
     float s = 0.f;
-    if (i < n) {
-      int r = g;
-      for (; r + 48 < nslots; r += 64) {       // four loads in flight, added in index order
-        const float a = src[(size_t)r * n + i], b = src[(size_t)(r + 16) * n + i], c = src[(size_t)(r + 32) * n + i], e = src[(size_t)(r + 48) * n + i];
-        s += a; s += b; s += c; s += e;
-      }
-      for (; r < nslots; r += 16) s += src[(size_t)r * n + i];
+    int r = g;
+    for (; r + 28 < nslots; r += 32) {
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = col[(size_t)(r + 4 * u) * n];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) s += v[u];
     }
+    for (; r < nslots; r += 4) s += col[(size_t)r * n];
     part[g][el] = s;
     __syncthreads();
-    if (g == 0 && i < n) {
-      float t = part[0][el];
-#pragma unroll
-      for (int q = 1; q < 16; ++q) t += part[q][el];
-      dst[i] = t;
-    }
+    if (g == 0 && i0 + el < n) dst[i0 + el] = ((part[0][el] + part[1][el]) + part[2][el]) + part[3][el];
     __syncthreads();
   }
 }
@@ -311,7 +309,7 @@ extern "C" int t3d_zero_batched(const long long* desc, int n, void* stream) {
 
 extern "C" int t3d_sum_slots_batched(const long long* desc, int n, void* stream) {
   if (!desc || n <= 0) return T3D_ERR_ARG;
-  T3D_LAUNCH(sum_slots_batched_kernel, dim3(n, 32), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), desc);
+  T3D_LAUNCH(sum_slots_batched_kernel, dim3(n, 48), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), desc);
   T3D_CHECK_LAUNCH();
   return T3D_OK;
 }

@@ -392,6 +392,134 @@ __global__ __launch_bounds__(SE_T) void se_bwd_group_kernel(const SeArgs a, cons
   });
 }
 
+
+// ------------------------------------------------------------------ round 6: one launch per PRODUCT, outputs sliced over workgroups
+// The group kernels above walk both products of a direction inside 64 workgroups: ~60 dependent rounds of sixteen L2 loads
+// per thread -- 27 / 37 us alone, but 33 / 105 us inside the step (rocprofv3, MobileNetV3-large: 8 gates = 0.84 ms of the
+// backward's critical stream for ~0.1 GFLOP; the rounds get longer when the weight-gradient stream is busy in L2).  Here a
+// workgroup owns SPG samples x 64 OUTPUTS of ONE product and its four waves split the contraction: 960 -> 240 is 15 rounds
+// instead of 30, 240 -> 960 four instead of 30, and 256 ... 960 small workgroups fill the chip instead of 64 large ones.
+// The price is a second launch per direction (a dependent kernel boundary, ~3 us).  Summation order: four contiguous
+// slices of the contraction, added in slice order -- deterministic, different in the last bits from the group kernels.
+constexpr int SL_OB = 64, SL_T = 256, SL_G = SL_T / SL_OB;
+// MODE 0: h = relu(W1 m + b1), m from the pooled sums   1: q = W2 h + b2, s = h_sigmoid(q)
+//      2: dp = relu'(h) (dq W2), dq from the per-sample sums   3: g = (dp W1) / HW + the BatchNorm-backward sums
+template <int MODE>
+__global__ __launch_bounds__(SL_T) void se_slice_kernel(const SeArgs a, const float* __restrict__ Wt, const int nrep, const long long rstride) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  constexpr bool FROM_C = MODE == 0 || MODE == 2;      // contraction over the C channels (else over the R hidden units)
+  const int I = FROM_C ? a.C : a.R, O = FROM_C ? a.R : a.C;
+  float* in = lds;                                     // [I][SPG]
+  float* red = in + (size_t)I * SPG;                   // [SL_T][SPG]
+  const int b0 = blockIdx.x * SPG, t = threadIdx.x;
+  const bool first = blockIdx.y == 0;                  // the slice that also stores the staged input (m / dq)
+  const float inv = 1.f / (float)a.HW;
+  for (int i = t; i < I * SPG; i += SL_T) {
+    const int c = i / SPG, s = i % SPG, b = b0 + s;
+    float v = 0.f;
+    if (b < a.B) {
+      const size_t k = (size_t)b * I + c;
+      if (MODE == 0) {
+        v = a.scale[c] * (t3d_pool_get(a.gap, k, a.gapq) * inv) + a.shift[c];
+        if (first) a.m[k] = v;
+      } else if (MODE == 1) {
+        v = a.h[k];
+      } else if (MODE == 2) {
+        const float ds = a.scale[c] * a.ps[2 * k + 1] + a.shift[c] * a.ps[2 * k];
+        const float q = a.q[k];
+        v = (q > -3.f && q < 3.f) ? ds * (1.f / 6.f) : 0.f;     // relu6 passes strictly inside
+        if (first) a.dq[k] = v;
+      } else {
+        v = a.dp[k];
+      }
+    }
+    in[i] = v;
+  }
+  __syncthreads();
+  const int grp = t / SL_OB, ol = t % SL_OB, o = blockIdx.y * SL_OB + ol;
+  const bool live = o < O;
+  const int per = (I + SL_G - 1) / SL_G, i0 = min(grp * per, I), i1 = min(i0 + per, I);
+  float acc[SPG];
+#pragma unroll
+  for (int s = 0; s < SPG; ++s) acc[s] = 0.f;
+  if (live) {
+    int i = i0;
+    for (; i + 16 <= i1; i += 16) {
+      float w[16];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) w[u] = Wt[(size_t)(i + u) * O + o];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) {
+        const float4 x0 = *reinterpret_cast<const float4*>(in + (i + u) * SPG);
+        acc[0] = fmaf(x0.x, w[u], acc[0]); acc[1] = fmaf(x0.y, w[u], acc[1]);
+        acc[2] = fmaf(x0.z, w[u], acc[2]); acc[3] = fmaf(x0.w, w[u], acc[3]);
+      }
+    }
+    for (; i < i1; ++i) {
+      const float w = Wt[(size_t)i * O + o];
+#pragma unroll
+      for (int s = 0; s < SPG; ++s) acc[s] = fmaf(in[i * SPG + s], w, acc[s]);
+    }
+  }
+  if (grp > 0) {
+#pragma unroll
+    for (int s = 0; s < SPG; ++s) red[(size_t)t * SPG + s] = acc[s];
+  }
+  __syncthreads();
+  if (grp != 0 || !live) return;
+#pragma unroll
+  for (int g = 1; g < SL_G; ++g)
+#pragma unroll
+    for (int s = 0; s < SPG; ++s) acc[s] += red[(size_t)(g * SL_OB + ol) * SPG + s];
+  if (MODE == 0) {
+    const float b1 = a.b1[o];
+#pragma unroll
+    for (int s = 0; s < SPG; ++s)
+      if (b0 + s < a.B) a.h[(size_t)(b0 + s) * a.R + o] = fmaxf(acc[s] + b1, 0.f);
+  } else if (MODE == 1) {
+    const float b2 = a.b2[o];
+#pragma unroll
+    for (int s = 0; s < SPG; ++s) {
+      if (b0 + s < a.B) {
+        const float q = acc[s] + b2;
+        a.q[(size_t)(b0 + s) * a.C + o] = q;
+        a.s[(size_t)(b0 + s) * a.C + o] = hsigmoid(q);
+      }
+    }
+  } else if (MODE == 2) {
+#pragma unroll
+    for (int s = 0; s < SPG; ++s)
+      if (b0 + s < a.B) a.dp[(size_t)(b0 + s) * a.R + o] = a.h[(size_t)(b0 + s) * a.R + o] > 0.f ? acc[s] : 0.f;
+  } else {
+    float v1 = 0.f, v2 = 0.f;
+#pragma unroll
+    for (int s = 0; s < SPG; ++s) {
+      if (b0 + s < a.B) {
+        const size_t k = (size_t)(b0 + s) * a.C + o;
+        const float gu = acc[s] * inv;                          // every pixel of u receives dL/dm / HW
+        a.g[k] = gu;
+        const float sg = a.s[k], p1 = a.ps[2 * k], p2 = a.ps[2 * k + 1];
+        v1 += sg * p1 + (float)a.HW * gu;
+        v2 += sg * p2 + gu * t3d_pool_get(a.gap, k, a.gapq);
+      }
+    }
+    if (a.stats) {      // one add per (sample group, channel), spread over the reduction replicas
+      double* st = a.stats + (size_t)(blockIdx.x % nrep) * rstride;
+      atomicAdd(st + o, (double)v1);
+      atomicAdd(st + a.C + o, (double)v2);
+    }
+  }
+}
+
+template <int MODE>
+static void se_slice_launch(const SeArgs& a, const float* Wt, hipStream_t st) {
+  const int I = (MODE == 0 || MODE == 2) ? a.C : a.R, O = (MODE == 0 || MODE == 2) ? a.R : a.C;
+  const size_t lds = ((size_t)I * SPG + (size_t)SL_T * SPG) * sizeof(float);
+  T3D_LAUNCH(se_slice_kernel<MODE>, dim3(cdiv(a.B, SPG), cdiv(O, SL_OB)), dim3(SL_T), lds, st, a, Wt, g_t3d_reduce.nrep < 1 ? 1 : g_t3d_reduce.nrep,
+             g_t3d_reduce.nrep < 1 ? 0 : g_t3d_reduce.stats_stride);
+}
+static bool se_sliced() { return !T3D_ENV_SET("T3D_SE_GROUP"); }      // (A/B: the one-launch group kernels)
+
 }  // namespace
 
 extern "C" int t3d_se_fwd(const float* gap_sum, const float* scale, const float* shift, const float* w1,
@@ -450,6 +578,12 @@ extern "C" int t3d_se_fwd_fused(const float* gap_sum, const float* scale, const 
   SeArgs a{};
   a.gap = gap_sum; a.gapq = g_t3d_reduce.pool_exact; a.scale = scale; a.shift = shift; a.b1 = b1; a.b2 = b2;
   a.m = m; a.h = h; a.q = q; a.s = s; a.B = B; a.C = C; a.R = R; a.HW = HW;
+  if (se_sliced()) {
+    se_slice_launch<0>(a, w1t, reinterpret_cast<hipStream_t>(stream));
+    se_slice_launch<1>(a, w2t, reinterpret_cast<hipStream_t>(stream));
+    T3D_CHECK_LAUNCH();
+    return T3D_OK;
+  }
   const size_t lds = se_group_lds(C, R);
   (void)t3d_max_lds((const void*)se_fwd_group_kernel, 96 * 1024);      // (cached per device and kernel, misc.hip)
   T3D_LAUNCH(se_fwd_group_kernel, dim3(cdiv(B, SPG)), dim3(SE_T), lds, reinterpret_cast<hipStream_t>(stream), a, w1t, w2t);
@@ -467,6 +601,12 @@ extern "C" int t3d_se_bwd_data(const float* ps_stats, const float* gap_sum, cons
   a.ps = ps_stats; a.gap = gap_sum; a.gapq = g_t3d_reduce.pool_exact; a.scale = scale; a.shift = shift; a.w1 = w1; a.w2 = w2;
   a.h = const_cast<float*>(h); a.q = const_cast<float*>(q); a.s = const_cast<float*>(s);
   a.g = g; a.dq = dq; a.dp = dp; a.stats = stats; a.B = B; a.C = C; a.R = R; a.HW = HW;
+  if (se_sliced()) {
+    se_slice_launch<2>(a, w2, reinterpret_cast<hipStream_t>(stream));      // W2 is [C][R] = [I][O]
+    se_slice_launch<3>(a, w1, reinterpret_cast<hipStream_t>(stream));      // W1 is [R][C] = [I][O]
+    T3D_CHECK_LAUNCH();
+    return T3D_OK;
+  }
   (void)t3d_max_lds((const void*)se_bwd_group_kernel, 96 * 1024);
   T3D_LAUNCH(se_bwd_group_kernel, dim3(cdiv(B, SPG)), dim3(SE_T), se_group_lds(C, R), reinterpret_cast<hipStream_t>(stream), a,
                      g_t3d_reduce.nrep, g_t3d_reduce.stats_stride);

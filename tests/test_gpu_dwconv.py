@@ -20,7 +20,9 @@ SHAPES = [  # B, C, H, W, k, s
     (2, 32, 24, 24, 3, 1), (2, 96, 24, 24, 3, 2), (3, 72, 13, 17, 5, 2), (2, 120, 12, 12, 5, 1),
     (2, 16, 48, 48, 3, 1), (4, 960, 3, 3, 5, 1), (2, 200, 6, 6, 3, 1), (1, 8, 7, 7, 3, 1), (2, 144, 56, 56, 3, 1),
     (2, 672, 14, 14, 5, 2), (3, 576, 6, 6, 3, 1), (2, 960, 3, 3, 3, 1), (2, 384, 12, 12, 3, 2), (5, 264, 9, 7, 3, 1),
-    (3, 40, 13, 17, 3, 2), (2, 576, 7, 7, 3, 2), (1, 24, 2, 2, 3, 2), (2, 144, 56, 56, 3, 2)]
+    (3, 40, 13, 17, 3, 2), (2, 576, 7, 7, 3, 2), (1, 24, 2, 2, 3, 2), (2, 144, 56, 56, 3, 2),
+    # 5x5 on 7x7 planes: a thread per (image, channel pair) holds the plane (csrc/dwconv5_plane7.hip); 72 channels = a partial slab
+    (5, 960, 7, 7, 5, 1), (3, 72, 7, 7, 5, 1), (9, 576, 7, 7, 5, 1)]
 
 
 @pytest.mark.parametrize('B,C,H,W,k,s', SHAPES)
@@ -163,7 +165,7 @@ def test_dwconv_bwd(B, C, H, W, k, s, dt, mode):
 
 
 @pytest.mark.parametrize('B,C,H,W,k,s', [(8, 32, 56, 56, 3, 1), (4, 144, 28, 28, 3, 1), (4, 192, 28, 28, 3, 2), (2, 960, 7, 7, 3, 1),
-                                         (4, 120, 28, 28, 5, 1), (4, 240, 14, 14, 5, 2), (2, 48, 14, 14, -5, 1)])
+                                         (4, 120, 28, 28, 5, 1), (4, 240, 14, 14, 5, 2), (2, 48, 14, 14, -5, 1), (6, 960, 7, 7, 5, 1)])
 def test_dwconv_bwd_weight_gradient_slots_are_exactly_reproducible(B, C, H, W, k, s, monkeypatch):
     """t3d_set_dw_slots (include/t3d.h): every workgroup stores its partial depthwise weight gradient into its own slot and
     t3d_sum_slots_batched adds the used slots in index order -- same result as the atomic replica form to fp32 rounding,

@@ -6,7 +6,7 @@ sys.path[:0] = [ROOT, os.path.join(ROOT, '3d-object-detection.pytorch_amd')]
 import torch
 from torchdet3d import _native as N
 
-args = [a for i, a in enumerate(sys.argv[1:]) if not a.startswith('--') and sys.argv[i] not in ('--reps', '--nrep')]
+args = [a for i, a in enumerate(sys.argv[1:]) if not a.startswith('--') and sys.argv[i] not in ('--reps', '--nrep', '--act')]
 reps = int(sys.argv[sys.argv.index('--reps') + 1]) if '--reps' in sys.argv else 5
 dt = torch.float32 if '--f32' in sys.argv else torch.bfloat16
 nrep = int(sys.argv[sys.argv.index('--nrep') + 1]) if '--nrep' in sys.argv else 1
@@ -21,12 +21,16 @@ if kind in ('dwfwd', 'dwbwd'):
     Ho, Wo = (H + 2 * (k // 2) - k) // s + 1, (W + 2 * (k // 2) - k) // s + 1
     x = rnd(B * H * W, C).to(dt); w = rnd(C, k * k) * 0.3
     sc, sh = torch.rand(C, device=dev) + 0.5, rnd(C) * 0.2
-    pro = N.prologue(sc, sh, None, 'relu6', False)
+    act = sys.argv[sys.argv.index('--act') + 1] if '--act' in sys.argv else 'relu6'
+    pro = N.prologue(sc, sh, None, act, False)
+    gap = torch.zeros(B, C, device=dev, dtype=torch.int64) if '--gap' in sys.argv else None     # squeeze-excite pooled sums (fixed point)
+    if gap is not None:
+        N.call('t3d_set_exact_pool', 1)
     y = torch.empty(B * Ho * Wo, C, device=dev, dtype=dt)
     stats = torch.zeros(nrep, 2 * C, device=dev, dtype=torch.float64)
     N.call('t3d_set_reduction_replicas', nrep, 2 * C)
     if kind == 'dwfwd':
-        fn = lambda: N.call('t3d_dwconv_fwd', N.dtype_code(x), N.ptr(x), pro, N.ptr(w), N.ptr(y), None if '--nostats' in sys.argv else N.ptr(stats), None,
+        fn = lambda: N.call('t3d_dwconv_fwd', N.dtype_code(x), N.ptr(x), pro, N.ptr(w), N.ptr(y), None if '--nostats' in sys.argv else N.ptr(stats), N.ptr(gap),
                             B, H, W, C, k, s, N.stream())
         nbytes = (x.numel() + y.numel()) * x.element_size()
     else:
