@@ -330,6 +330,10 @@ int t3d_dw5_plane7_bwd(int dtype, const void* dz, const void* y, const t3d_bnbwd
                        const t3d_prologue* pro, const void* residual, void* dx, double* stats, float* dw, int B, int C,
                        hipStream_t st);   // dwconv5_plane7.hip
 
+int t3d_dw5_tile_bwd(int dtype, const void* dz, const void* y, const t3d_bnbwd* bb, const float* w, const void* x,
+                     const t3d_prologue* pro, const void* residual, void* dx, double* stats, float* dw, int B, int H, int W, int C,
+                     int stride, hipStream_t st);   // dwconv5_tile.hip
+
 extern "C" int t3d_dwconv_bwd(int dtype, const void* dz, const void* y, const t3d_bnbwd* bb, const float* w,
                               const void* x, const t3d_prologue* pro, const void* residual, void* dx, double* stats,
                               float* dw, int B, int H, int W, int C, int k, int stride, void* stream) {
@@ -342,6 +346,10 @@ extern "C" int t3d_dwconv_bwd(int dtype, const void* dz, const void* y, const t3
   }
   if (k == 5 && stride == 1 && H == 7 && W == 7 && !getenv("T3D_DW_TILED")) {   // 7x7 planes in registers (dwconv5_plane7.hip)
     const int rc = t3d_dw5_plane7_bwd(dtype, dz, y, bb, w, x, pro, residual, dx, stats, dw, B, C, reinterpret_cast<hipStream_t>(stream));
+    if (rc != T3D_ERR_UNSUPPORTED) return rc;
+  }
+  if (k == 5 && !getenv("T3D_DW_TILED")) {   // register tiles (dwconv5_tile.hip)
+    const int rc = t3d_dw5_tile_bwd(dtype, dz, y, bb, w, x, pro, residual, dx, stats, dw, B, H, W, C, stride, reinterpret_cast<hipStream_t>(stream));
     if (rc != T3D_ERR_UNSUPPORTED) return rc;
   }
   if (k == 5 && !getenv("T3D_DW_TILED")) {   // 5x5: streaming kernels (dwconv5_bwd_stream.hip)

@@ -259,6 +259,9 @@ int t3d_dwk_fwd_stream(int dtype, const void* x, const t3d_prologue* pro, const 
 int t3d_dw5_plane7_fwd(int dtype, const void* x, const t3d_prologue* pro, const float* w, void* y, double* stats, float* gap_sum,
                        int B, int C, hipStream_t st);   // dwconv5_plane7.hip
 
+int t3d_dw5_tile_fwd(int dtype, const void* x, const t3d_prologue* pro, const float* w, void* y, double* stats, float* gap_sum,
+                     int B, int H, int W, int C, int stride, hipStream_t st);   // dwconv5_tile.hip
+
 extern "C" int t3d_dwconv_fwd(int dtype, const void* x, const t3d_prologue* pro, const float* w, void* y,
                               double* stats, float* gap_sum, int B, int H, int W, int C, int k, int stride,
                               void* stream) {
@@ -271,6 +274,11 @@ extern "C" int t3d_dwconv_fwd(int dtype, const void* x, const t3d_prologue* pro,
   if (k == 5 && stride == 1 && H == 7 && W == 7 && !getenv("T3D_DW_TILED")) {
     // 5x5 on 7x7 planes (the 1/32 stage of MobileNetV3): a thread per (image, channel pair) holds the plane (dwconv5_plane7.hip)
     const int rc = t3d_dw5_plane7_fwd(dtype, x, pro, w, y, stats, gap_sum, B, C, reinterpret_cast<hipStream_t>(stream));
+    if (rc != T3D_ERR_UNSUPPORTED) return rc;
+  }
+  if (k == 5 && !getenv("T3D_DW_TILED")) {
+    // 5x5 on planes up to 64x64: register tiles, every load of a tile's window up front (dwconv5_tile.hip)
+    const int rc = t3d_dw5_tile_fwd(dtype, x, pro, w, y, stats, gap_sum, B, H, W, C, stride, reinterpret_cast<hipStream_t>(stream));
     if (rc != T3D_ERR_UNSUPPORTED) return rc;
   }
   if ((k == 3 || k == 5) && (stride == 1 || stride == 2) && !(pro && pro->se) && !getenv("T3D_DW_TILED")) {

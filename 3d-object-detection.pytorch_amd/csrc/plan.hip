@@ -72,7 +72,7 @@ const Entry kEntries[] = {
     T3D_E(t3d_pwconv_fwd_mat), T3D_E(t3d_im2col), T3D_E(t3d_im2col_nchw), T3D_E(t3d_col2im_bwd), T3D_E(t3d_pack_conv_weight),
     T3D_E(t3d_unpack_conv_grad), T3D_E(t3d_maxpool_fwd), T3D_E(t3d_maxpool_bwd), T3D_E(t3d_res_relu_fwd),
     T3D_E(t3d_res_relu_bwd), T3D_E(t3d_subsample), T3D_E(t3d_ir_block_eval), T3D_E(t3d_bn_apply), T3D_E(t3d_bn_act_bwd),
-    T3D_E(t3d_gap_fwd), T3D_E(t3d_gap_bwd), T3D_E(t3d_pool_fwd), T3D_E(t3d_pool_bwd), T3D_E(t3d_head_fwd),
+    T3D_E(t3d_bn_apply_gram), T3D_E(t3d_gram_bn_finalize), T3D_E(t3d_gap_fwd), T3D_E(t3d_gap_bwd), T3D_E(t3d_pool_fwd), T3D_E(t3d_pool_bwd), T3D_E(t3d_head_fwd),
     T3D_E(t3d_linear_fwd), T3D_E(t3d_head_fwd_all), T3D_E(t3d_head_bwd), T3D_E(t3d_head_bwd_weights), T3D_E(t3d_se_fwd),
     T3D_E(t3d_se_bwd), T3D_E(t3d_se_fwd_fused), T3D_E(t3d_se_bwd_data), T3D_E(t3d_se_bwd_weights), T3D_E(t3d_se_after_sums),
     T3D_E(t3d_se_after_apply), T3D_E(t3d_set_reduction_replicas), T3D_E(t3d_set_workspace), T3D_E(t3d_set_main_workspace),

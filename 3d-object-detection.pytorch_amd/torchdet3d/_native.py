@@ -85,6 +85,8 @@ SIGNATURES = {
     't3d_subsample': [_I, _P, _P, _I, _I, _I, _I, _I, _I, _P],
     't3d_ir_block_eval': [_P, _P, _P, _P, _I, _P, _P, _P, _I, _P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _I, _P],
     't3d_bn_apply': [_I, _P, _PP, _P, _P, _I, _I, _P],
+    't3d_bn_apply_gram': [_I, _P, _PP, _P, _P, _P, _I, _I, _P],
+    't3d_gram_bn_finalize': [_P, _P, _I, _I, _D, _P, _P, _P, _P, _P, _F, _F, _P, _P, _P, _P, _P],
     't3d_bn_act_bwd': [_I, _P, _P, _PP, _P, _P, _I, _I, _P],
     't3d_gap_fwd': [_I, _P, _PP, _P, _I, _I, _I, _P],
     't3d_gap_bwd': [_I, _P, _P, _PP, _P, _P, _I, _I, _I, _P],

@@ -41,6 +41,11 @@ YFREE_MIN_ELEMS = int(os.environ.get('T3D_YFREE_MIN', 8 << 20))
 YFREE_FUSED = os.environ.get('T3D_YFREE_FUSED', '1') != '0'     # one-pass expand-layer backward (t3d_pwconv_bwd_yfree)
 YFREE_PREP_FUSED = os.environ.get('T3D_YFREE_PREP_FUSED', '1') != '0'   # ... with its weight rows built in its own prologue (A/B switch)
 EXPDW_EVAL = os.environ.get('T3D_EXPDW_EVAL', '1') != '0'      # fused expand + depthwise forward in 16-bit inference (A/B switch)
+# round 6: the same fused forward in TRAINING, the expansion's BatchNorm statistics taken from the Gram matrix of the narrow block
+# input (csrc/gram.hip).  OPT-IN (T3D_GRAM_FWD_MIN_HW = smallest input plane, in pixels per image, it is used at; 12544 = the
+# 112x112 block, the only stage where the fused launch with the expansion stored beats the two launches alone: DESIGN.md finding
+# 40): measured in the step it is 0.03-0.04 ms SLOWER than the two launches (finding 55), so the default is off.
+GRAM_FWD_MIN_HW = int(os.environ.get('T3D_GRAM_FWD_MIN_HW', 0))
 HOOK_MIN = 1 << 20              # gradient-exchange granularity (elements): parallel.GradSync's bucket size
 HOOK_ON_SIDE = True              # (round 3: the gradient exchange is issued from the second stream; the other order stalled the main one)
 
@@ -785,6 +790,17 @@ class Net:
         # W <= 213 -- a 448 ... 512-pixel crop reaches MobileNetV2's second block wider than that and takes the two launches)
         return bool(N.lib().t3d_expdw_supported(self.dt, N.ACT[blk.act], x.B, x.H, x.W, blk.cin, blk.cexp, blk.s))
 
+    def _gram_fwd_ok(self, blk, x):
+        """Training mode, bf16: may expand + depthwise of this block run as ONE launch, its BatchNorm statistics coming from the
+        Gram matrix of the block input (one pass over the NARROW tensor, the one that materialises it anyway)?"""
+        if not self.training or not GRAM_FWD_MIN_HW or self.dt != N.BF16 or x.H * x.W < GRAM_FWD_MIN_HW:
+            return False
+        if not (blk.expand and not blk.se and blk.k == 3 and blk.cin in (8, 16) and isinstance(blk.act, str) and blk.act in ('relu', 'relu6')):
+            return False
+        if x.pro is not None and (x.zbuf is None or x.pro.se is not None):
+            return False           # (a deferred activation that is not a pending block output: the two launches)
+        return bool(N.lib().t3d_expdw_supported(self.dt, N.ACT[blk.act], x.B, x.H, x.W, blk.cin, blk.cexp, blk.s))
+
     def _block_fwd(self, i, blk, x, sv):
         st, dt = N.stream(), self.dt
         p = f'features.{i + 1}.conv'
@@ -823,7 +839,38 @@ class Net:
             x = self._finish(x, f'z:in{i}')
         rec = dict(x=x)
         src = x
-        if blk.expand:                                                    # mobilenetv3.py:146-150
+        fused_dw = False
+        if blk.expand and self._gram_fwd_ok(blk, x):
+            # training, the 112x112 expansion: [materialise the block input + its Gram matrix] -> BatchNorm coefficients of the
+            # expansion from the K x K sums -> expand + BatchNorm + activation + depthwise in ONE launch, the raw expansion
+            # stored for the backward (csrc/gram.hip, csrc/expdw_fwd.hip; DESIGN.md finding 55)
+            bn1, bn2 = self.bns[p + '.1'], self.bns[p + '.4']
+            M, K, C = B * H * W, blk.cin, blk.cexp
+            gram = self._buf(f'gram:{i}', (K * (K + 1) // 2 + K,), torch.float64, zgroup='fwd')
+            if x.zbuf is not None:
+                self._settle_f(x.bn)
+                N.call('t3d_bn_apply_gram', dt, N.ptr(x.t), x.pro, N.ptr(x.zres), N.ptr(x.zbuf), N.ptr(gram), M, K, st,
+                       nbytes=2 * M * K * self.esz)
+                x.t, x.pro, x.zres, x.zbuf = x.zbuf, None, None, None
+            else:
+                N.call('t3d_bn_apply_gram', dt, N.ptr(x.t), None, None, None, N.ptr(gram), M, K, st, nbytes=M * K * self.esz)
+            N.call('t3d_gram_bn_finalize', N.ptr(gram), N.ptr(self.w[p + '.0.weight']), C, K, float(M), N.ptr(bn1.gamma),
+                   N.ptr(bn1.beta), N.ptr(bn1.rm), N.ptr(bn1.rv), N.ptr(bn1.nbt), BN_MOM, BN_EPS, N.ptr(bn1.scale), N.ptr(bn1.shift),
+                   N.ptr(bn1.mean), N.ptr(bn1.invstd), st)
+            bn1.count, bn1.pend[0] = float(M), False
+            Ho, Wo = (H + 2 - 3) // blk.s + 1, (W + 2 - 3) // blk.s + 1
+            M2 = B * Ho * Wo
+            y1 = self._buf(f'y1:{i}', (M, C))
+            y2 = self._buf(f'y2:{i}', (M2, C))
+            N.call('t3d_expdw_fwd', dt, N.ptr(x.t), N.ptr(self.w[p + '.0.weight']), N.ptr(bn1.scale), N.ptr(bn1.shift),
+                   N.ACT[blk.act], N.ptr(self.p[p + '.3.weight']), N.ptr(y1), N.ptr(y2), self._st(bn2), B, H, W, K, C, blk.s, st,
+                   nbytes=(M * K + 2 * M * C + M2 * C) * self.esz)      # (the two launches' algorithmic bytes, SURVEY 8d: fused > 1 is legitimate)
+            pro1 = self._pro(bn1, blk.act)
+            src = _Src(y1, pro1, B, H, W, C, raw=y1, bn=bn1, gpro=pro1)
+            rec['s1'] = src
+            dwn, bnn, pwn, bn3n = p + '.3.weight', p + '.4', p + '.7.weight', p + '.8'
+            fused_dw = True
+        elif blk.expand:                                                  # mobilenetv3.py:146-150
             bn1 = self.bns[p + '.1']
             M = B * H * W
             y1 = self._buf(f'y1:{i}', (M, blk.cexp))
@@ -846,9 +893,10 @@ class Net:
         # add integers, so the sums, the gate and everything behind it no longer depend on their arrival order
         gap = self._buf(f'gap:{i}', (B, blk.cexp), torch.int64, zgroup='fwd') if (blk.se and not se_after) else None
         self._pool_exact(gap is not None)
-        self._c('t3d_dwconv_fwd', dt, N.ptr(src.t), src.pro, N.ptr(self.p[dwn]), N.ptr(y2), self._st(bn2), N.ptr(gap),
-                B, H, W, blk.cexp, blk.k, blk.s, st, nbytes=(B * H * W + M2) * blk.cexp * self.esz,
-                fwd=src.bn if src.pro is not None else None)
+        if not fused_dw:
+            self._c('t3d_dwconv_fwd', dt, N.ptr(src.t), src.pro, N.ptr(self.p[dwn]), N.ptr(y2), self._st(bn2), N.ptr(gap),
+                    B, H, W, blk.cexp, blk.k, blk.s, st, nbytes=(B * H * W + M2) * blk.cexp * self.esz,
+                    fwd=src.bn if src.pro is not None else None)
         pro2 = self._bn_fwd(bn2, M2, blk.act)
         if blk.se:
             self._settle_f(bn2)          # the squeeze-excite kernels read bn2's affine first

@@ -31,11 +31,12 @@ HBM_PEAK = 8.0e12          # B/s, MI355X HBM3E spec (/opt/skills/guides/MI355X_M
 MNV2_TRAIN_MB_PER_CROP = 80.66   # algorithmic bytes, bf16, fwd + dgrad + wgrad
 CONV_KERNELS = ('t3d_dwconv_fwd', 't3d_dwconv_bwd', 't3d_pwconv_fwd', 't3d_pwconv_dgrad', 't3d_pwconv_wgrad',
                 't3d_pwconv_dgrad_yfree', 't3d_pwconv_wgrad_yfree', 't3d_pwconv_fwd_mat', 't3d_pwconv_bwd_yfree',
-                't3d_pwconv_wgrad_yfree_finish', 't3d_pwconv_yfree_prep', 't3d_pwconv_yfree_prep2')
+                't3d_pwconv_wgrad_yfree_finish', 't3d_pwconv_yfree_prep', 't3d_pwconv_yfree_prep2', 't3d_pwconv_bwd_yfree_w',
+                't3d_expdw_fwd', 't3d_bn_apply_gram', 't3d_gram_bn_finalize', 't3d_bn_apply', 't3d_bn_finalize')
 DW_ENTRIES = ('t3d_dwconv_fwd', 't3d_dwconv_bwd')
 # every convolution entry point whose main kernel takes a kernel-exact event pair (T3D_LAUNCH_TIMED in csrc): the families of
 # roofline.families (the driver line shows the WORST family beside the north-star's depthwise one)
-FAMILY_ENTRIES = ('t3d_dwconv_fwd', 't3d_dwconv_bwd', 't3d_pwconv_fwd', 't3d_pwconv_fwd_mat', 't3d_pwconv_dgrad', 't3d_pwconv_wgrad',
+FAMILY_ENTRIES = ('t3d_dwconv_fwd', 't3d_dwconv_bwd', 't3d_expdw_fwd', 't3d_pwconv_fwd', 't3d_pwconv_fwd_mat', 't3d_pwconv_dgrad', 't3d_pwconv_wgrad',
                   't3d_pwconv_dgrad_yfree', 't3d_pwconv_wgrad_yfree', 't3d_pwconv_bwd_yfree', 't3d_pwconv_bwd_yfree_w')
 MFMA_PEAK = 2.5e15         # FLOP/s, dense bf16 MFMA (same guide; fp32 storage runs v_mfma_f32_16x16x4_f32: 157 TFLOP/s)
 MFMA_PEAK_F32 = 157.3e12

@@ -235,6 +235,21 @@ int t3d_crop_resize_u8(const unsigned char* frame, const int* rects, unsigned ch
 int t3d_bn_apply(int dtype, const void* y, const t3d_prologue* pro, const void* residual, void* z, int M, int C,
                  void* stream);
 
+/* Round 6: the BatchNorm statistics of an expansion conv from the Gram matrix of its narrow input (csrc/gram.hip).  For
+ * y1 = W1 z (models/mobilenetv3.py:146-148: nn.Conv2d(inp, hidden_dim, 1) + nn.BatchNorm2d(hidden_dim)), sum(y1) = W1 (1^T z)
+ * and sum(y1^2)_c = w_c^T (z^T z) w_c: one pass over the NARROW tensor replaces the statistics the 1x1 conv's epilogue takes
+ * over the 6x wider one -- which is what lets the fused expand + depthwise forward (t3d_expdw_fwd) run in TRAINING mode.
+ *   t3d_bn_apply_gram: t3d_bn_apply (z may be NULL: y is the finished tensor already, pro and residual NULL) that also adds
+ *     [upper triangle of z^T z, row-major (i, j >= i) | 1^T z] into gram [K(K+1)/2 + K] fp64 (caller zeroes; order-independent
+ *     adds); bf16, K in {8, 16}; the sums are those of the STORED (rounded) z.
+ *   t3d_gram_bn_finalize: t3d_bn_finalize's outputs (scale, shift, mean, invstd, running statistics, num_batches_tracked) for
+ *     the C channels of W1 z from those sums; w [C,K] in the conv's storage dtype (bf16: the matrix the MFMA multiplies). */
+int t3d_bn_apply_gram(int dtype, const void* y, const t3d_prologue* pro, const void* residual, void* z, double* gram, int M,
+                      int K, void* stream);
+int t3d_gram_bn_finalize(const double* gram, const void* w, int C, int K, double count, const float* gamma, const float* beta,
+                         float* running_mean, float* running_var, int64_t* num_batches_tracked, float momentum, float eps,
+                         float* scale, float* shift, float* mean_out, float* invstd_out, void* stream);
+
 /* Backward of t3d_bn_apply's activation:  dzp = dz * act'(scale*y + shift);
  * stats [2*C] fp64 += sum(dzp), sum(dzp*y) (caller zeroes). */
 int t3d_bn_act_bwd(int dtype, const void* dz, const void* y, const t3d_prologue* pro, void* dzp, double* stats,

@@ -22,7 +22,9 @@ SHAPES = [  # B, C, H, W, k, s
     (2, 672, 14, 14, 5, 2), (3, 576, 6, 6, 3, 1), (2, 960, 3, 3, 3, 1), (2, 384, 12, 12, 3, 2), (5, 264, 9, 7, 3, 1),
     (3, 40, 13, 17, 3, 2), (2, 576, 7, 7, 3, 2), (1, 24, 2, 2, 3, 2), (2, 144, 56, 56, 3, 2),
     # 5x5 on 7x7 planes: a thread per (image, channel pair) holds the plane (csrc/dwconv5_plane7.hip); 72 channels = a partial slab
-    (5, 960, 7, 7, 5, 1), (3, 72, 7, 7, 5, 1), (9, 576, 7, 7, 5, 1)]
+    (5, 960, 7, 7, 5, 1), (3, 72, 7, 7, 5, 1), (9, 576, 7, 7, 5, 1),
+    # 5x5 stride 1 as register tiles (csrc/dwconv5_tile.hip): whole tiles, tiles hanging over both edges, a partial channel slab
+    (2, 120, 28, 28, 5, 1), (3, 40, 14, 14, 5, 1), (2, 48, 9, 13, 5, 1), (2, 72, 56, 56, 5, 2), (3, 24, 10, 15, 5, 2)]
 
 
 @pytest.mark.parametrize('B,C,H,W,k,s', SHAPES)

@@ -134,3 +134,100 @@ def test_wide_inputs_take_the_two_launches_instead_of_failing():
         del net
     assert (outs[torch.bfloat16][0] - outs[torch.float32][0]).abs().max().item() < 5e-3
     assert torch.isfinite(outs[torch.bfloat16][1]).all()
+
+
+@pytest.mark.parametrize('K,C,M,res', [(16, 96, 40000, False), (16, 96, 5001, True), (8, 48, 3000, True)])
+def test_gram_statistics_of_the_expansion_match_batchnorm_of_the_product(K, C, M, res):
+    """`t3d_bn_apply_gram` + `t3d_gram_bn_finalize` (csrc/gram.hip): the block input is materialised exactly as `t3d_bn_apply` does
+    it, and the BatchNorm coefficients of W1 z derived from the K x K Gram sums equal what `F.batch_norm` computes on the product
+    itself (fp64 reference on the same bf16 operands), running statistics included."""
+    from torchdet3d import _native as N
+    g = torch.Generator(device='cuda').manual_seed(K + C + M)
+    y = torch.randn(M, K, device='cuda', generator=g).to(torch.bfloat16)
+    sc, sh = torch.rand(K, device='cuda', generator=g) + 0.5, torch.randn(K, device='cuda', generator=g) * 0.3
+    r = torch.randn(M, K, device='cuda', generator=g).to(torch.bfloat16) if res else None
+    w = (torch.randn(C, K, device='cuda', generator=g) / K ** .5).to(torch.bfloat16)
+    gamma, beta = torch.rand(C, device='cuda', generator=g) + 0.5, torch.randn(C, device='cuda', generator=g) * 0.1
+    rm, rv = torch.randn(C, device='cuda', generator=g) * 0.1, torch.rand(C, device='cuda', generator=g) + 0.5
+    rm0, rv0 = rm.clone(), rv.clone()
+    nbt = torch.zeros(1, dtype=torch.int64, device='cuda')
+    z = torch.empty(M, K, device='cuda', dtype=torch.bfloat16)
+    z2 = torch.empty_like(z)
+    gram = torch.zeros(K * (K + 1) // 2 + K, device='cuda', dtype=torch.float64)
+    pro = N.prologue(sc, sh, None, 'none', False)
+    N.call('t3d_bn_apply_gram', N.BF16, N.ptr(y), pro, N.ptr(r), N.ptr(z), N.ptr(gram), M, K, N.stream())
+    N.call('t3d_bn_apply', N.BF16, N.ptr(y), pro, N.ptr(r), N.ptr(z2), M, K, N.stream())
+    scale, shift, mean, invstd = (torch.empty(C, device='cuda') for _ in range(4))
+    N.call('t3d_gram_bn_finalize', N.ptr(gram), N.ptr(w), C, K, float(M), N.ptr(gamma), N.ptr(beta), N.ptr(rm), N.ptr(rv), N.ptr(nbt),
+           0.1, 1e-5, N.ptr(scale), N.ptr(shift), N.ptr(mean), N.ptr(invstd), N.stream())
+    torch.cuda.synchronize()
+    assert torch.equal(z, z2)                                          # the same materialised tensor, bit for bit
+    zd = z.double().cpu()
+    iu = torch.triu_indices(K, K)
+    G = (zd.t() @ zd)[iu[0], iu[1]]
+    np_ = gram.cpu()
+    assert torch.allclose(np_[:G.numel()], G, rtol=1e-6, atol=1e-6 * M)
+    assert torch.allclose(np_[G.numel():], zd.sum(0), rtol=1e-6, atol=1e-6 * M)
+    y1 = zd @ w.double().cpu().t()                                     # the exact products the MFMA accumulates
+    m_ref, v_ref = y1.mean(0), y1.var(0, unbiased=False)
+    assert torch.allclose(mean.double().cpu(), m_ref, rtol=1e-5, atol=1e-6)
+    assert torch.allclose(invstd.double().cpu(), 1 / torch.sqrt(v_ref + 1e-5), rtol=1e-5)
+    assert torch.allclose(scale.double().cpu(), gamma.double().cpu() / torch.sqrt(v_ref + 1e-5), rtol=1e-5)
+    assert torch.allclose(shift.double().cpu(), beta.double().cpu() - m_ref * gamma.double().cpu() / torch.sqrt(v_ref + 1e-5), rtol=1e-4, atol=1e-5)
+    assert torch.allclose(rm.double().cpu(), 0.9 * rm0.double().cpu() + 0.1 * m_ref, rtol=1e-5, atol=1e-6)
+    assert torch.allclose(rv.double().cpu(), 0.9 * rv0.double().cpu() + 0.1 * v_ref * M / (M - 1), rtol=1e-5)
+    assert int(nbt) == 1
+    # an already finished tensor: statistics only, nothing written
+    gram2 = torch.zeros_like(gram)
+    N.call('t3d_bn_apply_gram', N.BF16, N.ptr(z), None, None, None, N.ptr(gram2), M, K, N.stream())
+    torch.cuda.synchronize()
+    assert torch.equal(gram2, gram)                                    # snapped sums: the same bits in any order
+
+
+def test_training_step_with_gram_statistics_matches_the_two_launch_path(monkeypatch):
+    """Engine level (DESIGN.md finding 55): MobileNetV2's first expanded block through [materialise + Gram] -> finalize ->
+    fused expand + depthwise with the expansion stored, against the two launches with the statistics from the conv's epilogue:
+    the same train step to bf16 rounding (the Gram statistics are those of the exact products, the epilogue's those of their
+    bf16 rounding), bit-reproducible run to run, the 1x1 + depthwise launches of that block gone."""
+    from oracle.weights import make_inputs, make_state_dict
+    from torchdet3d import _native as N
+    from torchdet3d.models import engine as E
+    B, HW = 16, 96
+    imgs, gt_kp, cats = make_inputs(B, HW, HW, 9)
+    sd = make_state_dict('mobilenetv2', 9)
+    ones = torch.ones(B, 1280, device='cuda')
+
+    def run(min_hw):
+        monkeypatch.setattr(E, 'GRAM_FWD_MIN_HW', min_hw)
+        net = E.Net('mobilenetv2', 9, 'cuda', torch.bfloat16)
+        net.load_state_dict(sd)
+        calls = []
+        real = N.call
+        monkeypatch.setattr(N, 'call', lambda name, *a, **k: (calls.append(name), real(name, *a, **k))[1])
+        kp, lg = net.forward(imgs.cuda(), cats.cuda(), train=True, dropout_mask=ones)
+        dkp, dlg = torch.randn(B, 18, device='cuda', generator=torch.Generator(device='cuda').manual_seed(1)) * 1e-2, torch.zeros(B, 9, device='cuda')
+        net.backward(dkp, dlg)
+        torch.cuda.synchronize()
+        monkeypatch.setattr(N, 'call', real)
+        bn1 = net.bns['features.2.conv.1']
+        out = (kp.float().cpu(), {k: v.float().cpu().clone() for k, v in net.g.items()}, {k: v.float().cpu().clone() for k, v in net.buffers.items()}, calls,
+               (bn1.scale.cpu().clone(), bn1.shift.cpu().clone(), bn1.mean.cpu().clone(), bn1.invstd.cpu().clone()))
+        del net
+        return out
+
+    kp0, g0, b0, c0, co0 = run(0)
+    kp1, g1, b1, c1, co1 = run(1)
+    kp2, g2, b2, c2, _ = run(1)
+    # the expansion's BatchNorm coefficients themselves: Gram-derived against epilogue sums of the rounded products
+    for u, v in zip(co0, co1):
+        assert torch.allclose(u, v, rtol=2e-3, atol=2e-4), (u - v).abs().max()
+    assert 't3d_bn_apply_gram' not in c0 and c1.count('t3d_bn_apply_gram') >= 1 and c1.count('t3d_expdw_fwd') == c1.count('t3d_bn_apply_gram')
+    assert c1.count('t3d_dwconv_fwd') == c0.count('t3d_dwconv_fwd') - c1.count('t3d_expdw_fwd')
+    assert torch.equal(kp1, kp2) and all(torch.equal(g1[k], g2[k]) for k in g1)            # run-to-run bit identity
+    print('[gram path] max keypoint difference against the two-launch path:', (kp1 - kp0).abs().max().item())
+    assert (kp1 - kp0).abs().max().item() < 6e-2           # (a randomly initialised bf16 network amplifies a 1e-6 change of one BatchNorm: section 2)
+    for k in ('features.2.conv.1.running_mean', 'features.2.conv.1.running_var'):
+        assert torch.allclose(b1[k], b0[k], rtol=2e-3, atol=2e-4), k
+    num = sum(((g1[k] - g0[k]) ** 2).sum().item() for k in g0)
+    den = sum((g0[k] ** 2).sum().item() for k in g0)
+    assert (num / den) ** .5 < 0.1, (num / den) ** .5               # two bf16 steps that round at different points (section 2)
