@@ -302,7 +302,8 @@ int launch_fwd(P7Args& a, int act, hipStream_t st) {
 
 template <typename T>
 int launch_bwd(P7Args& a, int act, hipStream_t st) {
-  const dim3 grid = plane_grid(a.B, a.C);
+  dim3 grid = plane_grid(a.B, a.C);
+  if (a.dw && g_t3d_reduce.dw_slots > 0 && (int)grid.x > g_t3d_reduce.dw_slots) grid.x = g_t3d_reduce.dw_slots;
   a.nrep = g_t3d_reduce.nrep;
   a.rstride = g_t3d_reduce.stats_stride;
   if (a.nrep < 1) { a.nrep = 1; a.rstride = 0; }

@@ -330,15 +330,19 @@ int t3d_dw5_plane7_bwd(int dtype, const void* dz, const void* y, const t3d_bnbwd
                        const t3d_prologue* pro, const void* residual, void* dx, double* stats, float* dw, int B, int C,
                        hipStream_t st);   // dwconv5_plane7.hip
 
-int t3d_dw5_tile_bwd(int dtype, const void* dz, const void* y, const t3d_bnbwd* bb, const float* w, const void* x,
-                     const t3d_prologue* pro, const void* residual, void* dx, double* stats, float* dw, int B, int H, int W, int C,
-                     int stride, hipStream_t st);   // dwconv5_tile.hip
+int t3d_dw_tile_bwd(int dtype, const void* dz, const void* y, const t3d_bnbwd* bb, const float* w, const void* x,
+                    const t3d_prologue* pro, const void* residual, void* dx, double* stats, float* dw, int B, int H, int W, int C,
+                    int k, int stride, hipStream_t st);   // dwconv_tile.hip
 
 extern "C" int t3d_dwconv_bwd(int dtype, const void* dz, const void* y, const t3d_bnbwd* bb, const float* w,
                               const void* x, const t3d_prologue* pro, const void* residual, void* dx, double* stats,
                               float* dw, int B, int H, int W, int C, int k, int stride, void* stream) {
   if (!dz || !y || !bb || !w || !x || !dx || B <= 0 || H <= 0 || W <= 0 || C <= 0 || (C % 8)) return T3D_ERR_ARG;
   if (pro && pro->se) return T3D_ERR_UNSUPPORTED;  // no SE gate ever precedes a depthwise conv
+  if (k == 3 && !getenv("T3D_DW_TILED")) {   // small planes: register tiles (dwconv_tile.hip)
+    const int rc = t3d_dw_tile_bwd(dtype, dz, y, bb, w, x, pro, residual, dx, stats, dw, B, H, W, C, 3, stride, reinterpret_cast<hipStream_t>(stream));
+    if (rc != T3D_ERR_UNSUPPORTED) return rc;
+  }
   if (k == 3 && (stride == 1 || (stride == 2 && !T3D_ENV_SET("T3D_DW_BWD_S2_TILED"))) && !getenv("T3D_DW_TILED")) {   // streaming kernel (dwconv3_bwd_stream.hip)
     const int rc = t3d_dw3_bwd_stream(dtype, dz, y, bb, w, x, pro, residual, dx, stats, dw, B, H, W, C, stride,
                                       reinterpret_cast<hipStream_t>(stream));
@@ -348,8 +352,8 @@ extern "C" int t3d_dwconv_bwd(int dtype, const void* dz, const void* y, const t3
     const int rc = t3d_dw5_plane7_bwd(dtype, dz, y, bb, w, x, pro, residual, dx, stats, dw, B, C, reinterpret_cast<hipStream_t>(stream));
     if (rc != T3D_ERR_UNSUPPORTED) return rc;
   }
-  if (k == 5 && !getenv("T3D_DW_TILED")) {   // register tiles (dwconv5_tile.hip)
-    const int rc = t3d_dw5_tile_bwd(dtype, dz, y, bb, w, x, pro, residual, dx, stats, dw, B, H, W, C, stride, reinterpret_cast<hipStream_t>(stream));
+  if (k == 5 && !getenv("T3D_DW_TILED")) {   // register tiles (dwconv_tile.hip)
+    const int rc = t3d_dw_tile_bwd(dtype, dz, y, bb, w, x, pro, residual, dx, stats, dw, B, H, W, C, 5, stride, reinterpret_cast<hipStream_t>(stream));
     if (rc != T3D_ERR_UNSUPPORTED) return rc;
   }
   if (k == 5 && !getenv("T3D_DW_TILED")) {   // 5x5: streaming kernels (dwconv5_bwd_stream.hip)

@@ -259,13 +259,18 @@ int t3d_dwk_fwd_stream(int dtype, const void* x, const t3d_prologue* pro, const 
 int t3d_dw5_plane7_fwd(int dtype, const void* x, const t3d_prologue* pro, const float* w, void* y, double* stats, float* gap_sum,
                        int B, int C, hipStream_t st);   // dwconv5_plane7.hip
 
-int t3d_dw5_tile_fwd(int dtype, const void* x, const t3d_prologue* pro, const float* w, void* y, double* stats, float* gap_sum,
-                     int B, int H, int W, int C, int stride, hipStream_t st);   // dwconv5_tile.hip
+int t3d_dw_tile_fwd(int dtype, const void* x, const t3d_prologue* pro, const float* w, void* y, double* stats, float* gap_sum,
+                    int B, int H, int W, int C, int k, int stride, hipStream_t st);   // dwconv_tile.hip
 
 extern "C" int t3d_dwconv_fwd(int dtype, const void* x, const t3d_prologue* pro, const float* w, void* y,
                               double* stats, float* gap_sum, int B, int H, int W, int C, int k, int stride,
                               void* stream) {
   if (!x || !w || !y || B <= 0 || H <= 0 || W <= 0 || C <= 0 || (C % 8)) return T3D_ERR_ARG;
+  if (k == 3 && !getenv("T3D_DW_TILED")) {
+    // 3x3 on the small planes (14x14 and below by default): register tiles, every load of a tile's window up front (dwconv_tile.hip)
+    const int rc = t3d_dw_tile_fwd(dtype, x, pro, w, y, stats, gap_sum, B, H, W, C, 3, stride, reinterpret_cast<hipStream_t>(stream));
+    if (rc != T3D_ERR_UNSUPPORTED) return rc;
+  }
   if (k == 3 && (stride == 1 || stride == 2) && !gap_sum && !(pro && pro->se) && !getenv("T3D_DW_TILED"))
     return t3d_dw3_fwd_stream(dtype, x, pro, w, y, stats, B, H, W, C, stride, reinterpret_cast<hipStream_t>(stream));
   // the kernels below read finished coefficients: a pending derive request for them becomes a launch of its own
@@ -277,8 +282,8 @@ extern "C" int t3d_dwconv_fwd(int dtype, const void* x, const t3d_prologue* pro,
     if (rc != T3D_ERR_UNSUPPORTED) return rc;
   }
   if (k == 5 && !getenv("T3D_DW_TILED")) {
-    // 5x5 on planes up to 64x64: register tiles, every load of a tile's window up front (dwconv5_tile.hip)
-    const int rc = t3d_dw5_tile_fwd(dtype, x, pro, w, y, stats, gap_sum, B, H, W, C, stride, reinterpret_cast<hipStream_t>(stream));
+    // 5x5 on planes up to 64x64: register tiles, every load of a tile's window up front (dwconv_tile.hip)
+    const int rc = t3d_dw_tile_fwd(dtype, x, pro, w, y, stats, gap_sum, B, H, W, C, 5, stride, reinterpret_cast<hipStream_t>(stream));
     if (rc != T3D_ERR_UNSUPPORTED) return rc;
   }
   if ((k == 3 || k == 5) && (stride == 1 || stride == 2) && !(pro && pro->se) && !getenv("T3D_DW_TILED")) {

@@ -1,4 +1,4 @@
-// Depthwise 5x5 stride-1 convolution, forward and backward, as REGISTER TILES (round 6; MobileNetV3's 5x5 layers at 28x28 and
+// Depthwise K x K convolution (K = 5; K = 3 on the small planes), stride 1 and 2, forward and backward, as REGISTER TILES (round 6; MobileNetV3's 5x5 layers at 28x28 and
 // 14x14: models/mobilenetv3.py:20-38 rows with k = 5, InvertedResidual :126-166) -- the 7x7 plane kernel of
 // dwconv5_plane7.hip generalised to any plane size.
 //
@@ -17,7 +17,7 @@
 
 namespace {
 
-constexpr int KK = 5, PADK = 2, SLAB = 128;
+constexpr int SLAB = 128;
 
 struct TileArgs {
   const void *x, *dz, *yraw, *res;
@@ -53,29 +53,30 @@ template <> struct Pair<float> {
 };
 template <typename T, int CH> using rawvec = T __attribute__((ext_vector_type(CH)));
 
+template <int K2>
 __device__ __forceinline__ void stage_weights(float* wl, const float* __restrict__ w, int cbase, int Cb) {
-  for (int i = threadIdx.x; i < 25 * Cb; i += 256) {
-    const int cl = i / 25, t = i - cl * 25;
-    wl[t * SLAB + cl] = w[(size_t)cbase * 25 + i];
+  for (int i = threadIdx.x; i < K2 * Cb; i += 256) {
+    const int cl = i / K2, t = i - cl * K2;
+    wl[t * SLAB + cl] = w[(size_t)cbase * K2 + i];
   }
 }
 
-template <typename T, int ACT, int TH, int TW>
+template <typename T, int ACT, int K, int TH, int TW>
 __global__ __launch_bounds__(256) void dw5_tile_fwd_kernel(const TileArgs a) {
-  constexpr int CH = 2, WH = TH + 4, WW = TW + 4;
-  __shared__ __attribute__((aligned(16))) float wl[25 * SLAB];
+  constexpr int CH = 2, KK = K, PADK = K / 2, K2 = K * K, WH = TH + K - 1, WW = TW + K - 1;
+  __shared__ __attribute__((aligned(16))) float wl[K2 * SLAB];
   __shared__ double lstat[2 * SLAB];
   using RV = rawvec<T, CH>;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int cbase = blockIdx.y * SLAB, Cb = min(SLAB, a.C - cbase);
   const bool on = 2 * lane < Cb;
   const int c0 = cbase + (on ? 2 * lane : 0);
-  stage_weights(wl, a.w, cbase, Cb);
+  stage_weights<K2>(wl, a.w, cbase, Cb);
   for (int i = threadIdx.x; i < 2 * SLAB; i += 256) lstat[i] = 0.0;
   __syncthreads();
-  f32x2 wt[25];
+  f32x2 wt[K2];
 #pragma unroll
-  for (int t = 0; t < 25; ++t) wt[t] = *reinterpret_cast<const f32x2*>(wl + t * SLAB + 2 * lane);
+  for (int t = 0; t < K2; ++t) wt[t] = *reinterpret_cast<const f32x2*>(wl + t * SLAB + 2 * lane);
   const float sc[CH] = {a.scale ? a.scale[c0] : 1.f, a.scale ? a.scale[c0 + 1] : 1.f};
   const float sh[CH] = {a.scale ? a.shift[c0] : 0.f, a.scale ? a.shift[c0 + 1] : 0.f};
   float psum[CH] = {0.f, 0.f}, psq[CH] = {0.f, 0.f};
@@ -161,23 +162,23 @@ __global__ __launch_bounds__(256) void dw5_tile_fwd_kernel(const TileArgs a) {
   }
 }
 
-template <typename T, int ACT, int TH, int TW>
+template <typename T, int ACT, int K, int TH, int TW>
 __global__ __launch_bounds__(256) void dw5_tile_bwd_kernel(const TileArgs a) {
-  constexpr int CH = 2, WH = TH + 4, WW = TW + 4;
+  constexpr int CH = 2, KK = K, PADK = K / 2, K2 = K * K, WH = TH + K - 1, WW = TW + K - 1;
   extern __shared__ __attribute__((aligned(16))) float lred[];       // weights [25][SLAB] fp32 | [27][Cb] fp64 accumulators
   float* wl = lred;
-  double* lacc = reinterpret_cast<double*>(lred + 25 * SLAB);
+  double* lacc = reinterpret_cast<double*>(lred + K2 * SLAB);
   using RV = rawvec<T, CH>;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int cbase = blockIdx.y * SLAB, Cb = min(SLAB, a.C - cbase);
   const bool on = 2 * lane < Cb;
   const int c0 = cbase + (on ? 2 * lane : 0);
-  stage_weights(wl, a.w, cbase, Cb);
-  for (int i = threadIdx.x; i < 27 * Cb; i += 256) lacc[i] = 0.0;
+  stage_weights<K2>(wl, a.w, cbase, Cb);
+  for (int i = threadIdx.x; i < (K2 + 2) * Cb; i += 256) lacc[i] = 0.0;
   __syncthreads();
-  f32x2 wt[25], wacc[25];
+  f32x2 wt[K2], wacc[K2];
 #pragma unroll
-  for (int t = 0; t < 25; ++t) {
+  for (int t = 0; t < K2; ++t) {
     wt[t] = *reinterpret_cast<const f32x2*>(wl + t * SLAB + 2 * lane);
     wacc[t] = f32x2{0.f, 0.f};
   }
@@ -249,7 +250,7 @@ __global__ __launch_bounds__(256) void dw5_tile_bwd_kernel(const TileArgs a) {
 #pragma unroll
         for (int ky = 0; ky < KK; ++ky)
 #pragma unroll
-          for (int kx = 0; kx < KK; ++kx) g = pk_fma(wt[ky * KK + kx], D[(r + 4 - ky) * WW + c + 4 - kx], g);
+          for (int kx = 0; kx < KK; ++kx) g = pk_fma(wt[ky * KK + kx], D[(r + K - 1 - ky) * WW + c + K - 1 - kx], g);
         float gv[CH] = {g[0], g[1]}, xv[CH] = {xr[0], xr[1]};
         act_grad_affine_vec<CH>(gv, xv, scf, shf, ACT);
         const bool inside = iy0 + r < a.H && ix0 + c < a.W;
@@ -287,7 +288,7 @@ __global__ __launch_bounds__(256) void dw5_tile_bwd_kernel(const TileArgs a) {
 #pragma unroll
         for (int ky = 0; ky < KK; ++ky)
 #pragma unroll
-          for (int kx = 0; kx < KK; ++kx) wacc[ky * KK + kx] = pk_fma(av, D[(r + 4 - ky) * WW + c + 4 - kx], wacc[ky * KK + kx]);
+          for (int kx = 0; kx < KK; ++kx) wacc[ky * KK + kx] = pk_fma(av, D[(r + K - 1 - ky) * WW + c + K - 1 - kx], wacc[ky * KK + kx]);
         __builtin_amdgcn_sched_barrier(0);
       }
   }
@@ -299,16 +300,16 @@ __global__ __launch_bounds__(256) void dw5_tile_bwd_kernel(const TileArgs a) {
         const int c = 2 * lane + e;
         if (a.dw) {
 #pragma unroll
-          for (int t = 0; t < 25; ++t) atomicAdd(lacc + t * Cb + c, (double)wacc[t][e]);
+          for (int t = 0; t < K2; ++t) atomicAdd(lacc + t * Cb + c, (double)wacc[t][e]);
         }
         if (a.stats) {
-          atomicAdd(lacc + 25 * Cb + c, (double)psum[e]);
-          atomicAdd(lacc + 26 * Cb + c, (double)psq[e]);
+          atomicAdd(lacc + K2 * Cb + c, (double)psum[e]);
+          atomicAdd(lacc + (K2 + 1) * Cb + c, (double)psq[e]);
         }
       }
     }
     __syncthreads();
-    t3d_dw_flush<25, 256>(lacc, Cb, cbase, a.C, a.dw, a.stats, a.nrep, a.rstride, a.dw_slots, (int)blockIdx.x, a.dw_used);
+    t3d_dw_flush<K2, 256>(lacc, Cb, cbase, a.C, a.dw, a.stats, a.nrep, a.rstride, a.dw_slots, (int)blockIdx.x, a.dw_used);
   }
 }
 
@@ -316,23 +317,23 @@ __global__ __launch_bounds__(256) void dw5_tile_bwd_kernel(const TileArgs a) {
 // (2 TH + 3) x (2 TW + 3) input window.  Backward: a thread owns a (2 TH) x (2 TW) tile of INPUT pixels; tap (ky, kx) reaches
 // input pixel (iy, ix) from output ((iy + 2 - ky) / 2, (ix + 2 - kx) / 2) when both are whole, i.e. ky has the parity of iy and
 // kx that of ix (tile origins are even) -- 25 / 4 taps per pixel on average, from a (TH + 2) x (TW + 2) window of dy.
-template <typename T, int ACT, int TH, int TW>
+template <typename T, int ACT, int K, int TH, int TW>
 __global__ __launch_bounds__(256) void dw5_tile_fwd_s2_kernel(const TileArgs a) {
-  constexpr int CH = 2, WH = 2 * TH + 3, WW = 2 * TW + 3;
-  __shared__ __attribute__((aligned(16))) float wl[25 * SLAB];
+  constexpr int CH = 2, KK = K, PADK = K / 2, K2 = K * K, WH = 2 * TH + K - 2, WW = 2 * TW + K - 2;
+  __shared__ __attribute__((aligned(16))) float wl[K2 * SLAB];
   __shared__ double lstat[2 * SLAB];
   using RV = rawvec<T, CH>;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int cbase = blockIdx.y * SLAB, Cb = min(SLAB, a.C - cbase);
   const bool on = 2 * lane < Cb;
   const int c0 = cbase + (on ? 2 * lane : 0);
-  const int Ho = (a.H - 1) / 2 + 1, Wo = (a.W - 1) / 2 + 1;
-  stage_weights(wl, a.w, cbase, Cb);
+  const int Ho = (a.H + 2 * PADK - K) / 2 + 1, Wo = (a.W + 2 * PADK - K) / 2 + 1;
+  stage_weights<K2>(wl, a.w, cbase, Cb);
   for (int i = threadIdx.x; i < 2 * SLAB; i += 256) lstat[i] = 0.0;
   __syncthreads();
-  f32x2 wt[25];
+  f32x2 wt[K2];
 #pragma unroll
-  for (int t = 0; t < 25; ++t) wt[t] = *reinterpret_cast<const f32x2*>(wl + t * SLAB + 2 * lane);
+  for (int t = 0; t < K2; ++t) wt[t] = *reinterpret_cast<const f32x2*>(wl + t * SLAB + 2 * lane);
   const float sc[CH] = {a.scale ? a.scale[c0] : 1.f, a.scale ? a.scale[c0 + 1] : 1.f};
   const float sh[CH] = {a.scale ? a.shift[c0] : 0.f, a.scale ? a.shift[c0 + 1] : 0.f};
   float psum[CH] = {0.f, 0.f}, psq[CH] = {0.f, 0.f};
@@ -418,24 +419,27 @@ __global__ __launch_bounds__(256) void dw5_tile_fwd_s2_kernel(const TileArgs a) 
   }
 }
 
-template <typename T, int ACT, int TH, int TW>
+template <typename T, int ACT, int K, int TH, int TW>
 __global__ __launch_bounds__(256) void dw5_tile_bwd_s2_kernel(const TileArgs a) {
-  constexpr int CH = 2, IH = 2 * TH, IW = 2 * TW, WH = TH + 2, WW = TW + 2;
+  // taps of an input row r (tile origin even): ky = (r + PAD) mod 2, +2, ...; they reach output rows (r + PAD - ky) / 2 relative
+  // to iy0 / 2: from LO = (PAD - kymax) / 2 (kymax: the largest tap of PAD's parity) to TH -- K = 5: -1 .. TH, K = 3: 0 .. TH
+  constexpr int CH = 2, KK = K, PADK = K / 2, K2 = K * K, IH = 2 * TH, IW = 2 * TW;
+  constexpr int KYMAX = (K - 1) - ((K - 1 - PADK) & 1), LO = (PADK - KYMAX) / 2, WH = TH - LO + 1, WW = TW - LO + 1;
   extern __shared__ __attribute__((aligned(16))) float lred[];
   float* wl = lred;
-  double* lacc = reinterpret_cast<double*>(lred + 25 * SLAB);
+  double* lacc = reinterpret_cast<double*>(lred + K2 * SLAB);
   using RV = rawvec<T, CH>;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int cbase = blockIdx.y * SLAB, Cb = min(SLAB, a.C - cbase);
   const bool on = 2 * lane < Cb;
   const int c0 = cbase + (on ? 2 * lane : 0);
-  const int Ho = (a.H - 1) / 2 + 1, Wo = (a.W - 1) / 2 + 1;
-  stage_weights(wl, a.w, cbase, Cb);
-  for (int i = threadIdx.x; i < 27 * Cb; i += 256) lacc[i] = 0.0;
+  const int Ho = (a.H + 2 * PADK - K) / 2 + 1, Wo = (a.W + 2 * PADK - K) / 2 + 1;
+  stage_weights<K2>(wl, a.w, cbase, Cb);
+  for (int i = threadIdx.x; i < (K2 + 2) * Cb; i += 256) lacc[i] = 0.0;
   __syncthreads();
-  f32x2 wt[25], wacc[25];
+  f32x2 wt[K2], wacc[K2];
 #pragma unroll
-  for (int t = 0; t < 25; ++t) {
+  for (int t = 0; t < K2; ++t) {
     wt[t] = *reinterpret_cast<const f32x2*>(wl + t * SLAB + 2 * lane);
     wacc[t] = f32x2{0.f, 0.f};
   }
@@ -464,13 +468,13 @@ __global__ __launch_bounds__(256) void dw5_tile_bwd_s2_kernel(const TileArgs a) 
     float rm[WH], cm[WW];
 #pragma unroll
     for (int r = 0; r < WH; ++r) {
-      const int oy = iy0 / 2 - 1 + r;
+      const int oy = iy0 / 2 + LO + r;
       rm[r] = (oy >= 0 && oy < Ho) ? 1.f : 0.f;
       roff[r] = min(max(oy, 0), Ho - 1) * Wo;
     }
 #pragma unroll
     for (int c = 0; c < WW; ++c) {
-      const int ox = ix0 / 2 - 1 + c;
+      const int ox = ix0 / 2 + LO + c;
       cm[c] = (ox >= 0 && ox < Wo) ? 1.f : 0.f;
       coff[c] = min(max(ox, 0), Wo - 1);
     }
@@ -496,7 +500,7 @@ __global__ __launch_bounds__(256) void dw5_tile_bwd_s2_kernel(const TileArgs a) 
         const float m = rm[r] * cm[c];
         D[r * WW + c] = pk_fma(al2, Pair<T>::widen(rz[r * WW + c]), pk_fma(be2, Pair<T>::widen(ry[r * WW + c]), ga2)) * f32x2{m, m};
       }
-    // phase 1: data gradient.  Local pixel (r, c), tap (ky, kx) of its parity: window row (r + 4 - ky) / 2, column (c + 4 - kx) / 2
+    // phase 1: data gradient.  Local pixel (r, c), tap (ky, kx) of its parity -> window row / column as in the header comment
 #pragma unroll
     for (int r = 0; r < IH; ++r)
 #pragma unroll
@@ -504,9 +508,9 @@ __global__ __launch_bounds__(256) void dw5_tile_bwd_s2_kernel(const TileArgs a) 
         const f32x2 xr = Pair<T>::widen(rx[r * IW + c]);
         f32x2 g = {0.f, 0.f};
 #pragma unroll
-        for (int ky = r & 1; ky < KK; ky += 2)
+        for (int ky = (r + PADK) & 1; ky < KK; ky += 2)
 #pragma unroll
-          for (int kx = c & 1; kx < KK; kx += 2) g = pk_fma(wt[ky * KK + kx], D[((r + 4 - ky) / 2) * WW + (c + 4 - kx) / 2], g);
+          for (int kx = (c + PADK) & 1; kx < KK; kx += 2) g = pk_fma(wt[ky * KK + kx], D[((r + PADK - ky) / 2 - LO) * WW + (c + PADK - kx) / 2 - LO], g);
         float gv[CH] = {g[0], g[1]}, xv[CH] = {xr[0], xr[1]};
         act_grad_affine_vec<CH>(gv, xv, scf, shf, ACT);
         const bool inside = iy0 + r < a.H && ix0 + c < a.W;
@@ -542,10 +546,10 @@ __global__ __launch_bounds__(256) void dw5_tile_bwd_s2_kernel(const TileArgs a) 
         const float m = (iy0 + r < a.H && ix0 + c < a.W) ? 1.f : 0.f;
         const f32x2 av = {t[0] * m, t[1] * m};
 #pragma unroll
-        for (int ky = r & 1; ky < KK; ky += 2)
+        for (int ky = (r + PADK) & 1; ky < KK; ky += 2)
 #pragma unroll
-          for (int kx = c & 1; kx < KK; kx += 2)
-            wacc[ky * KK + kx] = pk_fma(av, D[((r + 4 - ky) / 2) * WW + (c + 4 - kx) / 2], wacc[ky * KK + kx]);
+          for (int kx = (c + PADK) & 1; kx < KK; kx += 2)
+            wacc[ky * KK + kx] = pk_fma(av, D[((r + PADK - ky) / 2 - LO) * WW + (c + PADK - kx) / 2 - LO], wacc[ky * KK + kx]);
         __builtin_amdgcn_sched_barrier(0);
       }
   }
@@ -557,16 +561,16 @@ __global__ __launch_bounds__(256) void dw5_tile_bwd_s2_kernel(const TileArgs a) 
         const int c = 2 * lane + e;
         if (a.dw) {
 #pragma unroll
-          for (int t = 0; t < 25; ++t) atomicAdd(lacc + t * Cb + c, (double)wacc[t][e]);
+          for (int t = 0; t < K2; ++t) atomicAdd(lacc + t * Cb + c, (double)wacc[t][e]);
         }
         if (a.stats) {
-          atomicAdd(lacc + 25 * Cb + c, (double)psum[e]);
-          atomicAdd(lacc + 26 * Cb + c, (double)psq[e]);
+          atomicAdd(lacc + K2 * Cb + c, (double)psum[e]);
+          atomicAdd(lacc + (K2 + 1) * Cb + c, (double)psq[e]);
         }
       }
     }
     __syncthreads();
-    t3d_dw_flush<25, 256>(lacc, Cb, cbase, a.C, a.dw, a.stats, a.nrep, a.rstride, a.dw_slots, (int)blockIdx.x, a.dw_used);
+    t3d_dw_flush<K2, 256>(lacc, Cb, cbase, a.C, a.dw, a.stats, a.nrep, a.rstride, a.dw_slots, (int)blockIdx.x, a.dw_used);
   }
 }
 
@@ -582,110 +586,100 @@ static dim3 tile_grid(TileArgs& a, int waves_target, int PH = 0, int PW = 0) {
   return dim3(gx, ns);
 }
 
-constexpr int FTH = 4, FTW = 7, BTH = 2, BTW = 7;
+// tile shapes per stencil size: K = 5 -- 4 x 7 outputs forward (8 x 11 window), 2 x 7 pixels backward; stride 2: 2 x 4 outputs forward
+// (7 x 11 window), 4 x 8 input pixels backward (4 x 6 window of dy).  K = 3 -- 7 x 7 forward (9 x 9 window), 4 x 7 backward; stride 2:
+// 2 x 7 outputs forward (5 x 15 window), 4 x 8 input pixels backward (3 x 5 window).
+template <int K> struct TileShape;
+template <> struct TileShape<5> { static constexpr int FH = 4, FW = 7, BH = 2, BW = 7, F2H = 2, F2W = 4, B2H = 2, B2W = 4; };
+template <> struct TileShape<3> { static constexpr int FH = 7, FW = 7, BH = 4, BW = 7, F2H = 2, F2W = 7, B2H = 2, B2W = 4; };
 
-constexpr int F2H = 2, F2W = 4, B2H = 2, B2W = 4;     // stride 2: output tile forward, (2 B2H) x (2 B2W) input tile backward
+#define T3D_TILE_ACT(KERNEL, ...)                                                                                     \
+  switch (act) {                                                                                                      \
+    case T3D_ACT_RELU: T3D_LAUNCH_TIMED((KERNEL<T, T3D_ACT_RELU, __VA_ARGS__>), grid, dim3(256), lds, st, a); break;    \
+    case T3D_ACT_RELU6: T3D_LAUNCH_TIMED((KERNEL<T, T3D_ACT_RELU6, __VA_ARGS__>), grid, dim3(256), lds, st, a); break;  \
+    case T3D_ACT_HSWISH: T3D_LAUNCH_TIMED((KERNEL<T, T3D_ACT_HSWISH, __VA_ARGS__>), grid, dim3(256), lds, st, a); break; \
+    default: T3D_LAUNCH_TIMED((KERNEL<T, T3D_ACT_NONE, __VA_ARGS__>), grid, dim3(256), lds, st, a); break;              \
+  }
 
-template <typename T>
-int launch_fwd_s2(TileArgs& a, int act, hipStream_t st) {
-  const dim3 grid = tile_grid<F2H, F2W>(a, 4096, (a.H - 1) / 2 + 1, (a.W - 1) / 2 + 1);
+template <typename T, int K>
+int launch_fwd(TileArgs& a, int act, int stride, hipStream_t st) {
+  typedef TileShape<K> S;
+  const int Ho = stride == 2 ? (a.H + 2 * (K / 2) - K) / 2 + 1 : a.H, Wo = stride == 2 ? (a.W + 2 * (K / 2) - K) / 2 + 1 : a.W;
+  const dim3 grid = stride == 2 ? tile_grid<S::F2H, S::F2W>(a, 4096, Ho, Wo) : tile_grid<S::FH, S::FW>(a, 4096);
   a.nrep = g_t3d_reduce.nrep;
   a.rstride = g_t3d_reduce.stats_stride;
   if (a.stats && a.nrep < 1) { a.nrep = 1; a.rstride = 0; }
-  a.quant = (a.stats && std::is_same<T, bf16_t>::value && !T3D_ENV_SET("T3D_NO_SNAP"))
-                ? t3d_quant_for((long long)a.B * ((a.H - 1) / 2 + 1) * ((a.W - 1) / 2 + 1)) : T3dQuant{0.0, 0.0};
-  switch (act) {
-    case T3D_ACT_RELU: T3D_LAUNCH_TIMED((dw5_tile_fwd_s2_kernel<T, T3D_ACT_RELU, F2H, F2W>), grid, dim3(256), 0, st, a); break;
-    case T3D_ACT_RELU6: T3D_LAUNCH_TIMED((dw5_tile_fwd_s2_kernel<T, T3D_ACT_RELU6, F2H, F2W>), grid, dim3(256), 0, st, a); break;
-    case T3D_ACT_HSWISH: T3D_LAUNCH_TIMED((dw5_tile_fwd_s2_kernel<T, T3D_ACT_HSWISH, F2H, F2W>), grid, dim3(256), 0, st, a); break;
-    default: T3D_LAUNCH_TIMED((dw5_tile_fwd_s2_kernel<T, T3D_ACT_NONE, F2H, F2W>), grid, dim3(256), 0, st, a); break;
-  }
+  a.quant = (a.stats && std::is_same<T, bf16_t>::value && !T3D_ENV_SET("T3D_NO_SNAP")) ? t3d_quant_for((long long)a.B * Ho * Wo) : T3dQuant{0.0, 0.0};
+  const size_t lds = 0;
+  if (stride == 2) { T3D_TILE_ACT(dw5_tile_fwd_s2_kernel, K, S::F2H, S::F2W) }
+  else { T3D_TILE_ACT(dw5_tile_fwd_kernel, K, S::FH, S::FW) }
   T3D_CHECK_LAUNCH();
   return T3D_OK;
 }
 
-template <typename T>
-int launch_bwd_s2(TileArgs& a, int act, hipStream_t st) {
-  const dim3 grid = tile_grid<2 * B2H, 2 * B2W>(a, 4096);
+template <typename T, int K>
+int launch_bwd(TileArgs& a, int act, int stride, hipStream_t st) {
+  typedef TileShape<K> S;
+  dim3 grid = stride == 2 ? tile_grid<2 * S::B2H, 2 * S::B2W>(a, 4096) : tile_grid<S::BH, S::BW>(a, K == 5 ? 2048 : 4096);
+  // one weight-gradient slot per workgroup column (t3d_set_dw_slots): never more columns than slots -- past that the flush falls
+  // back to fp32 atomics and the step is no longer bit-reproducible (56x56x72 stride 2 wanted 1024 against the engine's 512)
+  if (a.dw && g_t3d_reduce.dw_slots > 0 && (int)grid.x > g_t3d_reduce.dw_slots) grid.x = g_t3d_reduce.dw_slots;
   a.nrep = g_t3d_reduce.nrep;
   a.rstride = g_t3d_reduce.stats_stride;
   if (a.nrep < 1) { a.nrep = 1; a.rstride = 0; }
   a.dw_slots = (a.dw && g_t3d_reduce.dw_slots >= (int)grid.x) ? (int)grid.x : 0;
   a.dw_used = a.dw ? g_t3d_reduce.dw_used : nullptr;
-  const size_t lds = (size_t)25 * SLAB * sizeof(float) + (size_t)27 * SLAB * sizeof(double);
-  switch (act) {
-    case T3D_ACT_RELU: T3D_LAUNCH_TIMED((dw5_tile_bwd_s2_kernel<T, T3D_ACT_RELU, B2H, B2W>), grid, dim3(256), lds, st, a); break;
-    case T3D_ACT_RELU6: T3D_LAUNCH_TIMED((dw5_tile_bwd_s2_kernel<T, T3D_ACT_RELU6, B2H, B2W>), grid, dim3(256), lds, st, a); break;
-    case T3D_ACT_HSWISH: T3D_LAUNCH_TIMED((dw5_tile_bwd_s2_kernel<T, T3D_ACT_HSWISH, B2H, B2W>), grid, dim3(256), lds, st, a); break;
-    default: T3D_LAUNCH_TIMED((dw5_tile_bwd_s2_kernel<T, T3D_ACT_NONE, B2H, B2W>), grid, dim3(256), lds, st, a); break;
-  }
+  const size_t lds = (size_t)K * K * SLAB * sizeof(float) + (size_t)(K * K + 2) * SLAB * sizeof(double);
+  if (stride == 2) { T3D_TILE_ACT(dw5_tile_bwd_s2_kernel, K, S::B2H, S::B2W) }
+  else { T3D_TILE_ACT(dw5_tile_bwd_kernel, K, S::BH, S::BW) }
   T3D_CHECK_LAUNCH();
   return T3D_OK;
 }
+#undef T3D_TILE_ACT
 
-template <typename T>
-int launch_fwd(TileArgs& a, int act, hipStream_t st) {
-  const dim3 grid = tile_grid<FTH, FTW>(a, 4096);
-  a.nrep = g_t3d_reduce.nrep;
-  a.rstride = g_t3d_reduce.stats_stride;
-  if (a.stats && a.nrep < 1) { a.nrep = 1; a.rstride = 0; }
-  a.quant = (a.stats && std::is_same<T, bf16_t>::value && !T3D_ENV_SET("T3D_NO_SNAP")) ? t3d_quant_for((long long)a.B * a.H * a.W) : T3dQuant{0.0, 0.0};
-  switch (act) {
-    case T3D_ACT_RELU: T3D_LAUNCH_TIMED((dw5_tile_fwd_kernel<T, T3D_ACT_RELU, FTH, FTW>), grid, dim3(256), 0, st, a); break;
-    case T3D_ACT_RELU6: T3D_LAUNCH_TIMED((dw5_tile_fwd_kernel<T, T3D_ACT_RELU6, FTH, FTW>), grid, dim3(256), 0, st, a); break;
-    case T3D_ACT_HSWISH: T3D_LAUNCH_TIMED((dw5_tile_fwd_kernel<T, T3D_ACT_HSWISH, FTH, FTW>), grid, dim3(256), 0, st, a); break;
-    default: T3D_LAUNCH_TIMED((dw5_tile_fwd_kernel<T, T3D_ACT_NONE, FTH, FTW>), grid, dim3(256), 0, st, a); break;
-  }
-  T3D_CHECK_LAUNCH();
-  return T3D_OK;
+// which planes take the tile kernels (isolated, B = 256, us tile | row walk; profiles/r6_*_dw5_isolated.txt, _dw3_small_planes_*):
+//   5x5 s1 28x28x120: forward 48 | 58 (79 before the chunk fix), backward 116 | 185;  5x5 s2 14x14x672: 55 | 74, 117 | 163;
+//   5x5 s2 56x56x72: 96 | 90, 171 | 178 -- no gain, stays on the walk;  7x7 planes: dwconv5_plane7.hip (17 | 67, 50 | 116).
+//   3x3: the tiles LOSE to the row-walk kernels of dwconv3_stream.hip / dwconv3_bwd_stream.hip on every plane of MobileNetV2
+//   (28x28x192: 50 | 36 forward, 127 | 85 backward; 14x14x384: 27 | 24, 66 | 42; 7x7x960: 18 | 19, 47 | 34) -- those kernels
+//   are at 3.2-4.4 TB/s alone, their in-step times are contention, not structure.  OPT-IN: T3D_DW3_TILE_MAX = largest plane side.
+static int dw3_tile_max() {      // (read per call: the test suite flips it inside one process, like T3D_DW_TILED)
+  const char* e = getenv("T3D_DW3_TILE_MAX");
+  return e ? atoi(e) : 0;
 }
-
-template <typename T>
-int launch_bwd(TileArgs& a, int act, hipStream_t st) {
-  const dim3 grid = tile_grid<BTH, BTW>(a, 2048);
-  a.nrep = g_t3d_reduce.nrep;
-  a.rstride = g_t3d_reduce.stats_stride;
-  if (a.nrep < 1) { a.nrep = 1; a.rstride = 0; }
-  a.dw_slots = (a.dw && g_t3d_reduce.dw_slots >= (int)grid.x) ? (int)grid.x : 0;
-  a.dw_used = a.dw ? g_t3d_reduce.dw_used : nullptr;
-  const size_t lds = (size_t)25 * SLAB * sizeof(float) + (size_t)27 * SLAB * sizeof(double);
-  switch (act) {
-    case T3D_ACT_RELU: T3D_LAUNCH_TIMED((dw5_tile_bwd_kernel<T, T3D_ACT_RELU, BTH, BTW>), grid, dim3(256), lds, st, a); break;
-    case T3D_ACT_RELU6: T3D_LAUNCH_TIMED((dw5_tile_bwd_kernel<T, T3D_ACT_RELU6, BTH, BTW>), grid, dim3(256), lds, st, a); break;
-    case T3D_ACT_HSWISH: T3D_LAUNCH_TIMED((dw5_tile_bwd_kernel<T, T3D_ACT_HSWISH, BTH, BTW>), grid, dim3(256), lds, st, a); break;
-    default: T3D_LAUNCH_TIMED((dw5_tile_bwd_kernel<T, T3D_ACT_NONE, BTH, BTW>), grid, dim3(256), lds, st, a); break;
-  }
-  T3D_CHECK_LAUNCH();
-  return T3D_OK;
+static bool tile_shape_ok(int k, int stride, int H, int W, int C) {
+  if ((C % 2) || H < 2 || W < 2) return false;
+  if (k == 5) return H >= 8 && W >= 8 && H <= (stride == 2 ? 28 : 64) && W <= (stride == 2 ? 28 : 64) && !T3D_ENV_SET("T3D_DW5_NO_TILE");
+  if (k == 3) return H <= dw3_tile_max() && W <= dw3_tile_max();
+  return false;
 }
-
-// which planes take the tile kernels: beyond 7x7 (dwconv5_plane7.hip) and small enough that the halo re-reads stay in L1 / L2
-static bool tile_shape_ok(int H, int W, int C) { return (C % 2) == 0 && H >= 8 && W >= 8 && H <= 64 && W <= 64 && !T3D_ENV_SET("T3D_DW5_NO_TILE"); }
 
 }  // namespace
 
-int t3d_dw5_tile_fwd(int dtype, const void* x, const t3d_prologue* pro, const float* w, void* y, double* stats, float* gap_sum,
-                     int B, int H, int W, int C, int stride, hipStream_t st) {
-  if (!tile_shape_ok(H, W, C) || (pro && pro->se) || (stride != 1 && stride != 2)) return T3D_ERR_UNSUPPORTED;
+int t3d_dw_tile_fwd(int dtype, const void* x, const t3d_prologue* pro, const float* w, void* y, double* stats, float* gap_sum,
+                    int B, int H, int W, int C, int k, int stride, hipStream_t st) {
+  if (!tile_shape_ok(k, stride, H, W, C) || (pro && pro->se) || (stride != 1 && stride != 2)) return T3D_ERR_UNSUPPORTED;
+  if (pro)
+    if (const int rc = t3d_fold_fallback(pro->scale, st)) return rc;      // finished coefficients (no derive prologue here)
   TileArgs a{};
   a.x = x; a.y = y; a.w = w; a.stats = stats; a.gap = gap_sum; a.gapq = g_t3d_reduce.pool_exact;
   if (pro) { a.scale = pro->scale; a.shift = pro->shift; }
   a.B = B; a.H = H; a.W = W; a.C = C;
   const int act = pro ? pro->act : T3D_ACT_NONE;
-  if (stride == 2) {
-    if (dtype == T3D_F32) return launch_fwd_s2<float>(a, act, st);
-    if (dtype == T3D_BF16) return launch_fwd_s2<bf16_t>(a, act, st);
-    return T3D_ERR_UNSUPPORTED;
+  if (k == 5) {
+    if (dtype == T3D_F32) return launch_fwd<float, 5>(a, act, stride, st);
+    if (dtype == T3D_BF16) return launch_fwd<bf16_t, 5>(a, act, stride, st);
+  } else {
+    if (dtype == T3D_F32) return launch_fwd<float, 3>(a, act, stride, st);
+    if (dtype == T3D_BF16) return launch_fwd<bf16_t, 3>(a, act, stride, st);
   }
-  if (dtype == T3D_F32) return launch_fwd<float>(a, act, st);
-  if (dtype == T3D_BF16) return launch_fwd<bf16_t>(a, act, st);
   return T3D_ERR_UNSUPPORTED;
 }
 
-int t3d_dw5_tile_bwd(int dtype, const void* dz, const void* y, const t3d_bnbwd* bb, const float* w, const void* x,
-                     const t3d_prologue* pro, const void* residual, void* dx, double* stats, float* dw, int B, int H, int W, int C,
-                     int stride, hipStream_t st) {
-  if (!tile_shape_ok(H, W, C) || (pro && pro->se) || (stride != 1 && stride != 2)) return T3D_ERR_UNSUPPORTED;
+int t3d_dw_tile_bwd(int dtype, const void* dz, const void* y, const t3d_bnbwd* bb, const float* w, const void* x,
+                    const t3d_prologue* pro, const void* residual, void* dx, double* stats, float* dw, int B, int H, int W, int C,
+                    int k, int stride, hipStream_t st) {
+  if (!tile_shape_ok(k, stride, H, W, C) || (pro && pro->se) || (stride != 1 && stride != 2)) return T3D_ERR_UNSUPPORTED;
   if (const int rc = t3d_fold_fallback(bb->alpha, st)) return rc;
   TileArgs a{};
   a.dz = dz; a.yraw = y; a.x = x; a.res = residual; a.dx = dx; a.w = w;
@@ -693,12 +687,12 @@ int t3d_dw5_tile_bwd(int dtype, const void* dz, const void* y, const t3d_bnbwd* 
   if (pro) { a.scale = pro->scale; a.shift = pro->shift; }
   a.stats = stats; a.dw = dw; a.B = B; a.H = H; a.W = W; a.C = C;
   const int act = pro ? pro->act : T3D_ACT_NONE;
-  if (stride == 2) {
-    if (dtype == T3D_F32) return launch_bwd_s2<float>(a, act, st);
-    if (dtype == T3D_BF16) return launch_bwd_s2<bf16_t>(a, act, st);
-    return T3D_ERR_UNSUPPORTED;
+  if (k == 5) {
+    if (dtype == T3D_F32) return launch_bwd<float, 5>(a, act, stride, st);
+    if (dtype == T3D_BF16) return launch_bwd<bf16_t, 5>(a, act, stride, st);
+  } else {
+    if (dtype == T3D_F32) return launch_bwd<float, 3>(a, act, stride, st);
+    if (dtype == T3D_BF16) return launch_bwd<bf16_t, 3>(a, act, stride, st);
   }
-  if (dtype == T3D_F32) return launch_bwd<float>(a, act, st);
-  if (dtype == T3D_BF16) return launch_bwd<bf16_t>(a, act, st);
   return T3D_ERR_UNSUPPORTED;
 }

@@ -19,11 +19,15 @@
 
 namespace {
 
+constexpr int GRAM_NREP = 16;
+
 template <int K>
 __global__ __launch_bounds__(256) void bn_apply_gram_kernel(const bf16_t* __restrict__ y, const float* __restrict__ scale,
                                                             const float* __restrict__ shift, int act,
                                                             const bf16_t* __restrict__ res, bf16_t* __restrict__ z,
                                                             double* __restrict__ gram, int M, T3dQuant quant) {
+  // gram: GRAM_NREP replicas of [NG + K] (workgroup b adds into replica b % GRAM_NREP): 1024 workgroups x 152 fp64 atomics on 152
+  // addresses made the first version 136 us for a 40-us pass (the round-1 lesson, DESIGN.md finding 1)
   constexpr int NG = K * (K + 1) / 2;          // upper triangle, row-major: (i, j >= i)
   __shared__ double lacc[NG + K];
   for (int i = threadIdx.x; i < NG + K; i += 256) lacc[i] = 0.0;
@@ -90,26 +94,35 @@ __global__ __launch_bounds__(256) void bn_apply_gram_kernel(const bf16_t* __rest
     if (lane == 0) atomicAdd(lacc + NG + k, t3d_snap(w, quant, false));
   }
   __syncthreads();
+  double* dst = gram + (size_t)(blockIdx.x % GRAM_NREP) * (NG + K);
   for (int i = threadIdx.x; i < NG + K; i += 256)
-    if (lacc[i] != 0.0) atomicAdd(gram + i, lacc[i]);
+    if (lacc[i] != 0.0) atomicAdd(dst + i, lacc[i]);
 }
 
-// one thread per expanded channel: the K x K form in fp64
-__global__ __launch_bounds__(64) void gram_bn_finalize_kernel(const double* __restrict__ gram, const bf16_t* __restrict__ w, int C, int K,
-                                                              double count, const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                              float* running_mean, float* running_var, int64_t* nbt, float momentum, float eps,
-                                                              float* scale, float* shift, float* mean_out, float* invstd_out) {
-  const int c = blockIdx.x * 64 + threadIdx.x;
+// one thread per expanded channel: the K x K form in fp64, the replica sums met in LDS first
+__global__ __launch_bounds__(128) void gram_bn_finalize_kernel(const double* __restrict__ gram, const bf16_t* __restrict__ w, int C, int K,
+                                                               double count, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                               float* running_mean, float* running_var, int64_t* nbt, float momentum, float eps,
+                                                               float* scale, float* shift, float* mean_out, float* invstd_out) {
+  __shared__ double gs[16 * 17 / 2 + 16];
+  const int NG = K * (K + 1) / 2, n = NG + K;
+  for (int i = threadIdx.x; i < n; i += 128) {
+    double v = 0.0;
+#pragma unroll
+    for (int r = 0; r < GRAM_NREP; ++r) v += gram[(size_t)r * n + i];
+    gs[i] = v;
+  }
+  __syncthreads();
+  const int c = blockIdx.x * 128 + threadIdx.x;
   if (c == 0 && nbt) *nbt += 1;
   if (c >= C) return;
-  const int NG = K * (K + 1) / 2;
   double wk[16];
   for (int k = 0; k < K; ++k) wk[k] = (double)(float)w[(size_t)c * K + k];
   double s1 = 0.0, s2 = 0.0;
   int t = 0;
   for (int i = 0; i < K; ++i) {
-    s1 += wk[i] * gram[NG + i];
-    for (int j = i; j < K; ++j, ++t) s2 += (i == j ? 1.0 : 2.0) * wk[i] * wk[j] * gram[t];
+    s1 += wk[i] * gs[NG + i];
+    for (int j = i; j < K; ++j, ++t) s2 += (i == j ? 1.0 : 2.0) * wk[i] * wk[j] * gs[t];
   }
   const double mean = s1 / count;
   double var = s2 / count - mean * mean;  // biased
@@ -139,7 +152,7 @@ extern "C" int t3d_bn_apply_gram(int dtype, const void* y, const t3d_prologue* p
   if (pro)
     if (const int rc = t3d_fold_fallback(pro->scale, st)) return rc;      // finished coefficients (no derive prologue here)
   const T3dQuant quant = T3D_ENV_SET("T3D_NO_SNAP") ? T3dQuant{0.0, 0.0} : t3d_quant_for(M);
-  const int grid = cdiv(M, 256) < 1024 ? cdiv(M, 256) : 1024;
+  const int grid = cdiv(M, 256) < 512 ? cdiv(M, 256) : 512;
   const bf16_t* yb = reinterpret_cast<const bf16_t*>(y);
   const bf16_t* rb = reinterpret_cast<const bf16_t*>(residual);
   bf16_t* zb = reinterpret_cast<bf16_t*>(z);
@@ -157,7 +170,7 @@ extern "C" int t3d_gram_bn_finalize(const double* gram, const void* w, int C, in
                                     float momentum, float eps, float* scale, float* shift, float* mean_out, float* invstd_out,
                                     void* stream) {
   if (!gram || !w || !scale || !shift || C <= 0 || K <= 0 || K > 16 || count <= 0) return T3D_ERR_ARG;
-  T3D_LAUNCH(gram_bn_finalize_kernel, dim3(cdiv(C, 64)), dim3(64), 0, reinterpret_cast<hipStream_t>(stream), gram,
+  T3D_LAUNCH(gram_bn_finalize_kernel, dim3(cdiv(C, 128)), dim3(128), 0, reinterpret_cast<hipStream_t>(stream), gram,
              reinterpret_cast<const bf16_t*>(w), C, K, count, gamma, beta, running_mean, running_var, num_batches_tracked, momentum, eps,
              scale, shift, mean_out, invstd_out);
   T3D_CHECK_LAUNCH();

@@ -846,7 +846,7 @@ class Net:
             # stored for the backward (csrc/gram.hip, csrc/expdw_fwd.hip; DESIGN.md finding 55)
             bn1, bn2 = self.bns[p + '.1'], self.bns[p + '.4']
             M, K, C = B * H * W, blk.cin, blk.cexp
-            gram = self._buf(f'gram:{i}', (K * (K + 1) // 2 + K,), torch.float64, zgroup='fwd')
+            gram = self._buf(f'gram:{i}', (16, K * (K + 1) // 2 + K), torch.float64, zgroup='fwd')      # 16 reduction replicas
             if x.zbuf is not None:
                 self._settle_f(x.bn)
                 N.call('t3d_bn_apply_gram', dt, N.ptr(x.t), x.pro, N.ptr(x.zres), N.ptr(x.zbuf), N.ptr(gram), M, K, st,

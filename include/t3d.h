@@ -240,10 +240,12 @@ int t3d_bn_apply(int dtype, const void* y, const t3d_prologue* pro, const void* 
  * and sum(y1^2)_c = w_c^T (z^T z) w_c: one pass over the NARROW tensor replaces the statistics the 1x1 conv's epilogue takes
  * over the 6x wider one -- which is what lets the fused expand + depthwise forward (t3d_expdw_fwd) run in TRAINING mode.
  *   t3d_bn_apply_gram: t3d_bn_apply (z may be NULL: y is the finished tensor already, pro and residual NULL) that also adds
- *     [upper triangle of z^T z, row-major (i, j >= i) | 1^T z] into gram [K(K+1)/2 + K] fp64 (caller zeroes; order-independent
- *     adds); bf16, K in {8, 16}; the sums are those of the STORED (rounded) z.
+ *     [upper triangle of z^T z, row-major (i, j >= i) | 1^T z] into gram [16][K(K+1)/2 + K] fp64 -- 16 reduction replicas, a
+ *     workgroup adds into one of them (caller zeroes all; order-independent adds); bf16, K in {8, 16}; the sums are those of the
+ *     STORED (rounded) z.
  *   t3d_gram_bn_finalize: t3d_bn_finalize's outputs (scale, shift, mean, invstd, running statistics, num_batches_tracked) for
- *     the C channels of W1 z from those sums; w [C,K] in the conv's storage dtype (bf16: the matrix the MFMA multiplies). */
+ *     the C channels of W1 z from those sums (the 16 replicas added first); w [C,K] in the conv's storage dtype (bf16: the matrix
+ *     the MFMA multiplies). */
 int t3d_bn_apply_gram(int dtype, const void* y, const t3d_prologue* pro, const void* residual, void* z, double* gram, int M,
                       int K, void* stream);
 int t3d_gram_bn_finalize(const double* gram, const void* w, int C, int K, double count, const float* gamma, const float* beta,

@@ -276,3 +276,15 @@ def test_dwconv_bwd_refused_by_the_streaming_kernel_keeps_its_pending_finalize(s
         assert torch.isfinite(a.float()).all() and torch.equal(a, b)
     # (the weight gradient of the tiled kernel without slots is a sum of fp32 atomics: equal up to their order)
     assert torch.allclose(res[False][5], res[True][5], rtol=1e-4, atol=1e-3)
+
+
+@pytest.mark.parametrize('B,C,H,W,k,s', [(2, 32, 24, 24, 3, 1), (2, 96, 24, 24, 3, 2), (5, 264, 9, 7, 3, 1), (3, 40, 13, 17, 3, 2), (2, 960, 7, 7, 3, 1)])
+@pytest.mark.parametrize('dt', ['f32', 'bf16'])
+def test_3x3_register_tiles_opt_in(B, C, H, W, k, s, dt, monkeypatch):
+    """The 3x3 instantiation of the register-tile kernels (csrc/dwconv_tile.hip) is opt-in -- it measured slower than the
+    row-walk kernels on every plane of MobileNetV2 -- but stays correct: the same forward / backward checks with
+    T3D_DW3_TILE_MAX covering the plane."""
+    monkeypatch.setenv('T3D_DW3_TILE_MAX', '64')
+    test_dwconv_fwd(B, C, H, W, k, s, dt, 'bnact')
+    test_dwconv_bwd(B, C, H, W, k, s, dt, 'bnact_ps')
+    test_dwconv_bwd(B, C, H, W, k, s, dt, 'plain_res')

@@ -1,7 +1,7 @@
 #!/bin/bash
 # everything the round's profiles/ are made of, in one GPU call.  usage: tools/profile_round.sh <tag> <commit>
 cd $GRAFT_REPO_ROOT; export TMPDIR=/tmp
-tag=${1:-r5}; commit=${2:-?}; o=gpurun_out/$tag; mkdir -p $o
+tag=${1:-r6}; commit=${2:-?}; o=gpurun_out/$tag; mkdir -p $o
 python3 bench.py --steps 30 --warmup 8 > $o/bench_bf16.json 2> $o/bench_bf16.err
 python3 bench.py --steps 30 --warmup 8 --no-cpu-baseline --profile-all > /dev/null 2> $o/bench_bf16_families.txt
 python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline --per-launch > /dev/null 2> $o/bench_bf16_per_launch.txt
@@ -31,6 +31,21 @@ find $d -name "*kernel_stats.csv" -exec cp {} $o/kernel_stats.csv \;
 python3 tools/trace_streams.py $(find $d -name "*kernel_trace.csv") > $o/stream_timeline.txt 2>&1
 python3 tools/trace_summary.py $(find $d -name "*kernel_trace.csv") > $o/step_kernel_table.txt 2>&1
 rm -rf $d
+# round 6: kernel stats of the reference-pinned model and of ResNet-50 (missing #4), matrix-core utilisation from the
+# SQ counters (missing #5), isolated timings of the pointwise backward and of the small-plane depthwise kernels
+for m in mobilenetv3_large resnet50; do
+  d=gpurun_out/trace_${tag}_$m; rm -rf $d
+  extra=""; [ $m = resnet50 ] && extra="--batch 64"
+  rocprofv3 --kernel-trace --stats --output-format csv -d $d -o t -- python3 bench.py --model $m $extra --steps 12 --warmup 4 --no-cpu-baseline > /dev/null 2>&1
+  find $d -name "*kernel_stats.csv" -exec cp {} $o/${m}_kernel_stats.csv \;
+  python3 tools/trace_summary.py $(find $d -name "*kernel_trace.csv") > $o/${m}_step_kernel_table.txt 2>&1
+  rm -rf $d
+done
+bash tools/pmc_mfma.sh $o/mfma_util_pmc.json > $o/mfma_util_pmc.log 2>&1
+bash tools/pmc_mfma.sh $o/mfma_util_pmc_resnet50.json --model resnet50 --batch 64 > $o/mfma_util_pmc_resnet50.log 2>&1
+bash tools/time_pw_bwd.sh $o/pw_bwd_isolated.txt > /dev/null 2>&1
+bash tools/time_dw5.sh > $o/dw5_isolated.txt 2>&1
+bash tools/time_dw3_small.sh > $o/dw3_small_planes_tile_vs_walk.txt 2>&1
 # HBM traffic (separate --pmc passes)
 bash tools/pmc_traffic.sh $o/hbm_traffic_pmc.json $commit > $o/pmc_traffic.log 2>&1
 tail -2 $o/pmc_traffic.log
