@@ -401,7 +401,7 @@ __global__ __launch_bounds__(SE_T) void se_bwd_group_kernel(const SeArgs a, cons
 // instead of 30, 240 -> 960 four instead of 30, and 256 ... 960 small workgroups fill the chip instead of 64 large ones.
 // The price is a second launch per direction (a dependent kernel boundary, ~3 us).  Summation order: four contiguous
 // slices of the contraction, added in slice order -- deterministic, different in the last bits from the group kernels.
-constexpr int SL_OB = 64, SL_T = 256, SL_G = SL_T / SL_OB;
+constexpr int SL_OB = 64, SL_T = 512, SL_G = SL_T / SL_OB;      // eight waves split the contraction (256 threads: 67 us in the backward)
 // MODE 0: h = relu(W1 m + b1), m from the pooled sums   1: q = W2 h + b2, s = h_sigmoid(q)
 //      2: dp = relu'(h) (dq W2), dq from the per-sample sums   3: g = (dp W1) / HW + the BatchNorm-backward sums
 template <int MODE>
@@ -443,22 +443,52 @@ __global__ __launch_bounds__(SL_T) void se_slice_kernel(const SeArgs a, const fl
 #pragma unroll
   for (int s = 0; s < SPG; ++s) acc[s] = 0.f;
   if (live) {
-    int i = i0;
-    for (; i + 16 <= i1; i += 16) {
-      float w[16];
+    // 32 weight loads in flight per thread (the walk is a chain of L2 round trips, ~4x longer beside the weight-gradient stream
+    // than alone); the 64 sample groups that read one output slice start at DIFFERENT rows of their slice of the contraction, so
+    // that they do not all ask L2 for the same line at the same time.  The order of a thread's adds is fixed by (workgroup,
+    // thread) alone: deterministic, as before.
+    const int n = i1 - i0, rot = n > 0 ? (int)((blockIdx.x * 37u) % (unsigned)n) : 0;
+    int done = 0;
+    for (; done + 32 <= n; done += 32) {
+      float w[32];
+      int ii[32];
 #pragma unroll
-      for (int u = 0; u < 16; ++u) w[u] = Wt[(size_t)(i + u) * O + o];
+      for (int u = 0; u < 32; ++u) {
+        int r = rot + done + u;
+        if (r >= n) r -= n;
+        ii[u] = i0 + r;
+        w[u] = Wt[(size_t)ii[u] * O + o];
+      }
 #pragma unroll
-      for (int u = 0; u < 16; ++u) {
-        const float4 x0 = *reinterpret_cast<const float4*>(in + (i + u) * SPG);
+      for (int u = 0; u < 32; ++u) {
+        const float4 x0 = *reinterpret_cast<const float4*>(in + ii[u] * SPG);
         acc[0] = fmaf(x0.x, w[u], acc[0]); acc[1] = fmaf(x0.y, w[u], acc[1]);
         acc[2] = fmaf(x0.z, w[u], acc[2]); acc[3] = fmaf(x0.w, w[u], acc[3]);
       }
     }
-    for (; i < i1; ++i) {
-      const float w = Wt[(size_t)i * O + o];
+    for (; done + 8 <= n; done += 8) {         // (the hidden-unit contractions: 24 ... 240 inputs over eight waves)
+      float w[8];
+      int ii[8];
 #pragma unroll
-      for (int s = 0; s < SPG; ++s) acc[s] = fmaf(in[i * SPG + s], w, acc[s]);
+      for (int u = 0; u < 8; ++u) {
+        int r = rot + done + u;
+        if (r >= n) r -= n;
+        ii[u] = i0 + r;
+        w[u] = Wt[(size_t)ii[u] * O + o];
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const float4 x0 = *reinterpret_cast<const float4*>(in + ii[u] * SPG);
+        acc[0] = fmaf(x0.x, w[u], acc[0]); acc[1] = fmaf(x0.y, w[u], acc[1]);
+        acc[2] = fmaf(x0.z, w[u], acc[2]); acc[3] = fmaf(x0.w, w[u], acc[3]);
+      }
+    }
+    for (; done < n; ++done) {
+      int r = rot + done;
+      if (r >= n) r -= n;
+      const float w = Wt[(size_t)(i0 + r) * O + o];
+#pragma unroll
+      for (int s = 0; s < SPG; ++s) acc[s] = fmaf(in[(i0 + r) * SPG + s], w, acc[s]);
     }
   }
   if (grp > 0) {
