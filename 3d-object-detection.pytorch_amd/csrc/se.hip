@@ -541,6 +541,10 @@ __global__ __launch_bounds__(SL_T) void se_slice_kernel(const SeArgs a, const fl
   }
 }
 
+// (Round 6b, measured and removed: the same products on v_mfma_f32_16x16x4_f32 -- a workgroup per 16 samples x 64 outputs, the 16 input
+// rows staged in LDS, exact fp32 products: correct (the suite passed on it) and 0.3 ms SLOWER per MobileNetV3-large step than the
+// slices (7.93 against 7.63 ms, two same-box pairs): staging 16 x 960 transformed inputs per workgroup is a 60-round chain of global
+// loads where the slice kernel's 4 x 960 over 512 threads is eight, and 64 workgroups do not fill the chip.)
 template <int MODE>
 static void se_slice_launch(const SeArgs& a, const float* Wt, hipStream_t st) {
   const int I = (MODE == 0 || MODE == 2) ? a.C : a.R, O = (MODE == 0 || MODE == 2) ? a.R : a.C;

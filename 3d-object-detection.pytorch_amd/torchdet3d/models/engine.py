@@ -38,6 +38,7 @@ WORKSPACE_BYTES = 64 << 20      # partial weight-gradient tiles (include/t3d.h: 
 MAIN_WORKSPACE_BYTES = 16 << 20
 # y-free expand-layer backward (csrc/pwconv_yfree.hip): minimum M*N elements of the expanded tensor; 0 disables
 YFREE_MIN_ELEMS = int(os.environ.get('T3D_YFREE_MIN', 8 << 20))
+YFREE_MAX_K = int(os.environ.get('T3D_YFREE_MAX_K', 112))     # widest narrow side the y-free backward is used for (the K x K Gram terms); round 6: 96 -> 112 takes MobileNetV3-large's two 112 -> 672 expansions at 14x14 (7.59-7.65 -> 7.43 ms per step; 160, the 7x7 stage: 7.53)
 YFREE_FUSED = os.environ.get('T3D_YFREE_FUSED', '1') != '0'     # one-pass expand-layer backward (t3d_pwconv_bwd_yfree)
 YFREE_PREP_FUSED = os.environ.get('T3D_YFREE_PREP_FUSED', '1') != '0'   # ... with its weight rows built in its own prologue (A/B switch)
 EXPDW_EVAL = os.environ.get('T3D_EXPDW_EVAL', '1') != '0'      # fused expand + depthwise forward in 16-bit inference (A/B switch)
@@ -1209,7 +1210,7 @@ class Net:
     def _yfree_ok(self, x, M, K, Nn):
         """Expand layer on a finished bf16 input, wide enough that skipping the two extra passes over the M x N tensors
         pays for the three tiny extra launches (csrc/pwconv_yfree.hip)."""
-        return (self.dt == N.BF16 and YFREE_MIN_ELEMS > 0 and x.pro is None and K <= 96
+        return (self.dt == N.BF16 and YFREE_MIN_ELEMS > 0 and x.pro is None and K <= YFREE_MAX_K
                 and M * Nn >= YFREE_MIN_ELEMS)
 
     def _expand_bwd_yfree(self, d1, bb1, bn1, wname, x, res, M, K, Nn, i):
