@@ -60,6 +60,7 @@ class FusedAdamW(torch.optim.Optimizer):
                 N.call('t3d_adamw_step', N.ptr(p), N.ptr(g), N.ptr(st['exp_avg']), N.ptr(st['exp_avg_sq']), p.numel(),
                        float(group['lr']), float(b1), float(b2), float(group['eps']), float(group['weight_decay']),
                        st['step'], float(self.grad_scale), N.stream())
+                N.call('t3d_set_grad_watch', None)            # (process-wide pointer: never left pointing at this optimizer's word)
                 torch.autograd.graph.increment_version(p)     # written through a raw pointer: tell version-tracking users
         return loss
 

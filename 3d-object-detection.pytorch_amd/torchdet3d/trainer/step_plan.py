@@ -164,6 +164,7 @@ class StepPlan:
             N.call('t3d_adamw_step', N.ptr(p), N.ptr(net.gflat), N.ptr(state['exp_avg']), N.ptr(state['exp_avg_sq']), p.numel(),
                    float(g['lr']), float(b1), float(b2), float(g['eps']), float(g['weight_decay']), state['step'],
                    float(opt.grad_scale), st, slots={5: N.SLOT_LR, 10: N.SLOT_STEP})
+            N.call('t3d_set_grad_watch', None)
             torch.autograd.graph.increment_version(p)
             if p.grad is not net.gflat:
                 p.grad = net.gflat                           # what `loss.backward()` leaves in the eager form
