@@ -647,9 +647,12 @@ static int dw3_tile_max() {      // (read per call: the test suite flips it insi
   const char* e = getenv("T3D_DW3_TILE_MAX");
   return e ? atoi(e) : 0;
 }
-static bool tile_shape_ok(int k, int stride, int H, int W, int C) {
+static bool tile_shape_ok(int k, int stride, int H, int W, int C, bool pooled = false) {
   if ((C % 2) || H < 2 || W < 2) return false;
   if (k == 5) return H >= 8 && W >= 8 && H <= (stride == 2 ? 28 : 64) && W <= (stride == 2 ? 28 : 64) && !T3D_ENV_SET("T3D_DW5_NO_TILE");
+  // 3x3 forward WITH squeeze-excite pooled sums on the 14x14 stage and below: those launches go to the generic walk of
+  // dwconvk_stream.hip (the 3x3 row-walk kernel has no pooled sums), which the tiles beat: 14x14x480 52 -> 36 us, x672 59 -> 51
+  if (k == 3 && pooled && stride == 1 && H <= 14 && W <= 14 && !T3D_ENV_SET("T3D_DW5_NO_TILE")) return true;
   if (k == 3) return H <= dw3_tile_max() && W <= dw3_tile_max();
   return false;
 }
@@ -658,7 +661,7 @@ static bool tile_shape_ok(int k, int stride, int H, int W, int C) {
 
 int t3d_dw_tile_fwd(int dtype, const void* x, const t3d_prologue* pro, const float* w, void* y, double* stats, float* gap_sum,
                     int B, int H, int W, int C, int k, int stride, hipStream_t st) {
-  if (!tile_shape_ok(k, stride, H, W, C) || (pro && pro->se) || (stride != 1 && stride != 2)) return T3D_ERR_UNSUPPORTED;
+  if (!tile_shape_ok(k, stride, H, W, C, gap_sum != nullptr) || (pro && pro->se) || (stride != 1 && stride != 2)) return T3D_ERR_UNSUPPORTED;
   if (pro)
     if (const int rc = t3d_fold_fallback(pro->scale, st)) return rc;      // finished coefficients (no derive prologue here)
   TileArgs a{};
