@@ -34,6 +34,25 @@ __device__ __forceinline__ f32x2 pk_fma_clamp01(f32x2 a, f32x2 b, f32x2 c) {
 
 typedef __attribute__((ext_vector_type(4))) short s16x4;
 
+// act_apply (common.h) on eight values, the switch outside the loop
+__device__ __forceinline__ void act_vec8(float* v, int act) {
+  switch (act) {
+    case T3D_ACT_RELU:
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = fmaxf(v[j], 0.f);
+      break;
+    case T3D_ACT_RELU6:
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = __builtin_amdgcn_fmed3f(v[j], 0.f, 6.f);
+      break;
+    case T3D_ACT_HSWISH:
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = v[j] * (__builtin_amdgcn_fmed3f(v[j] + 3.f, 0.f, 6.f) * T3D_SIXTH);
+      break;
+    default: break;
+  }
+}
+
 struct WgtArgs {
   const void *dz, *y, *x;
   const float *alpha, *beta, *gamma;
@@ -64,6 +83,11 @@ struct WgtArgs {
   // BatchNorm + activation prologue per channel c), zero outside the image
   struct { int on, H, W, Ho, Wo, C, lgC, stride; unsigned mulW, mulH; } cv;
   int assign;             // dw is WRITTEN, not accumulated into (the y-free product matrix: no clear needed ahead of the launch)
+  // squeeze-excite gate of the a side staged in LDS (GEN, `se` set): gs_ns = samples a block's pixel range can touch (0: the
+  // gates are read from global memory per staged vector, round 3's path), mulHW = ceil(2^32 / HW) for (m - first sample's
+  // first pixel) / HW -- exact for the small differences a block sees (launcher)
+  int gs_ns;
+  unsigned mulHW;
 };
 
 // one 16x16 tile row (transposed) fragment: pixels 8*lg .. 8*lg+7 of the step, channels ch0..ch0+15
@@ -91,7 +115,7 @@ __device__ __forceinline__ bf16x8 tr_frag(const bf16_t* tile, int rs, int ch0, i
 // channels of one pixel: 8-byte stores; the skip gradient and the raw tensor of the producer (BatchNorm-backward sums of x's
 // producer, exactly as in the streaming kernel's epilogue) are fetched with the step's operands.
 // CV: implicit 3x3 convolution on the a side (WgtArgs::cv) -- a compile-time variant, the plain kernels' staging is untouched
-template <int NTPW, int NTQ, bool SWAP, int G, int D, bool GEN, bool YF, int SK = 1, bool DGF = false, bool CV = false>
+template <int NTPW, int NTQ, bool SWAP, int G, int D, int GEN, bool YF, int SK = 1, bool DGF = false, bool CV = false>
 __global__ __launch_bounds__(256 * G) void pw_wgrad_tr_kernel(const WgtArgs a) {
   static_assert(!DGF || (YF && !SWAP), "the fused data gradient exists for the y-free layout only");
   constexpr int PB = 64 * NTPW, QB = 16 * NTQ;
@@ -156,6 +180,17 @@ __global__ __launch_bounds__(256 * G) void pw_wgrad_tr_kernel(const WgtArgs a) {
     const int kc = CV ? (k & (a.cv.C - 1)) : k;
     ca[i] = ((v && a.scale) ? a.scale[kc] : 1.f) * (c6 ? T3D_SIXTH : 1.f);
     ca[aB + i] = ((v && a.scale) ? a.shift[kc] : 0.f) * (c6 ? T3D_SIXTH : 1.f);
+  }
+  float* const gsl = coef + ((NCOEF + 3) & ~3);           // GEN: [gs_ns][aB] gate slice of this block's samples and channels
+  const int gs_b0 = GEN ? mbeg / a.HW : 0;
+  if constexpr (GEN == 2) {
+    {
+      const int nb = a.M / a.HW;
+      for (int i = threadIdx.x; i < a.gs_ns * aB; i += 256 * G) {
+        const int sb = i / aB, c = i % aB, b = min(gs_b0 + sb, nb - 1), k = a0c + c;
+        gsl[i] = k < a.K ? a.se[(size_t)b * a.K + k] : 0.f;
+      }
+    }
   }
   if constexpr (DGF) {
     if (a.wd) {
@@ -351,7 +386,7 @@ __global__ __launch_bounds__(256 * G) void pw_wgrad_tr_kernel(const WgtArgs a) {
         }
         float al[8], be[8], ga[8];
         ld8(cdy + dyB + cl, be);
-        if constexpr (GEN) {
+        if constexpr (GEN == 1) {
           if (a.per_sample) {
             const size_t pb = (size_t)(min(m, a.M - 1) / a.HW) * a.N + min(dy0 + cl, a.N - 8);
 #pragma unroll
@@ -384,13 +419,34 @@ __global__ __launch_bounds__(256 * G) void pw_wgrad_tr_kernel(const WgtArgs a) {
 #pragma unroll
           for (int j = 0; j < 8; ++j) u[j] = (float)rx[i][j];
           bool done = false;
-          if constexpr (GEN) {
+          if constexpr (GEN == 2) {
+            // gates from LDS; the activation switch outside the element loops
+            float svv[8];
+            const int rel = min(m, mend - 1) - gs_b0 * a.HW;
+            ld8(gsl + (int)__umulhi((unsigned)rel, a.mulHW) * aB + cl, svv);
+            if (a.se_after) {
+              act_affine_vec<8>(u, sc, sh, a.act);
+#pragma unroll
+              for (int j = 0; j < 8; ++j) u[j] *= svv[j];
+            } else {
+#pragma unroll
+              for (int j = 0; j < 8; ++j) u[j] = fmaf(u[j], sc[j], sh[j]) * svv[j];
+              act_vec8(u, a.act);
+            }
+            done = true;
+          }
+          if constexpr (GEN == 1) {
             if (a.se) {
-              const float* se = a.se + (size_t)(min(m, a.M - 1) / a.HW) * a.K + min(a0c + cl, a.K - 8);
+              float svv[8];
+              {
+                const float* se = a.se + (size_t)(min(m, a.M - 1) / a.HW) * a.K + min(a0c + cl, a.K - 8);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) svv[j] = se[j];
+              }
 #pragma unroll
               for (int j = 0; j < 8; ++j) {
                 float t = fmaf(u[j], sc[j], sh[j]);
-                const float sv = se[j];
+                const float sv = svv[j];
                 if (!a.se_after) t *= sv;
                 t = act_apply(t, a.act);
                 if (a.se_after) t *= sv;
@@ -657,7 +713,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_tr_kernel(const float* __res
   }
 }
 
-template <int NTPW, int NTQ, bool SWAP, int D, bool GEN, bool YF = false, int SK = 1, bool CV = false>
+template <int NTPW, int NTQ, bool SWAP, int D, int GEN, bool YF = false, int SK = 1, bool CV = false>
 int launch_d(WgtArgs& a, hipStream_t st) {
   constexpr int G = 2;
   constexpr int STEP = 32 * SK;
@@ -667,7 +723,7 @@ int launch_d(WgtArgs& a, hipStream_t st) {
   a.qtiles = cdiv(Q, QB);
   const int tiles = a.ptiles * a.qtiles;
   const int dyB = a.swap ? QB : PB, aB = a.swap ? PB : QB;
-  const size_t lds = (size_t)G * 2 * STEP * ((PB + 8) + (QB + 8)) * 2 + (size_t)(3 * dyB + 2 * aB) * 4;
+  size_t lds = (size_t)G * 2 * STEP * ((PB + 8) + (QB + 8)) * 2 + (size_t)(3 * dyB + 2 * aB) * 4;
   // pixel splits: fill the chip (2 blocks per CU), but keep the partial-dW flush (S * N*K atomics) below ~8 MB
   const int tgt_blocks = 256;
   const long long cap_mb = 8;
@@ -686,6 +742,15 @@ int launch_d(WgtArgs& a, hipStream_t st) {
   if (S < 1) S = 1;
   a.rows_per_split = cdiv(cdiv(a.M, S), STEP) * STEP;
   S = cdiv(a.M, a.rows_per_split);
+  a.gs_ns = 0;
+  if constexpr (GEN == 2) {
+    // the gate slice [samples of a block's pixel range][aB] has to fit LDS, the in-block sample index a 32-bit multiply-high
+    const long long ns = a.rows_per_split / a.HW + 2, span = (long long)a.rows_per_split + a.HW;
+    if (!a.se || a.per_sample || ns * aB * 4 > 32 * 1024 || span * a.HW >= (1ll << 32)) return launch_d<NTPW, NTQ, SWAP, 1, 1>(a, st);
+    a.gs_ns = (int)ns;
+    a.mulHW = (unsigned)(((1ull << 32) + a.HW - 1) / a.HW);
+    lds = ((lds + 15) & ~(size_t)15) + (size_t)ns * aB * 4;
+  }
   a.ws = use_ws ? reinterpret_cast<float*>(g_t3d_ws.ptr) : nullptr;
   // (atomics into dw: an assigned-to dw is cleared first; with partial tiles the reduction writes it)
   if (a.assign && !use_ws && hipMemsetAsync(a.dw, 0, (size_t)a.N * a.K * sizeof(float), st) != hipSuccess) return T3D_ERR_LAUNCH;
@@ -732,7 +797,12 @@ int launch_sw(WgtArgs& a, hipStream_t st) {
     }
     else return T3D_ERR_UNSUPPORTED;
   }
-  if (a.per_sample || a.se) return launch_d<NTPW, NTQ, SWAP, 1, true>(a, st);   // SE layers: per-sample coefficients / gates
+  // SE layers: per-sample coefficients / gates.  Gates staged in LDS (round 6): the loads of the step after next in flight, as in the
+  // plain kernel (the per-vector global gate reads of round 3 forced depth 1: two exposed round trips per 32-pixel step)
+  // (GEN = 1, round 3's path, keeps them as global reads inside the staging step -- and every conditional global load there makes
+  // the compiler drain ALL outstanding loads, the next steps' operands included: 2x the plain kernel's duration, isolated)
+  if (a.per_sample || (a.se && T3D_ENV_SET("T3D_WG_GATE_GLOBAL"))) return launch_d<NTPW, NTQ, SWAP, 1, 1>(a, st);
+  if (a.se) return launch_d<NTPW, NTQ, SWAP, 2, 2>(a, st);
   if (depth == 1) return launch_d<NTPW, NTQ, SWAP, 1, false>(a, st);
   // pixels per step (see the kernel): wider steps for the narrow tiles of the layers with many pixels per workgroup
   const int sk_env = 0;
@@ -781,6 +851,9 @@ static int choose_and_launch(WgtArgs& a, hipStream_t st) {
     return launch_cfg<1, 4>(a, st);
   }
   if (Q <= 96) return (P > 64 && steps_with(3, 96) >= min_steps) ? launch_cfg<3, 6>(a, st) : launch_cfg<1, 6>(a, st);
+  // 112 channels on the narrow side (MobileNetV3-large's 14x14 stage, 480 / 672 -> 112): seven column tiles -- the ten-tile kernel
+  // multiplied 30 % padding and, at three row tiles per wave, spilled (256 registers + 200-460 B of scratch)
+  if (Q <= 112) return (P > 64 && steps_with(3, 112) >= min_steps) ? launch_cfg<3, 7>(a, st) : launch_cfg<1, 7>(a, st);
   return (P > 64 && steps_with(3, 160) >= min_steps) ? launch_cfg<3, 10>(a, st) : launch_cfg<1, 10>(a, st);
 }
 

@@ -47,6 +47,7 @@ EXPDW_EVAL = os.environ.get('T3D_EXPDW_EVAL', '1') != '0'      # fused expand + 
 # 112x112 block, the only stage where the fused launch with the expansion stored beats the two launches alone: DESIGN.md finding
 # 40): measured in the step it is 0.03-0.04 ms SLOWER than the two launches (finding 55), so the default is off.
 GRAM_FWD_MIN_HW = int(os.environ.get('T3D_GRAM_FWD_MIN_HW', 0))
+SE_WGRAD_LATE = os.environ.get('T3D_SE_WGRAD_LATE', '0') == '1'   # (experiment) a gated layer's projection weight gradient forks AFTER the gate's backward
 HOOK_MIN = 1 << 20              # gradient-exchange granularity (elements): parallel.GradSync's bucket size
 HOOK_ON_SIDE = True              # (round 3: the gradient exchange is issued from the second stream; the other order stalled the main one)
 
@@ -1315,7 +1316,8 @@ class Net:
             # gated tensor: the data gradient reports per-SAMPLE sums; the gate's backward turns them into the
             # BatchNorm sums and the per-sample affine  dy = (alpha*s) dv + beta y + (gamma + alpha*g)
             C, R, sen = blk.cexp, blk.se, se['name']
-            proj_wgrad()
+            if not SE_WGRAD_LATE:
+                proj_wgrad()
             ps = self._buf(f'se_ps:{i}', (B, C, 2), torch.float32, zgroup='bwd')
             dv2 = self._buf(f'dv2:{i}', (M2, C))
             wd, wp = self._wsel(self.wt[pwn])
@@ -1330,6 +1332,8 @@ class Net:
                    N.ptr(self.p[sen + '.fc.0.weight']), N.ptr(self.p[sen + '.fc.2.weight']),
                    N.ptr(se['h']), N.ptr(se['q']), N.ptr(se['s']), N.ptr(g), N.ptr(dq), N.ptr(dp), self._bst(bn2),
                    B, C, R, se['HW'], st)
+            if SE_WGRAD_LATE:
+                proj_wgrad()
             self._se_wgrad(se, sen, dq, dp, B, C, R)
             self._bn_bwd(bn2)
             self._settle_b(bn2)

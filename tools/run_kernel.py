@@ -1,5 +1,5 @@
 """Profiling aid: launch ONE conv entry point repeatedly on a given shape (for rocprofv3 --pmc / --kernel-trace).
-usage: run_kernel.py dwfwd|dwbwd|pwfwd|pwdgrad|pwwgrad  B H W C [k s] | M HW K N   [--reps R] [--f32] [--res]"""
+usage: run_kernel.py dwfwd|dwbwd|pwfwd|pwdgrad|pwwgrad  B H W C [k s] | M HW K N   [--reps R] [--f32] [--res] [--gate]"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, '3d-object-detection.pytorch_amd')]
@@ -47,7 +47,8 @@ else:
     x = rnd(M, K).to(dt); wf = (rnd(Nn, K) / K ** .5)
     wq = wf.to(dt).contiguous(); wt = wf.t().contiguous().to(dt)
     sc, sh = torch.rand(K, device=dev) + 0.5, rnd(K) * 0.2
-    pro = N.prologue(sc, sh, None, 'relu6', False)
+    gate = torch.rand(M // HW, K, device=dev) if '--gate' in sys.argv else None      # squeeze-excite gate per (sample, channel) on the operand
+    pro = N.prologue(sc, sh, gate, sys.argv[sys.argv.index('--act') + 1] if '--act' in sys.argv else 'relu6', False)
     y = torch.empty(M, Nn, device=dev, dtype=dt)
     dz, yy = rnd(M, Nn).to(dt), rnd(M, Nn).to(dt)
     al, be, ga = torch.rand(Nn, device=dev) + 0.5, rnd(Nn) * 0.1, rnd(Nn) * 0.1
