@@ -725,7 +725,8 @@ int launch_d(WgtArgs& a, hipStream_t st) {
   const int dyB = a.swap ? QB : PB, aB = a.swap ? PB : QB;
   size_t lds = (size_t)G * 2 * STEP * ((PB + 8) + (QB + 8)) * 2 + (size_t)(3 * dyB + 2 * aB) * 4;
   // pixel splits: fill the chip (2 blocks per CU), but keep the partial-dW flush (S * N*K atomics) below ~8 MB
-  const int tgt_blocks = 256;
+  static const int tgt_env = getenv("T3D_WG_TGT_BLOCKS") ? atoi(getenv("T3D_WG_TGT_BLOCKS")) : 0;      // (sweep knob)
+  const int tgt_blocks = tgt_env ? tgt_env : 256;
   const long long cap_mb = 8;
   int S = (tgt_blocks + tiles - 1) / tiles;
   const long long tile_bytes = (long long)tiles * PB * QB * 4;
@@ -831,7 +832,8 @@ static int choose_and_launch(WgtArgs& a, hipStream_t st) {
   // every pipeline >= ~12 steps of 32 pixels when the chip is filled -- a wide tile reads each operand once but, on the
   // small-pixel-count layers, degenerates into a handful of steps followed by a large partial flush; a narrow tile
   // re-reads the (small) Q-side operand through L2 instead.
-  const int min_steps = 12;
+  static const int min_steps_env = getenv("T3D_WG_MIN_STEPS") ? atoi(getenv("T3D_WG_MIN_STEPS")) : 0;      // (sweep knob)
+  const int min_steps = min_steps_env ? min_steps_env : 12;
   auto steps_with = [&](int ntpw, int qb) {
     const int tiles = cdiv(P, 64 * ntpw) * cdiv(Q, qb);
     int S = cdiv(256, tiles);
@@ -850,10 +852,15 @@ static int choose_and_launch(WgtArgs& a, hipStream_t st) {
     if (P > 64 && steps_with(3, 64) >= min_steps) return launch_cfg<3, 4>(a, st);
     return launch_cfg<1, 4>(a, st);
   }
-  if (Q <= 96) return (P > 64 && steps_with(3, 96) >= min_steps) ? launch_cfg<3, 6>(a, st) : launch_cfg<1, 6>(a, st);
+  // (round 6 sweep, isolated, B = 256 at 14x14: 576 -> 96 55 -> 34 us and 384 -> 96 39 -> 30 us with the wide tile from 5 steps on;
+  // 480 -> 112 40 -> 36 us from 8; the 64- and 160-column tiles keep 12: 384 -> 64 and 320 -> 1280 lose below it)
+  if (Q <= 96) return (P > 64 && steps_with(3, 96) >= (min_steps_env ? min_steps : 5)) ? launch_cfg<3, 6>(a, st) : launch_cfg<1, 6>(a, st);
   // 112 channels on the narrow side (MobileNetV3-large's 14x14 stage, 480 / 672 -> 112): seven column tiles -- the ten-tile kernel
   // multiplied 30 % padding and, at three row tiles per wave, spilled (256 registers + 200-460 B of scratch)
-  if (Q <= 112) return (P > 64 && steps_with(3, 112) >= min_steps) ? launch_cfg<3, 7>(a, st) : launch_cfg<1, 7>(a, st);
+  if (Q <= 112) return (P > 64 && steps_with(3, 112) >= (min_steps_env ? min_steps : 8)) ? launch_cfg<3, 7>(a, st) : launch_cfg<1, 7>(a, st);
+  // 128 / 256 / 512 ... channels on the narrow side (ResNet-50's bottlenecks): eight column tiles, no padding -- ten multiplied
+  // 25 % zeros there and spilled at three row tiles per wave
+  if (Q % 128 == 0) return (P > 64 && steps_with(3, 128) >= min_steps) ? launch_cfg<3, 8>(a, st) : launch_cfg<1, 8>(a, st);
   return (P > 64 && steps_with(3, 160) >= min_steps) ? launch_cfg<3, 10>(a, st) : launch_cfg<1, 10>(a, st);
 }
 
