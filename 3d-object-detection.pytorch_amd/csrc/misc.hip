@@ -200,6 +200,26 @@ __global__ void se_bwd_affine_kernel(const float* __restrict__ s, const float* _
   }
 }
 
+// ... with the BatchNorm-backward finalize of (alpha, beta, gamma) derived HERE from the replica sums (common.h: a pending request
+// for `alpha`; round 6): a workgroup owns 32 channels of every sample, derives and PUBLISHES them (every channel has exactly one
+// owner), then forms its [B][32] slice -- the standalone 5-us finalize launch + its dispatch gap ahead of this 3-us kernel go
+// (8 gated blocks per MobileNetV3-large step)
+__global__ __launch_bounds__(256) void se_bwd_affine_fold_kernel(const float* __restrict__ s, const float* __restrict__ g,
+                                                                 const T3dFold* __restrict__ fold, float* __restrict__ aps,
+                                                                 float* __restrict__ gps, int B, int C) {
+  __shared__ float co[3][32];
+  const int c0 = blockIdx.x * 32, cb = min(32, C - c0);
+  t3d_fold_block(fold, c0, cb, &co[0][0], 32, true);      // (ends with a barrier)
+  for (int i = threadIdx.x; i < B * 32; i += 256) {
+    const int b = i >> 5, cl = i & 31;
+    if (cl < cb) {
+      const size_t o = (size_t)b * C + c0 + cl;
+      aps[o] = s[o] * co[0][cl];
+      gps[o] = co[2][cl] + g[o] * co[0][cl];
+    }
+  }
+}
+
 // Dropout(0.5) keep/scale factors {0, 2} from a counter-based generator (Philox-4x32-10 keyed by `seed`, counter =
 // (element index / 4, offset)): one launch, no state on the device, reproducible for a given (seed, offset).
 __device__ __forceinline__ void philox_round(uint32_t c[4], uint32_t k0, uint32_t k1) {
@@ -283,6 +303,11 @@ extern "C" int t3d_bn_bias_grad(const double* fwd_stats, const double* bwd_stats
 extern "C" int t3d_se_bwd_affine(const float* s, const float* g, const float* alpha, const float* gammac, float* aps,
                                  float* gps, int B, int C, void* stream) {
   if (!s || !g || !alpha || !gammac || !aps || !gps || B <= 0 || C <= 0) return T3D_ERR_ARG;
+  if (const T3dFold* fold = t3d_take_fold(alpha)) {
+    T3D_LAUNCH(se_bwd_affine_fold_kernel, dim3(cdiv(C, 32)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), s, g, fold, aps, gps, B, C);
+    T3D_CHECK_LAUNCH();
+    return T3D_OK;
+  }
   T3D_LAUNCH(se_bwd_affine_kernel, dim3(cdiv(B * C, 256) < 512 ? cdiv(B * C, 256) : 512), dim3(256), 0,
                      reinterpret_cast<hipStream_t>(stream), s, g, alpha, gammac, aps, gps, B, C);
   T3D_CHECK_LAUNCH();

@@ -747,7 +747,8 @@ int launch_d(WgtArgs& a, hipStream_t st) {
   if constexpr (GEN == 2) {
     // the gate slice [samples of a block's pixel range][aB] has to fit LDS, the in-block sample index a 32-bit multiply-high
     const long long ns = a.rows_per_split / a.HW + 2, span = (long long)a.rows_per_split + a.HW;
-    if (!a.se || a.per_sample || ns * aB * 4 > 32 * 1024 || span * a.HW >= (1ll << 32)) return launch_d<NTPW, NTQ, SWAP, 1, 1>(a, st);
+    // (HW = 1: ceil(2^32 / HW) does not fit 32 bits)
+    if (!a.se || a.per_sample || a.HW < 2 || ns * aB * 4 > 32 * 1024 || span * a.HW >= (1ll << 32)) return launch_d<NTPW, NTQ, SWAP, 1, 1>(a, st);
     a.gs_ns = (int)ns;
     a.mulHW = (unsigned)(((1ull << 32) + a.HW - 1) / a.HW);
     lds = ((lds + 15) & ~(size_t)15) + (size_t)ns * aB * 4;
@@ -848,7 +849,9 @@ static int choose_and_launch(WgtArgs& a, hipStream_t st) {
     return P <= 128 ? launch_cfg<2, 2>(a, st) : launch_cfg<3, 2>(a, st);
   }
   if (Q <= 64) {
-    if (P > 192 && steps_with(6, 64) >= min_steps) return launch_cfg<6, 4>(a, st);
+    // (six row tiles per wave spill outside the y-free layout -- 76-344 B of scratch at 256 registers: ResNet-50's 256 -> 64
+    // bottleneck entries 223 / 118 us per launch, 12.0 -> 11.4 ms per step without it; T3D_WG_6X4=1 restores it)
+    if (P > 192 && steps_with(6, 64) >= min_steps && (a.yfree || T3D_ENV_SET("T3D_WG_6X4"))) return launch_cfg<6, 4>(a, st);
     if (P > 64 && steps_with(3, 64) >= min_steps) return launch_cfg<3, 4>(a, st);
     return launch_cfg<1, 4>(a, st);
   }
@@ -923,10 +926,11 @@ static bool yf_cfg(int M, int K, int N, YfCfg& c) {
   if (K > 32 || P > 256 || P <= 64) return false;
   c.ntq = K <= 16 ? 1 : 2;
   c.ntpw = P <= 128 ? 2 : (P <= 192 ? 3 : 4);
-  c.sk = M >= (1 << 20) ? 2 : 1;
+  static const int sk_m_env = getenv("T3D_YF_SK_M") ? atoi(getenv("T3D_YF_SK_M")) : 0, s_env = getenv("T3D_YF_S") ? atoi(getenv("T3D_YF_S")) : 0;   // (sweep knobs)
+  c.sk = M >= (sk_m_env ? sk_m_env : (1 << 20)) ? 2 : 1;
   c.PB = 64 * c.ntpw; c.QB = 16 * c.ntq;
   const int step = 32 * c.sk;
-  int S = 256;
+  int S = s_env ? s_env : 256;
   const int maxs = cdiv(M, step * 4 * 2);
   if (S > maxs) S = maxs;
   if (S < 1) S = 1;

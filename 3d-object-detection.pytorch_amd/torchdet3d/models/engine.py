@@ -47,7 +47,7 @@ EXPDW_EVAL = os.environ.get('T3D_EXPDW_EVAL', '1') != '0'      # fused expand + 
 # 112x112 block, the only stage where the fused launch with the expansion stored beats the two launches alone: DESIGN.md finding
 # 40): measured in the step it is 0.03-0.04 ms SLOWER than the two launches (finding 55), so the default is off.
 GRAM_FWD_MIN_HW = int(os.environ.get('T3D_GRAM_FWD_MIN_HW', 0))
-SE_WGRAD_LATE = os.environ.get('T3D_SE_WGRAD_LATE', '0') == '1'   # (experiment) a gated layer's projection weight gradient forks AFTER the gate's backward
+SE_FOLD = os.environ.get('T3D_SE_FOLD', '1') != '0'   # gated blocks: the BatchNorm-backward finalizes ride on their first reader (round 6; 0: standalone launches)
 HOOK_MIN = 1 << 20              # gradient-exchange granularity (elements): parallel.GradSync's bucket size
 HOOK_ON_SIDE = True              # (round 3: the gradient exchange is issued from the second stream; the other order stalled the main one)
 
@@ -446,7 +446,7 @@ class Net:
     # backward half costs nothing either (7.64 ms both ways, 18 launches fewer), so both are on)
     _LAZY_DW = '1'
     DERIVING = frozenset(('t3d_pwconv_fwd', 't3d_pwconv_fwd_mat', 't3d_bn_apply', 't3d_pool_fwd', 't3d_pwconv_dgrad', 't3d_pwconv_yfree_prep',
-                          't3d_pwconv_yfree_prep2', 't3d_conv3x3_dgrad', 't3d_pwconv_bwd_yfree_w')
+                          't3d_pwconv_yfree_prep2', 't3d_conv3x3_dgrad', 't3d_pwconv_bwd_yfree_w', 't3d_se_bwd_affine')
                          + (('t3d_dwconv_fwd',) if _LAZY_DW in ('1', 'fwd') else ())
                          + (('t3d_dwconv_bwd',) if _LAZY_DW in ('1', 'bwd') else ()))
 
@@ -1275,7 +1275,7 @@ class Net:
         M2, HW2 = s2.B * s2.H * s2.W, s2.H * s2.W
         bb3 = self._bn_bwd(rec['bn3'])
         se = rec.get('se')
-        if se is not None:
+        if se is not None and not SE_FOLD:
             self._settle_b(rec['bn3'])
 
         def proj_wgrad():
@@ -1294,8 +1294,8 @@ class Net:
             proj_wgrad()
             dv = self._buf(f'dv2g:{i}', (M2, C))
             wd, wp = self._wsel(self.wt[pwn])
-            N.call('t3d_pwconv_dgrad', wd, N.ptr(dz), N.ptr(rec['y3']), bb3, wp, None, None, None,
-                   N.ptr(dv), None, None, M2, HW2, C, blk.cout, st, nbytes=M2 * (C + blk.cout) * self.esz)
+            self._c('t3d_pwconv_dgrad', wd, N.ptr(dz), N.ptr(rec['y3']), bb3, wp, None, None, None,
+                    N.ptr(dv), None, None, M2, HW2, C, blk.cout, st, nbytes=M2 * (C + blk.cout) * self.esz, bwd=rec['bn3'])
             ps = self._buf(f'se_ps:{i}', (B, C, 2), torch.float32)
             N.call('t3d_se_after_sums', dt, N.ptr(dv), N.ptr(s2.raw), se['pro2n'], N.ptr(ps), B, HW2, C, st)
             g = self._buf(f'se_g:{i}', (B, C), torch.float32)
@@ -1316,13 +1316,13 @@ class Net:
             # gated tensor: the data gradient reports per-SAMPLE sums; the gate's backward turns them into the
             # BatchNorm sums and the per-sample affine  dy = (alpha*s) dv + beta y + (gamma + alpha*g)
             C, R, sen = blk.cexp, blk.se, se['name']
-            if not SE_WGRAD_LATE:
-                proj_wgrad()
+            proj_wgrad()
             ps = self._buf(f'se_ps:{i}', (B, C, 2), torch.float32, zgroup='bwd')
             dv2 = self._buf(f'dv2:{i}', (M2, C))
             wd, wp = self._wsel(self.wt[pwn])
-            N.call('t3d_pwconv_dgrad', wd, N.ptr(dz), N.ptr(rec['y3']), bb3, wp, N.ptr(s2.raw), s2.gpro,
-                   None, N.ptr(dv2), None, N.ptr(ps), M2, HW2, C, blk.cout, st, nbytes=M2 * (C + blk.cout) * self.esz)
+            self._c('t3d_pwconv_dgrad', wd, N.ptr(dz), N.ptr(rec['y3']), bb3, wp, N.ptr(s2.raw), s2.gpro,
+                    None, N.ptr(dv2), None, N.ptr(ps), M2, HW2, C, blk.cout, st, nbytes=M2 * (C + blk.cout) * self.esz,
+                    bwd=rec['bn3'])
             g = self._buf(f'se_g:{i}', (B, C), torch.float32)
             dq = self._buf(f'se_dq:{i}', (B, C), torch.float32)
             dp = self._buf(f'se_dp:{i}', (B, R), torch.float32)
@@ -1332,15 +1332,14 @@ class Net:
                    N.ptr(self.p[sen + '.fc.0.weight']), N.ptr(self.p[sen + '.fc.2.weight']),
                    N.ptr(se['h']), N.ptr(se['q']), N.ptr(se['s']), N.ptr(g), N.ptr(dq), N.ptr(dp), self._bst(bn2),
                    B, C, R, se['HW'], st)
-            if SE_WGRAD_LATE:
-                proj_wgrad()
             self._se_wgrad(se, sen, dq, dp, B, C, R)
             self._bn_bwd(bn2)
-            self._settle_b(bn2)
+            if not SE_FOLD:
+                self._settle_b(bn2)
             aps = self._buf(f'se_aps:{i}', (B, C), torch.float32)
             gps = self._buf(f'se_gps:{i}', (B, C), torch.float32)
-            N.call('t3d_se_bwd_affine', N.ptr(se['s']), N.ptr(g), N.ptr(bn2.alpha), N.ptr(bn2.gammac), N.ptr(aps),
-                   N.ptr(gps), B, C, st)
+            self._c('t3d_se_bwd_affine', N.ptr(se['s']), N.ptr(g), N.ptr(bn2.alpha), N.ptr(bn2.gammac), N.ptr(aps),
+                    N.ptr(gps), B, C, st, bwd=bn2)
             bb2 = N.bnbwd(aps, bn2.bbeta, gps, True)
         M1 = B * x.H * x.W
         res = dz if blk.res else None

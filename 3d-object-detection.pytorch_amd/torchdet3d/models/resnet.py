@@ -59,15 +59,17 @@ class ResNetEngine(Net):
                         wdf = self._buf('wcdf:' + k, (lib.t3d_pwconv_frag_bytes(c, 9 * n) // 2,), zero=True)
                         self._conv3[k] = (fr, wd, wdf)
                     self._conv_pack.append((k, n, c, kk, kp, w32, fr, frt))
+            # storage-dtype copy, transposed copy and fragment-order copies of every patch-column matrix: ONE launch (round 6: 67 ->
+            # 18 launches per step; the 1x1 weights' table in engine.py `_pack` has the same rows)
+            rows = [[w32.data_ptr(), 0 if self.dt == N.F32 else self.w[k].data_ptr(), self.wt[k].data_ptr(), n, kp,
+                     0 if fr is None else fr.data_ptr(), 0 if frt is None else frt.data_ptr()]
+                    for k, n, c, kk, kp, w32, fr, frt in self._conv_pack]
+            self._conv_pack_desc = torch.tensor(rows, dtype=torch.int64, device=self.device) if rows else None
         for k, n, c, kk, kp, w32, fr, frt in self._conv_pack:
             N.call('t3d_pack_conv_weight', N.F32, N.ptr(self.p[k]), N.ptr(w32), n, c, kk, kp, st)
-            if self.dt != N.F32:
-                N.call('t3d_pack_weight', self.dt, N.ptr(w32), N.ptr(self.w[k]), n, kp, 0, st)
-            N.call('t3d_pack_weight', self.dt, N.ptr(w32), N.ptr(self.wt[k]), n, kp, 1, st)
-            if fr is not None:
-                N.call('t3d_pwconv_pack_frag', N.ptr(self.w[k]), N.ptr(fr), n, kp, st)
-            if frt is not None:
-                N.call('t3d_pwconv_pack_frag', N.ptr(self.wt[k]), N.ptr(frt), kp, n, st)
+        if self._conv_pack_desc is not None:
+            N.call('t3d_pack_weights_batched', self.dt, N.ptr(self._conv_pack_desc), self._conv_pack_desc.shape[0], st)
+        for k, n, c, kk, kp, w32, fr, frt in self._conv_pack:
             if k in self._conv3:
                 _, wd, wdf = self._conv3[k]
                 N.call('t3d_pack_conv3x3_dgrad_weight', N.ptr(self.p[k]), N.ptr(wd), n, c, st)

@@ -424,9 +424,13 @@ def test_pwconv_dgrad_f32_register_kernel(M, K, N, mode):
         np.testing.assert_allclose(st.cpu().numpy(), stt.cpu().numpy(), rtol=1e-5, atol=1e-3 * M ** .5)
 
 
-@pytest.mark.parametrize('B,HW,K,N', SHAPES + [(16, 196, 96, 576), (64, 49, 160, 960), (2, 49, 320, 1280), (3, 49, 960, 160)])
+# (round 6: 'se_pre' / 'se_post' = a squeeze-excite gate on the operand WITHOUT per-sample coefficients -- the projection layers of
+# MobileNetV3's gated blocks: the bf16 kernel stages the gate slice of a workgroup's samples in LDS; (168, 196, 672, 112) and
+# (85, 784, 512, 128) reach the seven- / eight-column tiles at three row tiles per wave, (40, 196, 480, 112) the one-row-tile form)
+@pytest.mark.parametrize('B,HW,K,N', SHAPES + [(16, 196, 96, 576), (64, 49, 160, 960), (2, 49, 320, 1280), (3, 49, 960, 160),
+                                               (168, 196, 672, 112), (40, 196, 480, 112), (85, 784, 512, 128), (37, 49, 672, 160)])
 @pytest.mark.parametrize('dt', ['f32', 'bf16'])
-@pytest.mark.parametrize('mode', ['plain', 'bnact', 'se_pre_ps'])
+@pytest.mark.parametrize('mode', ['plain', 'bnact', 'se_pre_ps', 'se_pre', 'se_post'])
 def test_pwconv_wgrad(B, HW, K, N, dt, mode):
     from torchdet3d import _native as Nt
     dtype = _dt(dt)
@@ -447,6 +451,8 @@ def test_pwconv_wgrad(B, HW, K, N, dt, mode):
         a = xq
     elif mode == 'bnact':
         a = _act(xq * scale + shift, 'relu6')
+    elif mode == 'se_post':
+        a = _act(xq * scale + shift, 'hswish') * se.repeat_interleave(HW, 0)
     else:
         a = _act((xq * scale + shift) * se.repeat_interleave(HW, 0), 'hswish')
     if mode == 'bnact' and dt == 'bf16':
@@ -461,8 +467,8 @@ def test_pwconv_wgrad(B, HW, K, N, dt, mode):
     dzd, yd, xd = d(dz), d(y), d(x)
     keep = [t.cuda().contiguous() for t in (alpha, beta, gamma, scale, shift, se)]
     bb = Nt.bnbwd(keep[0], keep[1], keep[2], ps)
-    pro = None if mode == 'plain' else Nt.prologue(keep[3], keep[4], keep[5] if ps else None,
-                                                   'relu6' if mode == 'bnact' else 'hswish', False)
+    pro = None if mode == 'plain' else Nt.prologue(keep[3], keep[4], keep[5] if mode.startswith('se_') else None,
+                                                   'relu6' if mode == 'bnact' else 'hswish', mode == 'se_post')
     dw = torch.zeros(N, K, device='cuda')
     Nt.call('t3d_pwconv_wgrad', Nt.dtype_code(dzd), Nt.ptr(dzd), Nt.ptr(yd), bb, Nt.ptr(xd), pro, Nt.ptr(dw),
             M, HW, K, N, Nt.stream())
