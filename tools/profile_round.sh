@@ -1,7 +1,7 @@
 #!/bin/bash
 # everything the round's profiles/ are made of, in one GPU call.  usage: tools/profile_round.sh <tag> <commit>
 cd $GRAFT_REPO_ROOT; export TMPDIR=/tmp
-tag=${1:-r6}; commit=${2:-?}; o=gpurun_out/$tag; mkdir -p $o
+tag=${1:-r6_g}; commit=${2:-?}; o=gpurun_out/$tag; mkdir -p $o
 python3 bench.py --steps 30 --warmup 8 > $o/bench_bf16.json 2> $o/bench_bf16.err
 python3 bench.py --steps 30 --warmup 8 --no-cpu-baseline --profile-all > /dev/null 2> $o/bench_bf16_families.txt
 python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline --per-launch > /dev/null 2> $o/bench_bf16_per_launch.txt
@@ -46,6 +46,13 @@ bash tools/pmc_mfma.sh $o/mfma_util_pmc_resnet50.json --model resnet50 --batch 6
 bash tools/time_pw_bwd.sh $o/pw_bwd_isolated.txt > /dev/null 2>&1
 bash tools/time_dw5.sh > $o/dw5_isolated.txt 2>&1
 bash tools/time_dw3_small.sh > $o/dw3_small_planes_tile_vs_walk.txt 2>&1
+# round 6b: gated against plain weight gradients (kernel-only durations), registers / scratch of the kernels each model launches,
+# what runs beside the gate's backward
+bash tools/time_gated_pw.sh > $o/gated_pw_wgrad_isolated.txt 2>&1
+bash tools/trace_resources.sh > $o/launched_kernel_resources.txt 2>&1
+bash tools/trace_resources.sh --model mobilenetv3_large > $o/mobilenetv3_large_launched_kernel_resources.txt 2>&1
+bash tools/trace_resources.sh --model resnet50 --batch 64 > $o/resnet50_launched_kernel_resources.txt 2>&1
+bash tools/trace_overlap.sh "se_slice_kernel<" --model mobilenetv3_large > $o/mobilenetv3_large_gate_backward_overlap.txt 2>&1
 # HBM traffic (separate --pmc passes)
 bash tools/pmc_traffic.sh $o/hbm_traffic_pmc.json $commit > $o/pmc_traffic.log 2>&1
 tail -2 $o/pmc_traffic.log
