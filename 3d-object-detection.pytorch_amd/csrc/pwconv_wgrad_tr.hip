@@ -726,6 +726,8 @@ int launch_d(WgtArgs& a, hipStream_t st) {
   size_t lds = (size_t)G * 2 * STEP * ((PB + 8) + (QB + 8)) * 2 + (size_t)(3 * dyB + 2 * aB) * 4;
   // pixel splits: fill the chip (2 blocks per CU), but keep the partial-dW flush (S * N*K atomics) below ~8 MB
   static const int tgt_env = getenv("T3D_WG_TGT_BLOCKS") ? atoi(getenv("T3D_WG_TGT_BLOCKS")) : 0;      // (sweep knob)
+  // (256 = one 512-thread workgroup per CU.  Round 6 sweeps, same box: 128 / 192 / 384 / 512 for every layer 7.08 / 6.93 / 6.98 / 7.07
+  // against 6.80-6.91 ms per step; 64 / 128 / 192 for the <= 14x14 layers only 7.11 / 7.02 / 6.93 against 6.89-6.90)
   const int tgt_blocks = tgt_env ? tgt_env : 256;
   const long long cap_mb = 8;
   int S = (tgt_blocks + tiles - 1) / tiles;

@@ -493,7 +493,7 @@ int t3d_sum_slots_batched(const long long* desc, int n, void* stream);
  * kernel boundary already orders the sums before them -- no device-wide barrier), and one workgroup per channel also
  * writes the finalize's outputs for every later reader.  Implemented by the bf16 streaming kernels (t3d_pwconv_fwd /
  * _dgrad / _wgrad (the weight gradient derives without publishing), t3d_dwconv_fwd / _bwd with k = 3) and
- * t3d_bn_apply; other launches
+ * t3d_bn_apply, t3d_se_bwd_affine (round 6); other launches
  * leave the request pending: check t3d_fold_pending() (returns 1 and clears it) right after the launch -- the launch
  * then read unfinalized coefficients and must be treated as failed (the entry points listed above fall back to a
  * finalize launch of their own on code paths without the derive prologue, e.g. fp32 storage).
@@ -553,7 +553,8 @@ int t3d_set_grad_watch(long long* first_bad_step);
  *  _bn_bias_grad gradient of the bias of a Linear that feeds a train-mode BatchNorm1d (classifier, mobilenetv3.py:191-194):
  *               sum_b dy = alpha*sum(dz) + beta*sum(y) + count*gammac from the forward / backward sum replicas;
  *  _se_bwd_affine the per-sample BatchNorm-backward affine behind a squeeze-excite gate: aps = s*alpha, gps = gammac + g*alpha
- *               ([B,C]; what t3d_bnbwd.per_sample reads);
+ *               ([B,C]; what t3d_bnbwd.per_sample reads); serves a pending t3d_fold_request for `alpha` (derives AND publishes
+ *               alpha / beta / gamma + the BatchNorm's parameter gradients, one owner workgroup per 32 channels);
  *  _dropout_mask nn.Dropout(p) keep/scale factors {0, 1/(1-p)} (model_builder.py:83) from Philox-4x32-10 keyed by
  *               (seed, offset): stateless and reproducible. */
 int t3d_copy_cols(const float* src, float* dst, int rows, int cols_src, int cols_dst, void* stream);
