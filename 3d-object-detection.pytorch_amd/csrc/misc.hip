@@ -209,8 +209,11 @@ __global__ __launch_bounds__(256) void se_bwd_affine_fold_kernel(const float* __
                                                                  float* __restrict__ gps, int B, int C) {
   __shared__ float co[3][32];
   const int c0 = blockIdx.x * 32, cb = min(32, C - c0);
-  t3d_fold_block(fold, c0, cb, &co[0][0], 32, true);      // (ends with a barrier)
-  for (int i = threadIdx.x; i < B * 32; i += 256) {
+  // blockIdx.y: a chunk of samples (the derive is repeated per chunk -- 32 channels x the replicas, a few hundred bytes; chunk 0
+  // publishes).  One workgroup per channel block walking all samples was a 17-us latency chain on 30 CUs.
+  t3d_fold_block(fold, c0, cb, &co[0][0], 32, blockIdx.y == 0);      // (ends with a barrier)
+  const int per = (B + gridDim.y - 1) / gridDim.y, b0 = blockIdx.y * per, b1 = min(B, b0 + per);
+  for (int i = b0 * 32 + threadIdx.x; i < b1 * 32; i += 256) {
     const int b = i >> 5, cl = i & 31;
     if (cl < cb) {
       const size_t o = (size_t)b * C + c0 + cl;
@@ -304,7 +307,7 @@ extern "C" int t3d_se_bwd_affine(const float* s, const float* g, const float* al
                                  float* gps, int B, int C, void* stream) {
   if (!s || !g || !alpha || !gammac || !aps || !gps || B <= 0 || C <= 0) return T3D_ERR_ARG;
   if (const T3dFold* fold = t3d_take_fold(alpha)) {
-    T3D_LAUNCH(se_bwd_affine_fold_kernel, dim3(cdiv(C, 32)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), s, g, fold, aps, gps, B, C);
+    T3D_LAUNCH(se_bwd_affine_fold_kernel, dim3(cdiv(C, 32), B >= 64 ? 8 : 1), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), s, g, fold, aps, gps, B, C);
     T3D_CHECK_LAUNCH();
     return T3D_OK;
   }

@@ -19,6 +19,7 @@ struct GemmArgs {
   void* out;
   double* stats;      // [2][Nout]
   float* ps_stats;    // [B][Nout][2] per-sample sums (SE case)
+  int ps_wave;        // per-sample sums: a WAVE owns whole samples (small planes; set by the launcher), else the workgroup does
   int M, HW, Kin, Nout, mtiles;
   int kz;             // generic kernel: contraction split over blockIdx.z (fp32 plain products of few-pixel layers),
   float* part;        // ... partial tiles [kz][M][Nout] in the workspace

@@ -220,9 +220,13 @@ __global__ __launch_bounds__(512, KU > 2 ? 1 : 2) void pw_stream_kernel(const Ge
   const bool ps_mode = GEN && a.ps_stats != nullptr;
   const int wv = xb * WAVES + wave, nwv = nxb * WAVES;
   const int gps = (a.HW + 16 * R - 1) / (16 * R);          // pixel groups per sample
-  const int s_end = ps_mode ? a.M / a.HW : 1, s_step = ps_mode ? nxb : 1;
-  for (int sb = ps_mode ? xb : 0; sb < s_end; sb += s_step) {
-  const int g_begin = ps_mode ? wave : wv, g_end = ps_mode ? gps : ngroups, g_step = ps_mode ? WAVES : nwv;
+  // ... or, on the small planes (<= 16 pixel groups per sample), the WAVE owns whole samples (round 6): its running sums are
+  // complete when it has walked the sample's groups -- no block-level exchange, no barrier per sample (at 7x7 a workgroup's four
+  // waves met twice per sample for ONE pixel group each: 672 <- 112 @14x14 69 us against 49 for the plain data gradient)
+  const bool wos = ps_mode && a.ps_wave;
+  const int s_end = ps_mode ? a.M / a.HW : 1, s_step = wos ? nwv : (ps_mode ? nxb : 1);
+  for (int sb = wos ? wv : (ps_mode ? xb : 0); sb < s_end; sb += s_step) {
+  const int g_begin = wos ? 0 : (ps_mode ? wave : wv), g_end = ps_mode ? gps : ngroups, g_step = wos ? 1 : (ps_mode ? WAVES : nwv);
   const int mbase = ps_mode ? sb * a.HW : 0, mlim = ps_mode ? min(a.M, (sb + 1) * a.HW) : a.M;
   for (int g = g_begin; g < g_end; g += g_step) {
     const int m0 = mbase + g * 16 * R;
@@ -507,7 +511,21 @@ __global__ __launch_bounds__(512, KU > 2 ? 1 : 2) void pw_stream_kernel(const Ge
       }
     }
   }
-  if (ps_mode) {      // sample sb is complete in this block
+  if (wos) {          // sample sb is complete in this wave: lanes of a channel meet by DPP, plain stores
+#pragma unroll
+    for (int q = 0; q < NT / 2; ++q) {
+      const int n = nb + 32 * q;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float s1 = row16_sum(st1[q][j]), s2 = row16_sum(st2[q][j]);
+        st1[q][j] = st2[q][j] = 0.f;
+        if (lc == 0 && n < a.Nout) {
+          a.ps_stats[((size_t)sb * a.Nout + n + j) * 2] = s1;
+          a.ps_stats[((size_t)sb * a.Nout + n + j) * 2 + 1] = s2;
+        }
+      }
+    }
+  } else if (ps_mode) {      // sample sb is complete in this block
 #pragma unroll
     for (int q = 0; q < NT / 2; ++q) {
       const int n = nb + 32 * q;
@@ -581,7 +599,8 @@ int launch_v(GemmArgs& a, int KS, hipStream_t st) {
   if (per_cu > by_lds) per_cu = by_lds;
   if (per_cu < 1) per_cu = 1;
   int nxb = (256 * per_cu) / nchunks;
-  const int need = ps ? a.M / a.HW : cdiv(ngroups, threads / 64);
+  a.ps_wave = (ps && gps <= 16 && !T3D_ENV_SET("T3D_PW_PS_BLOCK")) ? 1 : 0;
+  const int need = ps ? (a.ps_wave ? cdiv(a.M / a.HW, threads / 64) : a.M / a.HW) : cdiv(ngroups, threads / 64);
   if (nxb > need) nxb = need;
   if (nxb < 1) nxb = 1;
   if (nchunks > 1 && nxb >= 8) {              // whole lanes per XCD (see the kernel's block mapping)
