@@ -290,3 +290,48 @@ def test_launch_events_time_the_depthwise_kernel_itself():
     assert torch.equal(ref, y)
     mi, mo = sorted(inner)[len(inner) // 2], sorted(outer)[len(outer) // 2]
     assert 0.005 < mi <= mo * 1.02, (mi, mo)          # ms
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('B,C,nrep', [(256, 960, 4), (8, 72, 1), (100, 120, 16), (64, 672, 8)])
+def test_se_bwd_affine_serves_a_fold_request(B, C, nrep):
+    """t3d_se_bwd_affine with a pending BatchNorm-backward finalize request for `alpha` (include/t3d.h: t3d_fold_request) derives
+    AND publishes alpha / beta / gamma / dgamma / dbeta itself: everything equals the standalone t3d_bn_bwd_finalize followed by
+    the plain launch, bit for bit (same arithmetic in the same order, common.h)."""
+    from torchdet3d import _native as N
+    g = torch.Generator(device='cuda').manual_seed(B + C)
+    rnd = lambda *s: torch.randn(*s, device='cuda', generator=g)
+    s, gg = torch.rand(B, C, device='cuda', generator=g), rnd(B, C) * 0.1
+    gamma, mean, invstd = torch.rand(C, device='cuda', generator=g) + 0.5, rnd(C) * 0.1, torch.rand(C, device='cuda', generator=g) + 0.5
+    count = float(B * 49)
+    stride = 2 * C + 6                       # (replica stride larger than the row: as in the engine's shared statistics buffer)
+    bst = torch.zeros(nrep, stride, device='cuda', dtype=torch.float64)
+    bst[:, :2 * C] = torch.randn(nrep, 2 * C, device='cuda', generator=g, dtype=torch.float64) * 3
+    res = {}
+    for fold in (False, True):
+        al, be, ga, dg, db = (torch.full((C,), float('nan'), device='cuda') for _ in range(5))
+        aps, gps = torch.full((B, C), float('nan'), device='cuda'), torch.full((B, C), float('nan'), device='cuda')
+        N.call('t3d_set_reduction_replicas', nrep, stride)
+        try:
+            if fold:
+                f = N.BnFold()
+                f.kind, f.C, f.count, f.nrep, f.rstride = 2, C, count, nrep, stride
+                f.gamma, f.stats, f.mean, f.invstd = N.ptr(gamma), N.ptr(bst), N.ptr(mean), N.ptr(invstd)
+                f.o0, f.o1, f.o2, f.o3, f.o4 = N.ptr(al), N.ptr(be), N.ptr(ga), N.ptr(dg), N.ptr(db)
+                desc = torch.frombuffer(bytearray(bytes(f)), dtype=torch.uint8).cuda()
+                N.call('t3d_fold_request', N.ptr(desc), N.ptr(al))
+            else:
+                N.call('t3d_bn_bwd_finalize', N.ptr(bst), C, count, N.ptr(gamma), N.ptr(mean), N.ptr(invstd), N.ptr(al), N.ptr(be),
+                       N.ptr(ga), N.ptr(dg), N.ptr(db), N.stream())
+            N.call('t3d_se_bwd_affine', N.ptr(s), N.ptr(gg), N.ptr(al), N.ptr(ga), N.ptr(aps), N.ptr(gps), B, C, N.stream())
+            assert not N.lib().t3d_fold_pending()
+        finally:
+            N.call('t3d_set_reduction_replicas', 1, 0)
+        torch.cuda.synchronize()
+        res[fold] = (al, be, ga, dg, db, aps, gps)
+    for name, a, b in zip(('alpha', 'beta', 'gamma', 'dgamma', 'dbeta', 'aps', 'gps'), res[False], res[True]):
+        assert torch.isfinite(a).all(), name
+        assert torch.equal(a, b), name
+    # and against the definition
+    al, _, ga = res[True][:3]
+    assert torch.equal(res[True][5], s * al) and torch.allclose(res[True][6], ga + gg * al, rtol=0, atol=1e-7)
