@@ -412,7 +412,8 @@ extern "C" int t3d_pwconv_fwd_mat(int dtype, const void* y_in, const t3d_prologu
     a.z_res = residual; a.z_out = z_out;
     a.w = w; a.out = y; a.stats = stats;
     a.M = M; a.HW = HW; a.Kin = K; a.Nout = N;
-    const int rc = stream_launch(a, reinterpret_cast<hipStream_t>(stream));
+    int rc = wfrag ? wide_launch(a, reinterpret_cast<hipStream_t>(stream)) : T3D_ERR_UNSUPPORTED;
+    if (rc == T3D_ERR_UNSUPPORTED) rc = stream_launch(a, reinterpret_cast<hipStream_t>(stream));
     if (rc != T3D_ERR_UNSUPPORTED || wfrag) return rc;
   }
   if (wfrag) return T3D_ERR_ARG;

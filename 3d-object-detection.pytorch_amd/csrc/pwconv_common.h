@@ -62,6 +62,10 @@ int stream_launch(GemmArgs& a, hipStream_t st);
 // from L2); returns T3D_ERR_UNSUPPORTED for every other shape.  deep_shape: the shapes it takes (t3d_pwconv_wants_frag)
 int deep_launch(GemmArgs& a, hipStream_t st);
 bool deep_shape(int Kin, int Nout);
+// bf16 materialising forward of shallow contractions with wide outputs on the small planes (pwconv_wide.hip: operand staged once,
+// all output channels per workgroup); T3D_ERR_UNSUPPORTED for every other launch.  wide_shape: layers whose fragment-order copy it wants
+int wide_launch(GemmArgs& a, hipStream_t st);
+bool wide_shape(int Kin, int Nout);
 // the same kernel in fp16 storage, inference forward only (pwconv_stream_f16.hip)
 int stream_launch_f16(GemmArgs& a, hipStream_t st);
 // fp32 storage, inference forward of many-pixel layers (pwconv_f32_reg.hip); T3D_ERR_UNSUPPORTED for everything else

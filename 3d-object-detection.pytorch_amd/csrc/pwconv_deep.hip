@@ -452,7 +452,7 @@ extern "C" int t3d_pwconv_frag_bytes(int rows, int cols) {
 // where the fragment-order copy PAYS: the deep-contraction kernel's shapes.  (The streaming kernel takes the layout for every
 // shape of its own -- its weight staging becomes one linear copy -- but that is worth ~1 us per launch alone and nothing in
 // the step, less than packing a second copy of every layer costs: DESIGN finding 34.)
-extern "C" int t3d_pwconv_wants_frag(int K, int N) { return t3d_pw::deep_shape(K, N) ? 1 : 0; }
+extern "C" int t3d_pwconv_wants_frag(int K, int N) { return (t3d_pw::deep_shape(K, N) || t3d_pw::wide_shape(K, N)) ? 1 : 0; }
 
 extern "C" int t3d_pwconv_pack_frag(const void* w, void* out, int rows, int cols, void* stream) {
   if (!w || !out || rows <= 0 || cols <= 0) return T3D_ERR_ARG;

@@ -294,6 +294,52 @@ def test_pwconv_fwd_mat_f32_inference_one_launch(M, K, N, res, train):
         np.testing.assert_allclose(st[1].cpu().numpy(), (y[:M].double() ** 2).sum(0).cpu().numpy(), rtol=1e-5, atol=1e-4)
 
 
+# bf16 materialising forward of the small planes' expansions with FRAGMENT-ORDER weights: csrc/pwconv_wide.hip (operand staged once,
+# all output channels per workgroup) where the shape is one of its own, else the streaming kernel on the same layout; against
+# t3d_bn_apply (z, bit for bit) and an fp64 product of the stored z; ragged pixel counts, contractions that are not a multiple of 32
+# (80, 112, 200 outputs that end inside a 32-channel pair), statistics into replicas with a stride wider than the row
+@pytest.mark.parametrize('M,K,N', [(1568, 160, 960), (1000, 64, 384), (777, 96, 576), (640, 320, 1280), (900, 80, 200), (1031, 112, 672),
+                                   (513, 40, 120), (300, 24, 144), (2048, 16, 96)])
+@pytest.mark.parametrize('res', [False, True])
+@pytest.mark.parametrize('act', ['none', 'relu6', 'hswish'])
+def test_pwconv_fwd_mat_bf16_fragment_order_weights(M, K, N, res, act, monkeypatch):
+    from torchdet3d import _native as Nt
+    monkeypatch.setenv('T3D_PW_WIDE', '1')      # (opt-in kernel, csrc/pwconv_wide.hip; read per call)
+    g = torch.Generator().manual_seed(M + K + N + res)
+    bf = torch.bfloat16
+    y3 = torch.randn(M, K, generator=g).cuda().to(bf)
+    r = torch.randn(M, K, generator=g).cuda().to(bf) if res else None
+    w = (torch.randn(N, K, generator=g) / K ** 0.5).cuda()
+    wq = _pack(w, bf)
+    sc, sh = (torch.rand(K, generator=g) + 0.5).cuda(), (torch.randn(K, generator=g) * 0.3).cuda()
+    p = Nt.prologue(sc, sh, None, act, False)
+    z_ref = torch.empty(M, K, device='cuda', dtype=bf)
+    Nt.call('t3d_bn_apply', Nt.BF16, Nt.ptr(y3), p, Nt.ptr(r), Nt.ptr(z_ref), M, K, Nt.stream())
+    z = torch.full((M + 1, K), 7.0, device='cuda', dtype=bf)
+    y = torch.full((M + 1, N), 7.0, device='cuda', dtype=bf)
+    nrep, stride = 4, 2 * N + 10
+    stats = torch.zeros(nrep, stride, device='cuda', dtype=torch.float64)
+    wf = _frag(wq)
+    Nt.call('t3d_set_reduction_replicas', nrep, stride)
+    n0 = Nt.launch_count()
+    try:
+        Nt.call('t3d_pwconv_fwd_mat', Nt.BF16 | Nt.W_FRAG, Nt.ptr(y3), p, Nt.ptr(r), Nt.ptr(z), Nt.ptr(wf), Nt.ptr(y), Nt.ptr(stats), M, 1, K, N,
+                Nt.stream())
+    finally:
+        Nt.call('t3d_set_reduction_replicas', 1, 0)
+    torch.cuda.synchronize()
+    assert Nt.launch_count() - n0 == 1
+    assert torch.equal(z[:M], z_ref) and torch.all(z[M] == 7.0) and torch.all(y[M] == 7.0)
+    ref = z_ref.double() @ wq.double().t()
+    np.testing.assert_allclose(y[:M].float().cpu().numpy(), ref.float().cpu().numpy(), atol=8e-3 * max(1., ref.abs().max().item()), rtol=8e-3)
+    st = stats[:, :2 * N].sum(0).view(2, N)
+    assert torch.all(stats[:, 2 * N:] == 0)
+    yq = y[:M].double()
+    # the sums are those of the STORED (bf16-rounded) outputs, snapped onto the fixed grid of common.h (relative 2^-22 of the range)
+    np.testing.assert_allclose(st[0].cpu().numpy(), yq.sum(0).cpu().numpy(), rtol=1e-5, atol=2e-3 * M ** .5)
+    np.testing.assert_allclose(st[1].cpu().numpy(), (yq ** 2).sum(0).cpu().numpy(), rtol=1e-4, atol=1e-2)
+
+
 # projection-conv data gradients of the 14x14 / 7x7 stages: contraction over 96 / 160 / 320 channels -> the deep-round
 # variants with hoisted epilogue loads (pwconv_stream.hip: HOIST), incl. ragged widths
 DEEP_DG = [(16, 196, 576, 96), (8, 49, 960, 160), (3, 49, 960, 320), (5, 100, 384, 96), (7, 33, 200, 88), (2, 49, 104, 152)]
