@@ -248,14 +248,25 @@ __global__ __launch_bounds__(256) void se_after_apply_kernel(const EwArgs a) {
   if (a.stats) flush_stats(lstat, a.C, c0, on, s1, s2, a.stats);
 }
 
+// 256 threads = cgs channel groups (8 channels each) x 256 / cgs pixel slots: 32 x 8 for layers of >= 256 channels; narrower layers
+// give the idle group lanes to more pixel slots (round 6: MobileNetV3-small's 16-channel gated block at 56x56 ran two groups x 8 slots
+// -- 16 live threads per workgroup walking 392 pixels each: 135 us for 26 MB).  The slot sums meet in slot order: deterministic;
+// identical to the fixed 32 x 8 split where that applied.
+__device__ __forceinline__ int pool_cgs(int CG) {
+  int c = 1;
+  while (c < CG && c < 32) c <<= 1;
+  return c;
+}
+
 // step 1 of 2: ps[b][c][0] = sum_hw dv * act(scale*y + shift)  (= d loss / d gate), ps[b][c][1] = 0
 // grid (B, ceil(CG/32)), block 256 = 32 groups x 8 hw slots (as gap_fwd_kernel)
 template <typename T>
 __global__ __launch_bounds__(256) void se_after_sums_kernel(const EwArgs a) {
-  __shared__ float red[8][32 * 8];
+  __shared__ float red[8 * 32 * 8];
   const int CG = a.C / 8, b = blockIdx.x;
-  const int cgl = threadIdx.x & 31, slot = threadIdx.x >> 5;
-  const int cg = blockIdx.y * 32 + cgl;
+  const int cgs = pool_cgs(CG), nslots = 256 / cgs, rowl = cgs * 8;
+  const int cgl = threadIdx.x & (cgs - 1), slot = threadIdx.x / cgs;
+  const int cg = blockIdx.y * cgs + cgl;
   const bool on = cg < CG;
   const int c0 = on ? cg * 8 : 0;
   const T* __restrict__ dv = reinterpret_cast<const T*>(a.a);
@@ -265,7 +276,7 @@ __global__ __launch_bounds__(256) void se_after_sums_kernel(const EwArgs a) {
 #pragma unroll
   for (int j = 0; j < 8; ++j) acc[j] = 0.f;
   if (on) {
-    for (int hw = slot; hw < a.HW; hw += 8) {
+    for (int hw = slot; hw < a.HW; hw += nslots) {
       float v[8], d[8];
       const size_t off = ((size_t)b * a.HW + hw) * a.C + c0;
       Vec8<T>::load(y + off, v);
@@ -276,14 +287,13 @@ __global__ __launch_bounds__(256) void se_after_sums_kernel(const EwArgs a) {
     }
   }
 #pragma unroll
-  for (int j = 0; j < 8; ++j) red[slot][cgl * 8 + j] = acc[j];
+  for (int j = 0; j < 8; ++j) red[slot * rowl + cgl * 8 + j] = acc[j];
   __syncthreads();
   const int t = threadIdx.x;
-  const int c = blockIdx.y * 256 + t;
-  if (c < a.C) {
+  const int c = blockIdx.y * rowl + t;
+  if (t < rowl && c < a.C) {
     float s = 0.f;
-#pragma unroll
-    for (int q = 0; q < 8; ++q) s += red[q][t];
+    for (int q = 0; q < nslots; ++q) s += red[q * rowl + t];
     a.pooled[((size_t)b * a.C + c) * 2] = s;
     a.pooled[((size_t)b * a.C + c) * 2 + 1] = 0.f;
   }
@@ -294,12 +304,13 @@ __global__ __launch_bounds__(256) void se_after_sums_kernel(const EwArgs a) {
 // among equal values (what F.adaptive_max_pool2d's backward routes the gradient to).
 template <typename T>
 __global__ __launch_bounds__(256) void gap_fwd_kernel(const EwArgs a) {
-  __shared__ float red[8][32 * 8];
-  __shared__ float redm[8][32 * 8];
-  __shared__ int redi[8][32 * 8];
+  __shared__ float red[8 * 32 * 8];
+  __shared__ float redm[8 * 32 * 8];
+  __shared__ int redi[8 * 32 * 8];
   const int CG = a.C / 8, b = blockIdx.x;
-  const int cgl = threadIdx.x & 31, slot = threadIdx.x >> 5;
-  const int cg = blockIdx.y * 32 + cgl;
+  const int cgs = pool_cgs(CG), nslots = 256 / cgs, rowl = cgs * 8;
+  const int cgl = threadIdx.x & (cgs - 1), slot = threadIdx.x / cgs;
+  const int cg = blockIdx.y * cgs + cgl;
   const bool on = cg < CG;
   const int c0 = on ? cg * 8 : 0;
   const bool want_max = a.mode != T3D_POOL_AVG;
@@ -310,7 +321,7 @@ __global__ __launch_bounds__(256) void gap_fwd_kernel(const EwArgs a) {
 #pragma unroll
   for (int j = 0; j < 8; ++j) { acc[j] = 0.f; mx[j] = -INFINITY; mi[j] = 0; }
   if (on) {
-    for (int hw = slot; hw < a.HW; hw += 8) {
+    for (int hw = slot; hw < a.HW; hw += nslots) {
       float v[8];
       Vec8<T>::load(y + ((size_t)b * a.HW + hw) * a.C + c0, v);
       act_affine_vec<8>(v, sc, sh, a.act);
@@ -323,24 +334,22 @@ __global__ __launch_bounds__(256) void gap_fwd_kernel(const EwArgs a) {
   }
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
-    red[slot][cgl * 8 + j] = acc[j];
-    if (want_max) { redm[slot][cgl * 8 + j] = mx[j]; redi[slot][cgl * 8 + j] = mi[j]; }
+    red[slot * rowl + cgl * 8 + j] = acc[j];
+    if (want_max) { redm[slot * rowl + cgl * 8 + j] = mx[j]; redi[slot * rowl + cgl * 8 + j] = mi[j]; }
   }
   __syncthreads();
-  const int t = threadIdx.x;  // 256 = 32 groups x 8 channels
-  const int c = blockIdx.y * 256 + t;
-  if (c < a.C) {
+  const int t = threadIdx.x;  // the first cgs x 8 threads: one channel each
+  const int c = blockIdx.y * rowl + t;
+  if (t < rowl && c < a.C) {
     float s = 0.f;
-#pragma unroll
-    for (int q = 0; q < 8; ++q) s += red[q][t];
+    for (int q = 0; q < nslots; ++q) s += red[q * rowl + t];
     float out = s * a.inv_hw;
     if (want_max) {
-      float m = redm[0][t];
-      int im = redi[0][t];
-#pragma unroll
-      for (int q = 1; q < 8; ++q) {
-        const float mq = redm[q][t];
-        const int iq = redi[q][t];
+      float m = redm[t];
+      int im = redi[t];
+      for (int q = 1; q < nslots; ++q) {
+        const float mq = redm[q * rowl + t];
+        const int iq = redi[q * rowl + t];
         if (mq > m || (mq == m && iq < im)) { m = mq; im = iq; }
       }
       if (a.argmax) a.argmax[(size_t)b * a.C + c] = im;
@@ -353,10 +362,11 @@ __global__ __launch_bounds__(256) void gap_fwd_kernel(const EwArgs a) {
 // dz[b][hw][c] = dpooled[b][c]/HW * act'(scale*y+shift); stats.  grid (nb, ceil(CG/32)): block loops over samples
 template <typename T>
 __global__ __launch_bounds__(256) void gap_bwd_kernel(const EwArgs a, int B, const int g_nrep, const long long g_rstride) {
-  __shared__ float red[2][8][32 * 8];
+  __shared__ float red[2][8 * 32 * 8];
   const int CG = a.C / 8;
-  const int cgl = threadIdx.x & 31, slot = threadIdx.x >> 5;
-  const int cg = blockIdx.y * 32 + cgl;
+  const int cgs = pool_cgs(CG), nslots = 256 / cgs, rowl = cgs * 8;
+  const int cgl = threadIdx.x & (cgs - 1), slot = threadIdx.x / cgs;
+  const int cg = blockIdx.y * cgs + cgl;
   const bool on = cg < CG;
   const int c0 = on ? cg * 8 : 0;
   const T* __restrict__ y = reinterpret_cast<const T*>(a.a);
@@ -376,7 +386,7 @@ __global__ __launch_bounds__(256) void gap_bwd_kernel(const EwArgs a, int B, con
         dm[j] = (a.mode == T3D_POOL_AVG) ? 0.f : g;                  // the maximum's share, its position only
         am[j] = (a.mode == T3D_POOL_AVG) ? -1 : a.argmax[(size_t)b * a.C + c0 + j];
       }
-      for (int hw = slot; hw < a.HW; hw += 8) {
+      for (int hw = slot; hw < a.HW; hw += nslots) {
         const size_t off = ((size_t)b * a.HW + hw) * a.C + c0;
         float v[8], d[8];
         Vec8<T>::load(y + off, v);
@@ -396,17 +406,16 @@ __global__ __launch_bounds__(256) void gap_bwd_kernel(const EwArgs a, int B, con
   if (a.stats) {
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-      red[0][slot][cgl * 8 + j] = s1[j];
-      red[1][slot][cgl * 8 + j] = s2[j];
+      red[0][slot * rowl + cgl * 8 + j] = s1[j];
+      red[1][slot * rowl + cgl * 8 + j] = s2[j];
     }
     __syncthreads();
-    const int t = threadIdx.x, c = blockIdx.y * 256 + t;
-    if (c < a.C) {
+    const int t = threadIdx.x, c = blockIdx.y * rowl + t;
+    if (t < rowl && c < a.C) {
       double u1 = 0.0, u2 = 0.0;
-#pragma unroll
-      for (int q = 0; q < 8; ++q) {
-        u1 += (double)red[0][q][t];
-        u2 += (double)red[1][q][t];
+      for (int q = 0; q < nslots; ++q) {
+        u1 += (double)red[0][q * rowl + t];
+        u2 += (double)red[1][q * rowl + t];
       }
       // one add per (block, channel), 256 sample blocks per channel: spread over the reduction replicas
       double* st = a.stats + (size_t)(blockIdx.x % g_nrep) * g_rstride;
